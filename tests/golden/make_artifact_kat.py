@@ -1,0 +1,135 @@
+"""
+Regenerates tests/golden/artifact_kat.npz -- the only reference-produced golden
+vector for the hot path.
+
+Runs ONLY in the build container (needs /root/reference and the Boston table
+that ships with an old scikit-learn under /opt/conda); the GPU box and the test
+suite consume the committed .npz.  The reference's pickle
+experiments/boston_housing/boston_scfgp.pkl (written by SCFGP.save,
+SCFGP/SCFGP.py:296-302) is read AS DATA through a restricted unpickler: no
+reference code, Theano object or callable is ever instantiated, and nothing of
+the pickle is copied into the repo except the numeric arrays listed below.
+
+Fixture contents (float64):
+  X, y      scaled 400-row training split (what train_func received)
+  params    trained 1333-vector (a,b,c,l_f,r_f,l_p,p) found inside train_func
+  Li, alpha Theano-computed outputs stored by the reference
+  cost      evals['COST'][1][-1] recorded by optimize() (SCFGP/SCFGP.py:265-266)
+  S, M, D
+"""
+import collections
+import os
+import pickle
+import sys
+
+import numpy as np
+from scipy.stats import norm
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, '..', '..'))
+from oracle import scfgp_oracle as O   # noqa: E402
+
+PKL = '/root/reference/experiments/boston_housing/boston_scfgp.pkl'
+CSV = '/opt/conda/lib/python3.9/site-packages/sklearn/datasets/data/boston_house_prices.csv'
+
+
+class _Stub(object):
+    _args = (); _state = None
+
+    def __init__(self, *a, **k):
+        self._args = a
+
+    def __setstate__(self, s):
+        self._state = s
+
+
+_ALLOWED = {('numpy.core.multiarray', '_reconstruct'), ('numpy', 'ndarray'), ('numpy', 'dtype'),
+            ('numpy.core.multiarray', 'scalar'), ('collections', 'OrderedDict'),
+            ('builtins', 'slice'), ('__builtin__', 'slice')}
+
+
+class _DataOnlyUnpickler(pickle.Unpickler):
+    def find_class(self, module, name):
+        if (module, name) in _ALLOWED:
+            return super().find_class(module.replace('numpy.core', 'numpy._core'), name)
+        return type(name, (_Stub,), {})
+
+
+def _walk_arrays(obj, out, seen):
+    if id(obj) in seen:
+        return
+    seen.add(id(obj))
+    if isinstance(obj, np.ndarray):
+        out.append(obj)
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            _walk_arrays(v, out, seen)
+    elif isinstance(obj, (list, tuple, set)):
+        for v in obj:
+            _walk_arrays(v, out, seen)
+    elif isinstance(obj, _Stub):
+        _walk_arrays(getattr(obj, '_args', None), out, seen)
+        _walk_arrays(getattr(obj, '_state', None), out, seen)
+        _walk_arrays(obj.__dict__, out, seen)
+
+
+def _forward_scale(Xraw, data, inv_normal):
+    """Scaler.forward_transform for the two 'auto-*' modes (SCFGP/Scaler.py:107-116)."""
+    tX = Xraw[:, data['cols']]
+    tX = (tX - data['min']) / (data['max'] - data['min'])
+    lm = data['boxcox'][None, :]
+    bc = (np.sign(tX) * np.abs(tX) ** lm - 1) / lm
+    if inv_normal:
+        return norm.cdf(bc, data['mu'], data['std'])
+    return (bc - data['mu']) / data['std']
+
+
+def main():
+    with open(PKL, 'rb') as f:
+        d = _DataOnlyUnpickler(f).load()
+    M = int(d['M']); Li = np.asarray(d['Li'], np.float64); alpha = np.asarray(d['alpha'], np.float64)
+    K = Li.shape[0]; J = K // 2; S = J - M
+    xs = d['X_scaler'].__dict__ if d['X_scaler']._state is None else d['X_scaler']._state
+    ys = d['y_scaler'].__dict__ if d['y_scaler']._state is None else d['y_scaler']._state
+    D = len(xs['data']['cols'])
+    P = O.num_params(D, S, M)
+    arrs = []
+    _walk_arrays(d['train_func'], arrs, set())
+    cands = [a for a in arrs if a.dtype == np.float64 and a.size == P]
+    assert cands, 'trained parameter vector not found in train_func'
+    cost_rec = float(d['evals']['COST'][1][-1])
+
+    raw = np.loadtxt(CSV, delimiter=',', skiprows=2)
+    Xraw, yraw = raw[:, :13], raw[:, 13:14]
+    Xs = _forward_scale(Xraw, xs['data'], True)
+    ysc = _forward_scale(yraw, ys['data'], False)
+
+    best = None
+    for params in cands:
+        params = np.asarray(params, np.float64).ravel()
+        a = params[0]
+        Phi = O.feature_map(Xs, params, D, S, M)                       # (506,K)
+        # recover the 0/1 row-membership vector z from  sum_i z_i phi_i phi_i^T = L L^T - lam I
+        L = np.linalg.inv(Li)
+        A = L @ L.T - (np.exp(2 * a) + O.EPSILON) * np.eye(K)
+        iu = np.tril_indices(K)
+        Mat = np.stack([np.outer(Phi[i], Phi[i])[iu] for i in range(Phi.shape[0])], 1)
+        z, *_ = np.linalg.lstsq(Mat, A[iu], rcond=None)
+        dev = np.abs(z - np.round(z)).max()
+        if best is None or dev < best[0]:
+            best = (dev, params, np.round(z).astype(int))
+    dev, params, z = best
+    assert dev < 1e-6 and set(np.unique(z)) <= {0, 1}, dev
+    tr = np.where(z == 1)[0]
+    X, y = Xs[tr], ysc[tr]
+    cost, al, Li_o = O.forward(X, y, params, S, M, True)
+    rel = lambda u, v: np.linalg.norm(u - v) / np.linalg.norm(v)
+    print('rows', len(tr), 'split deviation', dev)
+    print('oracle vs artifact: Li %.2e alpha %.2e cost %.2e' % (
+        rel(Li_o, Li), rel(al, alpha), abs(cost - cost_rec) / abs(cost_rec)))
+    np.savez_compressed(os.path.join(HERE, 'artifact_kat.npz'), X=X, y=y, params=params,
+                        Li=Li, alpha=alpha, cost=cost_rec, S=S, M=M, D=D, train_rows=tr)
+
+
+if __name__ == '__main__':
+    main()
