@@ -1,0 +1,125 @@
+/*
+ * scfgp_hip.h -- C ABI of libscfgp_hip.so: the MI355X (gfx950) implementation of the
+ * SCFGP Fourier-feature marginal-likelihood hot path.
+ *
+ * The library stands behind the reference's "compiled function triple"
+ *     train_func(X,y)       -> [cost, alpha, Li]              SCFGP/SCFGP.py:132-135
+ *     train_iter_func(X,y)  -> same outputs + parameter update SCFGP/SCFGP.py:136-137
+ *     pred_func(Xs,alpha,Li)-> [mu, std]                       SCFGP/SCFGP.py:138-148
+ * i.e. it replaces what theano.function compiled from build_theano_models
+ * (SCFGP/SCFGP.py:92-148, gradient from TT.grad at :129).  The optimiser update rule
+ * (SCFGP/Optimizer.py) stays on the host above this boundary so its callback signature
+ * remains user-extensible; the library returns the exact gradient it needs.
+ *
+ * Conventions
+ *   - every function returns 0 or a negative error code; nothing throws across the ABI;
+ *     scfgp_last_error() gives a message for the last failure on that context
+ *   - the caller owns every host buffer; the library owns all device memory
+ *   - host matrices are row-major, C-contiguous float64 regardless of compute dtype
+ *     (the reference's graph is float64 throughout: TT.dmatrices, SCFGP/SCFGP.py:95-96,138)
+ *   - a context is bound to one GPU and is not thread-safe; calls are synchronous unless
+ *     stated otherwise (results are on the host when the call returns)
+ *   - K = 2*(S+M) is the Gram dimension, P = 3 + D*S + M*S + S + M the parameter count
+ *     (SCFGP/SCFGP.py:72)
+ */
+#ifndef SCFGP_HIP_H
+#define SCFGP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct scfgp_ctx scfgp_ctx;
+
+#define SCFGP_OK            0
+#define SCFGP_EARG         -1   /* bad argument / wrong call order                       */
+#define SCFGP_EHIP         -2   /* HIP runtime error                                     */
+#define SCFGP_ENOTPD       -3   /* A = Phi^T Phi + (e^{2a}+1e-6) I not positive definite:
+                                   the reference raises numpy.linalg.LinAlgError from its
+                                   Cholesky op (SCFGP/SCFGP.py:106)                      */
+#define SCFGP_ENONFINITE   -4   /* cost is NaN/Inf                                       */
+
+#define SCFGP_F64 0             /* fp64 MFMA everywhere (reference numerics)             */
+#define SCFGP_F32 1             /* N-sized products in exact-fp32 MFMA, fp64 projection,
+                                   fp64 cross-chunk accumulation and fp64 K x K stage    */
+
+/* ---- life cycle --------------------------------------------------------------------
+ * Replaces SCFGP.build_theano_models (SCFGP/SCFGP.py:92-148): "compile" becomes "create a
+ * context".  D,S,M as in SCFGP.__init__/set_data (SCFGP/SCFGP.py:36-37,164).
+ * `stream` is a hipStream_t (NULL = the context creates its own); passing the stream of
+ * the host framework keeps the library's work ordered with that framework's collectives. */
+int  scfgp_create(scfgp_ctx** out, int D, int S, int M, int dtype, int device, void* stream);
+void scfgp_destroy(scfgp_ctx* ctx);
+const char* scfgp_last_error(const scfgp_ctx* ctx);
+
+/* ---- implicit state: the shared parameter vector -------------------------------------
+ * The reference binds hyper-parameters with givens=[(params, self.params)]
+ * (SCFGP/SCFGP.py:134-137,147-148): they are state of the compiled functions, not
+ * arguments.  Layout [a,b,c,l_f(D*S),r_f(M*S),l_p(S),p(M)] (SCFGP/SCFGP.py:72,74-90). */
+int scfgp_set_params(scfgp_ctx* ctx, const double* params, int P);
+int scfgp_get_params(scfgp_ctx* ctx, double* params, int P);
+
+/* ---- training data: upload once, keep resident ----------------------------------------
+ * X (N,D), y (N) already scaled (what SCFGP.set_data stores in self.X/self.y,
+ * SCFGP/SCFGP.py:161-162).  n_global is the N the objective divides by and uses in
+ * 2(N-M)a (X.shape[0] at SCFGP/SCFGP.py:126,128): equal to N on one GPU, the sum over
+ * ranks when rows are sharded. */
+int scfgp_set_data(scfgp_ctx* ctx, const double* X, const double* y, int64_t N, int64_t n_global);
+
+/* ---- train_func / train_iter_func ------------------------------------------------------
+ * One evaluation at the current parameters.  X==NULL uses the resident rows; otherwise
+ * (minibatches, SCFGP/SCFGP.py:226-235) the given rows replace them first.
+ * want_grad=0 is train_func (forward only); want_grad=1 additionally returns
+ * d cost / d params (P) -- what TT.grad (SCFGP/SCFGP.py:129) feeds the update rule.
+ * Outputs (any may be NULL): cost (1), grad (P), alpha (K), Li (K*K row-major, lower
+ * triangular, zeros above the diagonal). */
+int scfgp_eval(scfgp_ctx* ctx, const double* X, const double* y, int64_t N, int want_grad,
+               double* cost, double* grad, double* alpha, double* Li);
+
+/* ---- pred_func  (SCFGP/SCFGP.py:138-148) ------------------------------------------------
+ * mu (T), std (T) for Xs (T,D) given alpha (K) and Li (K*K) as returned by scfgp_eval. */
+int scfgp_predict(scfgp_ctx* ctx, const double* Xs, int64_t T, const double* alpha, const double* Li,
+                  double* mu, double* std);
+
+/* ---- staged evaluation for row-sharded data parallelism ---------------------------------
+ * The objective needs three row sweeps separated by two K x K stages; with rows sharded
+ * over ranks each sweep ends in one sum over ranks.  The host framework (torch.distributed
+ * over RCCL) performs that sum in place on the device buffer scfgp_exchange() exposes:
+ *
+ *   scfgp_pass1   -> exchange 1 = [G (Kp*Kp) | Phi^T y (Kp) | y^T y ...]
+ *   scfgp_factor     (replicated: Cholesky, Li, alpha, log det)
+ *   scfgp_pass2   -> exchange 2 = [W (Kp*Kp) | Phi^T p (Kp) | T2, kbar ...]
+ *   scfgp_adjoint    (replicated: Abar)                      [want_grad only]
+ *   scfgp_pass3   -> exchange 3 = [X~^T Zbar | bbar ...]     [want_grad only]
+ *   scfgp_finish  -> outputs on the host
+ *
+ * These calls only enqueue work on the context's stream (asynchronous); scfgp_finish
+ * synchronises.  scfgp_eval is exactly this sequence without the sums. */
+int scfgp_pass1(scfgp_ctx* ctx);
+int scfgp_factor(scfgp_ctx* ctx);
+int scfgp_pass2(scfgp_ctx* ctx, int want_grad);
+int scfgp_adjoint(scfgp_ctx* ctx);
+int scfgp_pass3(scfgp_ctx* ctx);
+int scfgp_finish(scfgp_ctx* ctx, int want_grad, double* cost, double* grad, double* alpha, double* Li);
+/* device pointer + length (in doubles) of exchange buffer `stage` (1..3) */
+int scfgp_exchange(scfgp_ctx* ctx, int stage, void** dev_ptr, int64_t* count);
+
+/* ---- introspection ------------------------------------------------------------------------ */
+/* padded sizes the device buffers use: out[0]=K, out[1]=Kp, out[2]=Jp, out[3]=Dp, out[4]=Np, out[5]=P */
+int scfgp_get_dims(scfgp_ctx* ctx, int64_t* out, int n);
+/* profiling: enable per-stage hipEvent timing; after an evaluation read back up to n
+ * (name, milliseconds) pairs.  Returns the number of stages recorded. */
+int scfgp_set_profiling(scfgp_ctx* ctx, int enable);
+int scfgp_get_timings(scfgp_ctx* ctx, double* ms, const char** names, int n);
+/* copy an internal device buffer to the host for tests ("Phi","G","Li","B","V","Zbar","XZ",
+ * "W","Abar","p","q","alpha","scalars"); returns the number of bytes copied or <0 */
+int64_t scfgp_debug_read(scfgp_ctx* ctx, const char* name, void* host, int64_t max_bytes);
+/* tuning knobs: "gram_nsplit", "gram_chunk" (fp32 flush interval in rows), "xtz_nsplit" */
+int scfgp_set_option(scfgp_ctx* ctx, const char* name, int64_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCFGP_HIP_H */

@@ -1,0 +1,37 @@
+// Shared declarations for the scfgp HIP library (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+
+static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// device-side scalars derived from (a,b,c) once per parameter update
+struct Scal {
+    double a, b, c;
+    double s;        // e^b * sqrt(2/M)          SCFGP.py:98,102
+    double lam;      // e^{2a} + 1e-6            SCFGP.py:93,98,105
+    double kappa;    // log(1+e^c)               SCFGP.py:103
+    double em2a;     // e^{-2a}
+    double e2a;      // e^{2a}
+    double sigc;     // sigmoid(c) = d kappa / dc
+};
+
+// slots of the small scalar reduction vector kept on the device
+enum {
+    R_YY = 0, R_LOGDET, R_T2, R_KBAR, R_BBAR, R_TRABAR, R_GTALPHA, R_PEN, R_COST, R_FLAG, R_COUNT
+};
+
+// Dynamic LDS above 64 KiB needs an explicit opt-in per kernel on HIP.
+template <typename Kern>
+static inline void allow_big_lds(Kern kernel, int bytes) {
+    if (bytes > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}

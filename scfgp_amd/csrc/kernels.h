@@ -1,0 +1,78 @@
+// Host-callable launchers for every device kernel of the scfgp HIP library.
+// All launch asynchronously on `st`; none allocates or synchronises.
+#pragma once
+#include "common.h"
+
+// geometry shared by all sweeps (device buffers are padded so kernels need no edge code)
+struct Geom {
+    int D, S, M, J, K, P;
+    int Dp;      // round_up(D+1,16): X~ = [X | 1 | 0..]   (ones column carries the phase offsets)
+    int Jp;      // round_up(J,128)
+    int Kp;      // round_up(K,128)
+    int64_t N;   // valid local rows
+    int64_t Np;  // round_up(N,256)
+};
+
+template <typename T> struct SweepKernels {
+    // Phi = s*[cos Z, sin Z], Z = X~ . Fall                      (SCFGP.py:98-102 / :139-142)
+    static void featuremap(const Geom& g, const double* Xt, const double* Fall, const Scal* sc, T* Phi, hipStream_t st);
+    // lower tiles of  Phi^T diag(w) Phi  into per-split fp64 slabs (SCFGP.py:104; weighted: backward of :111-113)
+    static void gram(const Geom& g, const T* Phi, const double* w, int nsplit, int64_t chunk, double* slabs, hipStream_t st);
+    // out[c] = sum_n w[n] Phi[n][c]  -> partial[nsplit][Kp]          (SCFGP.py:108)
+    static void colsum(const Geom& g, const T* Phi, const double* w, int nsplit, double* partial, hipStream_t st);
+    // V = Phi . Bm, vpart[jt][n] = sum_{j in tile} Phi[n][j] V[n][j]    (SCFGP.py:112)
+    static void apply_v(const Geom& g, const T* Phi, const T* Bm, T* V, double* vpart, hipStream_t st);
+    // Phibar = 2 Phi.Abar + 2 q V + p alpha^T + y ut^T  (in place over V)
+    static void apply_phibar(const Geom& g, const T* Phi, const T* Abar, T* V, const double* p, const double* q,
+                             const double* y, const double* alpha, const double* ut, hipStream_t st);
+    // per-row moments and adjoint scalars; block partials of (T2, kbar)  (SCFGP.py:111-113,121-124)
+    static void rowstats(const Geom& g, const T* Phi, const double* alpha, const double* vpart, const double* y,
+                         const Scal* sc, double* p, double* q, double* partial, int nblocks, hipStream_t st);
+    // predictive mean / std                                          (SCFGP.py:143-144)
+    static void rowpredict(const Geom& g, const T* Phi, const double* alpha, const double* vpart, const Scal* sc,
+                           double* mu, double* sd, hipStream_t st);
+    // Zbar[n][j] = Phi[n][j] Phibar[n][J+j] - Phi[n][J+j] Phibar[n][j]; block partials of bbar
+    static void zbar(const Geom& g, const T* Phi, const T* Phibar, T* Zbar, double* partial, int nblocks, hipStream_t st);
+    // X~^T Zbar into per-split fp64 slabs
+    static void xtz(const Geom& g, const double* Xt, const T* Zbar, int nsplit, double* slabs, hipStream_t st);
+    // fp64 matrix -> T (no-op copy for double)
+    static void convert(const double* src, T* dst, int64_t n, hipStream_t st);
+};
+
+// ---- reductions ------------------------------------------------------------
+// out (ldo) = sum over splits of lower-tile slabs, mirrored into the upper triangle
+void reduce_tri_tiles(const double* slabs, int nsplit, int nts, double* out, int64_t ldo, hipStream_t st);
+// out (ldo) = sum over splits of a full ntm x ntn tile grid of slabs
+void reduce_full_tiles(const double* slabs, int nsplit, int ntm, int ntn, double* out, int64_t ldo, hipStream_t st);
+// out[i] = sum_s partial[s][i], i < n
+void reduce_rows(const double* partial, int nsplit, int64_t n, double* out, hipStream_t st);
+// scalars[slot0 + k] = sum_b partial[b*width + k], k < width
+void reduce_scalars(const double* partial, int nblocks, int width, double* scalars, int slot0, hipStream_t st);
+// scalars[slot] = sum y^2
+void sum_squares(const double* y, int64_t n, double* scalars, int slot, double* scratch, hipStream_t st);
+
+// ---- parameter unpack / gradient epilogue -----------------------------------
+void unpack_params(const Geom& g, const double* params, double* F, double* Fall, Scal* sc, hipStream_t st);
+void grad_epilogue(const Geom& g, const double* params, const double* F, const double* XZ, int64_t ldxz,
+                   double* work, double* scalars, int64_t Nglobal, double* grad, hipStream_t st);
+// yy -> y^T y, t2kb -> (T2, kbar), bbar -> bbar: device scalars living in the exchange buffers
+void finalize_cost(const Geom& g, const Scal* sc, double* scalars, const double* yy, const double* t2kb, const double* bbar,
+                   int64_t Nglobal, double* grad, int want_grad, hipStream_t st);
+// Xt (Np x Dp) = [X | 1 | 0], zero rows >= N; y padded with zeros
+void pack_data(const Geom& g, const double* Xraw, const double* yraw, double* Xt, double* y, hipStream_t st);
+// square K x K host-layout matrix (ld K) -> Kp x Kp with identity padding, and back
+void pad_square(const double* src, int K, int Kp, double* dst, hipStream_t st);
+
+// ---- K x K stage (fp64, all matrices Kp x Kp, leading dimension Kp) -----------
+struct KStage {
+    int K, Kp;
+    double *A;      // in: G + lam I (full, symmetric)  -> out: L in the lower blocks
+    double *Li;     // L^{-1} (lower, zero above)
+    double *B;      // Li^T Li
+    double *T1, *T2;// scratch Kp x Kp
+    double *g, *beta, *alpha, *h, *u, *ut;   // Kp vectors
+    double *scalars; int* flag;
+};
+void kstage_factor(const KStage& k, const Scal* sc, hipStream_t st);          // SCFGP.py:105-110,125
+void kstage_adjoint(const KStage& k, const double* W, double* Abar, const Scal* sc, hipStream_t st);
+void kstage_gram_li(const KStage& k, hipStream_t st);                         // B = Li^T Li only (predict)

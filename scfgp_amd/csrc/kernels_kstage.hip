@@ -1,0 +1,278 @@
+// K x K stage (fp64): A = G + lam I, blocked Cholesky, L^{-1} by recursive doubling,
+// B = Li^T Li, alpha, log det, and the K x K cotangent Abar of the backward pass.
+// Replaces Theano's Cholesky / MatrixInverse ops (SCFGP/SCFGP.py:105-110) and the
+// linear-algebra part of TT.grad (:129).  All matrices are Kp x Kp (Kp % 128 == 0)
+// with the padding block kept at identity, so no kernel needs edge handling.
+#include "kernels.h"
+#include "tile_engine.h"
+
+typedef TileCfg<double, 64, 64, 16, 2, 2> KCfg;
+#define SMEM_DECL extern __shared__ __attribute__((aligned(16))) char smem_raw[]
+
+struct GemmArgs {
+    const double* A; const double* B; double* C;
+    int64_t lda, ldb, ldc;
+    int M, N, K;
+    double alpha, beta;
+    int tri;        // 1: skip tiles strictly above the diagonal
+    int kskip;      // 1: operands are Li^T-shaped, contraction starts at max(m0,n0)
+};
+
+// C[m][n] = alpha * sum_k Aop[k][m] Bop[k][n] + beta * C[m][n]
+//   TRA=false: A stored [k][m] (Nat)   TRA=true: A stored [m][k]
+template <bool TRA, bool TRB>
+__device__ __forceinline__ void gemm64_body(const GemmArgs& a, int tm, int tn, double* smem) {
+    typedef KCfg Cfg;
+    if (tm * Cfg::BM >= a.M || tn * Cfg::BN >= a.N) return;
+    if (a.tri && tn > tm) return;
+    const int k0 = a.kskip ? (tm > tn ? tm : tn) * Cfg::BM : 0;
+    const int nkt = (a.K - k0) / Cfg::BK;
+    v4d acc[Cfg::TM][Cfg::TN];
+    acc_zero<Cfg>(acc);
+    if (TRA) {
+        TrLoader<double, double, Cfg::BM, Cfg::BK, Cfg::LDA, Cfg::THREADS> la(a.A + (int64_t)tm * Cfg::BM * a.lda + k0, a.lda, threadIdx.x);
+        if (TRB) {
+            TrLoader<double, double, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS> lb(a.B + (int64_t)tn * Cfg::BN * a.ldb + k0, a.ldb, threadIdx.x);
+            tile_mainloop<Cfg>(la, lb, nkt, acc, smem);
+        } else {
+            NatLoader<double, double, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS, false, false> lb(a.B + (int64_t)k0 * a.ldb + tn * Cfg::BN, a.ldb, threadIdx.x);
+            tile_mainloop<Cfg>(la, lb, nkt, acc, smem);
+        }
+    } else {
+        NatLoader<double, double, Cfg::BM, Cfg::BK, Cfg::LDA, Cfg::THREADS, false, false> la(a.A + (int64_t)k0 * a.lda + tm * Cfg::BM, a.lda, threadIdx.x);
+        if (TRB) {
+            TrLoader<double, double, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS> lb(a.B + (int64_t)tn * Cfg::BN * a.ldb + k0, a.ldb, threadIdx.x);
+            tile_mainloop<Cfg>(la, lb, nkt, acc, smem);
+        } else {
+            NatLoader<double, double, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS, false, false> lb(a.B + (int64_t)k0 * a.ldb + tn * Cfg::BN, a.ldb, threadIdx.x);
+            tile_mainloop<Cfg>(la, lb, nkt, acc, smem);
+        }
+    }
+    AccCoord<Cfg> co;
+#pragma unroll
+    for (int t1 = 0; t1 < Cfg::TM; ++t1)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double* c = a.C + (int64_t)(tm * Cfg::BM + co.row(t1, r)) * a.ldc + tn * Cfg::BN;
+#pragma unroll
+            for (int t2 = 0; t2 < Cfg::TN; ++t2) {
+                const double v = a.alpha * acc[t1][t2][r];
+                c[co.col(t2)] = a.beta == 0.0 ? v : v + a.beta * c[co.col(t2)];
+            }
+        }
+}
+
+template <bool TRA, bool TRB>
+__global__ __launch_bounds__(KCfg::THREADS) void gemm64_kernel(GemmArgs a) {
+    SMEM_DECL;
+    gemm64_body<TRA, TRB>(a, blockIdx.y, blockIdx.x, reinterpret_cast<double*>(smem_raw));
+}
+
+template <bool TRA, bool TRB>
+static void gemm64(const GemmArgs& a, hipStream_t st) {
+    if (a.M <= 0 || a.N <= 0) return;
+    hipLaunchKernelGGL((gemm64_kernel<TRA, TRB>), dim3(a.N / KCfg::BN, a.M / KCfg::BM), dim3(KCfg::THREADS), KCfg::LDS_BYTES, st, a);
+}
+
+// one recursive-doubling level of the triangular inverse, batched over block pairs (blockIdx.z)
+//   STEP 0:  Tmp21 = L21 . Inv11          STEP 1:  Li21 = - Inv22 . Tmp21
+template <int STEP>
+__global__ __launch_bounds__(KCfg::THREADS) void trinv_level_kernel(const double* __restrict__ L, double* Li, double* Tmp,
+                                                                    int64_t ld, int Kp, int sz) {
+    SMEM_DECL;
+    const int o1 = 2 * blockIdx.z * sz, o2 = o1 + sz;
+    const int n2 = Kp - o2 < sz ? Kp - o2 : sz;
+    GemmArgs a;
+    a.lda = a.ldb = a.ldc = ld; a.tri = 0; a.kskip = 0; a.beta = 0.0;
+    if (STEP == 0) {
+        a.A = L + (int64_t)o2 * ld + o1; a.B = Li + (int64_t)o1 * ld + o1; a.C = Tmp + (int64_t)o2 * ld + o1;
+        a.M = n2; a.N = sz; a.K = sz; a.alpha = 1.0;
+    } else {
+        a.A = Li + (int64_t)o2 * ld + o2; a.B = Tmp + (int64_t)o2 * ld + o1; a.C = Li + (int64_t)o2 * ld + o1;
+        a.M = n2; a.N = sz; a.K = n2; a.alpha = -1.0;
+    }
+    gemm64_body<true, false>(a, blockIdx.y, blockIdx.x, reinterpret_cast<double*>(smem_raw));
+}
+
+// ---------------------------------------------------------------------------
+// 64 x 64 diagonal block: unblocked Cholesky in LDS + its triangular inverse
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void potrf_diag_kernel(double* A, double* Li, int64_t ld, int p, int* flag) {
+    constexpr int NB = 64, LDS = NB + 1;
+    __shared__ double sL[NB * LDS];
+    __shared__ double sI[NB * LDS];
+    double* a = A + (int64_t)p * NB * ld + p * NB;
+    double* li = Li + (int64_t)p * NB * ld + p * NB;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < NB * NB; e += 256) sL[(e / NB) * LDS + e % NB] = a[(int64_t)(e / NB) * ld + e % NB];
+    for (int j = 0; j < NB; ++j) {
+        __syncthreads();
+        const double d = sL[j * LDS + j];
+        if (tid == 0 && !(d > 0.0)) *flag = 1;                      // not positive definite (or NaN)
+        const double sq = sqrt(d), inv = 1.0 / sq;
+        __syncthreads();
+        if (tid < NB && tid >= j) sL[tid * LDS + j] = tid == j ? sq : sL[tid * LDS + j] * inv;
+        __syncthreads();
+        for (int e = tid; e < NB * NB; e += 256) {
+            const int i = e / NB, k = e % NB;
+            if (k > j && i >= k) sL[i * LDS + k] -= sL[i * LDS + j] * sL[k * LDS + j];
+        }
+    }
+    __syncthreads();
+    if (tid < NB) {                                                 // column tid of L^{-1} by forward substitution
+        const int c = tid;
+        for (int i = 0; i < c; ++i) sI[i * LDS + c] = 0.0;
+        for (int i = c; i < NB; ++i) {
+            double s = i == c ? 1.0 : 0.0;
+            for (int k = c; k < i; ++k) s -= sL[i * LDS + k] * sI[k * LDS + c];
+            sI[i * LDS + c] = s / sL[i * LDS + i];
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < NB * NB; e += 256) {
+        const int i = e / NB, k = e % NB;
+        a[(int64_t)i * ld + k] = k <= i ? sL[i * LDS + k] : 0.0;
+        li[(int64_t)i * ld + k] = sI[i * LDS + k];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// small vector / diagonal kernels
+// ---------------------------------------------------------------------------
+__global__ void add_diag_kernel(double* A, int64_t ld, int K, int Kp, const Scal* __restrict__ sc) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < Kp) A[(int64_t)i * ld + i] += i < K ? sc->lam : 1.0;
+}
+
+// out[i] = sum_k M[i][k] v[k]      one wave per row
+__global__ __launch_bounds__(256) void gemv_rows_kernel(const double* __restrict__ M, int64_t ld, const double* __restrict__ v,
+                                                        double* __restrict__ out, int n) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    double s = 0;
+    for (int k = lane; k < n; k += 64) s += M[(int64_t)i * ld + k] * v[k];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+    if (lane == 0) out[i] = s;
+}
+// out[i] = sum_k M[k][i] v[k]      thread per column, 4 k-phases per block
+__global__ __launch_bounds__(256) void gemv_cols_kernel(const double* __restrict__ M, int64_t ld, const double* __restrict__ v,
+                                                        double* __restrict__ out, int n) {
+    __shared__ double red[4][64];
+    const int lane = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;
+    double s = 0;
+    if (i < n)
+        for (int k = ph; k < n; k += 4) s += M[(int64_t)k * ld + i] * v[k];
+    red[ph][lane] = s;
+    __syncthreads();
+    if (ph == 0 && i < n) out[i] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+}
+
+// scalars: logdet = 2 sum_{i<K} log L_ii ; g.alpha
+__global__ __launch_bounds__(256) void factor_scalars_kernel(const double* __restrict__ L, int64_t ld, int K,
+                                                             const double* __restrict__ g, const double* __restrict__ alpha,
+                                                             double* __restrict__ scalars) {
+    __shared__ double r1[256], r2[256];
+    double s1 = 0, s2 = 0;
+    for (int i = threadIdx.x; i < K; i += 256) { s1 += log(L[(int64_t)i * ld + i]); s2 += g[i] * alpha[i]; }
+    r1[threadIdx.x] = s1; r2[threadIdx.x] = s2;
+    __syncthreads();
+    for (int m = 128; m >= 1; m >>= 1) {
+        if (threadIdx.x < m) { r1[threadIdx.x] += r1[threadIdx.x + m]; r2[threadIdx.x] += r2[threadIdx.x + m]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { scalars[R_LOGDET] = 2.0 * r1[0]; scalars[R_GTALPHA] = r2[0]; }
+}
+
+// Abar = B - BWB - (u a^T + a u^T)/2 + e^{-2a} a a^T  on the K x K block (padding: B - BWB = I)
+__global__ __launch_bounds__(256) void abar_kernel(const double* __restrict__ B, const double* __restrict__ BWB, double* __restrict__ Abar,
+                                                   const double* __restrict__ u, const double* __restrict__ al, int Kp,
+                                                   const Scal* __restrict__ sc) {
+    const double em2a = sc->em2a;
+    const int64_t total = (int64_t)Kp * Kp;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int i = (int)(e / Kp), j = (int)(e % Kp);
+        Abar[e] = B[e] - BWB[e] - 0.5 * (u[i] * al[j] + al[i] * u[j]) + em2a * al[i] * al[j];
+    }
+}
+__global__ __launch_bounds__(256) void adjoint_vec_kernel(const double* __restrict__ Abar, int64_t ld, int K, int Kp,
+                                                          const double* __restrict__ u, const double* __restrict__ al,
+                                                          double* __restrict__ ut, const Scal* __restrict__ sc,
+                                                          double* __restrict__ scalars) {
+    __shared__ double r1[256];
+    const double em2a = sc->em2a;
+    double s = 0;
+    for (int i = threadIdx.x; i < Kp; i += 256) {
+        ut[i] = u[i] - 2.0 * em2a * al[i];
+        if (i < K) s += Abar[(int64_t)i * ld + i];
+    }
+    r1[threadIdx.x] = s;
+    __syncthreads();
+    for (int m = 128; m >= 1; m >>= 1) {
+        if (threadIdx.x < m) r1[threadIdx.x] += r1[threadIdx.x + m];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) scalars[R_TRABAR] = r1[0];
+}
+
+// ---------------------------------------------------------------------------
+// host drivers
+// ---------------------------------------------------------------------------
+static void cholesky_inplace(const KStage& k, hipStream_t st) {
+    const int Kp = k.Kp, nb = Kp / 64;
+    const int64_t ld = Kp;
+    for (int p = 0; p < nb; ++p) {
+        hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, st, k.A, k.Li, ld, p, k.flag);
+        const int rem = Kp - (p + 1) * 64;
+        if (rem <= 0) break;
+        double* A21 = k.A + (int64_t)(p + 1) * 64 * ld + p * 64;
+        GemmArgs pa = {A21, k.Li + (int64_t)p * 64 * ld + p * 64, A21, ld, ld, ld, rem, 64, 64, 1.0, 0.0, 0, 0};
+        gemm64<true, true>(pa, st);                                   // L21 = A21 . Inv11^T
+        double* A22 = k.A + (int64_t)(p + 1) * 64 * ld + (p + 1) * 64;
+        GemmArgs tr = {A21, A21, A22, ld, ld, ld, rem, rem, 64, -1.0, 1.0, 1, 0};
+        gemm64<true, true>(tr, st);                                   // A22 -= L21 . L21^T (lower tiles)
+    }
+}
+
+static void trinv(const KStage& k, hipStream_t st) {
+    const int Kp = k.Kp;
+    for (int sz = 64; sz < Kp; sz *= 2) {
+        const int npairs = (Kp - sz - 1) / (2 * sz) + 1;
+        dim3 grid(sz / 64, sz / 64, npairs);
+        hipLaunchKernelGGL((trinv_level_kernel<0>), grid, dim3(KCfg::THREADS), KCfg::LDS_BYTES, st, k.A, k.Li, k.T1, (int64_t)Kp, Kp, sz);
+        hipLaunchKernelGGL((trinv_level_kernel<1>), grid, dim3(KCfg::THREADS), KCfg::LDS_BYTES, st, k.A, k.Li, k.T1, (int64_t)Kp, Kp, sz);
+    }
+}
+
+void kstage_gram_li(const KStage& k, hipStream_t st) {
+    const int64_t ld = k.Kp;
+    GemmArgs a = {k.Li, k.Li, k.B, ld, ld, ld, k.Kp, k.Kp, k.Kp, 1.0, 0.0, 0, 1};
+    gemm64<false, false>(a, st);                                      // B = Li^T Li
+}
+
+void kstage_factor(const KStage& k, const Scal* sc, hipStream_t st) {
+    const int Kp = k.Kp;
+    const int64_t ld = Kp;
+    hipMemsetAsync(k.Li, 0, sizeof(double) * ld * Kp, st);
+    hipLaunchKernelGGL(add_diag_kernel, dim3((Kp + 255) / 256), dim3(256), 0, st, k.A, ld, k.K, Kp, sc);
+    cholesky_inplace(k, st);
+    trinv(k, st);
+    kstage_gram_li(k, st);
+    hipLaunchKernelGGL(gemv_rows_kernel, dim3((Kp + 3) / 4), dim3(256), 0, st, k.Li, ld, k.g, k.beta, Kp);      // beta = Li g
+    hipLaunchKernelGGL(gemv_cols_kernel, dim3((Kp + 63) / 64), dim3(256), 0, st, k.Li, ld, k.beta, k.alpha, Kp); // alpha = Li^T beta
+    hipLaunchKernelGGL(factor_scalars_kernel, dim3(1), dim3(256), 0, st, k.A, ld, k.K, k.g, k.alpha, k.scalars);
+}
+
+void kstage_adjoint(const KStage& k, const double* W, double* Abar, const Scal* sc, hipStream_t st) {
+    const int Kp = k.Kp;
+    const int64_t ld = Kp;
+    hipLaunchKernelGGL(gemv_rows_kernel, dim3((Kp + 3) / 4), dim3(256), 0, st, k.B, ld, k.h, k.u, Kp);           // u = B h
+    GemmArgs g1 = {W, k.B, k.T1, ld, ld, ld, Kp, Kp, Kp, 1.0, 0.0, 0, 0};
+    gemm64<false, false>(g1, st);                                     // T1 = W B   (W symmetric)
+    GemmArgs g2 = {k.B, k.T1, k.T2, ld, ld, ld, Kp, Kp, Kp, 1.0, 0.0, 0, 0};
+    gemm64<false, false>(g2, st);                                     // T2 = B W B
+    hipLaunchKernelGGL(abar_kernel, dim3(1024), dim3(256), 0, st, k.B, k.T2, Abar, k.u, k.alpha, Kp, sc);
+    hipLaunchKernelGGL(adjoint_vec_kernel, dim3(1), dim3(256), 0, st, Abar, ld, k.K, Kp, k.u, k.alpha, k.ut, sc, k.scalars);
+}

@@ -1,0 +1,170 @@
+// O(P) kernels either side of the sweeps: unpacking the flat hyper-parameter vector
+// (SCFGP/SCFGP.py:74-90,98,103), the frequency penalty (:114-117,127) and the chain
+// rule from (X~^T Zbar) back to the flat gradient -- the tail of TT.grad (:129).
+#include "kernels.h"
+
+// params layout (SCFGP.py:72): [a b c | l_f (D*S) | r_f (M*S) | l_p (S) | p (M)]
+__global__ void scal_kernel(const double* __restrict__ params, int M, Scal* sc) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double a = params[0], b = params[1], c = params[2];
+    sc->a = a; sc->b = b; sc->c = c;
+    sc->s = exp(b) * sqrt(2.0 / M);
+    sc->e2a = exp(2.0 * a);
+    sc->lam = sc->e2a + 1e-6;
+    sc->kappa = log(1.0 + exp(c));
+    sc->em2a = exp(-2.0 * a);
+    sc->sigc = 1.0 / (1.0 + exp(-c));
+}
+
+// F[d][m] = sum_s l_F[d][s] r_F[m][s]                                (SCFGP.py:83)
+__global__ void f_kernel(const double* __restrict__ params, int D, int S, int M, double* __restrict__ F) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)D * M) return;
+    const int d = (int)(i / M), m = (int)(i % M);
+    const double* lF = params + 3 + (int64_t)d * S;
+    const double* rF = params + 3 + (int64_t)D * S + (int64_t)m * S;
+    double s = 0;
+    for (int k = 0; k < S; ++k) s += lF[k] * rF[k];
+    F[i] = s;
+}
+
+// Fall (Dp x Jp): rows d<D = [l_F | F]; row D = phase offsets [l_P - mean_d l_F | P - mean_d F]  (SCFGP.py:88-89)
+__global__ void fall_kernel(const double* __restrict__ params, const double* __restrict__ F, int D, int S, int M, int Dp, int Jp,
+                            double* __restrict__ Fall) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)Dp * Jp) return;
+    const int d = (int)(i / Jp), j = (int)(i % Jp);
+    const int J = S + M;
+    const double* lF = params + 3;
+    double v = 0;
+    if (j < J) {
+        if (d < D) {
+            v = j < S ? lF[(int64_t)d * S + j] : F[(int64_t)d * M + (j - S)];
+        } else if (d == D) {
+            double s = 0;
+            if (j < S) {
+                for (int k = 0; k < D; ++k) s += lF[(int64_t)k * S + j];
+                v = params[3 + (int64_t)D * S + (int64_t)M * S + j] - s / D;
+            } else {
+                for (int k = 0; k < D; ++k) s += F[(int64_t)k * M + (j - S)];
+                v = params[3 + (int64_t)D * S + (int64_t)M * S + S + (j - S)] - s / D;
+            }
+        }
+    }
+    Fall[i] = v;
+}
+
+void unpack_params(const Geom& g, const double* params, double* F, double* Fall, Scal* sc, hipStream_t st) {
+    hipLaunchKernelGGL(scal_kernel, dim3(1), dim3(64), 0, st, params, g.M, sc);
+    const int64_t nf = (int64_t)g.D * g.M, nfa = (int64_t)g.Dp * g.Jp;
+    hipLaunchKernelGGL(f_kernel, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, st, params, g.D, g.S, g.M, F);
+    hipLaunchKernelGGL(fall_kernel, dim3((unsigned)((nfa + 255) / 256)), dim3(256), 0, st, params, F, g.D, g.S, g.M, g.Dp, g.Jp, Fall);
+}
+
+// ---------------------------------------------------------------------------
+// penalty statistics: per-row mean / population std of F (over M) and l_F (over S)
+//   work = [mF(D) sF(D) ml(D) sl(D) | mu_w sig_w mu_l sig_l | Fbar (D*M)]
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pen_rows_kernel(const double* __restrict__ params, const double* __restrict__ F, int D, int S,
+                                                       int M, double* __restrict__ work) {
+    __shared__ double red[256];
+    const int d = blockIdx.x;
+    for (int which = 0; which < 2; ++which) {
+        const double* row = which == 0 ? F + (int64_t)d * M : params + 3 + (int64_t)d * S;
+        const int n = which == 0 ? M : S;
+        double s = 0;
+        for (int k = threadIdx.x; k < n; k += 256) s += row[k];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        for (int m = 128; m >= 1; m >>= 1) { if (threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m]; __syncthreads(); }
+        const double mean = red[0] / n;
+        __syncthreads();
+        s = 0;
+        for (int k = threadIdx.x; k < n; k += 256) { const double t = row[k] - mean; s += t * t; }
+        red[threadIdx.x] = s;
+        __syncthreads();
+        for (int m = 128; m >= 1; m >>= 1) { if (threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m]; __syncthreads(); }
+        if (threadIdx.x == 0) { work[(2 * which) * D + d] = mean; work[(2 * which + 1) * D + d] = sqrt(red[0] / n); }
+        __syncthreads();
+    }
+}
+__global__ void pen_sums_kernel(int D, int S, int M, double* __restrict__ work, double* __restrict__ scalars) {
+    if (threadIdx.x != 0) return;
+    double s[4] = {0, 0, 0, 0};
+    for (int q = 0; q < 4; ++q)
+        for (int d = 0; d < D; ++d) s[q] += work[q * D + d];
+    for (int q = 0; q < 4; ++q) work[4 * D + q] = s[q];
+    const double mu_w = s[0], sig_w = s[1], mu_l = s[2], sig_l = s[3];
+    // kl(mu,sig) = sig + mu^2 - log sig   (SCFGP.py:94), weights M and S (SCFGP.py:127)
+    scalars[R_PEN] = ((sig_w + mu_w * mu_w - log(sig_w)) * M + (sig_l + mu_l * mu_l - log(sig_l)) * S) / (S + M);
+}
+// Fbar[d][m] = dcost*N / dF[d][m]  (data term, centring correction, penalty)
+__global__ void fbar_kernel(const double* __restrict__ F, const double* __restrict__ XZ, int64_t ldxz, int D, int S, int M,
+                            double* __restrict__ work) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)D * M) return;
+    const int d = (int)(i / M), m = (int)(i % M);
+    const double mu_w = work[4 * D + 0], sig_w = work[4 * D + 1];
+    const double wgt = (double)M / (S + M);
+    const double pen = wgt * ((1.0 - 1.0 / sig_w) * (F[i] - work[d]) / (M * work[D + d]) + 2.0 * mu_w / M);
+    work[4 * D + 4 + i] = XZ[(int64_t)d * ldxz + S + m] - XZ[(int64_t)D * ldxz + S + m] / D + pen;
+}
+// grad[3..] = [lbar_F, rbar_F, lbar_P, Pbar] / N
+__global__ void grad_tail_kernel(const double* __restrict__ params, const double* __restrict__ XZ, int64_t ldxz, int D, int S, int M,
+                                 const double* __restrict__ work, double invN, double* __restrict__ grad) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nDS = (int64_t)D * S, nMS = (int64_t)M * S;
+    const double* lF = params + 3;
+    const double* rF = params + 3 + nDS;
+    const double* Fbar = work + 4 * D + 4;
+    if (i < nDS) {
+        const int d = (int)(i / S), s = (int)(i % S);
+        const double mu_l = work[4 * D + 2], sig_l = work[4 * D + 3];
+        const double wgt = (double)S / (S + M);
+        double v = XZ[(int64_t)d * ldxz + s] - XZ[(int64_t)D * ldxz + s] / D
+                 + wgt * ((1.0 - 1.0 / sig_l) * (lF[i] - work[2 * D + d]) / (S * work[3 * D + d]) + 2.0 * mu_l / S);
+        for (int m = 0; m < M; ++m) v += Fbar[(int64_t)d * M + m] * rF[(int64_t)m * S + s];
+        grad[3 + i] = v * invN;
+    } else if (i < nDS + nMS) {
+        const int64_t t = i - nDS;
+        const int m = (int)(t / S), s = (int)(t % S);
+        double v = 0;
+        for (int d = 0; d < D; ++d) v += Fbar[(int64_t)d * M + m] * lF[(int64_t)d * S + s];
+        grad[3 + i] = v * invN;
+    } else if (i < nDS + nMS + S + M) {
+        const int j = (int)(i - nDS - nMS);                           // column of X~^T Zbar's ones row
+        grad[3 + i] = XZ[(int64_t)D * ldxz + j] * invN;
+    }
+}
+
+void grad_epilogue(const Geom& g, const double* params, const double* F, const double* XZ, int64_t ldxz, double* work,
+                   double* scalars, int64_t Nglobal, double* grad, hipStream_t st) {
+    const int D = g.D, S = g.S, M = g.M;
+    hipLaunchKernelGGL(pen_rows_kernel, dim3(D), dim3(256), 0, st, params, F, D, S, M, work);
+    hipLaunchKernelGGL(pen_sums_kernel, dim3(1), dim3(64), 0, st, D, S, M, work, scalars);
+    if (!grad) return;
+    const int64_t nf = (int64_t)D * M, nt = (int64_t)g.P - 3;
+    hipLaunchKernelGGL(fbar_kernel, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, st, F, XZ, ldxz, D, S, M, work);
+    hipLaunchKernelGGL(grad_tail_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, params, XZ, ldxz, D, S, M, work,
+                       1.0 / (double)Nglobal, grad);
+}
+
+// cost and the three scalar gradient entries  (SCFGP.py:125-128)
+__global__ void finalize_kernel(const Scal* __restrict__ sc, double* __restrict__ scalars, const double* __restrict__ yy,
+                                const double* __restrict__ t2kb, const double* __restrict__ bbar, int M, double N,
+                                double* __restrict__ grad, int want_grad) {
+    if (threadIdx.x != 0) return;
+    const double T1 = scalars[R_LOGDET], T2 = t2kb[0];
+    const double T3 = sc->em2a * (yy[0] - scalars[R_GTALPHA]);
+    const double T4 = 2.0 * (N - M) * sc->a;
+    scalars[R_COST] = (T1 + T2 + T3 + T4 + scalars[R_PEN]) / N;
+    if (want_grad) {
+        grad[0] = (2.0 * sc->e2a * scalars[R_TRABAR] - 2.0 * T3 + 2.0 * (N - M)) / N;
+        grad[1] = bbar[0] / N;
+        grad[2] = t2kb[1] * sc->sigc / N;
+    }
+}
+void finalize_cost(const Geom& g, const Scal* sc, double* scalars, const double* yy, const double* t2kb, const double* bbar,
+                   int64_t Nglobal, double* grad, int want_grad, hipStream_t st) {
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, st, sc, scalars, yy, t2kb, bbar, g.M, (double)Nglobal, grad, want_grad);
+}

@@ -1,0 +1,506 @@
+// Row-sweep kernels of the SCFGP objective: everything whose cost scales with N.
+// Built on tile_engine.h; templated on the compute type T (double | float).
+#include "kernels.h"
+#include "tile_engine.h"
+
+#define SMEM_DECL extern __shared__ __attribute__((aligned(16))) char smem_raw[]
+
+// --------------------------------------------------------------------------
+// tile configurations (tuning knobs)
+// --------------------------------------------------------------------------
+template <typename T> struct GramCfg { typedef TileCfg<T, 128, 128, 16, 2, 2> type; };
+template <typename T> struct ApplyCfg { typedef TileCfg<T, 128, 128, 16, 2, 2> type; };
+typedef TileCfg<double, 128, 64, 16, 2, 2> FmapCfg;
+typedef TileCfg<double, 128, 128, 16, 2, 2> XtzCfg;
+
+// --------------------------------------------------------------------------
+// feature map:  Z = X~ . Fall  (fp64 MFMA, K-dim = Dp),  Phi = s [cos Z | sin Z]
+// --------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(FmapCfg::THREADS) void featuremap_kernel(
+    const double* __restrict__ Xt, const double* __restrict__ Fall, const Scal* __restrict__ sc,
+    T* __restrict__ Phi, int Dp, int Jp, int Kp, int J, int64_t N, int njt) {
+    typedef FmapCfg Cfg;
+    SMEM_DECL;
+    double* smem = reinterpret_cast<double*>(smem_raw);
+    const int jt = blockIdx.x % njt;
+    const int64_t rb = blockIdx.x / njt;
+    TrLoader<double, double, Cfg::BM, Cfg::BK, Cfg::LDA, Cfg::THREADS> la(Xt + rb * Cfg::BM * Dp, Dp, threadIdx.x);
+    NatLoader<double, double, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS, false, false> lb(Fall + jt * Cfg::BN, Jp, threadIdx.x);
+    v4d acc[Cfg::TM][Cfg::TN];
+    acc_zero<Cfg>(acc);
+    tile_mainloop<Cfg>(la, lb, Dp / Cfg::BK, acc, smem);
+    const double s = sc->s;
+    AccCoord<Cfg> co;
+#pragma unroll
+    for (int tm = 0; tm < Cfg::TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < Cfg::TN; ++tn) {
+            const int j = jt * Cfg::BN + co.col(tn);
+            if (j >= J) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t n = rb * Cfg::BM + co.row(tm, r);
+                double sn, cs;
+                sincos(acc[tm][tn][r], &sn, &cs);
+                const double m = n < N ? s : 0.0;
+                Phi[n * Kp + j] = (T)(m * cs);
+                Phi[n * Kp + J + j] = (T)(m * sn);
+            }
+        }
+}
+
+template <typename T>
+void SweepKernels<T>::featuremap(const Geom& g, const double* Xt, const double* Fall, const Scal* sc, T* Phi, hipStream_t st) {
+    const int njt = g.Jp / FmapCfg::BN;
+    const int64_t nrb = g.Np / FmapCfg::BM;
+    allow_big_lds(featuremap_kernel<T>, FmapCfg::LDS_BYTES);
+    hipLaunchKernelGGL(featuremap_kernel<T>, dim3((unsigned)(njt * nrb)), dim3(FmapCfg::THREADS), FmapCfg::LDS_BYTES, st,
+                       Xt, Fall, sc, Phi, g.Dp, g.Jp, g.Kp, g.J, g.N, njt);
+}
+
+// --------------------------------------------------------------------------
+// TN products (contraction over rows): lower tiles of Phi^T diag(w) Phi, and X~^T Zbar.
+//   grid.x = tile, grid.y = row split.  fp32 accumulators are flushed into the
+//   workgroup's private fp64 slab every `chunk` rows (error of one fp32 chain stays
+//   ~sqrt(chunk)*2^-24); fp64 runs one chunk.
+// --------------------------------------------------------------------------
+template <class Cfg, typename SA, typename SB, bool WEIGHT, bool GUARDA, bool TRI>
+__global__ __launch_bounds__(Cfg::THREADS) void tn_kernel(
+    const SA* __restrict__ A, int64_t lda, const SB* __restrict__ B, int64_t ldb, const double* __restrict__ w,
+    int64_t Np, int64_t rows_per_split, int64_t chunk, int ntn, int mlim, double* __restrict__ slabs) {
+    typedef typename Cfg::T T;
+    SMEM_DECL;
+    T* smem = reinterpret_cast<T*>(smem_raw);
+    int ti, tj;
+    if (TRI) {
+        const int t = blockIdx.x;
+        ti = (int)((sqrtf(8.0f * t + 1.0f) - 1.0f) * 0.5f);
+        while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+        while (ti * (ti + 1) / 2 > t) --ti;
+        tj = t - ti * (ti + 1) / 2;
+    } else {
+        ti = blockIdx.x / ntn; tj = blockIdx.x % ntn;
+    }
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_split;
+    const int64_t r1 = r0 + rows_per_split < Np ? r0 + rows_per_split : Np;
+    double* slab = slabs + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (Cfg::BM * Cfg::BN);
+    typename MT<T>::acc_t acc[Cfg::TM][Cfg::TN];
+    AccCoord<Cfg> co;
+    bool first = true;
+    for (int64_t c0 = r0; c0 < r1 || first; c0 += chunk) {
+        const int64_t c1 = c0 + chunk < r1 ? c0 + chunk : r1;
+        acc_zero<Cfg>(acc);
+        if (c0 < r1) {
+            NatLoader<SA, T, Cfg::BM, Cfg::BK, Cfg::LDA, Cfg::THREADS, WEIGHT, GUARDA> la(
+                A + c0 * lda + (int64_t)ti * Cfg::BM, lda, threadIdx.x, WEIGHT ? w + c0 : nullptr, mlim - ti * Cfg::BM);
+            NatLoader<SB, T, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS, false, false> lb(
+                B + c0 * ldb + (int64_t)tj * Cfg::BN, ldb, threadIdx.x);
+            tile_mainloop<Cfg>(la, lb, (int)((c1 - c0) / Cfg::BK), acc, smem);
+        }
+#pragma unroll
+        for (int tm = 0; tm < Cfg::TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double* d = slab + co.row(tm, r) * Cfg::BN;
+#pragma unroll
+                for (int tn = 0; tn < Cfg::TN; ++tn) {
+                    const double v = (double)acc[tm][tn][r];
+                    d[co.col(tn)] = first ? v : d[co.col(tn)] + v;
+                }
+            }
+        first = false;
+    }
+}
+
+template <typename T>
+void SweepKernels<T>::gram(const Geom& g, const T* Phi, const double* w, int nsplit, int64_t chunk, double* slabs, hipStream_t st) {
+    typedef typename GramCfg<T>::type Cfg;
+    const int nts = g.Kp / Cfg::BM, ntiles = nts * (nts + 1) / 2;
+    const int64_t rps = round_up((g.Np + nsplit - 1) / nsplit, 256);
+    if (chunk <= 0 || chunk > rps) chunk = rps;
+    chunk = round_up(chunk, Cfg::BK);
+    allow_big_lds(tn_kernel<Cfg, T, T, true, false, true>, Cfg::LDS_BYTES);
+    allow_big_lds(tn_kernel<Cfg, T, T, false, false, true>, Cfg::LDS_BYTES);
+    if (w)
+        hipLaunchKernelGGL((tn_kernel<Cfg, T, T, true, false, true>), dim3(ntiles, nsplit), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st,
+                           Phi, (int64_t)g.Kp, Phi, (int64_t)g.Kp, w, g.Np, rps, chunk, nts, g.Kp, slabs);
+    else
+        hipLaunchKernelGGL((tn_kernel<Cfg, T, T, false, false, true>), dim3(ntiles, nsplit), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st,
+                           Phi, (int64_t)g.Kp, Phi, (int64_t)g.Kp, w, g.Np, rps, chunk, nts, g.Kp, slabs);
+}
+
+template <typename T>
+void SweepKernels<T>::xtz(const Geom& g, const double* Xt, const T* Zbar, int nsplit, double* slabs, hipStream_t st) {
+    typedef XtzCfg Cfg;
+    const int ntm = (g.Dp + Cfg::BM - 1) / Cfg::BM, ntn = g.Jp / Cfg::BN;
+    const int64_t rps = round_up((g.Np + nsplit - 1) / nsplit, 256);
+    allow_big_lds(tn_kernel<Cfg, double, T, false, true, false>, Cfg::LDS_BYTES);
+    hipLaunchKernelGGL((tn_kernel<Cfg, double, T, false, true, false>), dim3(ntm * ntn, nsplit), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st,
+                       Xt, (int64_t)g.Dp, Zbar, (int64_t)g.Jp, (const double*)nullptr, g.Np, rps, rps, ntn, g.Dp, slabs);
+}
+
+// --------------------------------------------------------------------------
+// NT products (contraction over feature columns):  C = Phi . Bm  with Bm symmetric
+//   EPI 0: V = C,  vpart[jt][n] = sum_j Phi[n][j] C[n][j]
+//   EPI 1: Phibar = 2 C + 2 q_n V[n][j] + p_n alpha_j + y_n ut_j   (in place over V)
+// --------------------------------------------------------------------------
+template <class Cfg, int EPI>
+__global__ __launch_bounds__(Cfg::THREADS) void apply_kernel(
+    const typename Cfg::T* __restrict__ Phi, const typename Cfg::T* __restrict__ Bm, typename Cfg::T* V,
+    double* __restrict__ vpart, const double* __restrict__ p, const double* __restrict__ q, const double* __restrict__ y,
+    const double* __restrict__ alpha, const double* __restrict__ ut, int Kp, int64_t Np, int njt) {
+    typedef typename Cfg::T T;
+    SMEM_DECL;
+    T* smem = reinterpret_cast<T*>(smem_raw);
+    const int jt = blockIdx.x % njt;
+    const int64_t rb = blockIdx.x / njt;
+    TrLoader<T, T, Cfg::BM, Cfg::BK, Cfg::LDA, Cfg::THREADS> la(Phi + rb * Cfg::BM * Kp, Kp, threadIdx.x);
+    NatLoader<T, T, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS, false, false> lb(Bm + jt * Cfg::BN, Kp, threadIdx.x);
+    typename MT<T>::acc_t acc[Cfg::TM][Cfg::TN];
+    acc_zero<Cfg>(acc);
+    tile_mainloop<Cfg>(la, lb, Kp / Cfg::BK, acc, smem);
+    AccCoord<Cfg> co;
+    if (EPI == 0) {
+        double* red = reinterpret_cast<double*>(smem_raw);          // [WGN][BM]; main loop ended with a barrier
+        const int wn = (threadIdx.x >> 6) % Cfg::WGN;
+#pragma unroll
+        for (int tm = 0; tm < Cfg::TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = co.row(tm, r);
+                const int64_t off = (rb * Cfg::BM + row) * Kp + (int64_t)jt * Cfg::BN;
+                double part = 0;
+#pragma unroll
+                for (int tn = 0; tn < Cfg::TN; ++tn) {
+                    const T c = acc[tm][tn][r];
+                    V[off + co.col(tn)] = c;
+                    part += (double)Phi[off + co.col(tn)] * (double)c;
+                }
+                part += __shfl_xor(part, 1); part += __shfl_xor(part, 2);
+                part += __shfl_xor(part, 4); part += __shfl_xor(part, 8);
+                if ((co.lane & 15) == 0) red[wn * Cfg::BM + row] = part;
+            }
+        __syncthreads();
+        if (threadIdx.x < Cfg::BM) {
+            double s = 0;
+#pragma unroll
+            for (int k = 0; k < Cfg::WGN; ++k) s += red[k * Cfg::BM + threadIdx.x];
+            vpart[(int64_t)jt * Np + rb * Cfg::BM + threadIdx.x] = s;
+        }
+    } else {
+#pragma unroll
+        for (int tm = 0; tm < Cfg::TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t n = rb * Cfg::BM + co.row(tm, r);
+                const int64_t off = n * Kp + (int64_t)jt * Cfg::BN;
+                const double qn = 2.0 * q[n], pn = p[n], yn = y[n];
+#pragma unroll
+                for (int tn = 0; tn < Cfg::TN; ++tn) {
+                    const int j = jt * Cfg::BN + co.col(tn);
+                    const double v = 2.0 * (double)acc[tm][tn][r] + qn * (double)V[off + co.col(tn)] + pn * alpha[j] + yn * ut[j];
+                    V[off + co.col(tn)] = (T)v;
+                }
+            }
+    }
+}
+
+template <typename T>
+void SweepKernels<T>::apply_v(const Geom& g, const T* Phi, const T* Bm, T* V, double* vpart, hipStream_t st) {
+    typedef typename ApplyCfg<T>::type Cfg;
+    const int njt = g.Kp / Cfg::BN;
+    const int64_t nrb = g.Np / Cfg::BM;
+    allow_big_lds(apply_kernel<Cfg, 0>, Cfg::LDS_BYTES);
+    hipLaunchKernelGGL((apply_kernel<Cfg, 0>), dim3((unsigned)(njt * nrb)), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st,
+                       Phi, Bm, V, vpart, (const double*)nullptr, (const double*)nullptr, (const double*)nullptr,
+                       (const double*)nullptr, (const double*)nullptr, g.Kp, g.Np, njt);
+}
+
+template <typename T>
+void SweepKernels<T>::apply_phibar(const Geom& g, const T* Phi, const T* Abar, T* V, const double* p, const double* q,
+                                   const double* y, const double* alpha, const double* ut, hipStream_t st) {
+    typedef typename ApplyCfg<T>::type Cfg;
+    const int njt = g.Kp / Cfg::BN;
+    const int64_t nrb = g.Np / Cfg::BM;
+    allow_big_lds(apply_kernel<Cfg, 1>, Cfg::LDS_BYTES);
+    hipLaunchKernelGGL((apply_kernel<Cfg, 1>), dim3((unsigned)(njt * nrb)), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st,
+                       Phi, Abar, V, (double*)nullptr, p, q, y, alpha, ut, g.Kp, g.Np, njt);
+}
+
+// number of 128-wide column tiles of the apply kernel (vpart leading count)
+template <typename T> static int apply_njt(const Geom& g) { return g.Kp / ApplyCfg<T>::type::BN; }
+
+// --------------------------------------------------------------------------
+// column sums  out[c] = sum_n w[n] Phi[n][c]   (Phi^T y, Phi^T p)
+//   grid.x = 16-byte column groups of 64 lanes, grid.y = row split; 4 waves stride rows
+// --------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ Phi, const double* __restrict__ w, int Kp,
+                                                     int64_t Np, int64_t rows_per_split, double* __restrict__ partial) {
+    constexpr int VS = Vec16<T>::N;
+    typedef typename Vec16<T>::type vec_t;
+    __shared__ double red[4][64 * VS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c0 = (blockIdx.x * 64 + lane) * VS;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_split;
+    const int64_t r1 = r0 + rows_per_split < Np ? r0 + rows_per_split : Np;
+    double acc[VS];
+#pragma unroll
+    for (int e = 0; e < VS; ++e) acc[e] = 0;
+    if (c0 < Kp)
+        for (int64_t n = r0 + wave; n < r1; n += 4) {
+            const vec_t v = *reinterpret_cast<const vec_t*>(Phi + n * Kp + c0);
+            const double wn = w[n];
+#pragma unroll
+            for (int e = 0; e < VS; ++e) acc[e] += wn * (double)v[e];
+        }
+#pragma unroll
+    for (int e = 0; e < VS; ++e) red[wave][lane * VS + e] = acc[e];
+    __syncthreads();
+    if (wave == 0 && c0 < Kp)
+#pragma unroll
+        for (int e = 0; e < VS; ++e)
+            partial[(int64_t)blockIdx.y * Kp + c0 + e] =
+                red[0][lane * VS + e] + red[1][lane * VS + e] + red[2][lane * VS + e] + red[3][lane * VS + e];
+}
+
+template <typename T>
+void SweepKernels<T>::colsum(const Geom& g, const T* Phi, const double* w, int nsplit, double* partial, hipStream_t st) {
+    constexpr int VS = Vec16<T>::N;
+    const int ngx = (g.Kp + 64 * VS - 1) / (64 * VS);
+    const int64_t rps = (g.Np + nsplit - 1) / nsplit;
+    hipLaunchKernelGGL(colsum_kernel<T>, dim3(ngx, nsplit), dim3(256), 0, st, Phi, w, g.Kp, g.Np, rps, partial);
+}
+
+// --------------------------------------------------------------------------
+// per-row statistics: one wave per row (grid-stride).
+//   mu = phi.alpha, v = sum_jt vpart, d = kappa (v+1), r = mu - y
+//   MODE 0 (train): p = 2r/d, e = 1/d - (r^2+v)/d^2, q = 1/d + kappa e; partial sums of
+//                   T2 = (r^2+v)/d + log(2 pi d) and kbar = e (v+1)
+//   MODE 1 (predict): mu, sd = sqrt(kappa (1+v))
+// --------------------------------------------------------------------------
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void rowstats_kernel(const T* __restrict__ Phi, const double* __restrict__ alpha,
+                                                       const double* __restrict__ vpart, int njt, const double* __restrict__ y,
+                                                       const Scal* __restrict__ sc, double* __restrict__ o1, double* __restrict__ o2,
+                                                       double* __restrict__ partial, int Kp, int64_t N, int64_t Np) {
+    constexpr int VS = Vec16<T>::N;
+    typedef typename Vec16<T>::type vec_t;
+    __shared__ double red[4][2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double kappa = sc->kappa;
+    double t2 = 0, kb = 0;
+    const int64_t nw = (int64_t)gridDim.x * 4;
+    for (int64_t n = (int64_t)blockIdx.x * 4 + wave; n < Np; n += nw) {
+        double mu = 0;
+        for (int c = lane * VS; c < Kp; c += 64 * VS) {
+            const vec_t v = *reinterpret_cast<const vec_t*>(Phi + n * Kp + c);
+#pragma unroll
+            for (int e = 0; e < VS; ++e) mu += (double)v[e] * alpha[c + e];
+        }
+        double v = 0;
+        for (int t = lane; t < njt; t += 64) v += vpart[(int64_t)t * Np + n];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { mu += __shfl_xor(mu, m); v += __shfl_xor(v, m); }
+        if (lane == 0) {
+            const double d = kappa * (v + 1.0);
+            if (MODE == 0) {
+                double pn = 0, qn = 0;
+                if (n < N) {
+                    const double r = mu - y[n];
+                    const double rv = r * r + v;
+                    const double e = 1.0 / d - rv / (d * d);
+                    pn = 2.0 * r / d;
+                    qn = 1.0 / d + kappa * e;
+                    t2 += rv / d + log(2.0 * M_PI * d);
+                    kb += e * (v + 1.0);
+                }
+                o1[n] = pn; o2[n] = qn;
+            } else if (n < N) {
+                o1[n] = mu; o2[n] = sqrt(d);
+            }
+        }
+    }
+    if (MODE == 0) {
+        if (lane == 0) { red[wave][0] = t2; red[wave][1] = kb; }
+        __syncthreads();
+        if (threadIdx.x < 2)
+            partial[blockIdx.x * 2 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    }
+}
+
+template <typename T>
+void SweepKernels<T>::rowstats(const Geom& g, const T* Phi, const double* alpha, const double* vpart, const double* y,
+                               const Scal* sc, double* p, double* q, double* partial, int nblocks, hipStream_t st) {
+    hipLaunchKernelGGL((rowstats_kernel<T, 0>), dim3(nblocks), dim3(256), 0, st, Phi, alpha, vpart, apply_njt<T>(g), y, sc, p, q,
+                       partial, g.Kp, g.N, g.Np);
+}
+
+template <typename T>
+void SweepKernels<T>::rowpredict(const Geom& g, const T* Phi, const double* alpha, const double* vpart, const Scal* sc,
+                                 double* mu, double* sd, hipStream_t st) {
+    int nblocks = (int)((g.Np / 4) < 4096 ? (g.Np / 4) : 4096);
+    hipLaunchKernelGGL((rowstats_kernel<T, 1>), dim3(nblocks), dim3(256), 0, st, Phi, alpha, vpart, apply_njt<T>(g),
+                       (const double*)nullptr, sc, mu, sd, (double*)nullptr, g.Kp, g.N, g.Np);
+}
+
+// --------------------------------------------------------------------------
+// Zbar and bbar:  streaming over (n, j < J)
+// --------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void zbar_kernel(const T* __restrict__ Phi, const T* __restrict__ Pb, T* __restrict__ Zb,
+                                                   double* __restrict__ partial, int J, int Jp, int Kp, int64_t Np) {
+    __shared__ double red[4];
+    double bb = 0;
+    const int64_t total = Np * (int64_t)J;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t n = i / J;
+        const int j = (int)(i - n * J);
+        const double fc = (double)Phi[n * Kp + j], fs = (double)Phi[n * Kp + J + j];
+        const double bc = (double)Pb[n * Kp + j], bs = (double)Pb[n * Kp + J + j];
+        Zb[n * Jp + j] = (T)(fc * bs - fs * bc);
+        bb += fc * bc + fs * bs;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) bb += __shfl_xor(bb, m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = bb;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+template <typename T>
+void SweepKernels<T>::zbar(const Geom& g, const T* Phi, const T* Phibar, T* Zbar, double* partial, int nblocks, hipStream_t st) {
+    hipLaunchKernelGGL(zbar_kernel<T>, dim3(nblocks), dim3(256), 0, st, Phi, Phibar, Zbar, partial, g.J, g.Jp, g.Kp, g.Np);
+}
+
+// --------------------------------------------------------------------------
+template <typename T>
+__global__ void convert_kernel(const double* __restrict__ src, T* __restrict__ dst, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = (T)src[i];
+}
+template <typename T>
+void SweepKernels<T>::convert(const double* src, T* dst, int64_t n, hipStream_t st) {
+    const int nb = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(convert_kernel<T>, dim3(nb), dim3(256), 0, st, src, dst, n);
+}
+
+template struct SweepKernels<double>;
+template struct SweepKernels<float>;
+
+// --------------------------------------------------------------------------
+// reductions (deterministic: fixed order over splits)
+// --------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void reduce_tri_kernel(const double* __restrict__ slabs, int nsplit, int ntiles, double* __restrict__ out,
+                                                         int64_t ldo) {
+    constexpr int B = 128;
+    const int t = blockIdx.x;
+    int ti = (int)((sqrtf(8.0f * t + 1.0f) - 1.0f) * 0.5f);
+    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    while (ti * (ti + 1) / 2 > t) --ti;
+    const int tj = t - ti * (ti + 1) / 2;
+    for (int e = threadIdx.x; e < B * B; e += 256) {
+        double s = 0;
+        for (int sp = 0; sp < nsplit; ++sp) s += slabs[((int64_t)sp * ntiles + t) * (B * B) + e];
+        const int i = ti * B + e / B, j = tj * B + e % B;
+        out[(int64_t)i * ldo + j] = s;
+        if (ti != tj) out[(int64_t)j * ldo + i] = s;
+    }
+}
+void reduce_tri_tiles(const double* slabs, int nsplit, int nts, double* out, int64_t ldo, hipStream_t st) {
+    const int ntiles = nts * (nts + 1) / 2;
+    hipLaunchKernelGGL(reduce_tri_kernel, dim3(ntiles), dim3(256), 0, st, slabs, nsplit, ntiles, out, ldo);
+}
+
+__global__ __launch_bounds__(256) void reduce_full_kernel(const double* __restrict__ slabs, int nsplit, int ntiles, int ntn,
+                                                          double* __restrict__ out, int64_t ldo) {
+    constexpr int B = 128;
+    const int t = blockIdx.x, ti = t / ntn, tj = t % ntn;
+    for (int e = threadIdx.x; e < B * B; e += 256) {
+        double s = 0;
+        for (int sp = 0; sp < nsplit; ++sp) s += slabs[((int64_t)sp * ntiles + t) * (B * B) + e];
+        out[(int64_t)(ti * B + e / B) * ldo + tj * B + e % B] = s;
+    }
+}
+void reduce_full_tiles(const double* slabs, int nsplit, int ntm, int ntn, double* out, int64_t ldo, hipStream_t st) {
+    hipLaunchKernelGGL(reduce_full_kernel, dim3(ntm * ntn), dim3(256), 0, st, slabs, nsplit, ntm * ntn, ntn, out, ldo);
+}
+
+__global__ void reduce_rows_kernel(const double* __restrict__ partial, int nsplit, int64_t n, double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = 0;
+    for (int sp = 0; sp < nsplit; ++sp) s += partial[(int64_t)sp * n + i];
+    out[i] = s;
+}
+void reduce_rows(const double* partial, int nsplit, int64_t n, double* out, hipStream_t st) {
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, partial, nsplit, n, out);
+}
+
+// single workgroup: fixed-order tree over block partials
+__global__ __launch_bounds__(256) void reduce_scalars_kernel(const double* __restrict__ partial, int nblocks, int width,
+                                                             double* __restrict__ scalars, int slot0) {
+    __shared__ double red[256];
+    for (int k = 0; k < width; ++k) {
+        double s = 0;
+        for (int b = threadIdx.x; b < nblocks; b += 256) s += partial[(int64_t)b * width + k];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        for (int m = 128; m >= 1; m >>= 1) {
+            if (threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) scalars[slot0 + k] = red[0];
+        __syncthreads();
+    }
+}
+void reduce_scalars(const double* partial, int nblocks, int width, double* scalars, int slot0, hipStream_t st) {
+    hipLaunchKernelGGL(reduce_scalars_kernel, dim3(1), dim3(256), 0, st, partial, nblocks, width, scalars, slot0);
+}
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const double* __restrict__ y, int64_t n, double* __restrict__ partial) {
+    __shared__ double red[256];
+    double s = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += y[i] * y[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int m = 128; m >= 1; m >>= 1) {
+        if (threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+void sum_squares(const double* y, int64_t n, double* scalars, int slot, double* scratch, hipStream_t st) {
+    const int nb = 256;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(256), 0, st, y, n, scratch);
+    reduce_scalars(scratch, nb, 1, scalars, slot, st);
+}
+
+// --------------------------------------------------------------------------
+// data staging
+// --------------------------------------------------------------------------
+__global__ void pack_data_kernel(const double* __restrict__ Xraw, const double* __restrict__ yraw, double* __restrict__ Xt,
+                                 double* __restrict__ y, int D, int Dp, int64_t N, int64_t Np) {
+    const int64_t total = Np * Dp;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t n = i / Dp;
+        const int d = (int)(i - n * Dp);
+        double v = 0;
+        if (n < N) v = d < D ? Xraw[n * D + d] : (d == D ? 1.0 : 0.0);
+        Xt[i] = v;
+        if (d == 0 && y) y[n] = (n < N && yraw) ? yraw[n] : 0.0;
+    }
+}
+void pack_data(const Geom& g, const double* Xraw, const double* yraw, double* Xt, double* y, hipStream_t st) {
+    hipLaunchKernelGGL(pack_data_kernel, dim3(4096), dim3(256), 0, st, Xraw, yraw, Xt, y, g.D, g.Dp, g.N, g.Np);
+}
+__global__ void pad_square_kernel(const double* __restrict__ src, int K, int Kp, double* __restrict__ dst) {
+    const int64_t total = (int64_t)Kp * Kp;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int i = (int)(e / Kp), j = (int)(e % Kp);
+        dst[e] = (i < K && j < K) ? src[(int64_t)i * K + j] : (i == j ? 1.0 : 0.0);
+    }
+}
+void pad_square(const double* src, int K, int Kp, double* dst, hipStream_t st) {
+    hipLaunchKernelGGL(pad_square_kernel, dim3(1024), dim3(256), 0, st, src, K, Kp, dst);
+}

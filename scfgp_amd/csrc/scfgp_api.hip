@@ -1,0 +1,539 @@
+// C ABI of libscfgp_hip.so (declared in include/scfgp_hip.h): context, device memory,
+// the staged evaluation  pass1 | factor | pass2 | adjoint | pass3 | finish  and predict.
+#include "../../include/scfgp_hip.h"
+#include "kernels.h"
+
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#define HIPCHK(ctx, call)                                                                           \
+    do {                                                                                            \
+        hipError_t e_ = (call);                                                                     \
+        if (e_ != hipSuccess) {                                                                     \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                         \
+            return SCFGP_EHIP;                                                                      \
+        }                                                                                           \
+    } while (0)
+
+static constexpr int TILE = 128;            // column tile of the Gram / apply kernels (kernels_sweep.hip)
+static constexpr int64_t PRED_ROWS = 32768; // predict processes test rows in chunks of this size
+
+struct ProfRec { std::string name; hipEvent_t e0, e1; };
+
+struct scfgp_ctx {
+    Geom g{};
+    int dtype = 0, device = 0;
+    hipStream_t st = nullptr; bool own_stream = false;
+    int64_t Ncap = 0, Nglobal = 0;
+    bool have_params = false, have_data = false;
+    int stage = 0, last_want_grad = 0;
+    std::vector<double> h_params;
+    // parameters
+    double *d_params = nullptr, *d_F = nullptr, *d_Fall = nullptr; Scal* d_sc = nullptr;
+    // rows
+    double *d_Xt = nullptr, *d_y = nullptr, *d_p = nullptr, *d_q = nullptr, *d_vpart = nullptr;
+    void *d_Phi = nullptr, *d_V = nullptr, *d_Zbar = nullptr;
+    // exchange buffers and K-stage
+    double *d_x1 = nullptr, *d_x2 = nullptr, *d_x3 = nullptr; int64_t n_x1 = 0, n_x2 = 0, n_x3 = 0; int Dpp = 0;
+    double *d_Li = nullptr, *d_B = nullptr, *d_T1 = nullptr, *d_T2 = nullptr, *d_Abar = nullptr;
+    void *d_BT = nullptr, *d_AbarT = nullptr;
+    double *d_vecs = nullptr;            // beta, alpha, u, ut, alpha_pred (Kp each)
+    double *d_scalars = nullptr, *d_yy = nullptr; int* d_flag = nullptr;
+    double *d_slabs = nullptr; size_t slabs_bytes = 0;
+    double *d_partial = nullptr; int64_t n_partial = 0;
+    double *d_work = nullptr, *d_grad = nullptr;
+    // predict chunk buffers
+    double *p_Xt = nullptr, *p_vpart = nullptr, *p_mu = nullptr, *p_sd = nullptr; void *p_Phi = nullptr, *p_V = nullptr;
+    // options
+    int gram_nsplit = 0, xtz_nsplit = 0, cs_nsplit = 128; int64_t gram_chunk = 4096;
+    // profiling
+    bool prof = false; std::vector<ProfRec> recs; std::vector<hipEvent_t> pool; size_t pool_used = 0;
+    std::string err;
+
+    double* beta() { return d_vecs; }
+    double* alpha() { return d_vecs + g.Kp; }
+    double* u() { return d_vecs + 2 * g.Kp; }
+    double* ut() { return d_vecs + 3 * g.Kp; }
+    double* alpha_pred() { return d_vecs + 4 * g.Kp; }
+    size_t tsize() const { return dtype == SCFGP_F32 ? 4 : 8; }
+    KStage kstage() {
+        KStage k; k.K = g.K; k.Kp = g.Kp; k.A = d_x1; k.Li = d_Li; k.B = d_B; k.T1 = d_T1; k.T2 = d_T2;
+        k.g = d_x1 + (int64_t)g.Kp * g.Kp; k.beta = beta(); k.alpha = alpha(); k.h = d_x2 + (int64_t)g.Kp * g.Kp;
+        k.u = u(); k.ut = ut(); k.scalars = d_scalars; k.flag = d_flag;
+        return k;
+    }
+};
+
+struct ProfScope {
+    scfgp_ctx* c; size_t idx = (size_t)-1;
+    ProfScope(scfgp_ctx* c_, const char* name) : c(c_) {
+        if (!c->prof) return;
+        auto get = [&]() {
+            if (c->pool_used == c->pool.size()) { hipEvent_t e; hipEventCreate(&e); c->pool.push_back(e); }
+            return c->pool[c->pool_used++];
+        };
+        ProfRec r; r.name = name; r.e0 = get(); r.e1 = get();
+        hipEventRecord(r.e0, c->st);
+        c->recs.push_back(r); idx = c->recs.size() - 1;
+    }
+    ~ProfScope() { if (idx != (size_t)-1) hipEventRecord(c->recs[idx].e1, c->st); }
+};
+
+template <typename P> static int dmalloc(scfgp_ctx* c, P** p, size_t bytes) {
+    HIPCHK(c, hipMalloc((void**)p, bytes ? bytes : 16));
+    return SCFGP_OK;
+}
+template <typename P> static void dfree(P*& p) { if (p) { hipFree((void*)p); p = nullptr; } }
+
+static int default_split(int ntiles, int64_t Np) {
+    int64_t s = (1024 + ntiles - 1) / ntiles;
+    const int64_t smax = Np / 256;
+    if (s > smax) s = smax;
+    if (s < 1) s = 1;
+    return (int)s;
+}
+
+static void free_rows(scfgp_ctx* c) {
+    dfree(c->d_Xt); dfree(c->d_y); dfree(c->d_p); dfree(c->d_q); dfree(c->d_vpart);
+    dfree(c->d_Phi); dfree(c->d_V); dfree(c->d_Zbar); dfree(c->d_slabs);
+    c->Ncap = 0; c->slabs_bytes = 0;
+}
+
+// (re)allocate every buffer whose size depends on the number of local rows
+static int ensure_rows(scfgp_ctx* c, int64_t N) {
+    Geom& g = c->g;
+    const int64_t Np = round_up(N > 0 ? N : 1, 256);
+    g.N = N; g.Np = Np;
+    const int nts = g.Kp / TILE, ntiles = nts * (nts + 1) / 2;
+    const int ntx = ((g.Dp + TILE - 1) / TILE) * (g.Jp / TILE);
+    const int gs = c->gram_nsplit > 0 ? (int)std::min<int64_t>(c->gram_nsplit, Np / 256) : default_split(ntiles, Np);
+    const int xs = c->xtz_nsplit > 0 ? (int)std::min<int64_t>(c->xtz_nsplit, Np / 256) : default_split(ntx, Np);
+    const size_t need = sizeof(double) * TILE * TILE * std::max<size_t>((size_t)gs * ntiles, (size_t)xs * ntx);
+    if (need > c->slabs_bytes) {
+        dfree(c->d_slabs);
+        if (int rc = dmalloc(c, &c->d_slabs, need)) return rc;
+        c->slabs_bytes = need;
+    }
+    if (Np <= c->Ncap) return SCFGP_OK;
+    dfree(c->d_Xt); dfree(c->d_y); dfree(c->d_p); dfree(c->d_q); dfree(c->d_vpart);
+    dfree(c->d_Phi); dfree(c->d_V); dfree(c->d_Zbar);
+    c->Ncap = 0;
+    const size_t ts = c->tsize();
+    int rc;
+    if ((rc = dmalloc(c, &c->d_Xt, sizeof(double) * Np * g.Dp))) return rc;
+    if ((rc = dmalloc(c, &c->d_y, sizeof(double) * Np))) return rc;
+    if ((rc = dmalloc(c, &c->d_p, sizeof(double) * Np))) return rc;
+    if ((rc = dmalloc(c, &c->d_q, sizeof(double) * Np))) return rc;
+    if ((rc = dmalloc(c, &c->d_vpart, sizeof(double) * Np * (g.Kp / TILE)))) return rc;
+    if ((rc = dmalloc(c, &c->d_Phi, ts * Np * g.Kp))) return rc;
+    if ((rc = dmalloc(c, &c->d_V, ts * Np * g.Kp))) return rc;
+    if ((rc = dmalloc(c, &c->d_Zbar, ts * Np * g.Jp))) return rc;
+    HIPCHK(c, hipMemsetAsync(c->d_Phi, 0, ts * Np * g.Kp, c->st));       // padding columns stay zero forever
+    HIPCHK(c, hipMemsetAsync(c->d_Zbar, 0, ts * Np * g.Jp, c->st));
+    c->Ncap = Np;
+    return SCFGP_OK;
+}
+
+extern "C" int scfgp_create(scfgp_ctx** out, int D, int S, int M, int dtype, int device, void* stream) {
+    if (!out || D < 1 || S < 1 || M < 1 || (dtype != SCFGP_F64 && dtype != SCFGP_F32)) return SCFGP_EARG;
+    scfgp_ctx* c = new scfgp_ctx();
+    *out = c;
+    c->dtype = dtype; c->device = device;
+    Geom& g = c->g;
+    g.D = D; g.S = S; g.M = M; g.J = S + M; g.K = 2 * g.J; g.P = 3 + D * S + M * S + S + M;
+    g.Dp = (int)round_up(D + 1, 16); g.Jp = (int)round_up(g.J, TILE); g.Kp = (int)round_up(g.K, TILE);
+    c->Dpp = (int)round_up(g.Dp, TILE);
+    HIPCHK(c, hipSetDevice(device));
+    if (stream) c->st = (hipStream_t)stream;
+    else { HIPCHK(c, hipStreamCreate(&c->st)); c->own_stream = true; }
+    const int64_t Kp = g.Kp, K2 = Kp * Kp;
+    c->n_x1 = K2 + Kp + 8; c->n_x2 = K2 + Kp + 8; c->n_x3 = (int64_t)c->Dpp * g.Jp + 8;
+    int rc;
+    if ((rc = dmalloc(c, &c->d_params, sizeof(double) * g.P))) return rc;
+    if ((rc = dmalloc(c, &c->d_F, sizeof(double) * D * M))) return rc;
+    if ((rc = dmalloc(c, &c->d_Fall, sizeof(double) * g.Dp * g.Jp))) return rc;
+    if ((rc = dmalloc(c, &c->d_sc, sizeof(Scal)))) return rc;
+    if ((rc = dmalloc(c, &c->d_x1, sizeof(double) * c->n_x1))) return rc;
+    if ((rc = dmalloc(c, &c->d_x2, sizeof(double) * c->n_x2))) return rc;
+    if ((rc = dmalloc(c, &c->d_x3, sizeof(double) * c->n_x3))) return rc;
+    if ((rc = dmalloc(c, &c->d_Li, sizeof(double) * K2))) return rc;
+    if ((rc = dmalloc(c, &c->d_B, sizeof(double) * K2))) return rc;
+    if ((rc = dmalloc(c, &c->d_T1, sizeof(double) * K2))) return rc;
+    if ((rc = dmalloc(c, &c->d_T2, sizeof(double) * K2))) return rc;
+    if ((rc = dmalloc(c, &c->d_Abar, sizeof(double) * K2))) return rc;
+    if (dtype == SCFGP_F32) {
+        if ((rc = dmalloc(c, &c->d_BT, sizeof(float) * K2))) return rc;
+        if ((rc = dmalloc(c, &c->d_AbarT, sizeof(float) * K2))) return rc;
+    }
+    if ((rc = dmalloc(c, &c->d_vecs, sizeof(double) * 5 * Kp))) return rc;
+    if ((rc = dmalloc(c, &c->d_scalars, sizeof(double) * 32))) return rc;
+    if ((rc = dmalloc(c, &c->d_yy, sizeof(double) * 8))) return rc;
+    if ((rc = dmalloc(c, &c->d_flag, sizeof(int) * 4))) return rc;
+    c->n_partial = std::max<int64_t>((int64_t)c->cs_nsplit * Kp, 16384);
+    if ((rc = dmalloc(c, &c->d_partial, sizeof(double) * c->n_partial))) return rc;
+    if ((rc = dmalloc(c, &c->d_work, sizeof(double) * (4 * D + 4 + (int64_t)D * M)))) return rc;
+    if ((rc = dmalloc(c, &c->d_grad, sizeof(double) * g.P))) return rc;
+    HIPCHK(c, hipMemsetAsync(c->d_x1, 0, sizeof(double) * c->n_x1, c->st));
+    HIPCHK(c, hipMemsetAsync(c->d_x2, 0, sizeof(double) * c->n_x2, c->st));
+    HIPCHK(c, hipMemsetAsync(c->d_x3, 0, sizeof(double) * c->n_x3, c->st));
+    HIPCHK(c, hipMemsetAsync(c->d_vecs, 0, sizeof(double) * 5 * Kp, c->st));
+    HIPCHK(c, hipMemsetAsync(c->d_scalars, 0, sizeof(double) * 32, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    return SCFGP_OK;
+}
+
+extern "C" void scfgp_destroy(scfgp_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->st) hipStreamSynchronize(c->st);
+    free_rows(c);
+    dfree(c->d_params); dfree(c->d_F); dfree(c->d_Fall); dfree(c->d_sc);
+    dfree(c->d_x1); dfree(c->d_x2); dfree(c->d_x3); dfree(c->d_Li); dfree(c->d_B); dfree(c->d_T1); dfree(c->d_T2);
+    dfree(c->d_Abar); dfree(c->d_BT); dfree(c->d_AbarT); dfree(c->d_vecs); dfree(c->d_scalars); dfree(c->d_yy);
+    dfree(c->d_flag); dfree(c->d_partial); dfree(c->d_work); dfree(c->d_grad);
+    dfree(c->p_Xt); dfree(c->p_vpart); dfree(c->p_mu); dfree(c->p_sd); dfree(c->p_Phi); dfree(c->p_V);
+    for (hipEvent_t e : c->pool) hipEventDestroy(e);
+    if (c->own_stream && c->st) hipStreamDestroy(c->st);
+    delete c;
+}
+
+extern "C" const char* scfgp_last_error(const scfgp_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+extern "C" int scfgp_set_params(scfgp_ctx* c, const double* params, int P) {
+    if (!c || !params || P != c->g.P) { if (c) c->err = "set_params: wrong parameter count"; return SCFGP_EARG; }
+    HIPCHK(c, hipSetDevice(c->device));
+    c->h_params.assign(params, params + P);
+    HIPCHK(c, hipMemcpyAsync(c->d_params, c->h_params.data(), sizeof(double) * P, hipMemcpyHostToDevice, c->st));
+    unpack_params(c->g, c->d_params, c->d_F, c->d_Fall, c->d_sc, c->st);
+    HIPCHK(c, hipGetLastError());
+    c->have_params = true;
+    return SCFGP_OK;
+}
+
+extern "C" int scfgp_get_params(scfgp_ctx* c, double* params, int P) {
+    if (!c || !params || P != c->g.P || !c->have_params) return SCFGP_EARG;
+    memcpy(params, c->h_params.data(), sizeof(double) * P);
+    return SCFGP_OK;
+}
+
+extern "C" int scfgp_set_data(scfgp_ctx* c, const double* X, const double* y, int64_t N, int64_t n_global) {
+    if (!c || !X || !y || N < 1) { if (c) c->err = "set_data: bad arguments"; return SCFGP_EARG; }
+    HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = ensure_rows(c, N)) return rc;
+    c->Nglobal = n_global > 0 ? n_global : N;
+    double *raw = nullptr, *yraw = nullptr;
+    if (int rc = dmalloc(c, &raw, sizeof(double) * N * c->g.D)) return rc;
+    if (int rc = dmalloc(c, &yraw, sizeof(double) * N)) { dfree(raw); return rc; }
+    HIPCHK(c, hipMemcpyAsync(raw, X, sizeof(double) * N * c->g.D, hipMemcpyHostToDevice, c->st));
+    HIPCHK(c, hipMemcpyAsync(yraw, y, sizeof(double) * N, hipMemcpyHostToDevice, c->st));
+    pack_data(c->g, raw, yraw, c->d_Xt, c->d_y, c->st);
+    sum_squares(c->d_y, c->g.Np, c->d_yy, 0, c->d_partial, c->st);
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    dfree(raw); dfree(yraw);
+    HIPCHK(c, hipGetLastError());
+    c->have_data = true; c->stage = 0;
+    return SCFGP_OK;
+}
+
+// ----------------------------------------------------------------------------------------------
+// staged evaluation
+// ----------------------------------------------------------------------------------------------
+template <typename T> struct Impl {
+    typedef SweepKernels<T> SK;
+    static const T* BT(scfgp_ctx* c) { return c->dtype == SCFGP_F32 ? (const T*)c->d_BT : (const T*)c->d_B; }
+    static const T* AbarT(scfgp_ctx* c) { return c->dtype == SCFGP_F32 ? (const T*)c->d_AbarT : (const T*)c->d_Abar; }
+
+    static void gram_to(scfgp_ctx* c, const double* w, double* out, const char* name) {
+        const Geom& g = c->g;
+        const int nts = g.Kp / TILE, ntiles = nts * (nts + 1) / 2;
+        const int gs = c->gram_nsplit > 0 ? (int)std::min<int64_t>(c->gram_nsplit, g.Np / 256) : default_split(ntiles, g.Np);
+        { ProfScope ps(c, name);
+          SK::gram(g, (const T*)c->d_Phi, w, gs, c->dtype == SCFGP_F32 ? c->gram_chunk : 0, c->d_slabs, c->st); }
+        { ProfScope ps(c, "reduce_tiles"); reduce_tri_tiles(c->d_slabs, gs, nts, out, g.Kp, c->st); }
+    }
+    static void colsum_to(scfgp_ctx* c, const double* w, double* out) {
+        const Geom& g = c->g;
+        const int ns = (int)std::min<int64_t>(c->cs_nsplit, g.Np / 4);
+        ProfScope ps(c, "colsum");
+        SK::colsum(g, (const T*)c->d_Phi, w, ns, c->d_partial, c->st);
+        reduce_rows(c->d_partial, ns, g.Kp, out, c->st);
+    }
+
+    static int pass1(scfgp_ctx* c) {
+        const Geom& g = c->g;
+        const int64_t K2 = (int64_t)g.Kp * g.Kp;
+        { ProfScope ps(c, "featuremap"); SK::featuremap(g, c->d_Xt, c->d_Fall, c->d_sc, (T*)c->d_Phi, c->st); }
+        gram_to(c, nullptr, c->d_x1, "gram");
+        colsum_to(c, c->d_y, c->d_x1 + K2);
+        HIPCHK(c, hipMemcpyAsync(c->d_x1 + K2 + g.Kp, c->d_yy, sizeof(double), hipMemcpyDeviceToDevice, c->st));
+        HIPCHK(c, hipGetLastError());
+        return SCFGP_OK;
+    }
+    static int factor(scfgp_ctx* c) {
+        const Geom& g = c->g;
+        HIPCHK(c, hipMemsetAsync(c->d_flag, 0, sizeof(int) * 4, c->st));
+        { ProfScope ps(c, "kstage_factor"); kstage_factor(c->kstage(), c->d_sc, c->st); }
+        if (c->dtype == SCFGP_F32) SK::convert(c->d_B, (T*)c->d_BT, (int64_t)g.Kp * g.Kp, c->st);
+        HIPCHK(c, hipGetLastError());
+        return SCFGP_OK;
+    }
+    static int pass2(scfgp_ctx* c, int want_grad) {
+        const Geom& g = c->g;
+        const int64_t K2 = (int64_t)g.Kp * g.Kp;
+        { ProfScope ps(c, "apply_v"); SK::apply_v(g, (const T*)c->d_Phi, BT(c), (T*)c->d_V, c->d_vpart, c->st); }
+        const int nb = (int)std::min<int64_t>(g.Np / 4, 2048);
+        { ProfScope ps(c, "rowstats");
+          SK::rowstats(g, (const T*)c->d_Phi, c->alpha(), c->d_vpart, c->d_y, c->d_sc, c->d_p, c->d_q, c->d_partial, nb, c->st);
+          reduce_scalars(c->d_partial, nb, 2, c->d_x2 + K2 + g.Kp, 0, c->st); }
+        if (want_grad) {
+            gram_to(c, c->d_q, c->d_x2, "gram_w");
+            colsum_to(c, c->d_p, c->d_x2 + K2);
+        }
+        HIPCHK(c, hipGetLastError());
+        return SCFGP_OK;
+    }
+    static int adjoint(scfgp_ctx* c) {
+        const Geom& g = c->g;
+        { ProfScope ps(c, "kstage_adjoint"); kstage_adjoint(c->kstage(), c->d_x2, c->d_Abar, c->d_sc, c->st); }
+        if (c->dtype == SCFGP_F32) SK::convert(c->d_Abar, (T*)c->d_AbarT, (int64_t)g.Kp * g.Kp, c->st);
+        HIPCHK(c, hipGetLastError());
+        return SCFGP_OK;
+    }
+    static int pass3(scfgp_ctx* c) {
+        const Geom& g = c->g;
+        { ProfScope ps(c, "apply_phibar");
+          SK::apply_phibar(g, (const T*)c->d_Phi, AbarT(c), (T*)c->d_V, c->d_p, c->d_q, c->d_y, c->alpha(), c->ut(), c->st); }
+        const int nb = 4096;
+        { ProfScope ps(c, "zbar");
+          SK::zbar(g, (const T*)c->d_Phi, (const T*)c->d_V, (T*)c->d_Zbar, c->d_partial, nb, c->st);
+          reduce_scalars(c->d_partial, nb, 1, c->d_x3 + (int64_t)c->Dpp * g.Jp, 0, c->st); }
+        const int ntm = c->Dpp / TILE, ntn = g.Jp / TILE;
+        const int xs = c->xtz_nsplit > 0 ? (int)std::min<int64_t>(c->xtz_nsplit, g.Np / 256) : default_split(ntm * ntn, g.Np);
+        { ProfScope ps(c, "xtz");
+          SK::xtz(g, c->d_Xt, (const T*)c->d_Zbar, xs, c->d_slabs, c->st);
+          reduce_full_tiles(c->d_slabs, xs, ntm, ntn, c->d_x3, g.Jp, c->st); }
+        HIPCHK(c, hipGetLastError());
+        return SCFGP_OK;
+    }
+    static int predict_chunk(scfgp_ctx* c, const Geom& g, const T* Bt) {
+        SK::featuremap(g, c->p_Xt, c->d_Fall, c->d_sc, (T*)c->p_Phi, c->st);
+        SK::apply_v(g, (const T*)c->p_Phi, Bt, (T*)c->p_V, c->p_vpart, c->st);
+        SK::rowpredict(g, (const T*)c->p_Phi, c->alpha_pred(), c->p_vpart, c->d_sc, c->p_mu, c->p_sd, c->st);
+        HIPCHK(c, hipGetLastError());
+        return SCFGP_OK;
+    }
+};
+
+#define DISPATCH(c, fn, ...) ((c)->dtype == SCFGP_F32 ? Impl<float>::fn(__VA_ARGS__) : Impl<double>::fn(__VA_ARGS__))
+
+static int ready(scfgp_ctx* c) {
+    if (!c) return SCFGP_EARG;
+    if (!c->have_params || !c->have_data) { c->err = "parameters and data must be set first"; return SCFGP_EARG; }
+    if (hipSetDevice(c->device) != hipSuccess) { c->err = "hipSetDevice failed"; return SCFGP_EHIP; }
+    return SCFGP_OK;
+}
+
+extern "C" int scfgp_pass1(scfgp_ctx* c) {
+    if (int rc = ready(c)) return rc;
+    if (c->prof) { c->recs.clear(); c->pool_used = 0; }
+    if (int rc = DISPATCH(c, pass1, c)) return rc;
+    c->stage = 1; return SCFGP_OK;
+}
+extern "C" int scfgp_factor(scfgp_ctx* c) {
+    if (int rc = ready(c)) return rc;
+    if (c->stage != 1) { c->err = "factor: call pass1 first"; return SCFGP_EARG; }
+    if (int rc = DISPATCH(c, factor, c)) return rc;
+    c->stage = 2; return SCFGP_OK;
+}
+extern "C" int scfgp_pass2(scfgp_ctx* c, int want_grad) {
+    if (int rc = ready(c)) return rc;
+    if (c->stage != 2) { c->err = "pass2: call factor first"; return SCFGP_EARG; }
+    if (int rc = DISPATCH(c, pass2, c, want_grad)) return rc;
+    c->last_want_grad = want_grad; c->stage = 3; return SCFGP_OK;
+}
+extern "C" int scfgp_adjoint(scfgp_ctx* c) {
+    if (int rc = ready(c)) return rc;
+    if (c->stage != 3 || !c->last_want_grad) { c->err = "adjoint: call pass2(want_grad=1) first"; return SCFGP_EARG; }
+    if (int rc = DISPATCH(c, adjoint, c)) return rc;
+    c->stage = 4; return SCFGP_OK;
+}
+extern "C" int scfgp_pass3(scfgp_ctx* c) {
+    if (int rc = ready(c)) return rc;
+    if (c->stage != 4) { c->err = "pass3: call adjoint first"; return SCFGP_EARG; }
+    if (int rc = DISPATCH(c, pass3, c)) return rc;
+    c->stage = 5; return SCFGP_OK;
+}
+
+extern "C" int scfgp_exchange(scfgp_ctx* c, int stage, void** dev_ptr, int64_t* count) {
+    if (!c || !dev_ptr || !count) return SCFGP_EARG;
+    const int64_t K2 = (int64_t)c->g.Kp * c->g.Kp;
+    if (stage == 1) { *dev_ptr = c->d_x1; *count = c->n_x1; }
+    else if (stage == 2) {
+        if (c->last_want_grad) { *dev_ptr = c->d_x2; *count = c->n_x2; }
+        else { *dev_ptr = c->d_x2 + K2 + c->g.Kp; *count = 8; }          // forward only: just (T2, kbar)
+    }
+    else if (stage == 3) { *dev_ptr = c->d_x3; *count = c->n_x3; }
+    else return SCFGP_EARG;
+    return SCFGP_OK;
+}
+
+extern "C" int scfgp_finish(scfgp_ctx* c, int want_grad, double* cost, double* grad, double* alpha, double* Li) {
+    if (int rc = ready(c)) return rc;
+    if ((want_grad && c->stage != 5) || (!want_grad && c->stage != 3)) { c->err = "finish: evaluation incomplete"; return SCFGP_EARG; }
+    const Geom& g = c->g;
+    const int64_t K2 = (int64_t)g.Kp * g.Kp;
+    {
+        ProfScope ps(c, "epilogue");
+        grad_epilogue(g, c->d_params, c->d_F, c->d_x3, g.Jp, c->d_work, c->d_scalars, c->Nglobal, want_grad ? c->d_grad : nullptr, c->st);
+        finalize_cost(g, c->d_sc, c->d_scalars, c->d_x1 + K2 + g.Kp, c->d_x2 + K2 + g.Kp, c->d_x3 + (int64_t)c->Dpp * g.Jp,
+                      c->Nglobal, c->d_grad, want_grad, c->st);
+    }
+    double h_cost = 0; int h_flag[4] = {0, 0, 0, 0};
+    {
+        ProfScope ps(c, "d2h");
+        HIPCHK(c, hipMemcpyAsync(&h_cost, c->d_scalars + R_COST, sizeof(double), hipMemcpyDeviceToHost, c->st));
+        HIPCHK(c, hipMemcpyAsync(h_flag, c->d_flag, sizeof(int) * 4, hipMemcpyDeviceToHost, c->st));
+        if (want_grad && grad) HIPCHK(c, hipMemcpyAsync(grad, c->d_grad, sizeof(double) * g.P, hipMemcpyDeviceToHost, c->st));
+        if (alpha) HIPCHK(c, hipMemcpyAsync(alpha, c->alpha(), sizeof(double) * g.K, hipMemcpyDeviceToHost, c->st));
+        if (Li) HIPCHK(c, hipMemcpy2DAsync(Li, sizeof(double) * g.K, c->d_Li, sizeof(double) * g.Kp, sizeof(double) * g.K, g.K,
+                                           hipMemcpyDeviceToHost, c->st));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    HIPCHK(c, hipGetLastError());
+    c->stage = 0;
+    if (cost) *cost = h_cost;
+    if (h_flag[0]) { c->err = "Phi^T Phi + (e^{2a}+1e-6) I is not positive definite"; return SCFGP_ENOTPD; }
+    if (!std::isfinite(h_cost)) { c->err = "non-finite cost"; return SCFGP_ENONFINITE; }
+    return SCFGP_OK;
+}
+
+extern "C" int scfgp_eval(scfgp_ctx* c, const double* X, const double* y, int64_t N, int want_grad,
+                          double* cost, double* grad, double* alpha, double* Li) {
+    if (!c) return SCFGP_EARG;
+    int rc;
+    if (X) { if ((rc = scfgp_set_data(c, X, y, N, N))) return rc; }
+    if ((rc = scfgp_pass1(c))) return rc;
+    if ((rc = scfgp_factor(c))) return rc;
+    if ((rc = scfgp_pass2(c, want_grad))) return rc;
+    if (want_grad) {
+        if ((rc = scfgp_adjoint(c))) return rc;
+        if ((rc = scfgp_pass3(c))) return rc;
+    }
+    return scfgp_finish(c, want_grad, cost, grad, alpha, Li);
+}
+
+extern "C" int scfgp_predict(scfgp_ctx* c, const double* Xs, int64_t T, const double* alpha, const double* Li,
+                             double* mu, double* sd) {
+    if (!c || !Xs || !alpha || !Li || !mu || !sd || T < 1) { if (c) c->err = "predict: bad arguments"; return SCFGP_EARG; }
+    if (!c->have_params) { c->err = "predict: parameters not set"; return SCFGP_EARG; }
+    HIPCHK(c, hipSetDevice(c->device));
+    const Geom& g0 = c->g;
+    const int64_t Kp = g0.Kp, K2 = Kp * Kp;
+    const size_t ts = c->tsize();
+    int rc;
+    if (!c->p_Xt) {
+        if ((rc = dmalloc(c, &c->p_Xt, sizeof(double) * PRED_ROWS * g0.Dp))) return rc;
+        if ((rc = dmalloc(c, &c->p_vpart, sizeof(double) * PRED_ROWS * (Kp / TILE)))) return rc;
+        if ((rc = dmalloc(c, &c->p_mu, sizeof(double) * PRED_ROWS))) return rc;
+        if ((rc = dmalloc(c, &c->p_sd, sizeof(double) * PRED_ROWS))) return rc;
+        if ((rc = dmalloc(c, &c->p_Phi, ts * PRED_ROWS * Kp))) return rc;
+        if ((rc = dmalloc(c, &c->p_V, ts * PRED_ROWS * Kp))) return rc;
+        HIPCHK(c, hipMemsetAsync(c->p_Phi, 0, ts * PRED_ROWS * Kp, c->st));
+    }
+    // Li (K x K host) -> T1 (Kp x Kp, identity padding); B = Li^T Li -> T2; typed copy -> AbarT scratch
+    double* raw = nullptr;
+    if ((rc = dmalloc(c, &raw, sizeof(double) * std::max<int64_t>((int64_t)g0.K * g0.K, PRED_ROWS * g0.D)))) return rc;
+    HIPCHK(c, hipMemcpyAsync(raw, Li, sizeof(double) * g0.K * g0.K, hipMemcpyHostToDevice, c->st));
+    pad_square(raw, g0.K, g0.Kp, c->d_T1, c->st);
+    HIPCHK(c, hipMemsetAsync(c->alpha_pred(), 0, sizeof(double) * Kp, c->st));
+    HIPCHK(c, hipMemcpyAsync(c->alpha_pred(), alpha, sizeof(double) * g0.K, hipMemcpyHostToDevice, c->st));
+    KStage k = c->kstage(); k.Li = c->d_T1; k.B = c->d_T2;
+    kstage_gram_li(k, c->st);
+    const void* Bt = c->d_T2;
+    if (c->dtype == SCFGP_F32) { SweepKernels<float>::convert(c->d_T2, (float*)c->d_AbarT, K2, c->st); Bt = c->d_AbarT; }
+    HIPCHK(c, hipStreamSynchronize(c->st));                     // raw is reused below
+    for (int64_t t0 = 0; t0 < T; t0 += PRED_ROWS) {
+        Geom g = g0;
+        g.N = std::min<int64_t>(PRED_ROWS, T - t0); g.Np = round_up(g.N, 256);
+        HIPCHK(c, hipMemcpyAsync(raw, Xs + t0 * g.D, sizeof(double) * g.N * g.D, hipMemcpyHostToDevice, c->st));
+        pack_data(g, raw, nullptr, c->p_Xt, nullptr, c->st);
+        rc = c->dtype == SCFGP_F32 ? Impl<float>::predict_chunk(c, g, (const float*)Bt) : Impl<double>::predict_chunk(c, g, (const double*)Bt);
+        if (rc) { dfree(raw); return rc; }
+        HIPCHK(c, hipMemcpyAsync(mu + t0, c->p_mu, sizeof(double) * g.N, hipMemcpyDeviceToHost, c->st));
+        HIPCHK(c, hipMemcpyAsync(sd + t0, c->p_sd, sizeof(double) * g.N, hipMemcpyDeviceToHost, c->st));
+        HIPCHK(c, hipStreamSynchronize(c->st));
+    }
+    dfree(raw);
+    HIPCHK(c, hipGetLastError());
+    return SCFGP_OK;
+}
+
+extern "C" int scfgp_get_dims(scfgp_ctx* c, int64_t* out, int n) {
+    if (!c || !out || n < 6) return SCFGP_EARG;
+    out[0] = c->g.K; out[1] = c->g.Kp; out[2] = c->g.Jp; out[3] = c->g.Dp; out[4] = c->g.Np; out[5] = c->g.P;
+    return SCFGP_OK;
+}
+
+extern "C" int scfgp_set_profiling(scfgp_ctx* c, int enable) {
+    if (!c) return SCFGP_EARG;
+    c->prof = enable != 0; c->recs.clear(); c->pool_used = 0;
+    return SCFGP_OK;
+}
+
+extern "C" int scfgp_get_timings(scfgp_ctx* c, double* ms, const char** names, int n) {
+    if (!c) return SCFGP_EARG;
+    hipStreamSynchronize(c->st);
+    int k = 0;
+    for (const ProfRec& r : c->recs) {
+        if (k >= n) break;
+        float t = 0;
+        if (hipEventElapsedTime(&t, r.e0, r.e1) != hipSuccess) t = -1;
+        if (ms) ms[k] = t;
+        if (names) names[k] = r.name.c_str();
+        ++k;
+    }
+    return k;
+}
+
+extern "C" int scfgp_set_option(scfgp_ctx* c, const char* name, int64_t value) {
+    if (!c || !name) return SCFGP_EARG;
+    const std::string s(name);
+    if (s == "gram_nsplit") c->gram_nsplit = (int)value;
+    else if (s == "gram_chunk") c->gram_chunk = value;
+    else if (s == "xtz_nsplit") c->xtz_nsplit = (int)value;
+    else { c->err = "unknown option " + s; return SCFGP_EARG; }
+    if (c->have_data) return ensure_rows(c, c->g.N);
+    return SCFGP_OK;
+}
+
+extern "C" int64_t scfgp_debug_read(scfgp_ctx* c, const char* name, void* host, int64_t max_bytes) {
+    if (!c || !name || !host) return SCFGP_EARG;
+    const Geom& g = c->g;
+    const std::string s(name);
+    const int64_t K2 = (int64_t)g.Kp * g.Kp;
+    const size_t ts = c->tsize();
+    const void* src = nullptr; int64_t bytes = 0;
+    if (s == "Phi") { src = c->d_Phi; bytes = ts * g.Np * g.Kp; }
+    else if (s == "V") { src = c->d_V; bytes = ts * g.Np * g.Kp; }
+    else if (s == "Zbar") { src = c->d_Zbar; bytes = ts * g.Np * g.Jp; }
+    else if (s == "G") { src = c->d_x1; bytes = 8 * c->n_x1; }
+    else if (s == "W") { src = c->d_x2; bytes = 8 * c->n_x2; }
+    else if (s == "XZ") { src = c->d_x3; bytes = 8 * c->n_x3; }
+    else if (s == "Li") { src = c->d_Li; bytes = 8 * K2; }
+    else if (s == "B") { src = c->d_B; bytes = 8 * K2; }
+    else if (s == "Abar") { src = c->d_Abar; bytes = 8 * K2; }
+    else if (s == "p") { src = c->d_p; bytes = 8 * g.Np; }
+    else if (s == "q") { src = c->d_q; bytes = 8 * g.Np; }
+    else if (s == "vecs") { src = c->d_vecs; bytes = 8 * 5 * g.Kp; }
+    else if (s == "Fall") { src = c->d_Fall; bytes = 8 * (int64_t)g.Dp * g.Jp; }
+    else if (s == "Xt") { src = c->d_Xt; bytes = 8 * g.Np * g.Dp; }
+    else if (s == "scalars") { src = c->d_scalars; bytes = 8 * 32; }
+    else { c->err = "debug_read: unknown buffer " + s; return SCFGP_EARG; }
+    if (!src) return SCFGP_EARG;
+    if (bytes > max_bytes) bytes = max_bytes;
+    if (hipStreamSynchronize(c->st) != hipSuccess) return SCFGP_EHIP;
+    if (hipMemcpy(host, src, bytes, hipMemcpyDeviceToHost) != hipSuccess) return SCFGP_EHIP;
+    return bytes;
+}

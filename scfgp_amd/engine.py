@@ -1,0 +1,192 @@
+"""
+HipEngine: thin, typed Python face of one scfgp_ctx (one GPU, one shard of rows).
+
+It adds nothing numerically -- every method is one call through the C ABI of
+libscfgp_hip.so (include/scfgp_hip.h) with numpy buffers allocated for the caller,
+and turns error codes into the exceptions the reference raises
+(numpy.linalg.LinAlgError for a failed Cholesky, SCFGP/SCFGP.py:106).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import SCFGP_F32, SCFGP_F64, dptr
+
+_DTYPES = {'f64': SCFGP_F64, 'float64': SCFGP_F64, 'f32': SCFGP_F32, 'float32': SCFGP_F32,
+           SCFGP_F64: SCFGP_F64, SCFGP_F32: SCFGP_F32}
+
+
+def num_params(D, S, M):
+    """Length of the flat hyper-parameter vector (SCFGP/SCFGP.py:72)."""
+    return 3 + D * S + M * S + S + M
+
+
+class HipEngine(object):
+
+    def __init__(self, D, S, M, dtype='f64', device=0, stream=None):
+        self.lib = _lib.load()
+        self.D, self.S, self.M = int(D), int(S), int(M)
+        self.J = self.S + self.M
+        self.K = 2 * self.J
+        self.P = num_params(D, S, M)
+        self.dtype = _DTYPES[dtype]
+        self.ctx = C.c_void_p()
+        rc = self.lib.scfgp_create(C.byref(self.ctx), self.D, self.S, self.M, self.dtype, int(device),
+                                   C.c_void_p(stream) if stream else None)
+        if rc != 0:
+            msg = self.lib.scfgp_last_error(self.ctx).decode() if self.ctx else ''
+            raise RuntimeError('scfgp_create failed (%d): %s' % (rc, msg))
+        self.N = 0
+        self.n_global = 0
+
+    def close(self):
+        if getattr(self, 'ctx', None):
+            self.lib.scfgp_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- error mapping ----------------------------------------------------------------
+    def _check(self, rc, what):
+        if rc == 0:
+            return
+        msg = self.lib.scfgp_last_error(self.ctx).decode()
+        if rc == -3:
+            raise np.linalg.LinAlgError('%s: %s' % (what, msg))
+        if rc == -4:
+            raise FloatingPointError('%s: %s' % (what, msg))
+        if rc == -1:
+            raise ValueError('%s: %s' % (what, msg))
+        raise RuntimeError('%s failed (%d, %s): %s' % (what, rc, _lib.ERRORS.get(rc, '?'), msg))
+
+    # -- state --------------------------------------------------------------------------
+    def set_params(self, params):
+        p = np.ascontiguousarray(params, dtype=np.float64).ravel()
+        if p.size != self.P:
+            raise ValueError('expected %d parameters, got %d' % (self.P, p.size))
+        self._check(self.lib.scfgp_set_params(self.ctx, dptr(p), self.P), 'set_params')
+
+    def get_params(self):
+        p = np.empty(self.P)
+        self._check(self.lib.scfgp_get_params(self.ctx, dptr(p), self.P), 'get_params')
+        return p
+
+    @staticmethod
+    def _check_xy(X, y, D):
+        # Theano's dmatrix inputs reject anything but 2-d float64 (SCFGP/SCFGP.py:95)
+        if not isinstance(X, np.ndarray) or X.dtype != np.float64 or X.ndim != 2:
+            raise TypeError('X must be a 2-d float64 ndarray')
+        if X.shape[1] != D:
+            raise ValueError('X has %d columns, expected %d' % (X.shape[1], D))
+        if y is not None:
+            if not isinstance(y, np.ndarray) or y.dtype != np.float64 or y.ndim != 2 or y.shape != (X.shape[0], 1):
+                raise TypeError('y must be a float64 ndarray of shape (N,1)')
+
+    def set_data(self, X, y, n_global=None):
+        self._check_xy(X, y, self.D)
+        X = np.ascontiguousarray(X); y = np.ascontiguousarray(y)
+        N = X.shape[0]
+        self.N = N
+        self.n_global = int(n_global) if n_global else N
+        self._check(self.lib.scfgp_set_data(self.ctx, dptr(X), dptr(y), N, self.n_global), 'set_data')
+
+    # -- whole evaluations ------------------------------------------------------------------
+    def _outputs(self, want_grad):
+        cost = np.zeros(1)
+        grad = np.empty(self.P) if want_grad else None
+        alpha = np.empty((self.K, 1))
+        Li = np.empty((self.K, self.K))
+        return cost, grad, alpha, Li
+
+    def eval(self, X=None, y=None, want_grad=True):
+        """(cost 0-d, grad|None, alpha (K,1), Li (K,K)); X=None evaluates the resident rows."""
+        cost, grad, alpha, Li = self._outputs(want_grad)
+        if X is not None:
+            self._check_xy(X, y, self.D)
+            X = np.ascontiguousarray(X); y = np.ascontiguousarray(y)
+            self.N = X.shape[0]; self.n_global = self.N
+        rc = self.lib.scfgp_eval(self.ctx, dptr(X), dptr(y), 0 if X is None else X.shape[0], int(bool(want_grad)),
+                                 dptr(cost), dptr(grad), dptr(alpha), dptr(Li))
+        self._check(rc, 'eval')
+        return cost.reshape(()), grad, alpha, Li
+
+    def predict(self, Xs, alpha, Li):
+        """pred_func (SCFGP/SCFGP.py:138-148): returns mu (T,1), std (T,)."""
+        self._check_xy(Xs, None, self.D)
+        Xs = np.ascontiguousarray(Xs)
+        alpha = np.ascontiguousarray(alpha, dtype=np.float64).reshape(-1)
+        Li = np.ascontiguousarray(Li, dtype=np.float64)
+        if alpha.size != self.K or Li.shape != (self.K, self.K):
+            raise ValueError('alpha/Li have the wrong shape for K=%d' % self.K)
+        T = Xs.shape[0]
+        mu = np.empty((T, 1)); sd = np.empty(T)
+        self._check(self.lib.scfgp_predict(self.ctx, dptr(Xs), T, dptr(alpha), dptr(Li), dptr(mu), dptr(sd)), 'predict')
+        return mu, sd
+
+    # -- staged evaluation (row-sharded data parallelism) --------------------------------------
+    def pass1(self):
+        self._check(self.lib.scfgp_pass1(self.ctx), 'pass1')
+
+    def factor(self):
+        self._check(self.lib.scfgp_factor(self.ctx), 'factor')
+
+    def pass2(self, want_grad=True):
+        self._check(self.lib.scfgp_pass2(self.ctx, int(bool(want_grad))), 'pass2')
+
+    def adjoint(self):
+        self._check(self.lib.scfgp_adjoint(self.ctx), 'adjoint')
+
+    def pass3(self):
+        self._check(self.lib.scfgp_pass3(self.ctx), 'pass3')
+
+    def finish(self, want_grad=True):
+        cost, grad, alpha, Li = self._outputs(want_grad)
+        rc = self.lib.scfgp_finish(self.ctx, int(bool(want_grad)), dptr(cost), dptr(grad), dptr(alpha), dptr(Li))
+        self._check(rc, 'finish')
+        return cost.reshape(()), grad, alpha, Li
+
+    def exchange_ptr(self, stage):
+        """(device pointer, number of float64) of exchange buffer `stage` (1..3)."""
+        p = C.c_void_p(); n = C.c_int64()
+        self._check(self.lib.scfgp_exchange(self.ctx, int(stage), C.byref(p), C.byref(n)), 'exchange')
+        return p.value, n.value
+
+    def exchange(self, stage):
+        """The exchange buffer as a torch CUDA tensor aliasing the library's device memory."""
+        import torch
+        ptr, n = self.exchange_ptr(stage)
+
+        class _Alias(object):
+            __cuda_array_interface__ = {'shape': (n,), 'typestr': '<f8', 'data': (ptr, False), 'version': 2}
+        return torch.as_tensor(_Alias(), device='cuda')
+
+    # -- introspection ----------------------------------------------------------------------------
+    def dims(self):
+        out = (C.c_int64 * 6)()
+        self._check(self.lib.scfgp_get_dims(self.ctx, out, 6), 'get_dims')
+        return dict(zip(('K', 'Kp', 'Jp', 'Dp', 'Np', 'P'), [int(v) for v in out]))
+
+    def set_profiling(self, on=True):
+        self._check(self.lib.scfgp_set_profiling(self.ctx, int(bool(on))), 'set_profiling')
+
+    def timings(self):
+        """[(stage name, milliseconds)] of the last evaluation (profiling must be on)."""
+        n = 64
+        ms = (C.c_double * n)(); names = (C.c_char_p * n)()
+        k = self.lib.scfgp_get_timings(self.ctx, ms, names, n)
+        return [(names[i].decode(), ms[i]) for i in range(max(k, 0))]
+
+    def set_option(self, name, value):
+        self._check(self.lib.scfgp_set_option(self.ctx, name.encode(), int(value)), 'set_option')
+
+    def debug_read(self, name, shape, dtype=np.float64):
+        out = np.empty(shape, dtype=dtype)
+        n = self.lib.scfgp_debug_read(self.ctx, name.encode(), out.ctypes.data_as(C.c_void_p), out.nbytes)
+        if n < 0:
+            self._check(int(n), 'debug_read')
+        return out
