@@ -1,0 +1,158 @@
+#!/usr/bin/env python
+"""
+bench.py -- NLML+grad evaluations/sec of the SCFGP hot path on MI355X.
+
+Workload (BASELINE.json `metric`): N=1e6, D=64, rank S=32, M=1024 (K=2112), fp32 compute
+mode, synthetic data; one "step" = one train_iter_func-equivalent evaluation with resident
+data: cost + full gradient + alpha + Li back on the host.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype f32|f64] [--rows N]
+
+N>1 is launched by torch.distributed.run (one rank per GPU, RCCL): the N rows are sharded
+over the ranks (strong scaling -- total work fixed), three all-reduces per evaluation.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from scfgp_amd import synth                                   # noqa: E402
+from scfgp_amd.engine import HipEngine                        # noqa: E402
+from scfgp_amd.sharded import ShardedEvaluator, shard_rows, torch_allreduce   # noqa: E402
+
+SEED = 0x5CF600FF
+PEAK_TFLOPS = {'f32': 157.3, 'f64': 78.6}     # dense MFMA peaks, MI355X_MICROARCH.md / datasheet
+
+
+def build_problem(eng, N, D, S, M, lo, hi, allreduce):
+    """Rows [lo,hi) of the synthetic problem; teacher response computed by the HIP predict path."""
+    K = 2 * (S + M)
+    X = synth.make_X(SEED, hi - lo, D, row0=lo)
+    teacher = synth.make_params(SEED + 0x0101, D, S, M, abc=(-1.0, 0.0, -1.0))
+    eng.set_params(teacher)
+    f, _ = eng.predict(X, synth.teacher_weights(SEED + 0x0303, K), np.eye(K))
+    y = f.ravel() + 0.1 * synth.normal(SEED + 0x0404, lo, hi - lo)
+    mom = np.array([y.sum(), (y * y).sum(), float(len(y))])
+    if allreduce is not None:
+        allreduce(mom)
+    mean = mom[0] / mom[2]; std = np.sqrt(mom[1] / mom[2] - mean * mean)
+    y = ((y - mean) / std).reshape(-1, 1)
+    params = synth.make_params(SEED + 0x0202, D, S, M, abc=(-1.0, 0.0, -1.0))
+    return X, y, params
+
+
+def cpu_baseline(X, y, params, S, M, N_full, budget_rows):
+    """Times the CPU oracle (numpy/BLAS restatement of the same 3-sweep evaluation) on the first
+    `budget_rows` rows of the same workload and scales to evaluations/sec at N_full rows."""
+    from oracle import scfgp_oracle as O
+    n = min(budget_rows, X.shape[0])
+    Xs, ys = np.ascontiguousarray(X[:n]), np.ascontiguousarray(y[:n])
+    t0 = time.time()
+    O.value_and_grad(Xs, ys, params, S, M, chunk=4096)
+    dt = time.time() - t0
+    try:
+        import threadpoolctl
+        cores = max([p['num_threads'] for p in threadpoolctl.threadpool_info()] or [os.cpu_count()])
+    except Exception:
+        cores = os.cpu_count()
+    return {"value": (n / float(N_full)) / dt, "unit": "evals/s", "cores": int(cores), "kind": "port",
+            "sample": "oracle.value_and_grad (numpy float64, 3-sweep) on the first %d of %d rows, %.1f s; "
+                      "scaled linearly in rows (the K^3 stage is not scaled down)" % (n, N_full, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--dtype', default='f32')
+    ap.add_argument('--rows', type=int, default=1000000)
+    ap.add_argument('--D', type=int, default=64)
+    ap.add_argument('--S', type=int, default=32)
+    ap.add_argument('--M', type=int, default=1024)
+    ap.add_argument('--cpu-rows', type=int, default=30000)
+    ap.add_argument('--no-cpu', action='store_true')
+    a = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get('RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    torch.cuda.set_device(local)
+    allreduce = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        allreduce = torch_allreduce()
+    N, D, S, M = a.rows, a.D, a.S, a.M
+    J = S + M; K = 2 * J
+    lo, hi = shard_rows(N, rank, world)
+    eng = HipEngine(D, S, M, dtype=a.dtype, device=local, stream=torch.cuda.current_stream().cuda_stream)
+    X, y, params = build_problem(eng, N, D, S, M, lo, hi, allreduce)
+    eng.set_params(params)
+    eng.set_data(X, y, n_global=N)
+    ev = ShardedEvaluator(eng, allreduce)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        ev.eval(True)
+    eng.set_profiling(True)
+    per_kernel = {}
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        cost, grad, alpha, Li = ev.eval(True)
+        for name, ms in eng.timings():
+            per_kernel.setdefault(name, []).append(ms)
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device='cuda')
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    if rank == 0:
+        ms_step = dt / a.steps * 1e3
+        # dominant kernel: the N x K x K "apply" product (Phi.B and Phi.Abar use the same kernel);
+        # algorithmic flops per launch = 2 * rows_on_this_rank * K^2   
+        ap_ms = np.mean(per_kernel.get('apply_v', [0]) + per_kernel.get('apply_phibar', [0]))
+        flops = 2.0 * (hi - lo) * K * K
+        ach = flops / (ap_ms * 1e-3) / 1e12 if ap_ms > 0 else 0.0
+        peak = PEAK_TFLOPS[a.dtype]
+        falg = 10.0 * N * K * K + 4.0 * N * D * J
+        out = {
+            "metric": "NLML+grad evals/sec", "value": a.steps / dt, "unit": "evals/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": "N=%d D=%d S=%d M=%d (K=%d), resident rows, cost+grad+alpha+Li to host" % (N, D, S, M, K),
+                       "rows_per_gpu": hi - lo, "parallelism": "row-sharded dp%d, 3 all-reduces/eval" % world,
+                       "F_alg_per_eval": falg, "F_alg_TFLOPs": falg / (dt / a.steps) / 1e12},
+            "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                         "traffic": None, "kernel": "apply_kernel (Phi.B / Phi.Abar, 2*N*K^2 flops per launch)",
+                         "avg_launch_ms": ap_ms},
+            "stages_ms": {k: float(np.mean(v)) for k, v in per_kernel.items()},
+            "cost": float(cost),
+        }
+        if not a.no_cpu and world == 1:
+            out["cpu_baseline"] = cpu_baseline(X, y, params, S, M, N, a.cpu_rows)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == '__main__':
+    main()

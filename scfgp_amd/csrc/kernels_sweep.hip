@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256) void reduce_tri_kernel(const double* __restric
     while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
     while (ti * (ti + 1) / 2 > t) --ti;
     const int tj = t - ti * (ti + 1) / 2;
-    for (int e = threadIdx.x; e < B * B; e += 256) {
+    for (int e = blockIdx.y * 256 + threadIdx.x; e < B * B; e += gridDim.y * 256) {
         double s = 0;
         for (int sp = 0; sp < nsplit; ++sp) s += slabs[((int64_t)sp * ntiles + t) * (B * B) + e];
         const int i = ti * B + e / B, j = tj * B + e % B;
@@ -409,21 +409,21 @@ __global__ __launch_bounds__(256) void reduce_tri_kernel(const double* __restric
 }
 void reduce_tri_tiles(const double* slabs, int nsplit, int nts, double* out, int64_t ldo, hipStream_t st) {
     const int ntiles = nts * (nts + 1) / 2;
-    hipLaunchKernelGGL(reduce_tri_kernel, dim3(ntiles), dim3(256), 0, st, slabs, nsplit, ntiles, out, ldo);
+    hipLaunchKernelGGL(reduce_tri_kernel, dim3(ntiles, 16), dim3(256), 0, st, slabs, nsplit, ntiles, out, ldo);
 }
 
 __global__ __launch_bounds__(256) void reduce_full_kernel(const double* __restrict__ slabs, int nsplit, int ntiles, int ntn,
                                                           double* __restrict__ out, int64_t ldo) {
     constexpr int B = 128;
     const int t = blockIdx.x, ti = t / ntn, tj = t % ntn;
-    for (int e = threadIdx.x; e < B * B; e += 256) {
+    for (int e = blockIdx.y * 256 + threadIdx.x; e < B * B; e += gridDim.y * 256) {
         double s = 0;
         for (int sp = 0; sp < nsplit; ++sp) s += slabs[((int64_t)sp * ntiles + t) * (B * B) + e];
         out[(int64_t)(ti * B + e / B) * ldo + tj * B + e % B] = s;
     }
 }
 void reduce_full_tiles(const double* slabs, int nsplit, int ntm, int ntn, double* out, int64_t ldo, hipStream_t st) {
-    hipLaunchKernelGGL(reduce_full_kernel, dim3(ntm * ntn), dim3(256), 0, st, slabs, nsplit, ntm * ntn, ntn, out, ldo);
+    hipLaunchKernelGGL(reduce_full_kernel, dim3(ntm * ntn, 16), dim3(256), 0, st, slabs, nsplit, ntm * ntn, ntn, out, ldo);
 }
 
 __global__ void reduce_rows_kernel(const double* __restrict__ partial, int nsplit, int64_t n, double* __restrict__ out) {

@@ -1,0 +1,107 @@
+"""
+The "compiled function triple" -- drop-in for what theano.function produces in
+SCFGP.build_theano_models (SCFGP/SCFGP.py:132-137,145-148):
+
+    train_func(X, y)          -> [cost, alpha, Li]
+    train_iter_func(X, y)     -> [cost, alpha, Li]  (at the PRE-update parameters) and then
+                                 applies the update rule to the shared parameter vector
+    pred_func(Xs, alpha, Li)  -> [mu (T,1), std (T,)]
+
+As in the reference the hyper-parameters are implicit state (givens=[(params,
+self.params)], SCFGP/SCFGP.py:134-137,147-148): the three callables share one `Shared`
+vector plus the optimiser moments created when the triple is built, so a triple handed
+to another model through optimize(funcs=...) keeps training ITS vector, exactly like a
+reused Theano triple does.
+
+All numerics happen in libscfgp_hip.so; this module only moves numpy buffers across the
+C ABI.  X and y stay resident on the GPU between calls while the caller keeps passing
+the same arrays (optimize() does: SCFGP/SCFGP.py:237).
+"""
+import numpy as np
+
+from .engine import HipEngine
+from .optimizer import Optimizer as OPT, Shared, apply_updates
+from .sharded import ShardedEvaluator
+
+
+class _GradSlot(object):
+    def __init__(self, P):
+        self._g = np.zeros(P)
+
+    def get_value(self, borrow=False):
+        return self._g
+
+    def set_value(self, g):
+        self._g = g
+
+
+def _fingerprint(X, y):
+    flat = X.reshape(-1)
+    step = max(1, flat.size // 257)
+    return (id(X), id(y), X.shape, X.ctypes.data, y.ctypes.data,
+            float(flat[::step].sum()), float(y.reshape(-1)[::max(1, y.size // 257)].sum()))
+
+
+class CompiledFuncs(object):
+    """Owns one HipEngine (one GPU) and the shared parameter/optimiser state."""
+
+    def __init__(self, D, S, M, params, algo='adam', algo_params=None, momentum=0.9,
+                 dtype='f64', device=0, stream=None, allreduce=None, n_global=None):
+        self.engine = HipEngine(D, S, M, dtype=dtype, device=device, stream=stream)
+        self.evaluator = ShardedEvaluator(self.engine, allreduce)
+        self.allreduce = allreduce
+        self.n_global = n_global
+        self.params = params if isinstance(params, Shared) else Shared(params)
+        self.grads = _GradSlot(self.engine.P)
+        if algo not in OPT.algos or algo.startswith('apply_'):
+            raise ValueError("unknown update rule %r (choose from %s)" % (algo, OPT.algos[2:]))
+        algo_params = {} if algo_params is None else algo_params
+        updates = getattr(OPT, algo)(self.params, self.grads, **algo_params)          # SCFGP.py:130
+        self.updates = OPT.apply_nesterov_momentum(updates, momentum=momentum)        # SCFGP.py:131
+        self._uploaded_version = None
+        self._resident = None
+
+    # -- state sync ----------------------------------------------------------------------
+    def _sync_params(self):
+        if self._uploaded_version != self.params.version:
+            self.engine.set_params(self.params.get_value(borrow=True))
+            self._uploaded_version = self.params.version
+
+    def _sync_data(self, X, y):
+        fp = _fingerprint(X, y)
+        if fp != self._resident:
+            n_global = self.n_global
+            if self.allreduce is not None and n_global is None:
+                n = np.array([float(X.shape[0])])
+                self.allreduce(n)
+                n_global = int(n[0])
+            self.engine.set_data(X, y, n_global)
+            self._resident = fp
+
+    def _evaluate(self, X, y, want_grad):
+        self._sync_params()
+        self._sync_data(X, y)
+        return self.evaluator.eval(want_grad)
+
+    # -- the triple ------------------------------------------------------------------------
+    def train_func(self, X, y):
+        cost, _, alpha, Li = self._evaluate(X, y, False)
+        return [cost, alpha, Li]
+
+    def train_iter_func(self, X, y):
+        cost, grad, alpha, Li = self._evaluate(X, y, True)
+        self.grads.set_value(grad)
+        apply_updates(self.updates)
+        return [cost, alpha, Li]
+
+    def pred_func(self, Xs, alpha, Li):
+        self._sync_params()
+        mu, sd = self.engine.predict(Xs, alpha, Li)
+        return [mu, sd]
+
+    def value_and_grad(self, X, y):
+        """cost, grad, alpha, Li at the current parameters without touching them."""
+        return self._evaluate(X, y, True)
+
+    def triple(self):
+        return self.train_func, self.train_iter_func, self.pred_func

@@ -1,0 +1,63 @@
+"""
+Row-sharded evaluation: one process per GPU, each holding a contiguous block of the
+training rows; three sums over ranks per NLML+grad evaluation.
+
+The reference has no multi-device code at all; what makes sharding exact is that
+every N-dependent quantity of SCFGP/SCFGP.py:104-126 is a sum over rows of per-row
+terms (Phi^T Phi, Phi^T y, y^T y; then the expected-NLL sum and the weighted Gram of
+the backward pass; then X^T Zbar).  The K x K stages run replicated on every rank.
+
+`engine` is anything with the staged interface of scfgp_amd.engine.HipEngine
+(pass1/factor/pass2/adjoint/pass3/finish/exchange); `allreduce(buf)` sums the buffer
+in place across ranks.  With torch.distributed (backend "nccl" == RCCL on ROCm) the
+buffers are CUDA tensors aliasing the library's device memory, so the collective runs
+over xGMI with no host copy.
+"""
+import numpy as np
+
+
+def torch_allreduce(group=None):
+    """All-reduce (sum, in place) through torch.distributed; accepts torch tensors or
+    numpy arrays (the latter for CPU/gloo rehearsals)."""
+    import torch
+    import torch.distributed as dist
+
+    def _ar(buf):
+        if isinstance(buf, np.ndarray):
+            if dist.get_backend(group) == 'nccl':          # host scalars (e.g. the global N)
+                t = torch.from_numpy(buf).cuda()
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+                buf[...] = t.cpu().numpy()
+            else:
+                dist.all_reduce(torch.from_numpy(buf), op=dist.ReduceOp.SUM, group=group)
+        else:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    return _ar
+
+
+def shard_rows(N, rank, world):
+    """Contiguous block [lo, hi) of rank `rank` out of `world` (sizes differ by at most 1)."""
+    base, rem = divmod(N, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class ShardedEvaluator(object):
+
+    def __init__(self, engine, allreduce=None):
+        self.engine = engine
+        self.allreduce = allreduce
+
+    def _sum(self, stage):
+        if self.allreduce is not None:
+            self.allreduce(self.engine.exchange(stage))
+
+    def eval(self, want_grad=True):
+        e = self.engine
+        e.pass1(); self._sum(1)
+        e.factor()
+        e.pass2(want_grad); self._sum(2)
+        if want_grad:
+            e.adjoint()
+            e.pass3(); self._sum(3)
+        return e.finish(want_grad)

@@ -1,0 +1,130 @@
+"""Host-side logic above the C ABI: update rules, scaler, sharding arithmetic, synth."""
+import numpy as np
+import pytest
+
+from scfgp_amd import synth
+from scfgp_amd.optimizer import Optimizer as OPT, Shared, apply_updates
+from scfgp_amd.scaler import Scaler
+from scfgp_amd.sharded import shard_rows
+
+
+class _G(object):
+    def __init__(self):
+        self.g = None
+
+    def get_value(self, borrow=False):
+        return self.g
+
+
+def _run(algo, kw, theta0, gs, momentum=0.9):
+    p = Shared(theta0); g = _G()
+    up = OPT.apply_nesterov_momentum(getattr(OPT, algo)(p, g, **kw), momentum=momentum)
+    out = []
+    for gi in gs:
+        g.g = gi
+        apply_updates(up)
+        out.append(p.get_value())
+    return out
+
+
+def test_adam_nesterov_three_steps():
+    # Literal recurrences of SCFGP/Optimizer.py:314-330 followed by :88-96.  NOTE the
+    # reference quirk reproduced here: apply_nesterov_momentum wraps
+    # list(updates.keys())[0], and adam() inserts m_prev FIRST (:325), so the momentum
+    # lands on the first-moment state, not on the parameter vector.
+    rng = np.random.default_rng(1)
+    th = rng.standard_normal(7); gs = [rng.standard_normal(7) for _ in range(3)]
+    lr, b1, b2, eps, mom = 0.01, 0.9, 0.999, 1e-8, 0.9
+    got = _run('adam', dict(learning_rate=lr, beta1=b1, beta2=b2, epsilon=eps), th, gs)
+    m = np.zeros(7); v = np.zeros(7); vel = np.zeros(7); t = 0; x = th.copy()
+    for k, g in enumerate(gs):
+        t += 1
+        a_t = lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+        m_t = b1 * m + (1 - b1) * g; v_t = b2 * v + (1 - b2) * g * g
+        x = x - a_t * m_t / (np.sqrt(v_t) + eps)            # params: plain adam step
+        vel_new = mom * vel + m_t - m                        # velocity of the m state
+        m = mom * vel_new + m_t; vel = vel_new; v = v_t
+        assert np.allclose(got[k], x, rtol=1e-13, atol=0)
+
+
+def test_sgd_nesterov_three_steps():
+    # sgd's only key is params (SCFGP/Optimizer.py:118), so here momentum acts on the vector
+    rng = np.random.default_rng(2)
+    th = rng.standard_normal(5); gs = [rng.standard_normal(5) for _ in range(3)]
+    got = _run('sgd', dict(learning_rate=0.1), th, gs)
+    vel = np.zeros(5); x = th.copy()
+    for k, g in enumerate(gs):
+        sg = x - 0.1 * g
+        vel = 0.9 * vel + sg - x
+        x = 0.9 * vel + sg
+        assert np.allclose(got[k], x, rtol=1e-13, atol=0)
+
+
+@pytest.mark.parametrize('algo,kw', [('sgd', {}), ('adagrad', {}), ('rmsprop', {}), ('adadelta', {}),
+                                      ('adamax', {}), ('adam', {})])
+def test_rules_run_and_descend(algo, kw):
+    # minimise 0.5*|x|^2 : every bare rule must reduce the objective over a few dozen steps
+    p = Shared(np.array([1.0, -2.0, 0.5])); g = _G()
+    up = getattr(OPT, algo)(p, g, **kw)
+    f0 = 0.5 * (p.get_value() ** 2).sum()
+    for _ in range(60):
+        g.g = p.get_value()
+        apply_updates(up)
+    assert 0.5 * (p.get_value() ** 2).sum() < f0
+
+
+def test_nesterov_wraps_first_key_like_the_reference():
+    # SCFGP/Optimizer.py:88: params = list(updates.keys())[0]
+    p = Shared(np.zeros(3)); g = _G()
+    base = OPT.adam(p, g)
+    first = list(base.keys())[0]
+    wrapped = OPT.apply_nesterov_momentum(base, momentum=0.9)
+    assert first is not p                                  # adam inserts m_prev first
+    assert len(wrapped) == len(base) + 1                   # one velocity state added
+    assert wrapped[p] is base[p]                           # the parameter update itself is untouched
+
+
+def test_defaults_match_reference():
+    import inspect
+    d = lambda f: {k: v.default for k, v in inspect.signature(f).parameters.items() if v.default is not inspect._empty}
+    assert d(OPT.adam) == dict(learning_rate=0.01, beta1=0.9, beta2=0.99, epsilon=1e-8)     # Optimizer.py:279-283
+    assert d(OPT.adamax) == dict(learning_rate=0.01, beta1=0.9, beta2=0.999, epsilon=1e-8)  # :334-338
+    assert d(OPT.adadelta) == dict(learning_rate=0.01, rho=0.95, epsilon=1e-6)              # :216-219
+    assert d(OPT.apply_nesterov_momentum) == dict(momentum=0.9)
+
+
+def test_simultaneous_update_semantics():
+    a = Shared(1.0); b = Shared(2.0)
+    apply_updates({a: lambda: b.get_value() + 0, b: lambda: a.get_value() + 0})
+    assert float(a.get_value()) == 2.0 and float(b.get_value()) == 1.0
+
+
+@pytest.mark.parametrize('algo', Scaler.algos)
+def test_scaler_round_trip(algo):
+    rng = np.random.default_rng(3)
+    X = np.exp(rng.standard_normal((200, 4))); X[:, 2] = 7.0                 # one constant column
+    s = Scaler(algo); s.fit(X)
+    t = s.forward_transform(X)
+    assert t.shape == (200, 3)
+    if algo != 'inv-normal':                                                # its backward is not an inverse in the reference
+        back = s.backward_transform(t)
+        assert np.allclose(back, X[:, [0, 1, 3]], rtol=1e-7, atol=1e-9)
+    if algo in ('inv-normal', 'auto-inv-normal'):
+        assert t.min() >= 0 and t.max() <= 1
+
+
+def test_shard_rows_partition():
+    for N, W in [(10, 3), (1000000, 8), (7, 8), (256, 2)]:
+        blocks = [shard_rows(N, r, W) for r in range(W)]
+        assert blocks[0][0] == 0 and blocks[-1][1] == N
+        assert all(blocks[i][1] == blocks[i + 1][0] for i in range(W - 1))
+        sizes = [hi - lo for lo, hi in blocks]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def test_synth_is_counter_based():
+    X = synth.make_X(123, 1000, 7)
+    assert X.min() >= 0 and X.max() < 1 and abs(X.mean() - 0.5) < 0.02
+    assert np.array_equal(synth.make_X(123, 100, 7, row0=400), X[400:500])   # any block, any rank
+    z = synth.normal(5, 0, 200000)
+    assert abs(z.mean()) < 0.01 and abs(z.std() - 1) < 0.01

@@ -1,0 +1,88 @@
+"""
+CPU tests that pin the oracle: (1) against the reference's own artifact (Theano-computed
+Li, alpha, COST), (2) against the committed oracle KATs, (3) gradient three-way agreement,
+(4) the invariances of the objective.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import scfgp_oracle as O
+from oracle import autograd_ref as AR
+from tests.golden.make_oracle_kats import CASES, case_inputs
+
+GOLD = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def rel(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / np.linalg.norm(np.asarray(b))
+
+
+def test_oracle_reproduces_reference_artifact():
+    z = np.load(os.path.join(GOLD, 'artifact_kat.npz'))
+    S, M = int(z['S']), int(z['M'])
+    cost, alpha, Li = O.forward(z['X'], z['y'], z['params'], S, M, gauss_hermite=True)
+    assert rel(Li, z['Li']) < 1e-12
+    assert rel(alpha, z['alpha']) < 1e-11
+    assert abs(cost - float(z['cost'])) < 1e-12 * abs(float(z['cost']))
+    # the closed form of the 30-point Gauss-Hermite term is exact
+    cost_cf, _, _ = O.forward(z['X'], z['y'], z['params'], S, M, gauss_hermite=False)
+    assert abs(cost_cf - cost) < 1e-13 * abs(cost)
+    # pair identity: A[j,j] + A[J+j,J+j] = N s^2 + 2 lam   (cos^2 + sin^2 = 1)
+    a, b = z['params'][0], z['params'][1]
+    L = np.linalg.inv(z['Li']); A = L @ L.T
+    J = S + M
+    n_rec = (np.diag(A)[:J] + np.diag(A)[J:] - 2 * (np.exp(2 * a) + 1e-6)) / (np.exp(2 * b) * 2.0 / M)
+    assert np.allclose(n_rec, 400.0, rtol=0, atol=1e-8)
+
+
+@pytest.mark.parametrize('name', list(CASES))
+def test_oracle_matches_committed_kats(name):
+    z = np.load(os.path.join(GOLD, 'oracle_kats.npz'))
+    N, D, S, M, T, seed = CASES[name]
+    X, y, params, Xs = case_inputs(name)
+    cost, grad, alpha, Li = O.value_and_grad(X, y, params, S, M, chunk=500)
+    assert abs(cost - float(z[name + '/cost'])) < 1e-11 * abs(cost)
+    assert rel(grad, z[name + '/grad']) < 1e-9
+    assert rel(alpha, z[name + '/alpha']) < 1e-8
+    if name + '/Li' in z.files:
+        assert rel(Li, z[name + '/Li']) < 1e-9
+    else:
+        assert rel(Li[z[name + '/Li_rows']], z[name + '/Li_sample']) < 1e-9
+        assert abs(np.linalg.norm(Li) - float(z[name + '/Li_fro'])) < 1e-9 * float(z[name + '/Li_fro'])
+    mu, std = O.predict(Xs, alpha, Li, params, S, M)
+    assert rel(mu, z[name + '/mu']) < 1e-8 and rel(std, z[name + '/std']) < 1e-9
+
+
+def test_gradient_three_way():
+    X, y, params, _ = case_inputs('tiny_257x5')
+    N, D, S, M, T, seed = CASES['tiny_257x5']
+    c1, g1, _, _ = O.value_and_grad(X, y, params, S, M, chunk=64)
+    c2, g2, _, _ = AR.value_and_grad(X, y, params, S, M)
+    assert abs(c1 - c2) < 1e-12 * abs(c2) and rel(g1, g2) < 1e-10
+    idx = np.arange(0, len(params), max(1, len(params) // 12))
+    fd = O.fd_grad(X, y, params, S, M, idx, h=1e-6)
+    assert np.abs(fd - g1[idx]).max() < 1e-6 * max(1.0, np.abs(g1).max())
+
+
+def test_invariances():
+    name = 'kin8nm_like'
+    N, D, S, M, T, seed = CASES[name]
+    X, y, params, _ = case_inputs(name)
+    c0, g0, al0, Li0 = O.value_and_grad(X, y, params, S, M)
+    # phase invariance: cost and non-phase gradient unchanged, phase gradient ~ 0
+    p2 = params.copy(); p2[-(S + M):] += np.linspace(0.1, 2.0, S + M)
+    c1, g1, _, _ = O.value_and_grad(X, y, p2, S, M)
+    assert abs(c1 - c0) < 1e-9 * abs(c0)
+    assert rel(g1[:-(S + M)], g0[:-(S + M)]) < 1e-6
+    assert np.abs(g0[-(S + M):]).max() < 1e-8 * np.abs(g0).max()
+    # row permutation invariance
+    perm = np.random.default_rng(0).permutation(N)
+    c2, g2, al2, _ = O.value_and_grad(X[perm], y[perm], params, S, M)
+    assert abs(c2 - c0) < 1e-10 * abs(c0) and rel(g2, g0) < 1e-7 and rel(al2, al0) < 1e-7
+    # staged engine == monolithic
+    e = O.OracleEngine(D, S, M); e.set_params(params); e.set_data(X, y)
+    e.pass1(); e.factor(); e.pass2(True); e.adjoint(); e.pass3()
+    c3, g3, al3, Li3 = e.finish(True)
+    assert abs(c3 - c0) < 1e-12 * abs(c0) and rel(g3, g0) < 1e-10
