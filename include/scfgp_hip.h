@@ -107,7 +107,7 @@ int scfgp_finish(scfgp_ctx* ctx, int want_grad, double* cost, double* grad, doub
 int scfgp_exchange(scfgp_ctx* ctx, int stage, void** dev_ptr, int64_t* count);
 
 /* ---- introspection ------------------------------------------------------------------------ */
-/* padded sizes the device buffers use: out[0]=K, out[1]=Kp, out[2]=Jp, out[3]=Dp, out[4]=Np, out[5]=P */
+/* padded sizes the device buffers use: out[0]=K, out[1]=Kp, out[2]=Jp, out[3]=Dp, out[4]=Np, out[5]=P, out[6]=tile */
 int scfgp_get_dims(scfgp_ctx* ctx, int64_t* out, int n);
 /* profiling: enable per-stage hipEvent timing; after an evaluation read back up to n
  * (name, milliseconds) pairs.  Returns the number of stages recorded. */

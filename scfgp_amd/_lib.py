@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libscfgp_hip.so')
+# SCFGP_LIB_VARIANT selects an alternative build (tuning experiments only, e.g. '_bk32')
+LIB_PATH = os.path.join(_HERE, 'lib', 'libscfgp_hip%s.so' % os.environ.get('SCFGP_LIB_VARIANT', ''))
 
 SCFGP_F64, SCFGP_F32 = 0, 1
 ERRORS = {-1: 'bad argument', -2: 'HIP error', -3: 'not positive definite', -4: 'non-finite cost'}

@@ -8,7 +8,8 @@ struct Geom {
     int D, S, M, J, K, P;
     int Dp;      // round_up(D+1,16): X~ = [X | 1 | 0..]   (ones column carries the phase offsets)
     int Jp;      // round_up(J,128)
-    int Kp;      // round_up(K,128)
+    int Kp;      // round_up(K,tile)
+    int tile;    // 128 or 192: column tile of the Gram / apply kernels, chosen to minimise Kp
     int64_t N;   // valid local rows
     int64_t Np;  // round_up(N,256)
 };
@@ -41,7 +42,7 @@ template <typename T> struct SweepKernels {
 
 // ---- reductions ------------------------------------------------------------
 // out (ldo) = sum over splits of lower-tile slabs, mirrored into the upper triangle
-void reduce_tri_tiles(const double* slabs, int nsplit, int nts, double* out, int64_t ldo, hipStream_t st);
+void reduce_tri_tiles(const double* slabs, int nsplit, int nts, int tile, double* out, int64_t ldo, hipStream_t st);
 // out (ldo) = sum over splits of a full ntm x ntn tile grid of slabs
 void reduce_full_tiles(const double* slabs, int nsplit, int ntm, int ntn, double* out, int64_t ldo, hipStream_t st);
 // out[i] = sum_s partial[s][i], i < n

@@ -52,7 +52,7 @@ __device__ __forceinline__ void gemm64_body(const GemmArgs& a, int tm, int tn, d
 #pragma unroll
     for (int t1 = 0; t1 < Cfg::TM; ++t1)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < Cfg::MTr::NACC; ++r) {
             double* c = a.C + (int64_t)(tm * Cfg::BM + co.row(t1, r)) * a.ldc + tn * Cfg::BN;
 #pragma unroll
             for (int t2 = 0; t2 < Cfg::TN; ++t2) {

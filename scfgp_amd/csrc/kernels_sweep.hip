@@ -8,10 +8,32 @@
 // --------------------------------------------------------------------------
 // tile configurations (tuning knobs)
 // --------------------------------------------------------------------------
-template <typename T> struct GramCfg { typedef TileCfg<T, 128, 128, 16, 2, 2> type; };
-template <typename T> struct ApplyCfg { typedef TileCfg<T, 128, 128, 16, 2, 2> type; };
+// Gram: square TILE x TILE output tiles; apply: 128 rows x TILE columns.
+// TILE = 192 (3 x 64) fits K = 2112 / 4224 exactly; fp64 needs 8 waves there to stay in registers.
+// Measured on MI355X (N = 5e5..1e6, K = 2112; tests/gpu_tune.py, profiles/r01_tuning.md):
+//   * 8-wave workgroups (2 waves per SIMD inside one workgroup) beat 4-wave ones for both dtypes;
+//     fp64 apply gains again with 16 waves (4 per SIMD): the 64-cycle fp64 MFMA leaves room
+//     for every other wave's LDS / global traffic and the barrier bubbles overlap.
+//   * BK = 32 (fewer barriers, lower occupancy) and the 32x32x2 fp32 MFMA shape are slower.
+//   * TILE = 192 removes the padding of K = 2112 but its 96 x 96 wave tile costs occupancy;
+//     it only pays when it shrinks Kp by >= 8 % (see scfgp_create).
+#ifndef SCFGP_BK
+#define SCFGP_BK 16
+#endif
+#ifndef SCFGP_F32_MS
+#define SCFGP_F32_MS 16          // fp32 MFMA shape: 16 -> 16x16x4, 32 -> 32x32x2
+#endif
+template <typename T> struct Tune;
+template <> struct Tune<float>  { static constexpr int MS = SCFGP_F32_MS, GRAM_WGM = 4, GRAM_WGN = 2, APPLY_BM = 256, APPLY_WGM = 4, APPLY_WGN = 2; };
+template <> struct Tune<double> { static constexpr int MS = 16,           GRAM_WGM = 4, GRAM_WGN = 2, APPLY_BM = 256, APPLY_WGM = 4, APPLY_WGN = 4; };
+template <typename T, int TILE> struct GramCfg {
+    typedef TileCfg<T, TILE, TILE, SCFGP_BK, Tune<T>::GRAM_WGM, Tune<T>::GRAM_WGN, Tune<T>::MS> type;
+};
+template <typename T, int TILE> struct ApplyCfg {
+    typedef TileCfg<T, Tune<T>::APPLY_BM, TILE, SCFGP_BK, Tune<T>::APPLY_WGM, Tune<T>::APPLY_WGN, Tune<T>::MS> type;
+};
 typedef TileCfg<double, 128, 64, 16, 2, 2> FmapCfg;
-typedef TileCfg<double, 128, 128, 16, 2, 2> XtzCfg;
+typedef TileCfg<double, 128, 128, 16, 4, 2> XtzCfg;
 
 // --------------------------------------------------------------------------
 // feature map:  Z = X~ . Fall  (fp64 MFMA, K-dim = Dp),  Phi = s [cos Z | sin Z]
@@ -27,7 +49,7 @@ __global__ __launch_bounds__(FmapCfg::THREADS) void featuremap_kernel(
     const int64_t rb = blockIdx.x / njt;
     TrLoader<double, double, Cfg::BM, Cfg::BK, Cfg::LDA, Cfg::THREADS> la(Xt + rb * Cfg::BM * Dp, Dp, threadIdx.x);
     NatLoader<double, double, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS, false, false> lb(Fall + jt * Cfg::BN, Jp, threadIdx.x);
-    v4d acc[Cfg::TM][Cfg::TN];
+    typename Cfg::MTr::acc_t acc[Cfg::TM][Cfg::TN];
     acc_zero<Cfg>(acc);
     tile_mainloop<Cfg>(la, lb, Dp / Cfg::BK, acc, smem);
     const double s = sc->s;
@@ -39,7 +61,7 @@ __global__ __launch_bounds__(FmapCfg::THREADS) void featuremap_kernel(
             const int j = jt * Cfg::BN + co.col(tn);
             if (j >= J) continue;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int r = 0; r < Cfg::MTr::NACC; ++r) {
                 const int64_t n = rb * Cfg::BM + co.row(tm, r);
                 double sn, cs;
                 sincos(acc[tm][tn][r], &sn, &cs);
@@ -85,7 +107,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void tn_kernel(
     const int64_t r0 = (int64_t)blockIdx.y * rows_per_split;
     const int64_t r1 = r0 + rows_per_split < Np ? r0 + rows_per_split : Np;
     double* slab = slabs + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (Cfg::BM * Cfg::BN);
-    typename MT<T>::acc_t acc[Cfg::TM][Cfg::TN];
+    typename Cfg::MTr::acc_t acc[Cfg::TM][Cfg::TN];
     AccCoord<Cfg> co;
     bool first = true;
     for (int64_t c0 = r0; c0 < r1 || first; c0 += chunk) {
@@ -101,7 +123,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void tn_kernel(
 #pragma unroll
         for (int tm = 0; tm < Cfg::TM; ++tm)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int r = 0; r < Cfg::MTr::NACC; ++r) {
                 double* d = slab + co.row(tm, r) * Cfg::BN;
 #pragma unroll
                 for (int tn = 0; tn < Cfg::TN; ++tn) {
@@ -113,9 +135,9 @@ __global__ __launch_bounds__(Cfg::THREADS) void tn_kernel(
     }
 }
 
-template <typename T>
-void SweepKernels<T>::gram(const Geom& g, const T* Phi, const double* w, int nsplit, int64_t chunk, double* slabs, hipStream_t st) {
-    typedef typename GramCfg<T>::type Cfg;
+template <typename T, int TILE>
+static void gram_launch(const Geom& g, const T* Phi, const double* w, int nsplit, int64_t chunk, double* slabs, hipStream_t st) {
+    typedef typename GramCfg<T, TILE>::type Cfg;
     const int nts = g.Kp / Cfg::BM, ntiles = nts * (nts + 1) / 2;
     const int64_t rps = round_up((g.Np + nsplit - 1) / nsplit, 256);
     if (chunk <= 0 || chunk > rps) chunk = rps;
@@ -128,6 +150,11 @@ void SweepKernels<T>::gram(const Geom& g, const T* Phi, const double* w, int nsp
     else
         hipLaunchKernelGGL((tn_kernel<Cfg, T, T, false, false, true>), dim3(ntiles, nsplit), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st,
                            Phi, (int64_t)g.Kp, Phi, (int64_t)g.Kp, w, g.Np, rps, chunk, nts, g.Kp, slabs);
+}
+template <typename T>
+void SweepKernels<T>::gram(const Geom& g, const T* Phi, const double* w, int nsplit, int64_t chunk, double* slabs, hipStream_t st) {
+    if (g.tile == 192) gram_launch<T, 192>(g, Phi, w, nsplit, chunk, slabs, st);
+    else gram_launch<T, 128>(g, Phi, w, nsplit, chunk, slabs, st);
 }
 
 template <typename T>
@@ -157,7 +184,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void apply_kernel(
     const int64_t rb = blockIdx.x / njt;
     TrLoader<T, T, Cfg::BM, Cfg::BK, Cfg::LDA, Cfg::THREADS> la(Phi + rb * Cfg::BM * Kp, Kp, threadIdx.x);
     NatLoader<T, T, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS, false, false> lb(Bm + jt * Cfg::BN, Kp, threadIdx.x);
-    typename MT<T>::acc_t acc[Cfg::TM][Cfg::TN];
+    typename Cfg::MTr::acc_t acc[Cfg::TM][Cfg::TN];
     acc_zero<Cfg>(acc);
     tile_mainloop<Cfg>(la, lb, Kp / Cfg::BK, acc, smem);
     AccCoord<Cfg> co;
@@ -167,7 +194,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void apply_kernel(
 #pragma unroll
         for (int tm = 0; tm < Cfg::TM; ++tm)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int r = 0; r < Cfg::MTr::NACC; ++r) {
                 const int row = co.row(tm, r);
                 const int64_t off = (rb * Cfg::BM + row) * Kp + (int64_t)jt * Cfg::BN;
                 double part = 0;
@@ -177,9 +204,9 @@ __global__ __launch_bounds__(Cfg::THREADS) void apply_kernel(
                     V[off + co.col(tn)] = c;
                     part += (double)Phi[off + co.col(tn)] * (double)c;
                 }
-                part += __shfl_xor(part, 1); part += __shfl_xor(part, 2);
-                part += __shfl_xor(part, 4); part += __shfl_xor(part, 8);
-                if ((co.lane & 15) == 0) red[wn * Cfg::BM + row] = part;
+#pragma unroll
+                for (int m = 1; m < Cfg::MS; m <<= 1) part += __shfl_xor(part, m);      // lanes of one MFMA row group
+                if ((co.lane % Cfg::MS) == 0) red[wn * Cfg::BM + row] = part;
             }
         __syncthreads();
         if (threadIdx.x < Cfg::BM) {
@@ -192,7 +219,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void apply_kernel(
 #pragma unroll
         for (int tm = 0; tm < Cfg::TM; ++tm)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int r = 0; r < Cfg::MTr::NACC; ++r) {
                 const int64_t n = rb * Cfg::BM + co.row(tm, r);
                 const int64_t off = n * Kp + (int64_t)jt * Cfg::BN;
                 const double qn = 2.0 * q[n], pn = p[n], yn = y[n];
@@ -206,30 +233,36 @@ __global__ __launch_bounds__(Cfg::THREADS) void apply_kernel(
     }
 }
 
-template <typename T>
-void SweepKernels<T>::apply_v(const Geom& g, const T* Phi, const T* Bm, T* V, double* vpart, hipStream_t st) {
-    typedef typename ApplyCfg<T>::type Cfg;
+template <typename T, int TILE>
+static void apply_launch(int epi, const Geom& g, const T* Phi, const T* Bm, T* V, double* vpart, const double* p, const double* q,
+                         const double* y, const double* alpha, const double* ut, hipStream_t st) {
+    typedef typename ApplyCfg<T, TILE>::type Cfg;
     const int njt = g.Kp / Cfg::BN;
     const int64_t nrb = g.Np / Cfg::BM;
-    allow_big_lds(apply_kernel<Cfg, 0>, Cfg::LDS_BYTES);
-    hipLaunchKernelGGL((apply_kernel<Cfg, 0>), dim3((unsigned)(njt * nrb)), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st,
-                       Phi, Bm, V, vpart, (const double*)nullptr, (const double*)nullptr, (const double*)nullptr,
-                       (const double*)nullptr, (const double*)nullptr, g.Kp, g.Np, njt);
+    if (epi == 0) {
+        allow_big_lds(apply_kernel<Cfg, 0>, Cfg::LDS_BYTES);
+        hipLaunchKernelGGL((apply_kernel<Cfg, 0>), dim3((unsigned)(njt * nrb)), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st,
+                           Phi, Bm, V, vpart, p, q, y, alpha, ut, g.Kp, g.Np, njt);
+    } else {
+        allow_big_lds(apply_kernel<Cfg, 1>, Cfg::LDS_BYTES);
+        hipLaunchKernelGGL((apply_kernel<Cfg, 1>), dim3((unsigned)(njt * nrb)), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st,
+                           Phi, Bm, V, vpart, p, q, y, alpha, ut, g.Kp, g.Np, njt);
+    }
 }
-
+template <typename T>
+void SweepKernels<T>::apply_v(const Geom& g, const T* Phi, const T* Bm, T* V, double* vpart, hipStream_t st) {
+    if (g.tile == 192) apply_launch<T, 192>(0, g, Phi, Bm, V, vpart, nullptr, nullptr, nullptr, nullptr, nullptr, st);
+    else apply_launch<T, 128>(0, g, Phi, Bm, V, vpart, nullptr, nullptr, nullptr, nullptr, nullptr, st);
+}
 template <typename T>
 void SweepKernels<T>::apply_phibar(const Geom& g, const T* Phi, const T* Abar, T* V, const double* p, const double* q,
                                    const double* y, const double* alpha, const double* ut, hipStream_t st) {
-    typedef typename ApplyCfg<T>::type Cfg;
-    const int njt = g.Kp / Cfg::BN;
-    const int64_t nrb = g.Np / Cfg::BM;
-    allow_big_lds(apply_kernel<Cfg, 1>, Cfg::LDS_BYTES);
-    hipLaunchKernelGGL((apply_kernel<Cfg, 1>), dim3((unsigned)(njt * nrb)), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st,
-                       Phi, Abar, V, (double*)nullptr, p, q, y, alpha, ut, g.Kp, g.Np, njt);
+    if (g.tile == 192) apply_launch<T, 192>(1, g, Phi, Abar, V, nullptr, p, q, y, alpha, ut, st);
+    else apply_launch<T, 128>(1, g, Phi, Abar, V, nullptr, p, q, y, alpha, ut, st);
 }
 
-// number of 128-wide column tiles of the apply kernel (vpart leading count)
-template <typename T> static int apply_njt(const Geom& g) { return g.Kp / ApplyCfg<T>::type::BN; }
+// number of column tiles of the apply kernel (vpart leading count)
+template <typename T> static int apply_njt(const Geom& g) { return g.Kp / g.tile; }
 
 // --------------------------------------------------------------------------
 // column sums  out[c] = sum_n w[n] Phi[n][c]   (Phi^T y, Phi^T p)
@@ -391,9 +424,8 @@ template struct SweepKernels<float>;
 // --------------------------------------------------------------------------
 // reductions (deterministic: fixed order over splits)
 // --------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void reduce_tri_kernel(const double* __restrict__ slabs, int nsplit, int ntiles, double* __restrict__ out,
-                                                         int64_t ldo) {
-    constexpr int B = 128;
+__global__ __launch_bounds__(256) void reduce_tri_kernel(const double* __restrict__ slabs, int nsplit, int ntiles, int B,
+                                                         double* __restrict__ out, int64_t ldo) {
     const int t = blockIdx.x;
     int ti = (int)((sqrtf(8.0f * t + 1.0f) - 1.0f) * 0.5f);
     while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
@@ -407,9 +439,9 @@ __global__ __launch_bounds__(256) void reduce_tri_kernel(const double* __restric
         if (ti != tj) out[(int64_t)j * ldo + i] = s;
     }
 }
-void reduce_tri_tiles(const double* slabs, int nsplit, int nts, double* out, int64_t ldo, hipStream_t st) {
+void reduce_tri_tiles(const double* slabs, int nsplit, int nts, int tile, double* out, int64_t ldo, hipStream_t st) {
     const int ntiles = nts * (nts + 1) / 2;
-    hipLaunchKernelGGL(reduce_tri_kernel, dim3(ntiles, 16), dim3(256), 0, st, slabs, nsplit, ntiles, out, ldo);
+    hipLaunchKernelGGL(reduce_tri_kernel, dim3(ntiles, 16), dim3(256), 0, st, slabs, nsplit, ntiles, tile, out, ldo);
 }
 
 __global__ __launch_bounds__(256) void reduce_full_kernel(const double* __restrict__ slabs, int nsplit, int ntiles, int ntn,

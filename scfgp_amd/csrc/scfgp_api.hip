@@ -4,6 +4,7 @@
 #include "kernels.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -17,7 +18,7 @@
         }                                                                                           \
     } while (0)
 
-static constexpr int TILE = 128;            // column tile of the Gram / apply kernels (kernels_sweep.hip)
+static constexpr int XT = 128;              // tile of the X~^T Zbar product and padding unit of J (kernels_sweep.hip)
 static constexpr int64_t PRED_ROWS = 32768; // predict processes test rows in chunks of this size
 
 struct ProfRec { std::string name; hipEvent_t e0, e1; };
@@ -88,7 +89,7 @@ template <typename P> static int dmalloc(scfgp_ctx* c, P** p, size_t bytes) {
 template <typename P> static void dfree(P*& p) { if (p) { hipFree((void*)p); p = nullptr; } }
 
 static int default_split(int ntiles, int64_t Np) {
-    int64_t s = (1024 + ntiles - 1) / ntiles;
+    int64_t s = (6144 + ntiles - 1) / ntiles;         // >> 768 resident workgroups: no tail quantisation
     const int64_t smax = Np / 256;
     if (s > smax) s = smax;
     if (s < 1) s = 1;
@@ -106,11 +107,11 @@ static int ensure_rows(scfgp_ctx* c, int64_t N) {
     Geom& g = c->g;
     const int64_t Np = round_up(N > 0 ? N : 1, 256);
     g.N = N; g.Np = Np;
-    const int nts = g.Kp / TILE, ntiles = nts * (nts + 1) / 2;
-    const int ntx = ((g.Dp + TILE - 1) / TILE) * (g.Jp / TILE);
+    const int nts = g.Kp / g.tile, ntiles = nts * (nts + 1) / 2;
+    const int ntx = ((g.Dp + XT - 1) / XT) * (g.Jp / XT);
     const int gs = c->gram_nsplit > 0 ? (int)std::min<int64_t>(c->gram_nsplit, Np / 256) : default_split(ntiles, Np);
     const int xs = c->xtz_nsplit > 0 ? (int)std::min<int64_t>(c->xtz_nsplit, Np / 256) : default_split(ntx, Np);
-    const size_t need = sizeof(double) * TILE * TILE * std::max<size_t>((size_t)gs * ntiles, (size_t)xs * ntx);
+    const size_t need = sizeof(double) * std::max<size_t>((size_t)gs * ntiles * g.tile * g.tile, (size_t)xs * ntx * XT * XT);
     if (need > c->slabs_bytes) {
         dfree(c->d_slabs);
         if (int rc = dmalloc(c, &c->d_slabs, need)) return rc;
@@ -126,7 +127,7 @@ static int ensure_rows(scfgp_ctx* c, int64_t N) {
     if ((rc = dmalloc(c, &c->d_y, sizeof(double) * Np))) return rc;
     if ((rc = dmalloc(c, &c->d_p, sizeof(double) * Np))) return rc;
     if ((rc = dmalloc(c, &c->d_q, sizeof(double) * Np))) return rc;
-    if ((rc = dmalloc(c, &c->d_vpart, sizeof(double) * Np * (g.Kp / TILE)))) return rc;
+    if ((rc = dmalloc(c, &c->d_vpart, sizeof(double) * Np * (g.Kp / g.tile)))) return rc;
     if ((rc = dmalloc(c, &c->d_Phi, ts * Np * g.Kp))) return rc;
     if ((rc = dmalloc(c, &c->d_V, ts * Np * g.Kp))) return rc;
     if ((rc = dmalloc(c, &c->d_Zbar, ts * Np * g.Jp))) return rc;
@@ -143,8 +144,12 @@ extern "C" int scfgp_create(scfgp_ctx** out, int D, int S, int M, int dtype, int
     c->dtype = dtype; c->device = device;
     Geom& g = c->g;
     g.D = D; g.S = S; g.M = M; g.J = S + M; g.K = 2 * g.J; g.P = 3 + D * S + M * S + S + M;
-    g.Dp = (int)round_up(D + 1, 16); g.Jp = (int)round_up(g.J, TILE); g.Kp = (int)round_up(g.K, TILE);
-    c->Dpp = (int)round_up(g.Dp, TILE);
+    g.Dp = (int)round_up(D + 1, 16); g.Jp = (int)round_up(g.J, XT);
+    // 192-wide tiles only when they cut the padded size by >= 8 % (their wave tile costs occupancy)
+    g.tile = round_up(g.K, 192) * 100 <= round_up(g.K, 128) * 92 ? 192 : 128;
+    if (const char* e = getenv("SCFGP_TILE")) { const int t = atoi(e); if (t == 128 || t == 192) g.tile = t; }   // tuning override
+    g.Kp = (int)round_up(g.K, g.tile);
+    c->Dpp = (int)round_up(g.Dp, XT);
     HIPCHK(c, hipSetDevice(device));
     if (stream) c->st = (hipStream_t)stream;
     else { HIPCHK(c, hipStreamCreate(&c->st)); c->own_stream = true; }
@@ -247,11 +252,11 @@ template <typename T> struct Impl {
 
     static void gram_to(scfgp_ctx* c, const double* w, double* out, const char* name) {
         const Geom& g = c->g;
-        const int nts = g.Kp / TILE, ntiles = nts * (nts + 1) / 2;
+        const int nts = g.Kp / g.tile, ntiles = nts * (nts + 1) / 2;
         const int gs = c->gram_nsplit > 0 ? (int)std::min<int64_t>(c->gram_nsplit, g.Np / 256) : default_split(ntiles, g.Np);
         { ProfScope ps(c, name);
           SK::gram(g, (const T*)c->d_Phi, w, gs, c->dtype == SCFGP_F32 ? c->gram_chunk : 0, c->d_slabs, c->st); }
-        { ProfScope ps(c, "reduce_tiles"); reduce_tri_tiles(c->d_slabs, gs, nts, out, g.Kp, c->st); }
+        { ProfScope ps(c, "reduce_tiles"); reduce_tri_tiles(c->d_slabs, gs, nts, g.tile, out, g.Kp, c->st); }
     }
     static void colsum_to(scfgp_ctx* c, const double* w, double* out) {
         const Geom& g = c->g;
@@ -309,7 +314,7 @@ template <typename T> struct Impl {
         { ProfScope ps(c, "zbar");
           SK::zbar(g, (const T*)c->d_Phi, (const T*)c->d_V, (T*)c->d_Zbar, c->d_partial, nb, c->st);
           reduce_scalars(c->d_partial, nb, 1, c->d_x3 + (int64_t)c->Dpp * g.Jp, 0, c->st); }
-        const int ntm = c->Dpp / TILE, ntn = g.Jp / TILE;
+        const int ntm = c->Dpp / XT, ntn = g.Jp / XT;
         const int xs = c->xtz_nsplit > 0 ? (int)std::min<int64_t>(c->xtz_nsplit, g.Np / 256) : default_split(ntm * ntn, g.Np);
         { ProfScope ps(c, "xtz");
           SK::xtz(g, c->d_Xt, (const T*)c->d_Zbar, xs, c->d_slabs, c->st);
@@ -435,7 +440,7 @@ extern "C" int scfgp_predict(scfgp_ctx* c, const double* Xs, int64_t T, const do
     int rc;
     if (!c->p_Xt) {
         if ((rc = dmalloc(c, &c->p_Xt, sizeof(double) * PRED_ROWS * g0.Dp))) return rc;
-        if ((rc = dmalloc(c, &c->p_vpart, sizeof(double) * PRED_ROWS * (Kp / TILE)))) return rc;
+        if ((rc = dmalloc(c, &c->p_vpart, sizeof(double) * PRED_ROWS * (Kp / g0.tile)))) return rc;
         if ((rc = dmalloc(c, &c->p_mu, sizeof(double) * PRED_ROWS))) return rc;
         if ((rc = dmalloc(c, &c->p_sd, sizeof(double) * PRED_ROWS))) return rc;
         if ((rc = dmalloc(c, &c->p_Phi, ts * PRED_ROWS * Kp))) return rc;
@@ -473,6 +478,7 @@ extern "C" int scfgp_predict(scfgp_ctx* c, const double* Xs, int64_t T, const do
 extern "C" int scfgp_get_dims(scfgp_ctx* c, int64_t* out, int n) {
     if (!c || !out || n < 6) return SCFGP_EARG;
     out[0] = c->g.K; out[1] = c->g.Kp; out[2] = c->g.Jp; out[3] = c->g.Dp; out[4] = c->g.Np; out[5] = c->g.P;
+    if (n >= 7) out[6] = c->g.tile;
     return SCFGP_OK;
 }
 

@@ -1,8 +1,8 @@
 // MFMA tile engine for gfx950: C[m][n] += sum_k Aop[k][m] * Bop[k][n]
 //
 // One code path serves fp64 (v_mfma_f64_16x16x4_f64) and exact fp32
-// (v_mfma_f32_16x16x4_f32): both take ONE scalar per lane for A and B with
-// lane l supplying A[i=l&15][k=l>>4] and B[k=l>>4][j=l&15], so the LDS image is
+// (v_mfma_f32_16x16x4_f32 / v_mfma_f32_32x32x2_f32): all take ONE scalar per lane for A and B
+// with lane l supplying A[i=l%MS][k=l/MS] and B[k=l/MS][j=l%MS], so the LDS image is
 // k-major -- sA[k][m], sB[k][n] -- and every fragment read is 16 consecutive
 // elements per k row: bank-conflict free with a row stride == 16 (mod 32)
 // elements (LD = B? + 16).  The two shapes differ only in the C/D row map.
@@ -16,36 +16,48 @@
 #pragma once
 #include "common.h"
 
-template <typename T> struct MT;
-template <> struct MT<double> {
+// MFMA traits: element type T and instruction shape MS (16: 16x16x4, 32: 32x32x2, f32 only).
+//   lane l supplies A[i = l % MS][k = l / MS] and B[k = l / MS][j = l % MS]
+template <typename T, int MS> struct MT;
+template <> struct MT<double, 16> {
     typedef v4d acc_t;
-    static constexpr int VEC = 2;                      // elements per 16 bytes
+    static constexpr int M = 16, KS = 4, NACC = 4;
     static __device__ __forceinline__ void mfma(acc_t& c, double a, double b) {
         c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
     }
     // C/D row held in accumulator register r of lane `lane` (f64 map, guide sec. 3)
     static __device__ __forceinline__ int crow(int lane, int r) { return (lane >> 4) + 4 * r; }
 };
-template <> struct MT<float> {
+template <> struct MT<float, 16> {
     typedef v4f acc_t;
-    static constexpr int VEC = 4;
+    static constexpr int M = 16, KS = 4, NACC = 4;
     static __device__ __forceinline__ void mfma(acc_t& c, float a, float b) {
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
     }
     static __device__ __forceinline__ int crow(int lane, int r) { return 4 * (lane >> 4) + r; }
 };
+typedef float v16f __attribute__((ext_vector_type(16)));
+template <> struct MT<float, 32> {
+    typedef v16f acc_t;
+    static constexpr int M = 32, KS = 2, NACC = 16;
+    static __device__ __forceinline__ void mfma(acc_t& c, float a, float b) {
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int crow(int lane, int r) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+};
 
-template <typename T_, int BM_, int BN_, int BK_, int WGM_, int WGN_>
+template <typename T_, int BM_, int BN_, int BK_, int WGM_, int WGN_, int MS_ = 16>
 struct TileCfg {
     typedef T_ T;
-    static constexpr int BM = BM_, BN = BN_, BK = BK_, WGM = WGM_, WGN = WGN_;
+    typedef MT<T_, MS_> MTr;
+    static constexpr int BM = BM_, BN = BN_, BK = BK_, WGM = WGM_, WGN = WGN_, MS = MS_;
     static constexpr int THREADS = 64 * WGM * WGN;
     static constexpr int WM = BM / WGM, WN = BN / WGN;
-    static constexpr int TM = WM / 16, TN = WN / 16;
+    static constexpr int TM = WM / MS, TN = WN / MS;
     static constexpr int LDA = BM + 16, LDB = BN + 16;
     static constexpr int SA = BK * LDA, SB = BK * LDB;        // elements per buffer
     static constexpr int LDS_BYTES = 2 * (SA + SB) * (int)sizeof(T);
-    static_assert(BM % (16 * WGM) == 0 && BN % (16 * WGN) == 0 && BK % 4 == 0, "tile shape");
+    static_assert(BM % (MS * WGM) == 0 && BN % (MS * WGN) == 0 && BK % MTr::KS == 0, "tile shape");
 };
 
 // 16-byte global vector of source type
@@ -64,7 +76,6 @@ struct NatLoader {
     static constexpr int VS = Vec16<S>::N;
     static constexpr int VPR = BX / VS;                       // vectors per k row
     static constexpr int NV = (BK * VPR + THREADS - 1) / THREADS;
-    static_assert((BK * VPR) % THREADS == 0 || NV == 1, "loader shape");
     const S* base; int64_t ld; const double* w; int xlim;     // xlim: first invalid x (GUARD)
     vec_t r[NV]; T wr[NV];
     int tid;
@@ -114,7 +125,6 @@ struct TrLoader {
     static constexpr int VS = Vec16<S>::N;
     static constexpr int VPR = BK / VS;                       // vectors per x row
     static constexpr int NV = (BX * VPR + THREADS - 1) / THREADS;
-    static_assert((BX * VPR) % THREADS == 0 || NV == 1, "loader shape");
     const S* base; int64_t ld; int tid;
     vec_t r[NV];
     __device__ __forceinline__ TrLoader(const S* b, int64_t l, int t) : base(b), ld(l), tid(t) {}
@@ -148,10 +158,11 @@ struct TrLoader {
 // ---------------------------------------------------------------------------
 template <class Cfg, class LA, class LB>
 __device__ __forceinline__ void tile_mainloop(LA& la, LB& lb, int nkt,
-                                              typename MT<typename Cfg::T>::acc_t (&acc)[Cfg::TM][Cfg::TN],
+                                              typename Cfg::MTr::acc_t (&acc)[Cfg::TM][Cfg::TN],
                                               typename Cfg::T* smem) {
     typedef typename Cfg::T T;
-    typedef MT<T> M;
+    typedef typename Cfg::MTr M;
+    constexpr int MS = Cfg::MS, KS = M::KS;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm0 = (wave / Cfg::WGN) * Cfg::WM, wn0 = (wave % Cfg::WGN) * Cfg::WN;
     T* sA = smem;
@@ -163,15 +174,15 @@ __device__ __forceinline__ void tile_mainloop(LA& la, LB& lb, int nkt,
         const int cur = kt & 1;
         const bool more = kt + 1 < nkt;
         if (more) { la.load(kt + 1); lb.load(kt + 1); }
-        const T* a_s = sA + cur * Cfg::SA + (lane >> 4) * Cfg::LDA + wm0 + (lane & 15);
-        const T* b_s = sB + cur * Cfg::SB + (lane >> 4) * Cfg::LDB + wn0 + (lane & 15);
+        const T* a_s = sA + cur * Cfg::SA + (lane / MS) * Cfg::LDA + wm0 + (lane % MS);
+        const T* b_s = sB + cur * Cfg::SB + (lane / MS) * Cfg::LDB + wn0 + (lane % MS);
 #pragma unroll
-        for (int kk = 0; kk < Cfg::BK / 4; ++kk) {
+        for (int kk = 0; kk < Cfg::BK / KS; ++kk) {
             T a[Cfg::TM], b[Cfg::TN];
 #pragma unroll
-            for (int tm = 0; tm < Cfg::TM; ++tm) a[tm] = a_s[kk * 4 * Cfg::LDA + tm * 16];
+            for (int tm = 0; tm < Cfg::TM; ++tm) a[tm] = a_s[kk * KS * Cfg::LDA + tm * MS];
 #pragma unroll
-            for (int tn = 0; tn < Cfg::TN; ++tn) b[tn] = b_s[kk * 4 * Cfg::LDB + tn * 16];
+            for (int tn = 0; tn < Cfg::TN; ++tn) b[tn] = b_s[kk * KS * Cfg::LDB + tn * MS];
 #pragma unroll
             for (int tm = 0; tm < Cfg::TM; ++tm)
 #pragma unroll
@@ -183,13 +194,13 @@ __device__ __forceinline__ void tile_mainloop(LA& la, LB& lb, int nkt,
 }
 
 template <class Cfg>
-__device__ __forceinline__ void acc_zero(typename MT<typename Cfg::T>::acc_t (&acc)[Cfg::TM][Cfg::TN]) {
+__device__ __forceinline__ void acc_zero(typename Cfg::MTr::acc_t (&acc)[Cfg::TM][Cfg::TN]) {
 #pragma unroll
     for (int tm = 0; tm < Cfg::TM; ++tm)
 #pragma unroll
         for (int tn = 0; tn < Cfg::TN; ++tn)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[tm][tn][r] = 0;
+            for (int r = 0; r < Cfg::MTr::NACC; ++r) acc[tm][tn][r] = 0;
 }
 
 // coordinates of accumulator element (tm,tn,r) inside the workgroup tile
@@ -201,8 +212,6 @@ struct AccCoord {
         const int wave = threadIdx.x >> 6;
         wm0 = (wave / Cfg::WGN) * Cfg::WM; wn0 = (wave % Cfg::WGN) * Cfg::WN;
     }
-    __device__ __forceinline__ int row(int tm, int r) const {
-        return wm0 + tm * 16 + MT<typename Cfg::T>::crow(lane, r);
-    }
-    __device__ __forceinline__ int col(int tn) const { return wn0 + tn * 16 + (lane & 15); }
+    __device__ __forceinline__ int row(int tm, int r) const { return wm0 + tm * Cfg::MS + Cfg::MTr::crow(lane, r); }
+    __device__ __forceinline__ int col(int tn) const { return wn0 + tn * Cfg::MS + (lane % Cfg::MS); }
 };

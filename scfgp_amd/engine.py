@@ -167,9 +167,9 @@ class HipEngine(object):
 
     # -- introspection ----------------------------------------------------------------------------
     def dims(self):
-        out = (C.c_int64 * 6)()
-        self._check(self.lib.scfgp_get_dims(self.ctx, out, 6), 'get_dims')
-        return dict(zip(('K', 'Kp', 'Jp', 'Dp', 'Np', 'P'), [int(v) for v in out]))
+        out = (C.c_int64 * 7)()
+        self._check(self.lib.scfgp_get_dims(self.ctx, out, 7), 'get_dims')
+        return dict(zip(('K', 'Kp', 'Jp', 'Dp', 'Np', 'P', 'tile'), [int(v) for v in out]))
 
     def set_profiling(self, on=True):
         self._check(self.lib.scfgp_set_profiling(self.ctx, int(bool(on))), 'set_profiling')
