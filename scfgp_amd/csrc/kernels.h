@@ -8,7 +8,7 @@ struct Geom {
     int D, S, M, J, K, P;
     int Dp;      // round_up(D+1,16): X~ = [X | 1 | 0..]   (ones column carries the phase offsets)
     int Jp;      // round_up(J,128)
-    int Kp;      // round_up(K,tile)
+    int Kp;      // round_up(K+2,tile): columns K and K+1 of Phi hold y and p (augmented Gram)
     int tile;    // 128 or 192: column tile of the Gram / apply kernels, chosen to minimise Kp
     int64_t N;   // valid local rows
     int64_t Np;  // round_up(N,256)
@@ -19,25 +19,27 @@ template <typename T> struct SweepKernels {
     static void featuremap(const Geom& g, const double* Xt, const double* Fall, const Scal* sc, T* Phi, hipStream_t st);
     // lower tiles of  Phi^T diag(w) Phi  into per-split fp64 slabs (SCFGP.py:104; weighted: backward of :111-113)
     static void gram(const Geom& g, const T* Phi, const double* w, int nsplit, int64_t chunk, double* slabs, hipStream_t st);
-    // out[c] = sum_n w[n] Phi[n][c]  -> partial[nsplit][Kp]          (SCFGP.py:108)
-    static void colsum(const Geom& g, const T* Phi, const double* w, int nsplit, double* partial, hipStream_t st);
     // V = Phi . Bm, vpart[jt][n] = sum_{j in tile} Phi[n][j] V[n][j]    (SCFGP.py:112)
     static void apply_v(const Geom& g, const T* Phi, const T* Bm, T* V, double* vpart, hipStream_t st);
-    // Phibar = 2 Phi.Abar + 2 q V + p alpha^T + y ut^T  (in place over V)
-    static void apply_phibar(const Geom& g, const T* Phi, const T* Abar, T* V, const double* p, const double* q,
-                             const double* y, const double* alpha, const double* ut, hipStream_t st);
+    // Phibar = 2 Phi.Abar + 2 q V + p alpha^T + y ut^T  (in place over V); bpart[block] = partial of
+    // bbar = sum Phibar o Phi.  Returns the number of blocks (= partials written).
+    static int apply_phibar(const Geom& g, const T* Phi, const T* Abar, T* V, const double* p, const double* q,
+                            const double* y, const double* alpha, const double* ut, double* bpart, hipStream_t st);
+    static int apply_blocks(const Geom& g);
     // per-row moments and adjoint scalars; block partials of (T2, kbar)  (SCFGP.py:111-113,121-124)
-    static void rowstats(const Geom& g, const T* Phi, const double* alpha, const double* vpart, const double* y,
+    static void rowstats(const Geom& g, T* Phi, const double* alpha, const double* vpart, const double* y,
                          const Scal* sc, double* p, double* q, double* partial, int nblocks, hipStream_t st);
     // predictive mean / std                                          (SCFGP.py:143-144)
     static void rowpredict(const Geom& g, const T* Phi, const double* alpha, const double* vpart, const Scal* sc,
                            double* mu, double* sd, hipStream_t st);
-    // Zbar[n][j] = Phi[n][j] Phibar[n][J+j] - Phi[n][J+j] Phibar[n][j]; block partials of bbar
-    static void zbar(const Geom& g, const T* Phi, const T* Phibar, T* Zbar, double* partial, int nblocks, hipStream_t st);
-    // X~^T Zbar into per-split fp64 slabs
-    static void xtz(const Geom& g, const double* Xt, const T* Zbar, int nsplit, double* slabs, hipStream_t st);
-    // fp64 matrix -> T (no-op copy for double)
-    static void convert(const double* src, T* dst, int64_t n, hipStream_t st);
+    // X~^T Zbar into per-split fp64 slabs, Zbar[n][j] = Phi[n][j] Phibar[n][J+j] - Phi[n][J+j] Phibar[n][j]
+    // formed inside the operand loader
+    static void xtz(const Geom& g, const double* Xt, const T* Phi, const T* Phibar, int nsplit, int64_t chunk, double* slabs,
+                    hipStream_t st);
+    // fp64 Kp x Kp matrix -> sweep operand (type T, rows/cols >= K zeroed)
+    static void convert(const double* src, T* dst, int K, int Kp, hipStream_t st);
+    // Phi[:, col] = src  (augmented columns)
+    static void set_col(const Geom& g, T* Phi, int col, const double* src, hipStream_t st);
 };
 
 // ---- reductions ------------------------------------------------------------
@@ -45,6 +47,8 @@ template <typename T> struct SweepKernels {
 void reduce_tri_tiles(const double* slabs, int nsplit, int nts, int tile, double* out, int64_t ldo, hipStream_t st);
 // out (ldo) = sum over splits of a full ntm x ntn tile grid of slabs
 void reduce_full_tiles(const double* slabs, int nsplit, int ntm, int ntn, double* out, int64_t ldo, hipStream_t st);
+// dst[j<K] = x[row][j], then zero rows/cols K, K+1 of the Kp x Kp matrix x (augmented Gram -> plain)
+void extract_aug(double* x, int K, int Kp, int row, double* dst, hipStream_t st);
 // out[i] = sum_s partial[s][i], i < n
 void reduce_rows(const double* partial, int nsplit, int64_t n, double* out, hipStream_t st);
 // scalars[slot0 + k] = sum_b partial[b*width + k], k < width

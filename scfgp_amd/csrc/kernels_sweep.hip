@@ -33,7 +33,7 @@ template <typename T, int TILE> struct ApplyCfg {
     typedef TileCfg<T, Tune<T>::APPLY_BM, TILE, SCFGP_BK, Tune<T>::APPLY_WGM, Tune<T>::APPLY_WGN, Tune<T>::MS> type;
 };
 typedef TileCfg<double, 128, 64, 16, 2, 2> FmapCfg;
-typedef TileCfg<double, 128, 128, 16, 4, 2> XtzCfg;
+template <typename T> struct XtzCfg { typedef TileCfg<T, 128, 128, 16, 4, 2, Tune<T>::MS> type; };
 
 // --------------------------------------------------------------------------
 // feature map:  Z = X~ . Fall  (fp64 MFMA, K-dim = Dp),  Phi = s [cos Z | sin Z]
@@ -82,55 +82,89 @@ void SweepKernels<T>::featuremap(const Geom& g, const double* Xt, const double* 
 }
 
 // --------------------------------------------------------------------------
-// TN products (contraction over rows): lower tiles of Phi^T diag(w) Phi, and X~^T Zbar.
-//   grid.x = tile, grid.y = row split.  fp32 accumulators are flushed into the
-//   workgroup's private fp64 slab every `chunk` rows (error of one fp32 chain stays
-//   ~sqrt(chunk)*2^-24); fp64 runs one chunk.
+// TN products (contraction over rows), one workgroup per (output tile, row split):
+//   gram_kernel  lower tiles of  Phi~^T diag(w) Phi~   (Phi~ = [Phi | y | p]: the augmented
+//                columns K, K+1 make Phi^T y and Phi^T p fall out of the same MFMA stream)
+//   xtz_kernel   X~^T Zbar with Zbar formed on the fly (ZbarLoader)
+// fp32 accumulators are flushed into the workgroup's private fp64 slab every `chunk` rows
+// (one fp32 chain stays ~sqrt(chunk)*2^-24); fp64 runs one chunk.
 // --------------------------------------------------------------------------
-template <class Cfg, typename SA, typename SB, bool WEIGHT, bool GUARDA, bool TRI>
-__global__ __launch_bounds__(Cfg::THREADS) void tn_kernel(
-    const SA* __restrict__ A, int64_t lda, const SB* __restrict__ B, int64_t ldb, const double* __restrict__ w,
-    int64_t Np, int64_t rows_per_split, int64_t chunk, int ntn, int mlim, double* __restrict__ slabs) {
+template <class Cfg>
+__device__ __forceinline__ void slab_flush(const typename Cfg::MTr::acc_t (&acc)[Cfg::TM][Cfg::TN], double* slab, bool first) {
+    AccCoord<Cfg> co;
+#pragma unroll
+    for (int tm = 0; tm < Cfg::TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < Cfg::MTr::NACC; ++r) {
+            double* d = slab + co.row(tm, r) * Cfg::BN;
+#pragma unroll
+            for (int tn = 0; tn < Cfg::TN; ++tn) {
+                const double v = (double)acc[tm][tn][r];
+                d[co.col(tn)] = first ? v : d[co.col(tn)] + v;
+            }
+        }
+}
+
+template <class Cfg, bool WEIGHT>
+__global__ __launch_bounds__(Cfg::THREADS) void gram_kernel(
+    const typename Cfg::T* __restrict__ Phi, int64_t ld, const double* __restrict__ w, int64_t Np, int64_t rows_per_split,
+    int64_t chunk, int nts, int xplain_col, double* __restrict__ slabs) {
     typedef typename Cfg::T T;
     SMEM_DECL;
     T* smem = reinterpret_cast<T*>(smem_raw);
-    int ti, tj;
-    if (TRI) {
-        const int t = blockIdx.x;
-        ti = (int)((sqrtf(8.0f * t + 1.0f) - 1.0f) * 0.5f);
-        while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-        while (ti * (ti + 1) / 2 > t) --ti;
-        tj = t - ti * (ti + 1) / 2;
-    } else {
-        ti = blockIdx.x / ntn; tj = blockIdx.x % ntn;
-    }
-    const int64_t r0 = (int64_t)blockIdx.y * rows_per_split;
+    const unsigned wid = xcd_remap(blockIdx.x, gridDim.x);
+    const int ntile = nts * (nts + 1) / 2;
+    const int t = (int)(wid % ntile), split = (int)(wid / ntile);
+    int ti = (int)((sqrtf(8.0f * t + 1.0f) - 1.0f) * 0.5f);
+    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    while (ti * (ti + 1) / 2 > t) --ti;
+    const int tj = t - ti * (ti + 1) / 2;
+    const int64_t r0 = (int64_t)split * rows_per_split;
     const int64_t r1 = r0 + rows_per_split < Np ? r0 + rows_per_split : Np;
-    double* slab = slabs + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (Cfg::BM * Cfg::BN);
+    double* slab = slabs + ((int64_t)split * ntile + t) * (Cfg::BM * Cfg::BN);
     typename Cfg::MTr::acc_t acc[Cfg::TM][Cfg::TN];
-    AccCoord<Cfg> co;
     bool first = true;
     for (int64_t c0 = r0; c0 < r1 || first; c0 += chunk) {
         const int64_t c1 = c0 + chunk < r1 ? c0 + chunk : r1;
         acc_zero<Cfg>(acc);
         if (c0 < r1) {
-            NatLoader<SA, T, Cfg::BM, Cfg::BK, Cfg::LDA, Cfg::THREADS, WEIGHT, GUARDA> la(
-                A + c0 * lda + (int64_t)ti * Cfg::BM, lda, threadIdx.x, WEIGHT ? w + c0 : nullptr, mlim - ti * Cfg::BM);
-            NatLoader<SB, T, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS, false, false> lb(
-                B + c0 * ldb + (int64_t)tj * Cfg::BN, ldb, threadIdx.x);
+            NatLoader<T, T, Cfg::BM, Cfg::BK, Cfg::LDA, Cfg::THREADS, WEIGHT, false> la(
+                Phi + c0 * ld + (int64_t)ti * Cfg::BM, ld, threadIdx.x, WEIGHT ? w + c0 : nullptr);
+            la.xplain = xplain_col - ti * Cfg::BM;             // the p column enters the weighted Gram unweighted
+            NatLoader<T, T, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS, false, false> lb(
+                Phi + c0 * ld + (int64_t)tj * Cfg::BN, ld, threadIdx.x);
             tile_mainloop<Cfg>(la, lb, (int)((c1 - c0) / Cfg::BK), acc, smem);
         }
-#pragma unroll
-        for (int tm = 0; tm < Cfg::TM; ++tm)
-#pragma unroll
-            for (int r = 0; r < Cfg::MTr::NACC; ++r) {
-                double* d = slab + co.row(tm, r) * Cfg::BN;
-#pragma unroll
-                for (int tn = 0; tn < Cfg::TN; ++tn) {
-                    const double v = (double)acc[tm][tn][r];
-                    d[co.col(tn)] = first ? v : d[co.col(tn)] + v;
-                }
-            }
+        slab_flush<Cfg>(acc, slab, first);
+        first = false;
+    }
+}
+
+template <class Cfg, typename S>
+__global__ __launch_bounds__(Cfg::THREADS) void xtz_kernel(
+    const double* __restrict__ Xt, int Dp, const S* __restrict__ Phi, const S* __restrict__ Pb, int64_t ld, int J, int64_t Np,
+    int64_t rows_per_split, int64_t chunk, int ntn, int ntile, double* __restrict__ slabs) {
+    typedef typename Cfg::T T;
+    SMEM_DECL;
+    T* smem = reinterpret_cast<T*>(smem_raw);
+    const unsigned wid = xcd_remap(blockIdx.x, gridDim.x);
+    const int t = (int)(wid % ntile), split = (int)(wid / ntile);
+    const int ti = t / ntn, tj = t % ntn;
+    const int64_t r0 = (int64_t)split * rows_per_split;
+    const int64_t r1 = r0 + rows_per_split < Np ? r0 + rows_per_split : Np;
+    double* slab = slabs + ((int64_t)split * ntile + t) * (Cfg::BM * Cfg::BN);
+    typename Cfg::MTr::acc_t acc[Cfg::TM][Cfg::TN];
+    bool first = true;
+    for (int64_t c0 = r0; c0 < r1 || first; c0 += chunk) {
+        const int64_t c1 = c0 + chunk < r1 ? c0 + chunk : r1;
+        acc_zero<Cfg>(acc);
+        if (c0 < r1) {
+            NatLoader<double, T, Cfg::BM, Cfg::BK, Cfg::LDA, Cfg::THREADS, false, true> la(
+                Xt + c0 * Dp + (int64_t)ti * Cfg::BM, Dp, threadIdx.x, nullptr, Dp - ti * Cfg::BM);
+            ZbarLoader<S, T, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS> lb(Phi + c0 * ld, Pb + c0 * ld, ld, J, tj * Cfg::BN, threadIdx.x);
+            tile_mainloop<Cfg>(la, lb, (int)((c1 - c0) / Cfg::BK), acc, smem);
+        }
+        slab_flush<Cfg>(acc, slab, first);
         first = false;
     }
 }
@@ -142,14 +176,14 @@ static void gram_launch(const Geom& g, const T* Phi, const double* w, int nsplit
     const int64_t rps = round_up((g.Np + nsplit - 1) / nsplit, 256);
     if (chunk <= 0 || chunk > rps) chunk = rps;
     chunk = round_up(chunk, Cfg::BK);
-    allow_big_lds(tn_kernel<Cfg, T, T, true, false, true>, Cfg::LDS_BYTES);
-    allow_big_lds(tn_kernel<Cfg, T, T, false, false, true>, Cfg::LDS_BYTES);
+    allow_big_lds(gram_kernel<Cfg, true>, Cfg::LDS_BYTES);
+    allow_big_lds(gram_kernel<Cfg, false>, Cfg::LDS_BYTES);
     if (w)
-        hipLaunchKernelGGL((tn_kernel<Cfg, T, T, true, false, true>), dim3(ntiles, nsplit), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st,
-                           Phi, (int64_t)g.Kp, Phi, (int64_t)g.Kp, w, g.Np, rps, chunk, nts, g.Kp, slabs);
+        hipLaunchKernelGGL((gram_kernel<Cfg, true>), dim3(ntiles * nsplit), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st,
+                           Phi, (int64_t)g.Kp, w, g.Np, rps, chunk, nts, g.K + 1, slabs);
     else
-        hipLaunchKernelGGL((tn_kernel<Cfg, T, T, false, false, true>), dim3(ntiles, nsplit), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st,
-                           Phi, (int64_t)g.Kp, Phi, (int64_t)g.Kp, w, g.Np, rps, chunk, nts, g.Kp, slabs);
+        hipLaunchKernelGGL((gram_kernel<Cfg, false>), dim3(ntiles * nsplit), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st,
+                           Phi, (int64_t)g.Kp, w, g.Np, rps, chunk, nts, -1, slabs);
 }
 template <typename T>
 void SweepKernels<T>::gram(const Geom& g, const T* Phi, const double* w, int nsplit, int64_t chunk, double* slabs, hipStream_t st) {
@@ -158,13 +192,16 @@ void SweepKernels<T>::gram(const Geom& g, const T* Phi, const double* w, int nsp
 }
 
 template <typename T>
-void SweepKernels<T>::xtz(const Geom& g, const double* Xt, const T* Zbar, int nsplit, double* slabs, hipStream_t st) {
-    typedef XtzCfg Cfg;
+void SweepKernels<T>::xtz(const Geom& g, const double* Xt, const T* Phi, const T* Phibar, int nsplit, int64_t chunk, double* slabs,
+                          hipStream_t st) {
+    typedef typename XtzCfg<T>::type Cfg;
     const int ntm = (g.Dp + Cfg::BM - 1) / Cfg::BM, ntn = g.Jp / Cfg::BN;
     const int64_t rps = round_up((g.Np + nsplit - 1) / nsplit, 256);
-    allow_big_lds(tn_kernel<Cfg, double, T, false, true, false>, Cfg::LDS_BYTES);
-    hipLaunchKernelGGL((tn_kernel<Cfg, double, T, false, true, false>), dim3(ntm * ntn, nsplit), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st,
-                       Xt, (int64_t)g.Dp, Zbar, (int64_t)g.Jp, (const double*)nullptr, g.Np, rps, rps, ntn, g.Dp, slabs);
+    if (chunk <= 0 || chunk > rps) chunk = rps;
+    chunk = round_up(chunk, Cfg::BK);
+    allow_big_lds(xtz_kernel<Cfg, T>, Cfg::LDS_BYTES);
+    hipLaunchKernelGGL((xtz_kernel<Cfg, T>), dim3(ntm * ntn * nsplit), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st,
+                       Xt, g.Dp, Phi, Phibar, (int64_t)g.Kp, g.J, g.Np, rps, chunk, ntn, ntm * ntn, slabs);
 }
 
 // --------------------------------------------------------------------------
@@ -176,12 +213,14 @@ template <class Cfg, int EPI>
 __global__ __launch_bounds__(Cfg::THREADS) void apply_kernel(
     const typename Cfg::T* __restrict__ Phi, const typename Cfg::T* __restrict__ Bm, typename Cfg::T* V,
     double* __restrict__ vpart, const double* __restrict__ p, const double* __restrict__ q, const double* __restrict__ y,
-    const double* __restrict__ alpha, const double* __restrict__ ut, int Kp, int64_t Np, int njt) {
+    const double* __restrict__ alpha, const double* __restrict__ ut, int K, int Kp, int64_t Np, int njt,
+    double* __restrict__ bpart) {
     typedef typename Cfg::T T;
     SMEM_DECL;
     T* smem = reinterpret_cast<T*>(smem_raw);
-    const int jt = blockIdx.x % njt;
-    const int64_t rb = blockIdx.x / njt;
+    const unsigned wid = xcd_remap(blockIdx.x, gridDim.x);
+    const int jt = wid % njt;
+    const int64_t rb = wid / njt;
     TrLoader<T, T, Cfg::BM, Cfg::BK, Cfg::LDA, Cfg::THREADS> la(Phi + rb * Cfg::BM * Kp, Kp, threadIdx.x);
     NatLoader<T, T, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS, false, false> lb(Bm + jt * Cfg::BN, Kp, threadIdx.x);
     typename Cfg::MTr::acc_t acc[Cfg::TM][Cfg::TN];
@@ -202,7 +241,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void apply_kernel(
                 for (int tn = 0; tn < Cfg::TN; ++tn) {
                     const T c = acc[tm][tn][r];
                     V[off + co.col(tn)] = c;
-                    part += (double)Phi[off + co.col(tn)] * (double)c;
+                    if (jt * Cfg::BN + co.col(tn) < K) part += (double)Phi[off + co.col(tn)] * (double)c;   // not the y, p columns
                 }
 #pragma unroll
                 for (int m = 1; m < Cfg::MS; m <<= 1) part += __shfl_xor(part, m);      // lanes of one MFMA row group
@@ -216,6 +255,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void apply_kernel(
             vpart[(int64_t)jt * Np + rb * Cfg::BM + threadIdx.x] = s;
         }
     } else {
+        double bb = 0;                                                  // bbar = sum Phibar o Phi  (d cost / d b)
 #pragma unroll
         for (int tm = 0; tm < Cfg::TM; ++tm)
 #pragma unroll
@@ -228,83 +268,58 @@ __global__ __launch_bounds__(Cfg::THREADS) void apply_kernel(
                     const int j = jt * Cfg::BN + co.col(tn);
                     const double v = 2.0 * (double)acc[tm][tn][r] + qn * (double)V[off + co.col(tn)] + pn * alpha[j] + yn * ut[j];
                     V[off + co.col(tn)] = (T)v;
+                    if (j < K) bb += v * (double)Phi[off + co.col(tn)];
                 }
             }
+        double* red = reinterpret_cast<double*>(smem_raw);
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) bb += __shfl_xor(bb, m);
+        if (co.lane == 0) red[threadIdx.x >> 6] = bb;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double s = 0;
+            for (int k = 0; k < Cfg::THREADS / 64; ++k) s += red[k];
+            bpart[blockIdx.x] = s;
+        }
     }
 }
 
 template <typename T, int TILE>
-static void apply_launch(int epi, const Geom& g, const T* Phi, const T* Bm, T* V, double* vpart, const double* p, const double* q,
-                         const double* y, const double* alpha, const double* ut, hipStream_t st) {
+static int apply_launch(int epi, const Geom& g, const T* Phi, const T* Bm, T* V, double* vpart, const double* p, const double* q,
+                        const double* y, const double* alpha, const double* ut, double* bpart, hipStream_t st) {
     typedef typename ApplyCfg<T, TILE>::type Cfg;
     const int njt = g.Kp / Cfg::BN;
     const int64_t nrb = g.Np / Cfg::BM;
     if (epi == 0) {
         allow_big_lds(apply_kernel<Cfg, 0>, Cfg::LDS_BYTES);
         hipLaunchKernelGGL((apply_kernel<Cfg, 0>), dim3((unsigned)(njt * nrb)), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st,
-                           Phi, Bm, V, vpart, p, q, y, alpha, ut, g.Kp, g.Np, njt);
+                           Phi, Bm, V, vpart, p, q, y, alpha, ut, g.K, g.Kp, g.Np, njt, bpart);
     } else {
         allow_big_lds(apply_kernel<Cfg, 1>, Cfg::LDS_BYTES);
         hipLaunchKernelGGL((apply_kernel<Cfg, 1>), dim3((unsigned)(njt * nrb)), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st,
-                           Phi, Bm, V, vpart, p, q, y, alpha, ut, g.Kp, g.Np, njt);
+                           Phi, Bm, V, vpart, p, q, y, alpha, ut, g.K, g.Kp, g.Np, njt, bpart);
     }
+    return (int)(njt * nrb);
 }
 template <typename T>
 void SweepKernels<T>::apply_v(const Geom& g, const T* Phi, const T* Bm, T* V, double* vpart, hipStream_t st) {
-    if (g.tile == 192) apply_launch<T, 192>(0, g, Phi, Bm, V, vpart, nullptr, nullptr, nullptr, nullptr, nullptr, st);
-    else apply_launch<T, 128>(0, g, Phi, Bm, V, vpart, nullptr, nullptr, nullptr, nullptr, nullptr, st);
+    if (g.tile == 192) apply_launch<T, 192>(0, g, Phi, Bm, V, vpart, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, st);
+    else apply_launch<T, 128>(0, g, Phi, Bm, V, vpart, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, st);
 }
 template <typename T>
-void SweepKernels<T>::apply_phibar(const Geom& g, const T* Phi, const T* Abar, T* V, const double* p, const double* q,
-                                   const double* y, const double* alpha, const double* ut, hipStream_t st) {
-    if (g.tile == 192) apply_launch<T, 192>(1, g, Phi, Abar, V, nullptr, p, q, y, alpha, ut, st);
-    else apply_launch<T, 128>(1, g, Phi, Abar, V, nullptr, p, q, y, alpha, ut, st);
+int SweepKernels<T>::apply_phibar(const Geom& g, const T* Phi, const T* Abar, T* V, const double* p, const double* q,
+                                  const double* y, const double* alpha, const double* ut, double* bpart, hipStream_t st) {
+    if (g.tile == 192) return apply_launch<T, 192>(1, g, Phi, Abar, V, nullptr, p, q, y, alpha, ut, bpart, st);
+    return apply_launch<T, 128>(1, g, Phi, Abar, V, nullptr, p, q, y, alpha, ut, bpart, st);
+}
+template <typename T>
+int SweepKernels<T>::apply_blocks(const Geom& g) {
+    const int bm = g.tile == 192 ? ApplyCfg<T, 192>::type::BM : ApplyCfg<T, 128>::type::BM;
+    return (int)((g.Kp / g.tile) * (g.Np / bm));
 }
 
 // number of column tiles of the apply kernel (vpart leading count)
 template <typename T> static int apply_njt(const Geom& g) { return g.Kp / g.tile; }
-
-// --------------------------------------------------------------------------
-// column sums  out[c] = sum_n w[n] Phi[n][c]   (Phi^T y, Phi^T p)
-//   grid.x = 16-byte column groups of 64 lanes, grid.y = row split; 4 waves stride rows
-// --------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ Phi, const double* __restrict__ w, int Kp,
-                                                     int64_t Np, int64_t rows_per_split, double* __restrict__ partial) {
-    constexpr int VS = Vec16<T>::N;
-    typedef typename Vec16<T>::type vec_t;
-    __shared__ double red[4][64 * VS];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c0 = (blockIdx.x * 64 + lane) * VS;
-    const int64_t r0 = (int64_t)blockIdx.y * rows_per_split;
-    const int64_t r1 = r0 + rows_per_split < Np ? r0 + rows_per_split : Np;
-    double acc[VS];
-#pragma unroll
-    for (int e = 0; e < VS; ++e) acc[e] = 0;
-    if (c0 < Kp)
-        for (int64_t n = r0 + wave; n < r1; n += 4) {
-            const vec_t v = *reinterpret_cast<const vec_t*>(Phi + n * Kp + c0);
-            const double wn = w[n];
-#pragma unroll
-            for (int e = 0; e < VS; ++e) acc[e] += wn * (double)v[e];
-        }
-#pragma unroll
-    for (int e = 0; e < VS; ++e) red[wave][lane * VS + e] = acc[e];
-    __syncthreads();
-    if (wave == 0 && c0 < Kp)
-#pragma unroll
-        for (int e = 0; e < VS; ++e)
-            partial[(int64_t)blockIdx.y * Kp + c0 + e] =
-                red[0][lane * VS + e] + red[1][lane * VS + e] + red[2][lane * VS + e] + red[3][lane * VS + e];
-}
-
-template <typename T>
-void SweepKernels<T>::colsum(const Geom& g, const T* Phi, const double* w, int nsplit, double* partial, hipStream_t st) {
-    constexpr int VS = Vec16<T>::N;
-    const int ngx = (g.Kp + 64 * VS - 1) / (64 * VS);
-    const int64_t rps = (g.Np + nsplit - 1) / nsplit;
-    hipLaunchKernelGGL(colsum_kernel<T>, dim3(ngx, nsplit), dim3(256), 0, st, Phi, w, g.Kp, g.Np, rps, partial);
-}
 
 // --------------------------------------------------------------------------
 // per-row statistics: one wave per row (grid-stride).
@@ -314,7 +329,7 @@ void SweepKernels<T>::colsum(const Geom& g, const T* Phi, const double* w, int n
 //   MODE 1 (predict): mu, sd = sqrt(kappa (1+v))
 // --------------------------------------------------------------------------
 template <typename T, int MODE>
-__global__ __launch_bounds__(256) void rowstats_kernel(const T* __restrict__ Phi, const double* __restrict__ alpha,
+__global__ __launch_bounds__(256) void rowstats_kernel(T* Phi, int pcol, const double* __restrict__ alpha,
                                                        const double* __restrict__ vpart, int njt, const double* __restrict__ y,
                                                        const Scal* __restrict__ sc, double* __restrict__ o1, double* __restrict__ o2,
                                                        double* __restrict__ partial, int Kp, int64_t N, int64_t Np) {
@@ -350,6 +365,7 @@ __global__ __launch_bounds__(256) void rowstats_kernel(const T* __restrict__ Phi
                     kb += e * (v + 1.0);
                 }
                 o1[n] = pn; o2[n] = qn;
+                Phi[n * Kp + pcol] = (T)pn;                          // augmented column for Phi^T p (weighted Gram)
             } else if (n < N) {
                 o1[n] = mu; o2[n] = sqrt(d);
             }
@@ -364,9 +380,9 @@ __global__ __launch_bounds__(256) void rowstats_kernel(const T* __restrict__ Phi
 }
 
 template <typename T>
-void SweepKernels<T>::rowstats(const Geom& g, const T* Phi, const double* alpha, const double* vpart, const double* y,
+void SweepKernels<T>::rowstats(const Geom& g, T* Phi, const double* alpha, const double* vpart, const double* y,
                                const Scal* sc, double* p, double* q, double* partial, int nblocks, hipStream_t st) {
-    hipLaunchKernelGGL((rowstats_kernel<T, 0>), dim3(nblocks), dim3(256), 0, st, Phi, alpha, vpart, apply_njt<T>(g), y, sc, p, q,
+    hipLaunchKernelGGL((rowstats_kernel<T, 0>), dim3(nblocks), dim3(256), 0, st, Phi, g.K + 1, alpha, vpart, apply_njt<T>(g), y, sc, p, q,
                        partial, g.Kp, g.N, g.Np);
 }
 
@@ -374,48 +390,33 @@ template <typename T>
 void SweepKernels<T>::rowpredict(const Geom& g, const T* Phi, const double* alpha, const double* vpart, const Scal* sc,
                                  double* mu, double* sd, hipStream_t st) {
     int nblocks = (int)((g.Np / 4) < 4096 ? (g.Np / 4) : 4096);
-    hipLaunchKernelGGL((rowstats_kernel<T, 1>), dim3(nblocks), dim3(256), 0, st, Phi, alpha, vpart, apply_njt<T>(g),
+    hipLaunchKernelGGL((rowstats_kernel<T, 1>), dim3(nblocks), dim3(256), 0, st, const_cast<T*>(Phi), 0, alpha, vpart, apply_njt<T>(g),
                        (const double*)nullptr, sc, mu, sd, (double*)nullptr, g.Kp, g.N, g.Np);
 }
 
 // --------------------------------------------------------------------------
-// Zbar and bbar:  streaming over (n, j < J)
-// --------------------------------------------------------------------------
+// fp64 Kp x Kp matrix -> sweep operand of type T with rows/columns >= K zeroed (the augmented
+// columns of Phi~ must not leak into Phi.B), optionally with column K := vec (unused: 0)
 template <typename T>
-__global__ __launch_bounds__(256) void zbar_kernel(const T* __restrict__ Phi, const T* __restrict__ Pb, T* __restrict__ Zb,
-                                                   double* __restrict__ partial, int J, int Jp, int Kp, int64_t Np) {
-    __shared__ double red[4];
-    double bb = 0;
-    const int64_t total = Np * (int64_t)J;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int64_t n = i / J;
-        const int j = (int)(i - n * J);
-        const double fc = (double)Phi[n * Kp + j], fs = (double)Phi[n * Kp + J + j];
-        const double bc = (double)Pb[n * Kp + j], bs = (double)Pb[n * Kp + J + j];
-        Zb[n * Jp + j] = (T)(fc * bs - fs * bc);
-        bb += fc * bc + fs * bs;
+__global__ void convert_kernel(const double* __restrict__ src, T* __restrict__ dst, int K, int Kp) {
+    const int64_t n = (int64_t)Kp * Kp;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / Kp), c = (int)(i % Kp);
+        dst[i] = (r < K && c < K) ? (T)src[i] : (T)0;
     }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) bb += __shfl_xor(bb, m);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = bb;
-    __syncthreads();
-    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
-}
-
-template <typename T>
-void SweepKernels<T>::zbar(const Geom& g, const T* Phi, const T* Phibar, T* Zbar, double* partial, int nblocks, hipStream_t st) {
-    hipLaunchKernelGGL(zbar_kernel<T>, dim3(nblocks), dim3(256), 0, st, Phi, Phibar, Zbar, partial, g.J, g.Jp, g.Kp, g.Np);
-}
-
-// --------------------------------------------------------------------------
-template <typename T>
-__global__ void convert_kernel(const double* __restrict__ src, T* __restrict__ dst, int64_t n) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = (T)src[i];
 }
 template <typename T>
-void SweepKernels<T>::convert(const double* src, T* dst, int64_t n, hipStream_t st) {
-    const int nb = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-    hipLaunchKernelGGL(convert_kernel<T>, dim3(nb), dim3(256), 0, st, src, dst, n);
+void SweepKernels<T>::convert(const double* src, T* dst, int K, int Kp, hipStream_t st) {
+    hipLaunchKernelGGL(convert_kernel<T>, dim3(2048), dim3(256), 0, st, src, dst, K, Kp);
+}
+template <typename T>
+__global__ void set_col_kernel(T* __restrict__ Phi, int Kp, int col, const double* __restrict__ src, int64_t Np) {
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < Np; n += (int64_t)gridDim.x * blockDim.x)
+        Phi[n * Kp + col] = (T)src[n];
+}
+template <typename T>
+void SweepKernels<T>::set_col(const Geom& g, T* Phi, int col, const double* src, hipStream_t st) {
+    hipLaunchKernelGGL(set_col_kernel<T>, dim3(1024), dim3(256), 0, st, Phi, g.Kp, col, src, g.Np);
 }
 
 template struct SweepKernels<double>;
@@ -535,4 +536,15 @@ __global__ void pad_square_kernel(const double* __restrict__ src, int K, int Kp,
 }
 void pad_square(const double* src, int K, int Kp, double* dst, hipStream_t st) {
     hipLaunchKernelGGL(pad_square_kernel, dim3(1024), dim3(256), 0, st, src, K, Kp, dst);
+}
+
+// dst[j] = x[row][j] (j < K), then clear the augmented rows/columns K, K+1 of the Kp x Kp matrix x
+__global__ void extract_aug_kernel(double* __restrict__ x, int K, int Kp, int row, double* __restrict__ dst) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= Kp) return;
+    dst[j] = j < K ? x[(int64_t)row * Kp + j] : 0.0;
+    for (int a = K; a < K + 2; ++a) { x[(int64_t)a * Kp + j] = 0.0; x[(int64_t)j * Kp + a] = 0.0; }
+}
+void extract_aug(double* x, int K, int Kp, int row, double* dst, hipStream_t st) {
+    hipLaunchKernelGGL(extract_aug_kernel, dim3((Kp + 255) / 256), dim3(256), 0, st, x, K, Kp, row, dst);
 }

@@ -35,7 +35,7 @@ struct scfgp_ctx {
     double *d_params = nullptr, *d_F = nullptr, *d_Fall = nullptr; Scal* d_sc = nullptr;
     // rows
     double *d_Xt = nullptr, *d_y = nullptr, *d_p = nullptr, *d_q = nullptr, *d_vpart = nullptr;
-    void *d_Phi = nullptr, *d_V = nullptr, *d_Zbar = nullptr;
+    void *d_Phi = nullptr, *d_V = nullptr; double* d_bpart = nullptr;
     // exchange buffers and K-stage
     double *d_x1 = nullptr, *d_x2 = nullptr, *d_x3 = nullptr; int64_t n_x1 = 0, n_x2 = 0, n_x3 = 0; int Dpp = 0;
     double *d_Li = nullptr, *d_B = nullptr, *d_T1 = nullptr, *d_T2 = nullptr, *d_Abar = nullptr;
@@ -96,9 +96,17 @@ static int default_split(int ntiles, int64_t Np) {
     return (int)s;
 }
 
+static int xtz_split(int ntiles, int64_t Np) {          // the X~^T Zbar grid has few tiles: ~2048 workgroups suffice
+    int64_t s = (2048 + ntiles - 1) / ntiles;
+    const int64_t smax = Np / 256;
+    if (s > smax) s = smax;
+    if (s < 1) s = 1;
+    return (int)s;
+}
+
 static void free_rows(scfgp_ctx* c) {
     dfree(c->d_Xt); dfree(c->d_y); dfree(c->d_p); dfree(c->d_q); dfree(c->d_vpart);
-    dfree(c->d_Phi); dfree(c->d_V); dfree(c->d_Zbar); dfree(c->d_slabs);
+    dfree(c->d_Phi); dfree(c->d_V); dfree(c->d_bpart); dfree(c->d_slabs);
     c->Ncap = 0; c->slabs_bytes = 0;
 }
 
@@ -110,7 +118,7 @@ static int ensure_rows(scfgp_ctx* c, int64_t N) {
     const int nts = g.Kp / g.tile, ntiles = nts * (nts + 1) / 2;
     const int ntx = ((g.Dp + XT - 1) / XT) * (g.Jp / XT);
     const int gs = c->gram_nsplit > 0 ? (int)std::min<int64_t>(c->gram_nsplit, Np / 256) : default_split(ntiles, Np);
-    const int xs = c->xtz_nsplit > 0 ? (int)std::min<int64_t>(c->xtz_nsplit, Np / 256) : default_split(ntx, Np);
+    const int xs = c->xtz_nsplit > 0 ? (int)std::min<int64_t>(c->xtz_nsplit, Np / 256) : xtz_split(ntx, Np);
     const size_t need = sizeof(double) * std::max<size_t>((size_t)gs * ntiles * g.tile * g.tile, (size_t)xs * ntx * XT * XT);
     if (need > c->slabs_bytes) {
         dfree(c->d_slabs);
@@ -119,7 +127,7 @@ static int ensure_rows(scfgp_ctx* c, int64_t N) {
     }
     if (Np <= c->Ncap) return SCFGP_OK;
     dfree(c->d_Xt); dfree(c->d_y); dfree(c->d_p); dfree(c->d_q); dfree(c->d_vpart);
-    dfree(c->d_Phi); dfree(c->d_V); dfree(c->d_Zbar);
+    dfree(c->d_Phi); dfree(c->d_V); dfree(c->d_bpart);
     c->Ncap = 0;
     const size_t ts = c->tsize();
     int rc;
@@ -130,9 +138,8 @@ static int ensure_rows(scfgp_ctx* c, int64_t N) {
     if ((rc = dmalloc(c, &c->d_vpart, sizeof(double) * Np * (g.Kp / g.tile)))) return rc;
     if ((rc = dmalloc(c, &c->d_Phi, ts * Np * g.Kp))) return rc;
     if ((rc = dmalloc(c, &c->d_V, ts * Np * g.Kp))) return rc;
-    if ((rc = dmalloc(c, &c->d_Zbar, ts * Np * g.Jp))) return rc;
-    HIPCHK(c, hipMemsetAsync(c->d_Phi, 0, ts * Np * g.Kp, c->st));       // padding columns stay zero forever
-    HIPCHK(c, hipMemsetAsync(c->d_Zbar, 0, ts * Np * g.Jp, c->st));
+    if ((rc = dmalloc(c, &c->d_bpart, sizeof(double) * (g.Kp / g.tile) * (Np / 128)))) return rc;
+    HIPCHK(c, hipMemsetAsync(c->d_Phi, 0, ts * Np * g.Kp, c->st));       // padding columns >= K+2 stay zero forever
     c->Ncap = Np;
     return SCFGP_OK;
 }
@@ -146,9 +153,9 @@ extern "C" int scfgp_create(scfgp_ctx** out, int D, int S, int M, int dtype, int
     g.D = D; g.S = S; g.M = M; g.J = S + M; g.K = 2 * g.J; g.P = 3 + D * S + M * S + S + M;
     g.Dp = (int)round_up(D + 1, 16); g.Jp = (int)round_up(g.J, XT);
     // 192-wide tiles only when they cut the padded size by >= 8 % (their wave tile costs occupancy)
-    g.tile = round_up(g.K, 192) * 100 <= round_up(g.K, 128) * 92 ? 192 : 128;
+    g.tile = round_up(g.K + 2, 192) * 100 <= round_up(g.K + 2, 128) * 92 ? 192 : 128;
     if (const char* e = getenv("SCFGP_TILE")) { const int t = atoi(e); if (t == 128 || t == 192) g.tile = t; }   // tuning override
-    g.Kp = (int)round_up(g.K, g.tile);
+    g.Kp = (int)round_up(g.K + 2, g.tile);          // + the two augmented columns (y, p) of Phi~
     c->Dpp = (int)round_up(g.Dp, XT);
     HIPCHK(c, hipSetDevice(device));
     if (stream) c->st = (hipStream_t)stream;
@@ -168,10 +175,8 @@ extern "C" int scfgp_create(scfgp_ctx** out, int D, int S, int M, int dtype, int
     if ((rc = dmalloc(c, &c->d_T1, sizeof(double) * K2))) return rc;
     if ((rc = dmalloc(c, &c->d_T2, sizeof(double) * K2))) return rc;
     if ((rc = dmalloc(c, &c->d_Abar, sizeof(double) * K2))) return rc;
-    if (dtype == SCFGP_F32) {
-        if ((rc = dmalloc(c, &c->d_BT, sizeof(float) * K2))) return rc;
-        if ((rc = dmalloc(c, &c->d_AbarT, sizeof(float) * K2))) return rc;
-    }
+    if ((rc = dmalloc(c, &c->d_BT, c->tsize() * K2))) return rc;        // sweep operands: typed, padding zeroed
+    if ((rc = dmalloc(c, &c->d_AbarT, c->tsize() * K2))) return rc;
     if ((rc = dmalloc(c, &c->d_vecs, sizeof(double) * 5 * Kp))) return rc;
     if ((rc = dmalloc(c, &c->d_scalars, sizeof(double) * 32))) return rc;
     if ((rc = dmalloc(c, &c->d_yy, sizeof(double) * 8))) return rc;
@@ -235,6 +240,8 @@ extern "C" int scfgp_set_data(scfgp_ctx* c, const double* X, const double* y, in
     HIPCHK(c, hipMemcpyAsync(yraw, y, sizeof(double) * N, hipMemcpyHostToDevice, c->st));
     pack_data(c->g, raw, yraw, c->d_Xt, c->d_y, c->st);
     sum_squares(c->d_y, c->g.Np, c->d_yy, 0, c->d_partial, c->st);
+    if (c->dtype == SCFGP_F32) SweepKernels<float>::set_col(c->g, (float*)c->d_Phi, c->g.K, c->d_y, c->st);
+    else SweepKernels<double>::set_col(c->g, (double*)c->d_Phi, c->g.K, c->d_y, c->st);
     HIPCHK(c, hipStreamSynchronize(c->st));
     dfree(raw); dfree(yraw);
     HIPCHK(c, hipGetLastError());
@@ -247,31 +254,25 @@ extern "C" int scfgp_set_data(scfgp_ctx* c, const double* X, const double* y, in
 // ----------------------------------------------------------------------------------------------
 template <typename T> struct Impl {
     typedef SweepKernels<T> SK;
-    static const T* BT(scfgp_ctx* c) { return c->dtype == SCFGP_F32 ? (const T*)c->d_BT : (const T*)c->d_B; }
-    static const T* AbarT(scfgp_ctx* c) { return c->dtype == SCFGP_F32 ? (const T*)c->d_AbarT : (const T*)c->d_Abar; }
+    static const T* BT(scfgp_ctx* c) { return (const T*)c->d_BT; }
+    static const T* AbarT(scfgp_ctx* c) { return (const T*)c->d_AbarT; }
 
-    static void gram_to(scfgp_ctx* c, const double* w, double* out, const char* name) {
+    // augmented Gram of Phi~ = [Phi | y | p] -> out = [Kp x Kp matrix | vector]; `row` is the augmented
+    // row that carries the wanted vector (K: Phi^T y, K+1: Phi^T p)
+    static void gram_to(scfgp_ctx* c, const double* w, double* out, int row, const char* name) {
         const Geom& g = c->g;
         const int nts = g.Kp / g.tile, ntiles = nts * (nts + 1) / 2;
         const int gs = c->gram_nsplit > 0 ? (int)std::min<int64_t>(c->gram_nsplit, g.Np / 256) : default_split(ntiles, g.Np);
         { ProfScope ps(c, name);
           SK::gram(g, (const T*)c->d_Phi, w, gs, c->dtype == SCFGP_F32 ? c->gram_chunk : 0, c->d_slabs, c->st); }
-        { ProfScope ps(c, "reduce_tiles"); reduce_tri_tiles(c->d_slabs, gs, nts, g.tile, out, g.Kp, c->st); }
+        { ProfScope ps(c, "reduce_tiles"); reduce_tri_tiles(c->d_slabs, gs, nts, g.tile, out, g.Kp, c->st);
+          extract_aug(out, g.K, g.Kp, row, out + (int64_t)g.Kp * g.Kp, c->st); }
     }
-    static void colsum_to(scfgp_ctx* c, const double* w, double* out) {
-        const Geom& g = c->g;
-        const int ns = (int)std::min<int64_t>(c->cs_nsplit, g.Np / 4);
-        ProfScope ps(c, "colsum");
-        SK::colsum(g, (const T*)c->d_Phi, w, ns, c->d_partial, c->st);
-        reduce_rows(c->d_partial, ns, g.Kp, out, c->st);
-    }
-
     static int pass1(scfgp_ctx* c) {
         const Geom& g = c->g;
         const int64_t K2 = (int64_t)g.Kp * g.Kp;
         { ProfScope ps(c, "featuremap"); SK::featuremap(g, c->d_Xt, c->d_Fall, c->d_sc, (T*)c->d_Phi, c->st); }
-        gram_to(c, nullptr, c->d_x1, "gram");
-        colsum_to(c, c->d_y, c->d_x1 + K2);
+        gram_to(c, nullptr, c->d_x1, g.K, "gram");
         HIPCHK(c, hipMemcpyAsync(c->d_x1 + K2 + g.Kp, c->d_yy, sizeof(double), hipMemcpyDeviceToDevice, c->st));
         HIPCHK(c, hipGetLastError());
         return SCFGP_OK;
@@ -280,7 +281,7 @@ template <typename T> struct Impl {
         const Geom& g = c->g;
         HIPCHK(c, hipMemsetAsync(c->d_flag, 0, sizeof(int) * 4, c->st));
         { ProfScope ps(c, "kstage_factor"); kstage_factor(c->kstage(), c->d_sc, c->st); }
-        if (c->dtype == SCFGP_F32) SK::convert(c->d_B, (T*)c->d_BT, (int64_t)g.Kp * g.Kp, c->st);
+        SK::convert(c->d_B, (T*)c->d_BT, g.K, g.Kp, c->st);
         HIPCHK(c, hipGetLastError());
         return SCFGP_OK;
     }
@@ -290,11 +291,10 @@ template <typename T> struct Impl {
         { ProfScope ps(c, "apply_v"); SK::apply_v(g, (const T*)c->d_Phi, BT(c), (T*)c->d_V, c->d_vpart, c->st); }
         const int nb = (int)std::min<int64_t>(g.Np / 4, 2048);
         { ProfScope ps(c, "rowstats");
-          SK::rowstats(g, (const T*)c->d_Phi, c->alpha(), c->d_vpart, c->d_y, c->d_sc, c->d_p, c->d_q, c->d_partial, nb, c->st);
+          SK::rowstats(g, (T*)c->d_Phi, c->alpha(), c->d_vpart, c->d_y, c->d_sc, c->d_p, c->d_q, c->d_partial, nb, c->st);
           reduce_scalars(c->d_partial, nb, 2, c->d_x2 + K2 + g.Kp, 0, c->st); }
         if (want_grad) {
-            gram_to(c, c->d_q, c->d_x2, "gram_w");
-            colsum_to(c, c->d_p, c->d_x2 + K2);
+            gram_to(c, c->d_q, c->d_x2, g.K + 1, "gram_w");
         }
         HIPCHK(c, hipGetLastError());
         return SCFGP_OK;
@@ -302,22 +302,20 @@ template <typename T> struct Impl {
     static int adjoint(scfgp_ctx* c) {
         const Geom& g = c->g;
         { ProfScope ps(c, "kstage_adjoint"); kstage_adjoint(c->kstage(), c->d_x2, c->d_Abar, c->d_sc, c->st); }
-        if (c->dtype == SCFGP_F32) SK::convert(c->d_Abar, (T*)c->d_AbarT, (int64_t)g.Kp * g.Kp, c->st);
+        SK::convert(c->d_Abar, (T*)c->d_AbarT, g.K, g.Kp, c->st);
         HIPCHK(c, hipGetLastError());
         return SCFGP_OK;
     }
     static int pass3(scfgp_ctx* c) {
         const Geom& g = c->g;
         { ProfScope ps(c, "apply_phibar");
-          SK::apply_phibar(g, (const T*)c->d_Phi, AbarT(c), (T*)c->d_V, c->d_p, c->d_q, c->d_y, c->alpha(), c->ut(), c->st); }
-        const int nb = 4096;
-        { ProfScope ps(c, "zbar");
-          SK::zbar(g, (const T*)c->d_Phi, (const T*)c->d_V, (T*)c->d_Zbar, c->d_partial, nb, c->st);
-          reduce_scalars(c->d_partial, nb, 1, c->d_x3 + (int64_t)c->Dpp * g.Jp, 0, c->st); }
+          const int nb = SK::apply_phibar(g, (const T*)c->d_Phi, AbarT(c), (T*)c->d_V, c->d_p, c->d_q, c->d_y, c->alpha(), c->ut(),
+                                          c->d_bpart, c->st);
+          reduce_scalars(c->d_bpart, nb, 1, c->d_x3 + (int64_t)c->Dpp * g.Jp, 0, c->st); }
         const int ntm = c->Dpp / XT, ntn = g.Jp / XT;
-        const int xs = c->xtz_nsplit > 0 ? (int)std::min<int64_t>(c->xtz_nsplit, g.Np / 256) : default_split(ntm * ntn, g.Np);
+        const int xs = c->xtz_nsplit > 0 ? (int)std::min<int64_t>(c->xtz_nsplit, g.Np / 256) : xtz_split(ntm * ntn, g.Np);
         { ProfScope ps(c, "xtz");
-          SK::xtz(g, c->d_Xt, (const T*)c->d_Zbar, xs, c->d_slabs, c->st);
+          SK::xtz(g, c->d_Xt, (const T*)c->d_Phi, (const T*)c->d_V, xs, c->dtype == SCFGP_F32 ? c->gram_chunk : 0, c->d_slabs, c->st);
           reduce_full_tiles(c->d_slabs, xs, ntm, ntn, c->d_x3, g.Jp, c->st); }
         HIPCHK(c, hipGetLastError());
         return SCFGP_OK;
@@ -456,8 +454,9 @@ extern "C" int scfgp_predict(scfgp_ctx* c, const double* Xs, int64_t T, const do
     HIPCHK(c, hipMemcpyAsync(c->alpha_pred(), alpha, sizeof(double) * g0.K, hipMemcpyHostToDevice, c->st));
     KStage k = c->kstage(); k.Li = c->d_T1; k.B = c->d_T2;
     kstage_gram_li(k, c->st);
-    const void* Bt = c->d_T2;
-    if (c->dtype == SCFGP_F32) { SweepKernels<float>::convert(c->d_T2, (float*)c->d_AbarT, K2, c->st); Bt = c->d_AbarT; }
+    const void* Bt = c->d_AbarT;                                  // AbarT is scratch outside adjoint..pass3
+    if (c->dtype == SCFGP_F32) SweepKernels<float>::convert(c->d_T2, (float*)c->d_AbarT, g0.K, g0.Kp, c->st);
+    else SweepKernels<double>::convert(c->d_T2, (double*)c->d_AbarT, g0.K, g0.Kp, c->st);
     HIPCHK(c, hipStreamSynchronize(c->st));                     // raw is reused below
     for (int64_t t0 = 0; t0 < T; t0 += PRED_ROWS) {
         Geom g = g0;
@@ -523,7 +522,6 @@ extern "C" int64_t scfgp_debug_read(scfgp_ctx* c, const char* name, void* host, 
     const void* src = nullptr; int64_t bytes = 0;
     if (s == "Phi") { src = c->d_Phi; bytes = ts * g.Np * g.Kp; }
     else if (s == "V") { src = c->d_V; bytes = ts * g.Np * g.Kp; }
-    else if (s == "Zbar") { src = c->d_Zbar; bytes = ts * g.Np * g.Jp; }
     else if (s == "G") { src = c->d_x1; bytes = 8 * c->n_x1; }
     else if (s == "W") { src = c->d_x2; bytes = 8 * c->n_x2; }
     else if (s == "XZ") { src = c->d_x3; bytes = 8 * c->n_x3; }

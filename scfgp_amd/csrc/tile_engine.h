@@ -16,6 +16,13 @@
 #pragma once
 #include "common.h"
 
+#ifndef SCFGP_DRY_LOOP
+#define SCFGP_DRY_LOOP 0
+#endif
+#ifndef SCFGP_PREFETCH2
+#define SCFGP_PREFETCH2 0        // 1: global loads run two k-tiles ahead (two register sets); measured slower
+#endif
+
 // MFMA traits: element type T and instruction shape MS (16: 16x16x4, 32: 32x32x2, f32 only).
 //   lane l supplies A[i = l % MS][k = l / MS] and B[k = l / MS][j = l % MS]
 template <typename T, int MS> struct MT;
@@ -77,10 +84,12 @@ struct NatLoader {
     static constexpr int VPR = BX / VS;                       // vectors per k row
     static constexpr int NV = (BK * VPR + THREADS - 1) / THREADS;
     const S* base; int64_t ld; const double* w; int xlim;     // xlim: first invalid x (GUARD)
-    vec_t r[NV]; T wr[NV];
+    int xplain = -1;                                          // WEIGHT: this x is stored unweighted
+    vec_t r[1 + SCFGP_PREFETCH2][NV]; T wr[1 + SCFGP_PREFETCH2][NV];
     int tid;
     __device__ __forceinline__ NatLoader(const S* b, int64_t l, int t, const double* w_ = nullptr, int xl = 0)
         : base(b), ld(l), w(w_), xlim(xl), tid(t) {}
+    template <int SET = 0>
     __device__ __forceinline__ void load(int kt) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
@@ -92,10 +101,11 @@ struct NatLoader {
             for (int e = 0; e < VS; ++e) val[e] = 0;
             if (ok && (!GUARD || xv * VS < xlim))
                 val = *reinterpret_cast<const vec_t*>(base + (int64_t)(kt * BK + k) * ld + xv * VS);
-            r[i] = val;
-            if (WEIGHT) wr[i] = ok ? (T)w[kt * BK + k] : (T)0;
+            r[SET][i] = val;
+            if (WEIGHT) wr[SET][i] = ok ? (T)w[kt * BK + k] : (T)0;
         }
     }
+    template <int SET = 0>
     __device__ __forceinline__ void store(T* s) const {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
@@ -109,7 +119,8 @@ struct NatLoader {
             for (int e0 = 0; e0 < VS; e0 += TV) {
                 tv_t o;
 #pragma unroll
-                for (int e = 0; e < TV; ++e) o[e] = WEIGHT ? (T)r[i][e0 + e] * wr[i] : (T)r[i][e0 + e];
+                for (int e = 0; e < TV; ++e)
+                    o[e] = (WEIGHT && xv * VS + e0 + e != xplain) ? (T)r[SET][i][e0 + e] * wr[SET][i] : (T)r[SET][i][e0 + e];
                 *reinterpret_cast<tv_t*>(d + e0) = o;
             }
         }
@@ -126,8 +137,9 @@ struct TrLoader {
     static constexpr int VPR = BK / VS;                       // vectors per x row
     static constexpr int NV = (BX * VPR + THREADS - 1) / THREADS;
     const S* base; int64_t ld; int tid;
-    vec_t r[NV];
+    vec_t r[1 + SCFGP_PREFETCH2][NV];
     __device__ __forceinline__ TrLoader(const S* b, int64_t l, int t) : base(b), ld(l), tid(t) {}
+    template <int SET = 0>
     __device__ __forceinline__ void load(int kt) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
@@ -138,9 +150,10 @@ struct TrLoader {
 #pragma unroll
             for (int e = 0; e < VS; ++e) val[e] = 0;
             if (ok) val = *reinterpret_cast<const vec_t*>(base + (int64_t)x * ld + kt * BK + kv * VS);
-            r[i] = val;
+            r[SET][i] = val;
         }
     }
+    template <int SET = 0>
     __device__ __forceinline__ void store(T* s) const {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
@@ -148,7 +161,7 @@ struct TrLoader {
             if ((BX * VPR) % THREADS != 0 && v >= BX * VPR) continue;
             const int x = v / VPR, kv = v % VPR;
 #pragma unroll
-            for (int e = 0; e < VS; ++e) s[(kv * VS + e) * LD + x] = (T)r[i][e];
+            for (int e = 0; e < VS; ++e) s[(kv * VS + e) * LD + x] = (T)r[SET][i][e];
         }
     }
 };
@@ -156,41 +169,171 @@ struct TrLoader {
 // ---------------------------------------------------------------------------
 // main loop: accumulates nkt k-tiles into acc[TM][TN]; smem = 2*(SA+SB) elements
 // ---------------------------------------------------------------------------
-template <class Cfg, class LA, class LB>
-__device__ __forceinline__ void tile_mainloop(LA& la, LB& lb, int nkt,
-                                              typename Cfg::MTr::acc_t (&acc)[Cfg::TM][Cfg::TN],
-                                              typename Cfg::T* smem) {
+// ---------------------------------------------------------------------------
+// ZbarLoader: B operand of X~^T Zbar, formed on the fly from the resident Phi and Phibar:
+//   s[k=n][x=j] = Phi[n][j] * Phibar[n][J+j] - Phi[n][J+j] * Phibar[n][j]      (0 for j >= J)
+// the cotangent of the phase argument (cos' = -sin, sin' = cos), so no N x J buffer exists.
+// ---------------------------------------------------------------------------
+template <typename S, typename T, int BX, int BK, int LD, int THREADS>
+struct ZbarLoader {
+    static constexpr int VS = Vec16<S>::N;
+    static constexpr int VPR = BX / VS;
+    static constexpr int NV = (BK * VPR + THREADS - 1) / THREADS;
+    const S* phi; const S* pb; int64_t ld; int J, j0, tid; bool vec;
+    T r[1][NV][VS];
+    __device__ __forceinline__ ZbarLoader(const S* phi_, const S* pb_, int64_t ld_, int J_, int j0_, int t)
+        : phi(phi_), pb(pb_), ld(ld_), J(J_), j0(j0_), tid(t), vec(J_ % VS == 0) {}
+    template <int SET = 0>
+    __device__ __forceinline__ void load(int kt) {
+        typedef typename Vec16<S>::type vec_t;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int v = tid + i * THREADS;
+            const int k = v / VPR, j = j0 + (v % VPR) * VS;
+            const bool ok = (BK * VPR) % THREADS == 0 || v < BK * VPR;
+            const S* f = phi + (int64_t)(kt * BK + k) * ld;
+            const S* b = pb + (int64_t)(kt * BK + k) * ld;
+            if (ok && vec && j + VS <= J) {
+                const vec_t fc = *reinterpret_cast<const vec_t*>(f + j), fs = *reinterpret_cast<const vec_t*>(f + J + j);
+                const vec_t bc = *reinterpret_cast<const vec_t*>(b + j), bs = *reinterpret_cast<const vec_t*>(b + J + j);
+#pragma unroll
+                for (int e = 0; e < VS; ++e) r[0][i][e] = (T)fc[e] * (T)bs[e] - (T)fs[e] * (T)bc[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < VS; ++e)
+                    r[0][i][e] = (ok && j + e < J) ? (T)f[j + e] * (T)b[J + j + e] - (T)f[J + j + e] * (T)b[j + e] : (T)0;
+            }
+        }
+    }
+    template <int SET = 0>
+    __device__ __forceinline__ void store(T* s) const {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int v = tid + i * THREADS;
+            if ((BK * VPR) % THREADS != 0 && v >= BK * VPR) continue;
+            T* d = s + (v / VPR) * LD + (v % VPR) * VS;
+#pragma unroll
+            for (int e = 0; e < VS; ++e) d[e] = r[0][i][e];
+        }
+    }
+};
+
+// MFMAs of one k-tile out of LDS buffer `cur`
+template <class Cfg>
+__device__ __forceinline__ void tile_compute(const typename Cfg::T* sA, const typename Cfg::T* sB,
+                                             typename Cfg::MTr::acc_t (&acc)[Cfg::TM][Cfg::TN]) {
     typedef typename Cfg::T T;
     typedef typename Cfg::MTr M;
     constexpr int MS = Cfg::MS, KS = M::KS;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm0 = (wave / Cfg::WGN) * Cfg::WM, wn0 = (wave % Cfg::WGN) * Cfg::WN;
+    const T* a_s = sA + (lane / MS) * Cfg::LDA + wm0 + (lane % MS);
+    const T* b_s = sB + (lane / MS) * Cfg::LDB + wn0 + (lane % MS);
+#pragma unroll
+    for (int kk = 0; kk < Cfg::BK / KS; ++kk) {
+        T a[Cfg::TM], b[Cfg::TN];
+#pragma unroll
+        for (int tm = 0; tm < Cfg::TM; ++tm) a[tm] = a_s[kk * KS * Cfg::LDA + tm * MS];
+#pragma unroll
+        for (int tn = 0; tn < Cfg::TN; ++tn) b[tn] = b_s[kk * KS * Cfg::LDB + tn * MS];
+#pragma unroll
+        for (int tm = 0; tm < Cfg::TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < Cfg::TN; ++tn) M::mfma(acc[tm][tn], a[tm], b[tn]);
+    }
+}
+
+#ifndef SCFGP_INTERLEAVE
+#define SCFGP_INTERLEAVE 0       // >0: ask the scheduler to spread staging instructions between MFMAs
+#endif
+
+// scheduling hint: after every MFMA allow one DS read / VALU / VMEM / DS write to issue, so the
+// staging work of the next k-tile hides in the MFMA shadows instead of clustering at the ends
+template <int NMFMA>
+__device__ __forceinline__ void interleave_hint() {
+#if SCFGP_INTERLEAVE
+#pragma unroll
+    for (int i = 0; i < NMFMA; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 DS read
+        __builtin_amdgcn_sched_group_barrier(0x002, SCFGP_INTERLEAVE, 0);      // VALU
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // 1 VMEM read
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // 1 DS write
+    }
+#endif
+}
+
+// one pipeline step.  PREFETCH2: k-tile kt is in LDS buffer PAR, k-tile kt+1 in register set 1-PAR
+// (requested a whole step ago), k-tile kt+2 is requested now into set PAR.  Otherwise: k-tile kt+1
+// is requested now into set 0 and stored after the MFMAs.
+template <class Cfg, int PAR, class LA, class LB>
+__device__ __forceinline__ void tile_step(LA& la, LB& lb, int kt, int nkt,
+                                          typename Cfg::MTr::acc_t (&acc)[Cfg::TM][Cfg::TN], typename Cfg::T* sA,
+                                          typename Cfg::T* sB) {
+#if SCFGP_DRY_LOOP == 1 || SCFGP_DRY_LOOP == 2     // diagnostic builds (results are wrong):
+    const bool st1 = false, st2 = false;            //   1: no staging, no barrier   2: no staging, barrier kept
+#else                                               //   3: staging kept, no barrier
+    const bool st1 = kt + 1 < nkt, st2 = kt + 2 < nkt;
+#endif
+#if SCFGP_PREFETCH2
+    if (st2) { la.template load<PAR>(kt + 2); lb.template load<PAR>(kt + 2); }
+    tile_compute<Cfg>(sA + PAR * Cfg::SA, sB + PAR * Cfg::SB, acc);
+    if (st1) { la.template store<1 - PAR>(sA + (1 - PAR) * Cfg::SA); lb.template store<1 - PAR>(sB + (1 - PAR) * Cfg::SB); }
+#else
+    (void)st2;
+    if (st1) { la.template load<0>(kt + 1); lb.template load<0>(kt + 1); }
+    tile_compute<Cfg>(sA + PAR * Cfg::SA, sB + PAR * Cfg::SB, acc);
+    if (st1) { la.template store<0>(sA + (1 - PAR) * Cfg::SA); lb.template store<0>(sB + (1 - PAR) * Cfg::SB); }
+#endif
+    interleave_hint<Cfg::TM * Cfg::TN * (Cfg::BK / Cfg::MTr::KS)>();
+#if SCFGP_DRY_LOOP != 1 && SCFGP_DRY_LOOP != 3
+    __syncthreads();
+#endif
+}
+
+// ---------------------------------------------------------------------------
+// main loop: accumulates nkt k-tiles into acc[TM][TN]; smem = 2*(SA+SB) elements.
+// LDS is double buffered (buffer = k-tile parity), one barrier per k-tile.
+// ---------------------------------------------------------------------------
+template <class Cfg, class LA, class LB>
+__device__ __forceinline__ void tile_mainloop(LA& la, LB& lb, int nkt,
+                                              typename Cfg::MTr::acc_t (&acc)[Cfg::TM][Cfg::TN],
+                                              typename Cfg::T* smem) {
+    typedef typename Cfg::T T;
     T* sA = smem;
     T* sB = smem + 2 * Cfg::SA;
-    la.load(0); lb.load(0);
-    la.store(sA); lb.store(sB);
+    la.template load<0>(0); lb.template load<0>(0);
+#if SCFGP_PREFETCH2
+    if (nkt > 1) { la.template load<1>(1); lb.template load<1>(1); }
+#endif
+    la.template store<0>(sA); lb.template store<0>(sB);
     __syncthreads();
+#if SCFGP_PREFETCH2
+    int kt = 0;
+    for (; kt + 1 < nkt; kt += 2) {
+        tile_step<Cfg, 0>(la, lb, kt, nkt, acc, sA, sB);
+        tile_step<Cfg, 1>(la, lb, kt + 1, nkt, acc, sA, sB);
+    }
+    if (kt < nkt) tile_step<Cfg, 0>(la, lb, kt, nkt, acc, sA, sB);
+#else
+    // rolled loop with a run-time buffer index: smaller code and fewer live registers than the
+    // parity-unrolled form (which cost the fp32 apply kernel an occupancy step)
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
-        const bool more = kt + 1 < nkt;
-        if (more) { la.load(kt + 1); lb.load(kt + 1); }
-        const T* a_s = sA + cur * Cfg::SA + (lane / MS) * Cfg::LDA + wm0 + (lane % MS);
-        const T* b_s = sB + cur * Cfg::SB + (lane / MS) * Cfg::LDB + wn0 + (lane % MS);
-#pragma unroll
-        for (int kk = 0; kk < Cfg::BK / KS; ++kk) {
-            T a[Cfg::TM], b[Cfg::TN];
-#pragma unroll
-            for (int tm = 0; tm < Cfg::TM; ++tm) a[tm] = a_s[kk * KS * Cfg::LDA + tm * MS];
-#pragma unroll
-            for (int tn = 0; tn < Cfg::TN; ++tn) b[tn] = b_s[kk * KS * Cfg::LDB + tn * MS];
-#pragma unroll
-            for (int tm = 0; tm < Cfg::TM; ++tm)
-#pragma unroll
-                for (int tn = 0; tn < Cfg::TN; ++tn) M::mfma(acc[tm][tn], a[tm], b[tn]);
-        }
-        if (more) { la.store(sA + (cur ^ 1) * Cfg::SA); lb.store(sB + (cur ^ 1) * Cfg::SB); }
+#if SCFGP_DRY_LOOP == 1 || SCFGP_DRY_LOOP == 2
+        const bool stage = false;
+#else
+        const bool stage = kt + 1 < nkt;
+#endif
+        if (stage) { la.template load<0>(kt + 1); lb.template load<0>(kt + 1); }
+        tile_compute<Cfg>(sA + cur * Cfg::SA, sB + cur * Cfg::SB, acc);
+        if (stage) { la.template store<0>(sA + (cur ^ 1) * Cfg::SA); lb.template store<0>(sB + (cur ^ 1) * Cfg::SB); }
+        interleave_hint<Cfg::TM * Cfg::TN * (Cfg::BK / Cfg::MTr::KS)>();
+#if SCFGP_DRY_LOOP != 1 && SCFGP_DRY_LOOP != 3
         __syncthreads();
+#endif
     }
+#endif
 }
 
 template <class Cfg>
@@ -215,3 +358,17 @@ struct AccCoord {
     __device__ __forceinline__ int row(int tm, int r) const { return wm0 + tm * Cfg::MS + Cfg::MTr::crow(lane, r); }
     __device__ __forceinline__ int col(int tn) const { return wn0 + tn * Cfg::MS + (lane % Cfg::MS); }
 };
+
+// XCD-aware work-item id (guide T1): hardware deals consecutive workgroup ids round-robin over
+// the 8 XCDs, so ids b and b+8 share an L2.  Mapping id b to the b/8-th item of a contiguous
+// chunk owned by XCD b%8 makes workgroups that share operand panels (same rows, different
+// column tiles) run on ONE XCD: the panel crosses the fabric once instead of up to 8 times.
+// Placement is only a speed matter; the map is a bijection for any n.
+__device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned n) {
+#if SCFGP_NO_XCD_REMAP
+    return b;
+#else
+    const unsigned q = n / 8, r = n % 8, xcd = b % 8, local = b / 8;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+#endif
+}

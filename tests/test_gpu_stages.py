@@ -41,7 +41,9 @@ def test_stages_match_oracle(name, dtype, tol):
     eng.pass1(); ora.pass1()
     Phi = eng.debug_read('Phi', (Np, Kp), tdt).astype(np.float64)
     assert rel(Phi[:N, :K], ora.Ph) < (1e-12 if dtype == 'f64' else 1e-6)
-    assert np.all(Phi[N:] == 0) and np.all(Phi[:, K:] == 0)
+    # augmented columns: K carries y (for Phi^T y out of the Gram), K+1 is filled with p in pass 2
+    assert np.all(Phi[N:] == 0) and np.all(Phi[:, K + 1:] == 0)
+    assert np.array_equal(Phi[:N, K], y.ravel().astype(tdt).astype(np.float64))
     x1 = eng.debug_read('G', (Kp * Kp + Kp + 8,))
     G = x1[:Kp * Kp].reshape(Kp, Kp)
     assert rel(G[:K, :K], ora.x1[:K * K].reshape(K, K)) < tol
@@ -65,6 +67,8 @@ def test_stages_match_oracle(name, dtype, tol):
     p = eng.debug_read('p', (Np,)); q = eng.debug_read('q', (Np,))
     assert rel(p[:N], ora.p) < ctol and rel(q[:N], ora.q) < ctol
     assert np.all(p[N:] == 0) and np.all(q[N:] == 0)
+    Phi2 = eng.debug_read('Phi', (Np, Kp), tdt).astype(np.float64)
+    assert np.array_equal(Phi2[:, K + 1], p.astype(tdt).astype(np.float64)) and np.all(Phi2[:, K + 2:] == 0)
     x2 = eng.debug_read('W', (Kp * Kp + Kp + 8,))
     W = x2[:Kp * Kp].reshape(Kp, Kp)
     assert rel(W[:K, :K], ora.x2[:K * K].reshape(K, K)) < ctol
@@ -78,12 +82,11 @@ def test_stages_match_oracle(name, dtype, tol):
 
     # sweep 3
     eng.pass3(); ora.pass3()
-    Zb = eng.debug_read('Zbar', (Np, Jp), tdt).astype(np.float64)
     x3 = eng.debug_read('XZ', (Dpp * Jp + 8,))
     XZ = x3[:Dpp * Jp].reshape(Dpp, Jp)
     assert rel(XZ[:D, :J], ora.x3[:D * J].reshape(D, J)) < ctol
     assert abs(x3[Dpp * Jp] - ora.x3[-1]) < ctol * max(1.0, abs(ora.x3[-1]))
-    assert np.all(Zb[N:] == 0) and np.all(Zb[:, J:] == 0)
+    assert np.all(XZ[Dp:] == 0) and np.all(XZ[:, J:] == 0)
 
     cost, grad, alpha, Li_h = eng.finish(True)
     c_o, g_o, al_o, Li_o = ora.finish(True)
