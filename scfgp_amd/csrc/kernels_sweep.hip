@@ -36,6 +36,38 @@ typedef TileCfg<double, 128, 64, 16, 2, 2> FmapCfg;
 template <typename T> struct XtzCfg { typedef TileCfg<T, 128, 128, 16, 4, 2, Tune<T>::MS> type; };
 
 // --------------------------------------------------------------------------
+// sin/cos for |z| up to ~1e5 rad: two-term Cody-Waite reduction by pi/2 in fp64 (fdlibm's
+// medium-argument constants: exact n*pio2_1 for |n| < 2^20) and fdlibm's kernel polynomials on
+// [-pi/4, pi/4] (< 1 ulp).  Branch-free; the library sincos carries a Payne-Hanek path the
+// phases of this model never need (|FF| is tens to hundreds of radians).
+// --------------------------------------------------------------------------
+__device__ __forceinline__ void fast_sincos(double z, double& sn, double& cs) {
+    const double fn = rint(z * 6.36619772367581382433e-01);              // 2/pi
+    const double r = fma(-fn, 1.57079632673412561417e+00, z);            // pio2_1 (33 bits)
+    const double w = fn * 6.07710050650619224932e-11;                    // pio2_1t
+    const double x = r - w;
+    const double y = (r - x) - w;                                        // tail of x
+    const double z2 = x * x;
+    // __kernel_sin(x, y, 1)
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double v = z2 * x;
+    const double rs = S2 + z2 * (S3 + z2 * (S4 + z2 * (S5 + z2 * S6)));
+    const double s = x - ((z2 * (0.5 * y - v * rs) - y) - v * S1);
+    // __kernel_cos(x, y)
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double rc = z2 * (C1 + z2 * (C2 + z2 * (C3 + z2 * (C4 + z2 * (C5 + z2 * C6)))));
+    const double hz = 0.5 * z2;
+    const double wc = 1.0 - hz;
+    const double c = wc + (((1.0 - wc) - hz) + (z2 * rc - x * y));
+    const int q = (int)fn & 3;
+    const double ss = (q & 1) ? c : s, cc = (q & 1) ? s : c;
+    sn = (q & 2) ? -ss : ss;
+    cs = ((q + 1) & 2) ? -cc : cc;
+}
+
+// --------------------------------------------------------------------------
 // feature map:  Z = X~ . Fall  (fp64 MFMA, K-dim = Dp),  Phi = s [cos Z | sin Z]
 // --------------------------------------------------------------------------
 template <typename T>
@@ -64,7 +96,7 @@ __global__ __launch_bounds__(FmapCfg::THREADS) void featuremap_kernel(
             for (int r = 0; r < Cfg::MTr::NACC; ++r) {
                 const int64_t n = rb * Cfg::BM + co.row(tm, r);
                 double sn, cs;
-                sincos(acc[tm][tn][r], &sn, &cs);
+                fast_sincos(acc[tm][tn][r], sn, cs);
                 const double m = n < N ? s : 0.0;
                 Phi[n * Kp + j] = (T)(m * cs);
                 Phi[n * Kp + J + j] = (T)(m * sn);

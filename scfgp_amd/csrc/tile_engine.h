@@ -83,26 +83,36 @@ struct NatLoader {
     static constexpr int VS = Vec16<S>::N;
     static constexpr int VPR = BX / VS;                       // vectors per k row
     static constexpr int NV = (BK * VPR + THREADS - 1) / THREADS;
-    const S* base; int64_t ld; const double* w; int xlim;     // xlim: first invalid x (GUARD)
+    // Loads are issued for consecutive k-tiles (0, 1, 2, ...): each vector keeps a running pointer
+    // that advances by BK rows per call, so the loop carries no 64-bit multiplies.
+    const S* ptr[NV]; const double* wptr[NV]; int64_t step; int xlim;     // xlim: first invalid x (GUARD)
     int xplain = -1;                                          // WEIGHT: this x is stored unweighted
     vec_t r[1 + SCFGP_PREFETCH2][NV]; T wr[1 + SCFGP_PREFETCH2][NV];
     int tid;
     __device__ __forceinline__ NatLoader(const S* b, int64_t l, int t, const double* w_ = nullptr, int xl = 0)
-        : base(b), ld(l), w(w_), xlim(xl), tid(t) {}
-    template <int SET = 0>
-    __device__ __forceinline__ void load(int kt) {
+        : step((int64_t)BK * l), xlim(xl), tid(t) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int v = tid + i * THREADS;
             const int k = v / VPR, xv = v % VPR;
+            ptr[i] = b + (int64_t)k * l + xv * VS;
+            wptr[i] = WEIGHT ? w_ + k : nullptr;
+        }
+    }
+    template <int SET = 0>
+    __device__ __forceinline__ void load(int) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int v = tid + i * THREADS;
+            const int xv = v % VPR;
             const bool ok = (BK * VPR) % THREADS == 0 || v < BK * VPR;
             vec_t val;
 #pragma unroll
             for (int e = 0; e < VS; ++e) val[e] = 0;
-            if (ok && (!GUARD || xv * VS < xlim))
-                val = *reinterpret_cast<const vec_t*>(base + (int64_t)(kt * BK + k) * ld + xv * VS);
+            if (ok && (!GUARD || xv * VS < xlim)) val = *reinterpret_cast<const vec_t*>(ptr[i]);
             r[SET][i] = val;
-            if (WEIGHT) wr[SET][i] = ok ? (T)w[kt * BK + k] : (T)0;
+            if (WEIGHT) { wr[SET][i] = ok ? (T)*wptr[i] : (T)0; wptr[i] += BK; }
+            ptr[i] += step;
         }
     }
     template <int SET = 0>
@@ -136,21 +146,27 @@ struct TrLoader {
     static constexpr int VS = Vec16<S>::N;
     static constexpr int VPR = BK / VS;                       // vectors per x row
     static constexpr int NV = (BX * VPR + THREADS - 1) / THREADS;
-    const S* base; int64_t ld; int tid;
+    const S* ptr[NV]; int tid;
     vec_t r[1 + SCFGP_PREFETCH2][NV];
-    __device__ __forceinline__ TrLoader(const S* b, int64_t l, int t) : base(b), ld(l), tid(t) {}
-    template <int SET = 0>
-    __device__ __forceinline__ void load(int kt) {
+    __device__ __forceinline__ TrLoader(const S* b, int64_t l, int t) : tid(t) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int v = tid + i * THREADS;
-            const int x = v / VPR, kv = v % VPR;
+            ptr[i] = b + (int64_t)(v / VPR) * l + (v % VPR) * VS;
+        }
+    }
+    template <int SET = 0>
+    __device__ __forceinline__ void load(int) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int v = tid + i * THREADS;
             const bool ok = (BX * VPR) % THREADS == 0 || v < BX * VPR;
             vec_t val;
 #pragma unroll
             for (int e = 0; e < VS; ++e) val[e] = 0;
-            if (ok) val = *reinterpret_cast<const vec_t*>(base + (int64_t)x * ld + kt * BK + kv * VS);
+            if (ok) val = *reinterpret_cast<const vec_t*>(ptr[i]);
             r[SET][i] = val;
+            ptr[i] += BK;
         }
     }
     template <int SET = 0>
@@ -179,12 +195,12 @@ struct ZbarLoader {
     static constexpr int VS = Vec16<S>::N;
     static constexpr int VPR = BX / VS;
     static constexpr int NV = (BK * VPR + THREADS - 1) / THREADS;
-    const S* phi; const S* pb; int64_t ld; int J, j0, tid; bool vec;
+    const S* phi; const S* pb; int64_t ld; int J, j0, tid; bool vec; int kt = 0;   // consecutive k-tiles
     T r[1][NV][VS];
     __device__ __forceinline__ ZbarLoader(const S* phi_, const S* pb_, int64_t ld_, int J_, int j0_, int t)
         : phi(phi_), pb(pb_), ld(ld_), J(J_), j0(j0_), tid(t), vec(J_ % VS == 0) {}
     template <int SET = 0>
-    __device__ __forceinline__ void load(int kt) {
+    __device__ __forceinline__ void load(int) {
         typedef typename Vec16<S>::type vec_t;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
@@ -204,6 +220,7 @@ struct ZbarLoader {
                     r[0][i][e] = (ok && j + e < J) ? (T)f[j + e] * (T)b[J + j + e] - (T)f[J + j + e] * (T)b[j + e] : (T)0;
             }
         }
+        ++kt;
     }
     template <int SET = 0>
     __device__ __forceinline__ void store(T* s) const {
