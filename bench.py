@@ -131,6 +131,13 @@ def main():
         ach = flops / (ap_ms * 1e-3) / 1e12 if ap_ms > 0 else 0.0
         peak = PEAK_TFLOPS[a.dtype]
         falg = 10.0 * N * K * K + 4.0 * N * D * J
+        traffic, traffic_src = None, None
+        tp = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+        if os.path.exists(tp) and (N, D, S, M, a.dtype, world) == (1000000, 64, 32, 1024, 'f32', 1):
+            # HBM-side bytes per launch of the same kernel on the same workload, from rocprofv3 PMC passes
+            # (FETCH_SIZE x2 + WRITE_SIZE, one counter per pass): it cannot be collected inside this process
+            traffic = json.load(open(tp))['apply_kernel_mean_GB_per_launch'] * 1e9
+            traffic_src = 'profiles/r01_pmc_traffic.json'
         out = {
             "metric": "NLML+grad evals/sec", "value": a.steps / dt, "unit": "evals/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
@@ -140,7 +147,7 @@ def main():
                        "rows_per_gpu": hi - lo, "parallelism": "row-sharded dp%d, 3 all-reduces/eval" % world,
                        "F_alg_per_eval": falg, "F_alg_TFLOPs": falg / (dt / a.steps) / 1e12},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                         "traffic": None, "kernel": "apply_kernel (Phi.B / Phi.Abar, 2*N*K^2 flops per launch)",
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "apply_kernel (Phi.B / Phi.Abar, 2*N*K^2 flops per launch)",
                          "avg_launch_ms": ap_ms},
             "stages_ms": {k: float(np.mean(v)) for k, v in per_kernel.items()},
             "cost": float(cost),

@@ -127,6 +127,34 @@ def test_minibatches_of_different_sizes():
         assert abs(float(c) - c0) < 1e-10 * abs(c0) and rel(g, g0) < 1e-7 and rel(a, a0) < 1e-7
 
 
+@pytest.mark.parametrize('N,D,S,M', [(1, 1, 2, 2), (3, 2, 2, 3), (255, 3, 2, 5), (513, 70, 5, 60),
+                                     (300, 200, 3, 9), (1000, 5, 64, 3), (2000, 7, 31, 33)])
+@pytest.mark.parametrize('dtype', ['f64', 'f32'])
+def test_ragged_and_degenerate_shapes(N, D, S, M, dtype):
+    """Sizes that are not multiples of any tile: padding rows/columns must never leak."""
+    from scfgp_amd.engine import HipEngine
+    rng = np.random.default_rng(N * 7 + D)
+    X = rng.random((N, D)); y = rng.standard_normal((N, 1))
+    params = O.init_params(D, S, M, rng)
+    params[0] = -0.5; params[1] = 0.1; params[2] = -0.7; params[3:3 + D * S] *= 0.7
+    Xs = rng.random((17, D))
+    eng = HipEngine(D, S, M, dtype=dtype); eng.set_params(params); eng.set_data(X, y)
+    cost, grad, alpha, Li = eng.eval(want_grad=True)
+    c0, g0, a0, L0 = O.value_and_grad(X, y, params, S, M)
+    tol = 1e-8 if dtype == 'f64' else 2e-3
+    assert abs(float(cost) - c0) < (1e-10 if dtype == 'f64' else 2e-5) * max(1.0, abs(c0))
+    assert rel(grad, g0) < tol and rel(alpha, a0) < tol and rel(Li, L0) < tol
+    mu, sd = eng.predict(Xs, a0, L0)
+    mu0, sd0 = O.predict(Xs, a0, L0, params, S, M)
+    assert rel(mu, mu0) < tol and rel(sd, sd0) < tol
+    # a second, smaller data set through the same context (capacity is kept, padding rewritten)
+    n2 = max(1, N // 3)
+    c2, g2, _, _ = eng.eval(np.ascontiguousarray(X[:n2]), np.ascontiguousarray(y[:n2]), want_grad=True)
+    c3, g3, _, _ = O.value_and_grad(X[:n2], y[:n2], params, S, M)
+    assert abs(float(c2) - c3) < (1e-10 if dtype == 'f64' else 2e-5) * max(1.0, abs(c3)) and rel(g2, g3) < tol
+    eng.close()
+
+
 # ---------------------------------------------------------------------------------------------
 def _synthetic(N, D, S, M, seed):
     X = synth.make_X(seed, N, D)
