@@ -79,16 +79,20 @@ def main():
     ap.add_argument('--M', type=int, default=1024)
     ap.add_argument('--cpu-rows', type=int, default=30000)
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--backend', default='nccl', help="'gloo' rehearses the multi-rank flow on one GPU")
     a = ap.parse_args()
 
     import torch
     rank = int(os.environ.get('RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1))
-    local = int(os.environ.get('LOCAL_RANK', 0))
+    local = int(os.environ.get('LOCAL_RANK', 0)) % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     allreduce = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if a.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(a.backend)
         allreduce = torch_allreduce()
     N, D, S, M = a.rows, a.D, a.S, a.M
     J = S + M; K = 2 * J
@@ -117,7 +121,7 @@ def main():
             per_kernel.setdefault(name, []).append(ms)
     barrier()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], device='cuda')
+    tmax = torch.tensor([dt], device='cuda' if a.backend == 'nccl' else 'cpu')
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())

@@ -23,13 +23,18 @@ def torch_allreduce(group=None):
     import torch.distributed as dist
 
     def _ar(buf):
+        backend = dist.get_backend(group)
         if isinstance(buf, np.ndarray):
-            if dist.get_backend(group) == 'nccl':          # host scalars (e.g. the global N)
+            if backend == 'nccl':                          # host scalars (e.g. the global N)
                 t = torch.from_numpy(buf).cuda()
                 dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
                 buf[...] = t.cpu().numpy()
             else:
                 dist.all_reduce(torch.from_numpy(buf), op=dist.ReduceOp.SUM, group=group)
+        elif buf.is_cuda and backend == 'gloo':            # CPU-backend rehearsal of the GPU path
+            h = buf.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+            buf.copy_(h)
         else:
             dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
     return _ar
