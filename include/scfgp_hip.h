@@ -106,6 +106,23 @@ int scfgp_finish(scfgp_ctx* ctx, int want_grad, double* cost, double* grad, doub
 /* device pointer + length (in doubles) of exchange buffer `stage` (1..3) */
 int scfgp_exchange(scfgp_ctx* ctx, int stage, void** dev_ptr, int64_t* count);
 
+/* ---- on-device update rule and multi-iteration residency -------------
+ * The arithmetic of SCFGP/Optimizer.py as a device kernel behind the evaluation, so a training
+ * iteration (SCFGP/SCFGP.py:237: train_iter_func) needs no host round trip; from the second
+ * iteration on the whole iteration is ONE captured hipGraph launch.
+ *   algo   0 sgd, 1 adagrad, 2 rmsprop, 3 adadelta, 4 adam, 5 adamax  (SCFGP/Optimizer.py:99-382)
+ *   hyper  [learning_rate, beta1 (rho for rmsprop/adadelta), beta2, epsilon]
+ *   momentum  Nesterov momentum as the reference applies it (SCFGP/Optimizer.py:62-97, on the FIRST
+ *             state of the rule's update dictionary); negative = none
+ * scfgp_train runs n_iters x (evaluate + update) on the resident rows (single GPU), returns the cost
+ * of every iteration (each at its pre-update parameters, like train_iter_func) and, if non-NULL,
+ * alpha / Li of the LAST evaluation; the updated vector is read with scfgp_get_params.
+ * scfgp_opt_state copies optimiser state to (set=0) or from (set=1) the host: which 0,1 = the rule's
+ * two state vectors, 2 = Nesterov velocity (P doubles each), 3 = step counter (1 double). */
+int scfgp_opt_init(scfgp_ctx* ctx, int algo, const double* hyper, int nhyper, double momentum);
+int scfgp_opt_state(scfgp_ctx* ctx, int set, int which, double* buf);
+int scfgp_train(scfgp_ctx* ctx, int n_iters, double* cost_hist, double* alpha, double* Li);
+
 /* ---- introspection ------------------------------------------------------------------------ */
 /* padded sizes the device buffers use: out[0]=K, out[1]=Kp, out[2]=Jp, out[3]=Dp, out[4]=Np, out[5]=P, out[6]=tile */
 int scfgp_get_dims(scfgp_ctx* ctx, int64_t* out, int n);
@@ -116,7 +133,7 @@ int scfgp_get_timings(scfgp_ctx* ctx, double* ms, const char** names, int n);
 /* copy an internal device buffer to the host for tests ("Phi","G","Li","B","V","Zbar","XZ",
  * "W","Abar","p","q","alpha","scalars"); returns the number of bytes copied or <0 */
 int64_t scfgp_debug_read(scfgp_ctx* ctx, const char* name, void* host, int64_t max_bytes);
-/* tuning knobs: "gram_nsplit", "gram_chunk" (fp32 flush interval in rows), "xtz_nsplit" */
+/* tuning knobs: "gram_nsplit", "gram_chunk" (fp32 flush interval in rows), "xtz_nsplit", "use_graph" */
 int scfgp_set_option(scfgp_ctx* ctx, const char* name, int64_t value);
 
 #ifdef __cplusplus

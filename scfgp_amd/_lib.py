@@ -36,6 +36,9 @@ SIGNATURES = {
     'scfgp_pass3': (C.c_int, [C.c_void_p]),
     'scfgp_finish': (C.c_int, [C.c_void_p, C.c_int, _c_double_p, _c_double_p, _c_double_p, _c_double_p]),
     'scfgp_exchange': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), _c_i64_p]),
+    'scfgp_opt_init': (C.c_int, [C.c_void_p, C.c_int, _c_double_p, C.c_int, C.c_double]),
+    'scfgp_opt_state': (C.c_int, [C.c_void_p, C.c_int, C.c_int, _c_double_p]),
+    'scfgp_train': (C.c_int, [C.c_void_p, C.c_int, _c_double_p, _c_double_p, _c_double_p]),
     'scfgp_get_dims': (C.c_int, [C.c_void_p, _c_i64_p, C.c_int]),
     'scfgp_set_profiling': (C.c_int, [C.c_void_p, C.c_int]),
     'scfgp_get_timings': (C.c_int, [C.c_void_p, _c_double_p, C.POINTER(C.c_char_p), C.c_int]),

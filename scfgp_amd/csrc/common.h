@@ -30,8 +30,9 @@ enum {
 };
 
 // Dynamic LDS above 64 KiB needs an explicit opt-in per kernel on HIP.
+extern thread_local bool g_scfgp_capturing;      // set while a hipGraph is being captured (scfgp_api.hip)
 template <typename Kern>
 static inline void allow_big_lds(Kern kernel, int bytes) {
-    if (bytes > 64 * 1024)
+    if (bytes > 64 * 1024 && !g_scfgp_capturing)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }

@@ -68,6 +68,12 @@ void pack_data(const Geom& g, const double* Xraw, const double* yraw, double* Xt
 // square K x K host-layout matrix (ld K) -> Kp x Kp with identity padding, and back
 void pad_square(const double* src, int K, int Kp, double* dst, hipStream_t st);
 
+// ---- on-device update rules (SCFGP/Optimizer.py) --------------------------------------------
+struct OptHyper { double lr, b1, b2, eps, momentum; };   // b1 doubles as rho for rmsprop/adadelta; momentum < 0: no Nesterov
+// theta <- rule(theta, grad); st = [s1 | s2 | velocity]; tctr[0] = step counter, tctr[1] = index into hist
+void opt_update(int algo, const OptHyper& h, int P, double* theta, const double* grad, double* st, double* tctr,
+                const double* scalars, double* hist, int hist_cap, hipStream_t stream);
+
 // ---- K x K stage (fp64, all matrices Kp x Kp, leading dimension Kp) -----------
 struct KStage {
     int K, Kp;

@@ -168,3 +168,59 @@ void finalize_cost(const Geom& g, const Scal* sc, double* scalars, const double*
                    int64_t Nglobal, double* grad, int want_grad, hipStream_t st) {
     hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, st, sc, scalars, yy, t2kb, bbar, g.M, (double)Nglobal, grad, want_grad);
 }
+
+// ---------------------------------------------------------------------------
+// Update rules on the device (SCFGP/Optimizer.py:99-382) followed by the Nesterov wrapper exactly
+// as the reference applies it (:62-97): to the FIRST key of the rule's update dictionary --
+// params for sgd, `accu` for adagrad/rmsprop/adadelta, `m` for adam/adamax.  All states are read
+// before any is written (Theano's simultaneous-update semantics).
+//   st = [s1 (P) | s2 (P) | vel (P)], tctr = step counter t (device scalar), hist[t] = cost
+// ---------------------------------------------------------------------------
+__global__ void opt_update_kernel(int algo, OptHyper h, int P, double* __restrict__ theta, const double* __restrict__ grad,
+                                  double* __restrict__ st, const double* __restrict__ tctr) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    double* s1 = st; double* s2 = st + P; double* vel = st + 2 * (int64_t)P;
+    const double g = grad[i], th = theta[i], a1 = s1[i], a2 = s2[i], v = vel[i];
+    const double t = tctr[0] + 1.0;
+    const bool nest = h.momentum >= 0.0;
+    double th_new = th, a1_new = a1, a2_new = a2, first_step;      // first_step: plain new value of the rule's first key
+    switch (algo) {
+    case 0:   // sgd                                            :99-119
+        th_new = th - h.lr * g; first_step = th_new; break;
+    case 1:   // adagrad                                        :121-164
+        a1_new = a1 + g * g; th_new = th - h.lr * g / sqrt(a1_new + h.eps); first_step = a1_new; break;
+    case 2:   // rmsprop (the formula its docstring states)    :166-213
+        a1_new = h.b1 * a1 + (1.0 - h.b1) * g * g; th_new = th - h.lr * g / sqrt(a1_new + h.eps); first_step = a1_new; break;
+    case 3: { // adadelta                                       :215-276
+        a1_new = h.b1 * a1 + (1.0 - h.b1) * g * g;
+        const double up = g * sqrt(a2 + h.eps) / sqrt(a1_new + h.eps);
+        th_new = th - h.lr * up; a2_new = h.b1 * a2 + (1.0 - h.b1) * up * up; first_step = a1_new; break; }
+    case 4: { // adam                                           :278-331
+        const double at = h.lr * sqrt(1.0 - pow(h.b2, t)) / (1.0 - pow(h.b1, t));
+        a1_new = h.b1 * a1 + (1.0 - h.b1) * g; a2_new = h.b2 * a2 + (1.0 - h.b2) * g * g;
+        th_new = th - at * a1_new / (sqrt(a2_new) + h.eps); first_step = a1_new; break; }
+    default: { // adamax                                        :333-382
+        const double at = h.lr / (1.0 - pow(h.b1, t));
+        a1_new = h.b1 * a1 + (1.0 - h.b1) * g; a2_new = fmax(h.b2 * a2, fabs(g));
+        th_new = th - at * a1_new / (a2_new + h.eps); first_step = a1_new; break; }
+    }
+    if (nest) {                                                   // :92-96 on the first key
+        const double old_first = algo == 0 ? th : a1;
+        const double x = h.momentum * v + first_step - old_first;
+        vel[i] = x;
+        if (algo == 0) th_new = h.momentum * x + first_step; else a1_new = h.momentum * x + first_step;
+    }
+    theta[i] = th_new; s1[i] = a1_new; s2[i] = a2_new;
+}
+__global__ void opt_tick_kernel(double* tctr, const double* __restrict__ scalars, double* __restrict__ hist, int hist_cap) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int t = (int)tctr[1];                                   // iterations done in this scfgp_train call
+    if (t < hist_cap) hist[t] = scalars[R_COST];
+    tctr[0] += 1.0; tctr[1] += 1.0;
+}
+void opt_update(int algo, const OptHyper& h, int P, double* theta, const double* grad, double* st, double* tctr,
+                const double* scalars, double* hist, int hist_cap, hipStream_t stream) {
+    hipLaunchKernelGGL(opt_update_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, algo, h, P, theta, grad, st, tctr);
+    hipLaunchKernelGGL(opt_tick_kernel, dim3(1), dim3(64), 0, stream, tctr, scalars, hist, hist_cap);
+}

@@ -3,6 +3,7 @@
 #include "../../include/scfgp_hip.h"
 #include "kernels.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -20,6 +21,8 @@
 
 static constexpr int XT = 128;              // tile of the X~^T Zbar product and padding unit of J (kernels_sweep.hip)
 static constexpr int64_t PRED_ROWS = 32768; // predict processes test rows in chunks of this size
+
+thread_local bool g_scfgp_capturing = false;
 
 struct ProfRec { std::string name; hipEvent_t e0, e1; };
 
@@ -47,6 +50,10 @@ struct scfgp_ctx {
     double *d_work = nullptr, *d_grad = nullptr;
     // predict chunk buffers
     double *p_Xt = nullptr, *p_vpart = nullptr, *p_mu = nullptr, *p_sd = nullptr; void *p_Phi = nullptr, *p_V = nullptr;
+    // on-device optimiser + captured training iteration
+    int opt_algo = -1; OptHyper opt_h{}; double *d_opt = nullptr, *d_tctr = nullptr, *d_hist = nullptr; int hist_cap = 0;
+    hipGraph_t graph = nullptr; hipGraphExec_t gexec = nullptr; int64_t graph_N = -1; bool in_train = false, warm = false;
+    int use_graph = 1;
     // options
     int gram_nsplit = 0, xtz_nsplit = 0, cs_nsplit = 128; int64_t gram_chunk = 4096;
     // profiling
@@ -70,7 +77,7 @@ struct scfgp_ctx {
 struct ProfScope {
     scfgp_ctx* c; size_t idx = (size_t)-1;
     ProfScope(scfgp_ctx* c_, const char* name) : c(c_) {
-        if (!c->prof) return;
+        if (!c->prof || g_scfgp_capturing) return;
         auto get = [&]() {
             if (c->pool_used == c->pool.size()) { hipEvent_t e; hipEventCreate(&e); c->pool.push_back(e); }
             return c->pool[c->pool_used++];
@@ -88,9 +95,12 @@ template <typename P> static int dmalloc(scfgp_ctx* c, P** p, size_t bytes) {
 }
 template <typename P> static void dfree(P*& p) { if (p) { hipFree((void*)p); p = nullptr; } }
 
+// row splits of the Gram products: enough workgroups (>> 768 resident) that the tail does not
+// quantise, but at least 2048 rows per split so the slab traffic (nsplit x K^2/2 x 8 B written and
+// re-read by the reduction) stays far below the Phi traffic
 static int default_split(int ntiles, int64_t Np) {
-    int64_t s = (6144 + ntiles - 1) / ntiles;         // >> 768 resident workgroups: no tail quantisation
-    const int64_t smax = Np / 256;
+    int64_t s = (6144 + ntiles - 1) / ntiles;
+    const int64_t smax = std::max<int64_t>(Np / 2048, 1);
     if (s > smax) s = smax;
     if (s < 1) s = 1;
     return (int)s;
@@ -98,7 +108,7 @@ static int default_split(int ntiles, int64_t Np) {
 
 static int xtz_split(int ntiles, int64_t Np) {          // the X~^T Zbar grid has few tiles: ~2048 workgroups suffice
     int64_t s = (2048 + ntiles - 1) / ntiles;
-    const int64_t smax = Np / 256;
+    const int64_t smax = std::max<int64_t>(Np / 2048, 1);
     if (s > smax) s = smax;
     if (s < 1) s = 1;
     return (int)s;
@@ -113,6 +123,8 @@ static void free_rows(scfgp_ctx* c) {
 // (re)allocate every buffer whose size depends on the number of local rows
 static int ensure_rows(scfgp_ctx* c, int64_t N) {
     Geom& g = c->g;
+    if (c->gexec) { hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }      // captured pointers/sizes may change
+    if (c->graph) { hipGraphDestroy(c->graph); c->graph = nullptr; }
     const int64_t Np = round_up(N > 0 ? N : 1, 256);
     g.N = N; g.Np = Np;
     const int nts = g.Kp / g.tile, ntiles = nts * (nts + 1) / 2;
@@ -204,6 +216,9 @@ extern "C" void scfgp_destroy(scfgp_ctx* c) {
     dfree(c->d_Abar); dfree(c->d_BT); dfree(c->d_AbarT); dfree(c->d_vecs); dfree(c->d_scalars); dfree(c->d_yy);
     dfree(c->d_flag); dfree(c->d_partial); dfree(c->d_work); dfree(c->d_grad);
     dfree(c->p_Xt); dfree(c->p_vpart); dfree(c->p_mu); dfree(c->p_sd); dfree(c->p_Phi); dfree(c->p_V);
+    if (c->gexec) hipGraphExecDestroy(c->gexec);
+    if (c->graph) hipGraphDestroy(c->graph);
+    dfree(c->d_opt); dfree(c->d_tctr); dfree(c->d_hist);
     for (hipEvent_t e : c->pool) hipEventDestroy(e);
     if (c->own_stream && c->st) hipStreamDestroy(c->st);
     delete c;
@@ -271,6 +286,7 @@ template <typename T> struct Impl {
     static int pass1(scfgp_ctx* c) {
         const Geom& g = c->g;
         const int64_t K2 = (int64_t)g.Kp * g.Kp;
+        if (!c->in_train) HIPCHK(c, hipMemsetAsync(c->d_flag, 0, sizeof(int) * 4, c->st));
         { ProfScope ps(c, "featuremap"); SK::featuremap(g, c->d_Xt, c->d_Fall, c->d_sc, (T*)c->d_Phi, c->st); }
         gram_to(c, nullptr, c->d_x1, g.K, "gram");
         HIPCHK(c, hipMemcpyAsync(c->d_x1 + K2 + g.Kp, c->d_yy, sizeof(double), hipMemcpyDeviceToDevice, c->st));
@@ -279,7 +295,6 @@ template <typename T> struct Impl {
     }
     static int factor(scfgp_ctx* c) {
         const Geom& g = c->g;
-        HIPCHK(c, hipMemsetAsync(c->d_flag, 0, sizeof(int) * 4, c->st));
         { ProfScope ps(c, "kstage_factor"); kstage_factor(c->kstage(), c->d_sc, c->st); }
         SK::convert(c->d_B, (T*)c->d_BT, g.K, g.Kp, c->st);
         HIPCHK(c, hipGetLastError());
@@ -382,17 +397,21 @@ extern "C" int scfgp_exchange(scfgp_ctx* c, int stage, void** dev_ptr, int64_t* 
     return SCFGP_OK;
 }
 
+static void enqueue_epilogue(scfgp_ctx* c, int want_grad) {
+    const Geom& g = c->g;
+    const int64_t K2 = (int64_t)g.Kp * g.Kp;
+    ProfScope ps(c, "epilogue");
+    grad_epilogue(g, c->d_params, c->d_F, c->d_x3, g.Jp, c->d_work, c->d_scalars, c->Nglobal, want_grad ? c->d_grad : nullptr, c->st);
+    finalize_cost(g, c->d_sc, c->d_scalars, c->d_x1 + K2 + g.Kp, c->d_x2 + K2 + g.Kp, c->d_x3 + (int64_t)c->Dpp * g.Jp,
+                  c->Nglobal, c->d_grad, want_grad, c->st);
+}
+
 extern "C" int scfgp_finish(scfgp_ctx* c, int want_grad, double* cost, double* grad, double* alpha, double* Li) {
     if (int rc = ready(c)) return rc;
     if ((want_grad && c->stage != 5) || (!want_grad && c->stage != 3)) { c->err = "finish: evaluation incomplete"; return SCFGP_EARG; }
     const Geom& g = c->g;
     const int64_t K2 = (int64_t)g.Kp * g.Kp;
-    {
-        ProfScope ps(c, "epilogue");
-        grad_epilogue(g, c->d_params, c->d_F, c->d_x3, g.Jp, c->d_work, c->d_scalars, c->Nglobal, want_grad ? c->d_grad : nullptr, c->st);
-        finalize_cost(g, c->d_sc, c->d_scalars, c->d_x1 + K2 + g.Kp, c->d_x2 + K2 + g.Kp, c->d_x3 + (int64_t)c->Dpp * g.Jp,
-                      c->Nglobal, c->d_grad, want_grad, c->st);
-    }
+    enqueue_epilogue(c, want_grad);
     double h_cost = 0; int h_flag[4] = {0, 0, 0, 0};
     {
         ProfScope ps(c, "d2h");
@@ -405,7 +424,7 @@ extern "C" int scfgp_finish(scfgp_ctx* c, int want_grad, double* cost, double* g
     }
     HIPCHK(c, hipStreamSynchronize(c->st));
     HIPCHK(c, hipGetLastError());
-    c->stage = 0;
+    c->stage = 0; c->warm = true;
     if (cost) *cost = h_cost;
     if (h_flag[0]) { c->err = "Phi^T Phi + (e^{2a}+1e-6) I is not positive definite"; return SCFGP_ENOTPD; }
     if (!std::isfinite(h_cost)) { c->err = "non-finite cost"; return SCFGP_ENONFINITE; }
@@ -474,6 +493,109 @@ extern "C" int scfgp_predict(scfgp_ctx* c, const double* Xs, int64_t T, const do
     return SCFGP_OK;
 }
 
+// ----------------------------------------------------------------------------------------------
+// on-device optimiser and the captured training iteration
+// ----------------------------------------------------------------------------------------------
+extern "C" int scfgp_opt_init(scfgp_ctx* c, int algo, const double* hyper, int nhyper, double momentum) {
+    if (!c || algo < 0 || algo > 5 || !hyper || nhyper < 4) { if (c) c->err = "opt_init: bad arguments"; return SCFGP_EARG; }
+    HIPCHK(c, hipSetDevice(c->device));
+    const int P = c->g.P;
+    if (!c->d_opt) {
+        if (int rc = dmalloc(c, &c->d_opt, sizeof(double) * 3 * P)) return rc;
+        if (int rc = dmalloc(c, &c->d_tctr, sizeof(double) * 8)) return rc;
+    }
+    HIPCHK(c, hipMemsetAsync(c->d_opt, 0, sizeof(double) * 3 * P, c->st));
+    HIPCHK(c, hipMemsetAsync(c->d_tctr, 0, sizeof(double) * 8, c->st));
+    c->opt_algo = algo;
+    c->opt_h = OptHyper{hyper[0], hyper[1], hyper[2], hyper[3], momentum};
+    if (c->gexec) { hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
+    if (c->graph) { hipGraphDestroy(c->graph); c->graph = nullptr; }
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    return SCFGP_OK;
+}
+
+// which: 0 = s1, 1 = s2, 2 = velocity (P doubles each), 3 = step counter t (1 double)
+extern "C" int scfgp_opt_state(scfgp_ctx* c, int set, int which, double* buf) {
+    if (!c || !buf || c->opt_algo < 0 || which < 0 || which > 3) return SCFGP_EARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    double* dev = which == 3 ? c->d_tctr : c->d_opt + (int64_t)which * c->g.P;
+    const size_t bytes = sizeof(double) * (which == 3 ? 1 : c->g.P);
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    if (set) HIPCHK(c, hipMemcpy(dev, buf, bytes, hipMemcpyHostToDevice));
+    else HIPCHK(c, hipMemcpy(buf, dev, bytes, hipMemcpyDeviceToHost));
+    return SCFGP_OK;
+}
+
+static int enqueue_train_iter(scfgp_ctx* c) {
+    int rc;
+    if ((rc = DISPATCH(c, pass1, c))) return rc;
+    if ((rc = DISPATCH(c, factor, c))) return rc;
+    if ((rc = DISPATCH(c, pass2, c, 1))) return rc;
+    if ((rc = DISPATCH(c, adjoint, c))) return rc;
+    if ((rc = DISPATCH(c, pass3, c))) return rc;
+    enqueue_epilogue(c, 1);
+    opt_update(c->opt_algo, c->opt_h, c->g.P, c->d_params, c->d_grad, c->d_opt, c->d_tctr, c->d_scalars, c->d_hist, c->hist_cap, c->st);
+    unpack_params(c->g, c->d_params, c->d_F, c->d_Fall, c->d_sc, c->st);
+    HIPCHK(c, hipGetLastError());
+    return SCFGP_OK;
+}
+
+extern "C" int scfgp_train(scfgp_ctx* c, int n_iters, double* cost_hist, double* alpha, double* Li) {
+    if (int rc = ready(c)) return rc;
+    if (c->opt_algo < 0 || n_iters < 1) { c->err = "train: call scfgp_opt_init first"; return SCFGP_EARG; }
+    const Geom& g = c->g;
+    if (n_iters > c->hist_cap) {
+        dfree(c->d_hist);
+        if (int rc = dmalloc(c, &c->d_hist, sizeof(double) * n_iters)) return rc;
+        c->hist_cap = n_iters;
+        if (c->gexec) { hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
+        if (c->graph) { hipGraphDestroy(c->graph); c->graph = nullptr; }
+    }
+    HIPCHK(c, hipMemsetAsync(c->d_flag, 0, sizeof(int) * 4, c->st));
+    HIPCHK(c, hipMemsetAsync(c->d_tctr + 1, 0, sizeof(double), c->st));
+    c->in_train = true;
+    int rc = SCFGP_OK, done = 0;
+    const bool graph_ok = c->use_graph && !c->prof;
+    if (graph_ok && !c->warm) { rc = enqueue_train_iter(c); done = 1; c->warm = true; }     // first touch of every kernel: eager
+    if (rc == SCFGP_OK && graph_ok && done < n_iters) {
+        if (!c->gexec || c->graph_N != g.N) {
+            if (c->gexec) { hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
+            if (c->graph) { hipGraphDestroy(c->graph); c->graph = nullptr; }
+            hipError_t e = hipStreamBeginCapture(c->st, hipStreamCaptureModeThreadLocal);
+            if (e == hipSuccess) {
+                g_scfgp_capturing = true;
+                rc = enqueue_train_iter(c);
+                g_scfgp_capturing = false;
+                e = hipStreamEndCapture(c->st, &c->graph);
+                if (rc == SCFGP_OK && e == hipSuccess) e = hipGraphInstantiate(&c->gexec, c->graph, nullptr, nullptr, 0);
+            }
+            if (e != hipSuccess || rc != SCFGP_OK) {                 // fall back to eager launches
+                if (c->graph) { hipGraphDestroy(c->graph); c->graph = nullptr; }
+                c->gexec = nullptr; (void)hipGetLastError(); rc = SCFGP_OK;
+            } else c->graph_N = g.N;
+        }
+        if (c->gexec)
+            for (; done < n_iters && rc == SCFGP_OK; ++done)
+                if (hipGraphLaunch(c->gexec, c->st) != hipSuccess) { c->err = "hipGraphLaunch failed"; rc = SCFGP_EHIP; }
+    }
+    for (; done < n_iters && rc == SCFGP_OK; ++done) rc = enqueue_train_iter(c);
+    c->in_train = false;
+    if (rc != SCFGP_OK) return rc;
+    int h_flag[4] = {0, 0, 0, 0};
+    if (cost_hist) HIPCHK(c, hipMemcpyAsync(cost_hist, c->d_hist, sizeof(double) * n_iters, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipMemcpyAsync(c->h_params.data(), c->d_params, sizeof(double) * g.P, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipMemcpyAsync(h_flag, c->d_flag, sizeof(int) * 4, hipMemcpyDeviceToHost, c->st));
+    if (alpha) HIPCHK(c, hipMemcpyAsync(alpha, c->alpha(), sizeof(double) * g.K, hipMemcpyDeviceToHost, c->st));
+    if (Li) HIPCHK(c, hipMemcpy2DAsync(Li, sizeof(double) * g.K, c->d_Li, sizeof(double) * g.Kp, sizeof(double) * g.K, g.K,
+                                       hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    HIPCHK(c, hipGetLastError());
+    c->stage = 0;
+    if (h_flag[0]) { c->err = "Phi^T Phi + (e^{2a}+1e-6) I is not positive definite"; return SCFGP_ENOTPD; }
+    if (cost_hist) for (int i = 0; i < n_iters; ++i) if (!std::isfinite(cost_hist[i])) { c->err = "non-finite cost"; return SCFGP_ENONFINITE; }
+    return SCFGP_OK;
+}
+
 extern "C" int scfgp_get_dims(scfgp_ctx* c, int64_t* out, int n) {
     if (!c || !out || n < 6) return SCFGP_EARG;
     out[0] = c->g.K; out[1] = c->g.Kp; out[2] = c->g.Jp; out[3] = c->g.Dp; out[4] = c->g.Np; out[5] = c->g.P;
@@ -508,6 +630,7 @@ extern "C" int scfgp_set_option(scfgp_ctx* c, const char* name, int64_t value) {
     if (s == "gram_nsplit") c->gram_nsplit = (int)value;
     else if (s == "gram_chunk") c->gram_chunk = value;
     else if (s == "xtz_nsplit") c->xtz_nsplit = (int)value;
+    else if (s == "use_graph") c->use_graph = (int)value;
     else { c->err = "unknown option " + s; return SCFGP_EARG; }
     if (c->have_data) return ensure_rows(c, c->g.N);
     return SCFGP_OK;

@@ -165,6 +165,28 @@ class HipEngine(object):
             __cuda_array_interface__ = {'shape': (n,), 'typestr': '<f8', 'data': (ptr, False), 'version': 2}
         return torch.as_tensor(_Alias(), device='cuda')
 
+    # -- on-device optimiser ------------------------------------------------------------------------
+    ALGOS = {'sgd': 0, 'adagrad': 1, 'rmsprop': 2, 'adadelta': 3, 'adam': 4, 'adamax': 5}
+
+    def opt_init(self, algo, learning_rate=0.01, beta1=0.9, beta2=0.999, epsilon=1e-8, momentum=0.9):
+        """Device-side update rule (beta1 doubles as rho for rmsprop/adadelta); momentum<0: no Nesterov."""
+        h = np.array([learning_rate, beta1, beta2, epsilon], dtype=np.float64)
+        self._check(self.lib.scfgp_opt_init(self.ctx, self.ALGOS[algo], dptr(h), 4, float(momentum)), 'opt_init')
+
+    def opt_state(self, which, value=None):
+        buf = np.empty(1 if which == 3 else self.P) if value is None else np.ascontiguousarray(value, dtype=np.float64).ravel()
+        self._check(self.lib.scfgp_opt_state(self.ctx, 0 if value is None else 1, int(which), dptr(buf)), 'opt_state')
+        return buf
+
+    def train(self, n_iters, want_factors=True):
+        """n_iters x (NLML+grad evaluation + update) on the resident rows without host round trips.
+        Returns (cost history (n,), alpha, Li of the last evaluation)."""
+        hist = np.empty(int(n_iters))
+        alpha = np.empty((self.K, 1)) if want_factors else None
+        Li = np.empty((self.K, self.K)) if want_factors else None
+        self._check(self.lib.scfgp_train(self.ctx, int(n_iters), dptr(hist), dptr(alpha), dptr(Li)), 'train')
+        return hist, alpha, Li
+
     # -- introspection ----------------------------------------------------------------------------
     def dims(self):
         out = (C.c_int64 * 7)()

@@ -46,7 +46,7 @@ class CompiledFuncs(object):
     """Owns one HipEngine (one GPU) and the shared parameter/optimiser state."""
 
     def __init__(self, D, S, M, params, algo='adam', algo_params=None, momentum=0.9,
-                 dtype='f64', device=0, stream=None, allreduce=None, n_global=None):
+                 dtype='f64', device=0, stream=None, allreduce=None, n_global=None, device_optimizer=False):
         self.engine = HipEngine(D, S, M, dtype=dtype, device=device, stream=stream)
         self.evaluator = ShardedEvaluator(self.engine, allreduce)
         self.allreduce = allreduce
@@ -60,6 +60,20 @@ class CompiledFuncs(object):
         self.updates = OPT.apply_nesterov_momentum(updates, momentum=momentum)        # SCFGP.py:131
         self._uploaded_version = None
         self._resident = None
+        # device_optimizer: the same rule runs as a device kernel behind the evaluation and whole
+        # iterations are replayed as one hipGraph (single GPU); the host update dictionary above is
+        # then bypassed, so a user-supplied callback cannot be used in this mode.
+        self.device_optimizer = bool(device_optimizer)
+        if self.device_optimizer:
+            if allreduce is not None:
+                raise ValueError('device_optimizer needs the whole evaluation on one GPU')
+            import inspect
+            sig = inspect.signature(getattr(OPT, algo)).parameters
+            kw = {k: v.default for k, v in sig.items() if v.default is not inspect._empty}
+            kw.update(algo_params)
+            self.engine.opt_init(algo, learning_rate=kw.get('learning_rate', 0.01),
+                                 beta1=kw.get('beta1', kw.get('rho', 0.9)), beta2=kw.get('beta2', 0.999),
+                                 epsilon=kw.get('epsilon', 1e-8), momentum=momentum)
 
     # -- state sync ----------------------------------------------------------------------
     def _sync_params(self):
@@ -88,7 +102,22 @@ class CompiledFuncs(object):
         cost, _, alpha, Li = self._evaluate(X, y, False)
         return [cost, alpha, Li]
 
+    def train_iters(self, X, y, n):
+        """n training iterations on the device (device_optimizer mode): cost history, alpha, Li of
+        the last evaluation; the shared vector is refreshed from the device afterwards."""
+        if not self.device_optimizer:
+            raise RuntimeError('train_iters needs device_optimizer=True')
+        self._sync_params()
+        self._sync_data(X, y)
+        hist, alpha, Li = self.engine.train(n)
+        self.params.set_value(self.engine.get_params())
+        self._uploaded_version = self.params.version           # device already holds this vector
+        return hist, alpha, Li
+
     def train_iter_func(self, X, y):
+        if self.device_optimizer:
+            hist, alpha, Li = self.train_iters(X, y, 1)
+            return [np.array(hist[0]), alpha, Li]
         cost, grad, alpha, Li = self._evaluate(X, y, True)
         self.grads.set_value(grad)
         apply_updates(self.updates)

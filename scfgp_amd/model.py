@@ -49,7 +49,7 @@ class SCFGP(object):
 
     def __init__(self, sparsity=20, nfeats=18, evals=None,
                  X_scaling_method='auto-inv-normal', y_scaling_method='auto-normal', verbose=False,
-                 dtype='f64', device=0, compat_noop_restore=False):
+                 dtype='f64', device=0, compat_noop_restore=False, device_optimizer=False):
         self.S = sparsity
         self.M = nfeats
         self.X_scaler = Scaler(X_scaling_method)
@@ -58,6 +58,7 @@ class SCFGP(object):
         self.verbose = verbose
         self.dtype, self.device = dtype, device
         self.compat_noop_restore = compat_noop_restore
+        self.device_optimizer = device_optimizer
         self.generate_ID()
 
     def message(self, *arg):
@@ -86,7 +87,8 @@ class SCFGP(object):
         """Counterpart of build_theano_models (SCFGP/SCFGP.py:92-148): creates the GPU context
         and optimiser state bound to self.params; no symbolic build, no C compile."""
         self._compiled = CompiledFuncs(self.D, self.S, self.M, self.params, algo, algo_params,
-                                       dtype=self.dtype, device=self.device)
+                                       dtype=self.dtype, device=self.device,
+                                       device_optimizer=self.device_optimizer)
         self.train_func, self.train_iter_func, self.pred_func = self._compiled.triple()
 
     build_theano_models = build_hip_models          # drop-in name

@@ -142,8 +142,9 @@ def test_ragged_and_degenerate_shapes(N, D, S, M, dtype):
     cost, grad, alpha, Li = eng.eval(want_grad=True)
     c0, g0, a0, L0 = O.value_and_grad(X, y, params, S, M)
     tol = 1e-8 if dtype == 'f64' else 2e-3
+    ftol = tol if dtype == 'f64' else 2e-2      # alpha, Li carry cond(A) times the fp32 Gram error
     assert abs(float(cost) - c0) < (1e-10 if dtype == 'f64' else 2e-5) * max(1.0, abs(c0))
-    assert rel(grad, g0) < tol and rel(alpha, a0) < tol and rel(Li, L0) < tol
+    assert rel(grad, g0) < tol and rel(alpha, a0) < ftol and rel(Li, L0) < ftol
     mu, sd = eng.predict(Xs, a0, L0)
     mu0, sd0 = O.predict(Xs, a0, L0, params, S, M)
     assert rel(mu, mu0) < tol and rel(sd, sd0) < tol
@@ -312,3 +313,33 @@ def test_facade_fit_predict_save_load(tmp_path):
     before = model.params.get_value()
     m3.optimize(None, None, model.get_compiled_funcs(), max_iter=3)
     assert not np.array_equal(model.params.get_value(), before)
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('algo,kw', [('adam', {'learning_rate': 0.02, 'beta1': 0.9, 'beta2': 0.999, 'epsilon': 1e-8}),
+                                      ('adamax', {'learning_rate': 0.02}), ('sgd', {'learning_rate': 1e-3}),
+                                      ('adagrad', {'learning_rate': 0.05}), ('adadelta', {'learning_rate': 1.0})])
+def test_device_optimizer_matches_host_rules(algo, kw):
+    """n iterations with the update rule on the device (one hipGraph launch per iteration) follow the
+    host-side rule (the reference's Optimizer arithmetic incl. its Nesterov placement) step for step."""
+    from scfgp_amd.funcs import CompiledFuncs
+    name = 'c1_boston_shape'
+    N, D, S, M, T, seed = CASES[name]
+    X, y, params, _ = case_inputs(name)
+    host = CompiledFuncs(D, S, M, params.copy(), algo, kw)
+    dev = CompiledFuncs(D, S, M, params.copy(), algo, kw, device_optimizer=True)
+    n = 7
+    costs_h = [float(host.train_iter_func(X, y)[0]) for _ in range(n)]
+    hist, alpha, Li = dev.train_iters(X, y, n)
+    assert np.allclose(hist, costs_h, rtol=1e-9, atol=0)
+    assert rel(dev.params.get_value(), host.params.get_value()) < 1e-7
+    # alpha / Li belong to the LAST evaluation (pre-update parameters of iteration n)
+    c_more = dev.train_iter_func(X, y)                       # single-step path in device mode
+    c_h = host.train_iter_func(X, y)
+    assert abs(float(c_more[0]) - float(c_h[0])) < 1e-9 * abs(float(c_h[0]))
+    assert rel(c_more[1], c_h[1]) < 1e-6 and rel(c_more[2], c_h[2]) < 1e-6     # fma contraction in the device rule
+    # graph replay == eager launches
+    eager = CompiledFuncs(D, S, M, params.copy(), algo, kw, device_optimizer=True)
+    eager.engine.set_option('use_graph', 0)
+    hist_e, _, _ = eager.train_iters(X, y, n)
+    assert np.array_equal(hist_e, hist)
