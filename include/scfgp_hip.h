@@ -78,6 +78,13 @@ int scfgp_set_data(scfgp_ctx* ctx, const double* X, const double* y, int64_t N, 
 int scfgp_eval(scfgp_ctx* ctx, const double* X, const double* y, int64_t N, int want_grad,
                double* cost, double* grad, double* alpha, double* Li);
 
+/* ---- minibatches by index list ----------------------------------------
+ * The reference's minibatch loop (SCFGP/SCFGP.py:172-182,226-235) fancy-indexes host copies of X, y
+ * and re-passes them; here the batch is a gather of n rows of the RESIDENT data set on the device.
+ * Same per-batch semantics (N := n in 2(N-M)a and /N).  A later scfgp_eval(X=NULL) sees all rows again. */
+int scfgp_eval_rows(scfgp_ctx* ctx, const int64_t* idx, int64_t n, int want_grad,
+                    double* cost, double* grad, double* alpha, double* Li);
+
 /* ---- pred_func  (SCFGP/SCFGP.py:138-148) ------------------------------------------------
  * mu (T), std (T) for Xs (T,D) given alpha (K) and Li (K*K) as returned by scfgp_eval. */
 int scfgp_predict(scfgp_ctx* ctx, const double* Xs, int64_t T, const double* alpha, const double* Li,

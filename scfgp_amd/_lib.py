@@ -28,6 +28,7 @@ SIGNATURES = {
     'scfgp_set_data': (C.c_int, [C.c_void_p, _c_double_p, _c_double_p, C.c_int64, C.c_int64]),
     'scfgp_eval': (C.c_int, [C.c_void_p, _c_double_p, _c_double_p, C.c_int64, C.c_int,
                              _c_double_p, _c_double_p, _c_double_p, _c_double_p]),
+    'scfgp_eval_rows': (C.c_int, [C.c_void_p, _c_i64_p, C.c_int64, C.c_int, _c_double_p, _c_double_p, _c_double_p, _c_double_p]),
     'scfgp_predict': (C.c_int, [C.c_void_p, _c_double_p, C.c_int64, _c_double_p, _c_double_p, _c_double_p, _c_double_p]),
     'scfgp_pass1': (C.c_int, [C.c_void_p]),
     'scfgp_factor': (C.c_int, [C.c_void_p]),

@@ -544,20 +544,21 @@ void sum_squares(const double* y, int64_t n, double* scalars, int slot, double* 
 // --------------------------------------------------------------------------
 // data staging
 // --------------------------------------------------------------------------
-__global__ void pack_data_kernel(const double* __restrict__ Xraw, const double* __restrict__ yraw, double* __restrict__ Xt,
-                                 double* __restrict__ y, int D, int Dp, int64_t N, int64_t Np) {
+__global__ void pack_data_kernel(const double* __restrict__ Xraw, const double* __restrict__ yraw, const int64_t* __restrict__ idx,
+                                 double* __restrict__ Xt, double* __restrict__ y, int D, int Dp, int64_t N, int64_t Np) {
     const int64_t total = Np * Dp;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t n = i / Dp;
         const int d = (int)(i - n * Dp);
+        const int64_t src = (n < N && idx) ? idx[n] : n;           // row gather for index-list minibatches
         double v = 0;
-        if (n < N) v = d < D ? Xraw[n * D + d] : (d == D ? 1.0 : 0.0);
+        if (n < N) v = d < D ? Xraw[src * D + d] : (d == D ? 1.0 : 0.0);
         Xt[i] = v;
-        if (d == 0 && y) y[n] = (n < N && yraw) ? yraw[n] : 0.0;
+        if (d == 0 && y) y[n] = (n < N && yraw) ? yraw[src] : 0.0;
     }
 }
-void pack_data(const Geom& g, const double* Xraw, const double* yraw, double* Xt, double* y, hipStream_t st) {
-    hipLaunchKernelGGL(pack_data_kernel, dim3(4096), dim3(256), 0, st, Xraw, yraw, Xt, y, g.D, g.Dp, g.N, g.Np);
+void pack_data(const Geom& g, const double* Xraw, const double* yraw, const int64_t* idx, double* Xt, double* y, hipStream_t st) {
+    hipLaunchKernelGGL(pack_data_kernel, dim3(4096), dim3(256), 0, st, Xraw, yraw, idx, Xt, y, g.D, g.Dp, g.N, g.Np);
 }
 __global__ void pad_square_kernel(const double* __restrict__ src, int K, int Kp, double* __restrict__ dst) {
     const int64_t total = (int64_t)Kp * Kp;

@@ -36,6 +36,9 @@ struct scfgp_ctx {
     std::vector<double> h_params;
     // parameters
     double *d_params = nullptr, *d_F = nullptr, *d_Fall = nullptr; Scal* d_sc = nullptr;
+    // dataset store (raw rows as uploaded) and the working set the sweeps run on
+    double *d_Xraw = nullptr, *d_yraw = nullptr; int64_t Nstore = 0, store_cap = 0; bool work_full = false;
+    int64_t* d_idx = nullptr; int64_t idx_cap = 0;
     // rows
     double *d_Xt = nullptr, *d_y = nullptr, *d_p = nullptr, *d_q = nullptr, *d_vpart = nullptr;
     void *d_Phi = nullptr, *d_V = nullptr; double* d_bpart = nullptr;
@@ -211,6 +214,7 @@ extern "C" void scfgp_destroy(scfgp_ctx* c) {
     hipSetDevice(c->device);
     if (c->st) hipStreamSynchronize(c->st);
     free_rows(c);
+    dfree(c->d_Xraw); dfree(c->d_yraw); dfree(c->d_idx);
     dfree(c->d_params); dfree(c->d_F); dfree(c->d_Fall); dfree(c->d_sc);
     dfree(c->d_x1); dfree(c->d_x2); dfree(c->d_x3); dfree(c->d_Li); dfree(c->d_B); dfree(c->d_T1); dfree(c->d_T2);
     dfree(c->d_Abar); dfree(c->d_BT); dfree(c->d_AbarT); dfree(c->d_vecs); dfree(c->d_scalars); dfree(c->d_yy);
@@ -243,24 +247,35 @@ extern "C" int scfgp_get_params(scfgp_ctx* c, double* params, int P) {
     return SCFGP_OK;
 }
 
-extern "C" int scfgp_set_data(scfgp_ctx* c, const double* X, const double* y, int64_t N, int64_t n_global) {
-    if (!c || !X || !y || N < 1) { if (c) c->err = "set_data: bad arguments"; return SCFGP_EARG; }
-    HIPCHK(c, hipSetDevice(c->device));
-    if (int rc = ensure_rows(c, N)) return rc;
-    c->Nglobal = n_global > 0 ? n_global : N;
-    double *raw = nullptr, *yraw = nullptr;
-    if (int rc = dmalloc(c, &raw, sizeof(double) * N * c->g.D)) return rc;
-    if (int rc = dmalloc(c, &yraw, sizeof(double) * N)) { dfree(raw); return rc; }
-    HIPCHK(c, hipMemcpyAsync(raw, X, sizeof(double) * N * c->g.D, hipMemcpyHostToDevice, c->st));
-    HIPCHK(c, hipMemcpyAsync(yraw, y, sizeof(double) * N, hipMemcpyHostToDevice, c->st));
-    pack_data(c->g, raw, yraw, c->d_Xt, c->d_y, c->st);
+// working set := rows of the store selected by idx (NULL = all rows, in order)
+static int load_working_set(scfgp_ctx* c, const int64_t* d_idx, int64_t n, int64_t n_global) {
+    if (int rc = ensure_rows(c, n)) return rc;
+    c->Nglobal = n_global > 0 ? n_global : n;
+    pack_data(c->g, c->d_Xraw, c->d_yraw, d_idx, c->d_Xt, c->d_y, c->st);
     sum_squares(c->d_y, c->g.Np, c->d_yy, 0, c->d_partial, c->st);
     if (c->dtype == SCFGP_F32) SweepKernels<float>::set_col(c->g, (float*)c->d_Phi, c->g.K, c->d_y, c->st);
     else SweepKernels<double>::set_col(c->g, (double*)c->d_Phi, c->g.K, c->d_y, c->st);
-    HIPCHK(c, hipStreamSynchronize(c->st));
-    dfree(raw); dfree(yraw);
     HIPCHK(c, hipGetLastError());
+    c->work_full = d_idx == nullptr;
     c->have_data = true; c->stage = 0;
+    return SCFGP_OK;
+}
+
+extern "C" int scfgp_set_data(scfgp_ctx* c, const double* X, const double* y, int64_t N, int64_t n_global) {
+    if (!c || !X || !y || N < 1) { if (c) c->err = "set_data: bad arguments"; return SCFGP_EARG; }
+    HIPCHK(c, hipSetDevice(c->device));
+    if (N > c->store_cap) {
+        HIPCHK(c, hipStreamSynchronize(c->st));
+        dfree(c->d_Xraw); dfree(c->d_yraw); c->store_cap = 0;
+        if (int rc = dmalloc(c, &c->d_Xraw, sizeof(double) * N * c->g.D)) return rc;
+        if (int rc = dmalloc(c, &c->d_yraw, sizeof(double) * N)) return rc;
+        c->store_cap = N;
+    }
+    c->Nstore = N;
+    HIPCHK(c, hipMemcpyAsync(c->d_Xraw, X, sizeof(double) * N * c->g.D, hipMemcpyHostToDevice, c->st));
+    HIPCHK(c, hipMemcpyAsync(c->d_yraw, y, sizeof(double) * N, hipMemcpyHostToDevice, c->st));
+    if (int rc = load_working_set(c, nullptr, N, n_global)) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->st));            // the caller may reuse X, y as soon as we return
     return SCFGP_OK;
 }
 
@@ -431,11 +446,8 @@ extern "C" int scfgp_finish(scfgp_ctx* c, int want_grad, double* cost, double* g
     return SCFGP_OK;
 }
 
-extern "C" int scfgp_eval(scfgp_ctx* c, const double* X, const double* y, int64_t N, int want_grad,
-                          double* cost, double* grad, double* alpha, double* Li) {
-    if (!c) return SCFGP_EARG;
+static int run_eval(scfgp_ctx* c, int want_grad, double* cost, double* grad, double* alpha, double* Li) {
     int rc;
-    if (X) { if ((rc = scfgp_set_data(c, X, y, N, N))) return rc; }
     if ((rc = scfgp_pass1(c))) return rc;
     if ((rc = scfgp_factor(c))) return rc;
     if ((rc = scfgp_pass2(c, want_grad))) return rc;
@@ -444,6 +456,36 @@ extern "C" int scfgp_eval(scfgp_ctx* c, const double* X, const double* y, int64_
         if ((rc = scfgp_pass3(c))) return rc;
     }
     return scfgp_finish(c, want_grad, cost, grad, alpha, Li);
+}
+
+extern "C" int scfgp_eval(scfgp_ctx* c, const double* X, const double* y, int64_t N, int want_grad,
+                          double* cost, double* grad, double* alpha, double* Li) {
+    if (!c) return SCFGP_EARG;
+    int rc;
+    if (X) { if ((rc = scfgp_set_data(c, X, y, N, N))) return rc; }
+    else if (c->have_data && !c->work_full) {           // a row subset was evaluated last: bring all rows back
+        if (hipSetDevice(c->device) != hipSuccess) return SCFGP_EHIP;
+        if ((rc = load_working_set(c, nullptr, c->Nstore, c->Nstore))) return rc;
+    }
+    return run_eval(c, want_grad, cost, grad, alpha, Li);
+}
+
+extern "C" int scfgp_eval_rows(scfgp_ctx* c, const int64_t* idx, int64_t n, int want_grad,
+                               double* cost, double* grad, double* alpha, double* Li) {
+    if (!c || !idx || n < 1) { if (c) c->err = "eval_rows: bad arguments"; return SCFGP_EARG; }
+    if (!c->have_data || c->Nstore < 1) { c->err = "eval_rows: no resident data set"; return SCFGP_EARG; }
+    for (int64_t i = 0; i < n; ++i)
+        if (idx[i] < 0 || idx[i] >= c->Nstore) { c->err = "eval_rows: index out of range"; return SCFGP_EARG; }
+    HIPCHK(c, hipSetDevice(c->device));
+    if (n > c->idx_cap) {
+        HIPCHK(c, hipStreamSynchronize(c->st));
+        dfree(c->d_idx);
+        if (int rc = dmalloc(c, &c->d_idx, sizeof(int64_t) * n)) return rc;
+        c->idx_cap = n;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_idx, idx, sizeof(int64_t) * n, hipMemcpyHostToDevice, c->st));
+    if (int rc = load_working_set(c, c->d_idx, n, n)) return rc;       // per-batch N, as SCFGP.py:126,128
+    return run_eval(c, want_grad, cost, grad, alpha, Li);
 }
 
 extern "C" int scfgp_predict(scfgp_ctx* c, const double* Xs, int64_t T, const double* alpha, const double* Li,
@@ -481,7 +523,7 @@ extern "C" int scfgp_predict(scfgp_ctx* c, const double* Xs, int64_t T, const do
         Geom g = g0;
         g.N = std::min<int64_t>(PRED_ROWS, T - t0); g.Np = round_up(g.N, 256);
         HIPCHK(c, hipMemcpyAsync(raw, Xs + t0 * g.D, sizeof(double) * g.N * g.D, hipMemcpyHostToDevice, c->st));
-        pack_data(g, raw, nullptr, c->p_Xt, nullptr, c->st);
+        pack_data(g, raw, nullptr, nullptr, c->p_Xt, nullptr, c->st);
         rc = c->dtype == SCFGP_F32 ? Impl<float>::predict_chunk(c, g, (const float*)Bt) : Impl<double>::predict_chunk(c, g, (const double*)Bt);
         if (rc) { dfree(raw); return rc; }
         HIPCHK(c, hipMemcpyAsync(mu + t0, c->p_mu, sizeof(double) * g.N, hipMemcpyDeviceToHost, c->st));

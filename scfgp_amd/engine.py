@@ -115,6 +115,15 @@ class HipEngine(object):
         self._check(rc, 'eval')
         return cost.reshape(()), grad, alpha, Li
 
+    def eval_rows(self, idx, want_grad=True):
+        """Evaluation on the rows `idx` of the resident data set (device-side gather; per-batch N)."""
+        idx = np.ascontiguousarray(idx, dtype=np.int64).ravel()
+        cost, grad, alpha, Li = self._outputs(want_grad)
+        rc = self.lib.scfgp_eval_rows(self.ctx, idx.ctypes.data_as(C.POINTER(C.c_int64)), idx.size, int(bool(want_grad)),
+                                      dptr(cost), dptr(grad), dptr(alpha), dptr(Li))
+        self._check(rc, 'eval_rows')
+        return cost.reshape(()), grad, alpha, Li
+
     def predict(self, Xs, alpha, Li):
         """pred_func (SCFGP/SCFGP.py:138-148): returns mu (T,1), std (T,)."""
         self._check_xy(Xs, None, self.D)

@@ -123,6 +123,18 @@ class CompiledFuncs(object):
         apply_updates(self.updates)
         return [cost, alpha, Li]
 
+    def train_iter_rows(self, X, y, idx):
+        """train_iter_func on rows `idx` of (X, y) without re-uploading them: X, y become (or stay) the
+        resident data set and the batch is gathered on the device (single GPU, host update rule)."""
+        if self.allreduce is not None or self.device_optimizer:
+            return self.train_iter_func(np.ascontiguousarray(X[idx]), np.ascontiguousarray(y[idx]))
+        self._sync_params()
+        self._sync_data(X, y)
+        cost, grad, alpha, Li = self.engine.eval_rows(idx, True)
+        self.grads.set_value(grad)
+        apply_updates(self.updates)
+        return [cost, alpha, Li]
+
     def pred_func(self, Xs, alpha, Li):
         self._sync_params()
         mu, sd = self.engine.predict(Xs, alpha, Li)

@@ -113,16 +113,17 @@ class SCFGP(object):
         else:
             cost, self.alpha, self.Li = self.train_func(self.X, self.y)
 
+    def minibatch_indices(self, n, batchsize, shuffle=True):
+        """Row indices of successive minibatches (same shuffling and truncation as SCFGP.py:172-182)."""
+        inds = np.arange(n)
+        if shuffle:
+            np.random.shuffle(inds)
+        for start_ind in range(0, n - batchsize + 1, batchsize):
+            yield inds[start_ind:start_ind + batchsize]
+
     def minibatches(self, X, y, batchsize, shuffle=True):
         assert len(X) == len(y)
-        if shuffle:
-            inds = np.arange(len(X))
-            np.random.shuffle(inds)
-        for start_ind in range(0, len(X) - batchsize + 1, batchsize):
-            if shuffle:
-                batch = inds[start_ind:start_ind + batchsize]
-            else:
-                batch = slice(start_ind, start_ind + batchsize)
+        for batch in self.minibatch_indices(len(X), batchsize, shuffle):
             yield np.ascontiguousarray(X[batch]), np.ascontiguousarray(y[batch])
 
     # -- training ---------------------------------------------------------------------------------
@@ -161,9 +162,13 @@ class SCFGP(object):
         for iter in range(max_iter):
             if nbatches > 1:
                 cost_sum, params_list, batch_count = 0, [], 0
-                for X, y in self.minibatches(self.X, self.y, batchsize):
+                for batch in self.minibatch_indices(len(self.X), batchsize):
                     params_list.append(live.get_value())
-                    cost, self.alpha, self.Li = self.train_iter_func(X, y)
+                    if isinstance(owner, CompiledFuncs):      # gather the batch from the resident rows on the GPU
+                        cost, self.alpha, self.Li = owner.train_iter_rows(self.X, self.y, batch)
+                    else:
+                        cost, self.alpha, self.Li = self.train_iter_func(np.ascontiguousarray(self.X[batch]),
+                                                                         np.ascontiguousarray(self.y[batch]))
                     cost_sum += cost; batch_count += 1
                     if batch_count == nbatches:
                         break

@@ -343,3 +343,31 @@ def test_device_optimizer_matches_host_rules(algo, kw):
     eager.engine.set_option('use_graph', 0)
     hist_e, _, _ = eager.train_iters(X, y, n)
     assert np.array_equal(hist_e, hist)
+
+
+def test_index_list_minibatches_on_resident_rows():
+    """scfgp_eval_rows: a batch gathered on the device equals the same rows uploaded from the host, and
+    the full set is back for the next plain evaluation; the facade's minibatch loop uses it."""
+    from scfgp_amd.engine import HipEngine
+    from scfgp_amd import SCFGP
+    name = 'kin8nm_like'
+    N, D, S, M, T, seed = CASES[name]
+    X, y, params, _ = case_inputs(name)
+    eng = HipEngine(D, S, M); eng.set_params(params); eng.set_data(X, y)
+    c_full, g_full, _, _ = eng.eval(want_grad=True)
+    rng = np.random.default_rng(3)
+    for n in (150, 1, 999, 300):
+        idx = rng.choice(N, n, replace=False)
+        c, g, a, L = eng.eval_rows(idx, True)
+        c0, g0, a0, L0 = O.value_and_grad(X[idx], y[idx], params, S, M)
+        assert abs(float(c) - c0) < 1e-10 * abs(c0) and rel(g, g0) < 1e-7 and rel(a, a0) < 1e-7
+    c2, g2, _, _ = eng.eval(want_grad=True)                 # all rows again
+    assert float(c2) == float(c_full) and np.array_equal(g2, g_full)
+    with pytest.raises(ValueError):
+        eng.eval_rows(np.array([0, N]), True)
+    eng.close()
+    np.random.seed(11)
+    model = SCFGP(sparsity=4, nfeats=10)
+    model.set_data(X * 3 - 1, np.sin(X[:, :1] * 5) + 0.1 * y)
+    model.optimize(None, None, max_iter=6, nbatches=3, batchsize=120)
+    assert len(model.evals['COST'][1]) == 7 and np.all(np.isfinite(model.evals['COST'][1]))
