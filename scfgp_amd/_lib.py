@@ -36,6 +36,7 @@ SIGNATURES = {
     'scfgp_adjoint': (C.c_int, [C.c_void_p]),
     'scfgp_pass3': (C.c_int, [C.c_void_p]),
     'scfgp_finish': (C.c_int, [C.c_void_p, C.c_int, _c_double_p, _c_double_p, _c_double_p, _c_double_p]),
+    'scfgp_fetch_factors': (C.c_int, [C.c_void_p, _c_double_p, _c_double_p]),
     'scfgp_exchange': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), _c_i64_p]),
     'scfgp_opt_init': (C.c_int, [C.c_void_p, C.c_int, _c_double_p, C.c_int, C.c_double]),
     'scfgp_opt_state': (C.c_int, [C.c_void_p, C.c_int, C.c_int, _c_double_p]),

@@ -30,6 +30,7 @@ struct scfgp_ctx {
     Geom g{};
     int dtype = 0, device = 0;
     hipStream_t st = nullptr; bool own_stream = false;
+    hipStream_t copy_st = nullptr; hipEvent_t ev_factor = nullptr; bool fetch_pending = false;   // alpha/Li D2H beside pass 2/3
     int64_t Ncap = 0, Nglobal = 0;
     bool have_params = false, have_data = false;
     int stage = 0, last_want_grad = 0;
@@ -175,6 +176,8 @@ extern "C" int scfgp_create(scfgp_ctx** out, int D, int S, int M, int dtype, int
     HIPCHK(c, hipSetDevice(device));
     if (stream) c->st = (hipStream_t)stream;
     else { HIPCHK(c, hipStreamCreate(&c->st)); c->own_stream = true; }
+    HIPCHK(c, hipStreamCreateWithFlags(&c->copy_st, hipStreamNonBlocking));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_factor, hipEventDisableTiming));
     const int64_t Kp = g.Kp, K2 = Kp * Kp;
     c->n_x1 = K2 + Kp + 8; c->n_x2 = K2 + Kp + 8; c->n_x3 = (int64_t)c->Dpp * g.Jp + 8;
     int rc;
@@ -224,6 +227,8 @@ extern "C" void scfgp_destroy(scfgp_ctx* c) {
     if (c->graph) hipGraphDestroy(c->graph);
     dfree(c->d_opt); dfree(c->d_tctr); dfree(c->d_hist);
     for (hipEvent_t e : c->pool) hipEventDestroy(e);
+    if (c->copy_st) { hipStreamSynchronize(c->copy_st); hipStreamDestroy(c->copy_st); }
+    if (c->ev_factor) hipEventDestroy(c->ev_factor);
     if (c->own_stream && c->st) hipStreamDestroy(c->st);
     delete c;
 }
@@ -378,6 +383,7 @@ extern "C" int scfgp_factor(scfgp_ctx* c) {
     if (int rc = ready(c)) return rc;
     if (c->stage != 1) { c->err = "factor: call pass1 first"; return SCFGP_EARG; }
     if (int rc = DISPATCH(c, factor, c)) return rc;
+    if (!g_scfgp_capturing) HIPCHK(c, hipEventRecord(c->ev_factor, c->st));
     c->stage = 2; return SCFGP_OK;
 }
 extern "C" int scfgp_pass2(scfgp_ctx* c, int want_grad) {
@@ -412,6 +418,20 @@ extern "C" int scfgp_exchange(scfgp_ctx* c, int stage, void** dev_ptr, int64_t* 
     return SCFGP_OK;
 }
 
+// alpha and Li are final once scfgp_factor has run; their copy to the host (K^2 doubles, 35.7 MB at
+// K = 2112) goes on a second stream so it overlaps passes 2 and 3 instead of trailing the evaluation
+extern "C" int scfgp_fetch_factors(scfgp_ctx* c, double* alpha, double* Li) {
+    if (int rc = ready(c)) return rc;
+    if (c->stage < 2) { c->err = "fetch_factors: call factor first"; return SCFGP_EARG; }
+    const Geom& g = c->g;
+    HIPCHK(c, hipStreamWaitEvent(c->copy_st, c->ev_factor, 0));
+    if (alpha) HIPCHK(c, hipMemcpyAsync(alpha, c->alpha(), sizeof(double) * g.K, hipMemcpyDeviceToHost, c->copy_st));
+    if (Li) HIPCHK(c, hipMemcpy2DAsync(Li, sizeof(double) * g.K, c->d_Li, sizeof(double) * g.Kp, sizeof(double) * g.K, g.K,
+                                       hipMemcpyDeviceToHost, c->copy_st));
+    c->fetch_pending = true;
+    return SCFGP_OK;
+}
+
 static void enqueue_epilogue(scfgp_ctx* c, int want_grad) {
     const Geom& g = c->g;
     const int64_t K2 = (int64_t)g.Kp * g.Kp;
@@ -438,6 +458,7 @@ extern "C" int scfgp_finish(scfgp_ctx* c, int want_grad, double* cost, double* g
                                            hipMemcpyDeviceToHost, c->st));
     }
     HIPCHK(c, hipStreamSynchronize(c->st));
+    if (c->fetch_pending) { HIPCHK(c, hipStreamSynchronize(c->copy_st)); c->fetch_pending = false; }
     HIPCHK(c, hipGetLastError());
     c->stage = 0; c->warm = true;
     if (cost) *cost = h_cost;
@@ -455,7 +476,9 @@ static int run_eval(scfgp_ctx* c, int want_grad, double* cost, double* grad, dou
         if ((rc = scfgp_adjoint(c))) return rc;
         if ((rc = scfgp_pass3(c))) return rc;
     }
-    return scfgp_finish(c, want_grad, cost, grad, alpha, Li);
+    // everything is queued: the factor outputs now stream to the host beside passes 2 and 3
+    if ((alpha || Li) && (rc = scfgp_fetch_factors(c, alpha, Li))) return rc;
+    return scfgp_finish(c, want_grad, cost, grad, nullptr, nullptr);
 }
 
 extern "C" int scfgp_eval(scfgp_ctx* c, const double* X, const double* y, int64_t N, int want_grad,

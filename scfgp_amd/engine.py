@@ -143,6 +143,13 @@ class HipEngine(object):
 
     def factor(self):
         self._check(self.lib.scfgp_factor(self.ctx), 'factor')
+        self._early = None
+
+    def fetch_factors(self):
+        """Start the alpha / Li device-to-host copy now (overlaps passes 2 and 3); finish() returns them."""
+        alpha = np.empty((self.K, 1)); Li = np.empty((self.K, self.K))
+        self._check(self.lib.scfgp_fetch_factors(self.ctx, dptr(alpha), dptr(Li)), 'fetch_factors')
+        self._early = (alpha, Li)
 
     def pass2(self, want_grad=True):
         self._check(self.lib.scfgp_pass2(self.ctx, int(bool(want_grad))), 'pass2')
@@ -155,7 +162,13 @@ class HipEngine(object):
 
     def finish(self, want_grad=True):
         cost, grad, alpha, Li = self._outputs(want_grad)
-        rc = self.lib.scfgp_finish(self.ctx, int(bool(want_grad)), dptr(cost), dptr(grad), dptr(alpha), dptr(Li))
+        early = getattr(self, '_early', None)
+        if early is not None:
+            alpha, Li = early
+            rc = self.lib.scfgp_finish(self.ctx, int(bool(want_grad)), dptr(cost), dptr(grad), None, None)
+        else:
+            rc = self.lib.scfgp_finish(self.ctx, int(bool(want_grad)), dptr(cost), dptr(grad), dptr(alpha), dptr(Li))
+        self._early = None
         self._check(rc, 'finish')
         return cost.reshape(()), grad, alpha, Li
 
