@@ -19,9 +19,6 @@
 #ifndef SCFGP_DRY_LOOP
 #define SCFGP_DRY_LOOP 0
 #endif
-#ifndef SCFGP_PREFETCH2
-#define SCFGP_PREFETCH2 0        // 1: global loads run two k-tiles ahead (two register sets); measured slower
-#endif
 
 // MFMA traits: element type T and instruction shape MS (16: 16x16x4, 32: 32x32x2, f32 only).
 //   lane l supplies A[i = l % MS][k = l / MS] and B[k = l / MS][j = l % MS]
@@ -87,7 +84,7 @@ struct NatLoader {
     // that advances by BK rows per call, so the loop carries no 64-bit multiplies.
     const S* ptr[NV]; const double* wptr[NV]; int64_t step; int xlim;     // xlim: first invalid x (GUARD)
     int xplain = -1;                                          // WEIGHT: this x is stored unweighted
-    vec_t r[1 + SCFGP_PREFETCH2][NV]; T wr[1 + SCFGP_PREFETCH2][NV];
+    vec_t r[1][NV]; T wr[1][NV];
     int tid;
     __device__ __forceinline__ NatLoader(const S* b, int64_t l, int t, const double* w_ = nullptr, int xl = 0)
         : step((int64_t)BK * l), xlim(xl), tid(t) {
@@ -147,7 +144,7 @@ struct TrLoader {
     static constexpr int VPR = BK / VS;                       // vectors per x row
     static constexpr int NV = (BX * VPR + THREADS - 1) / THREADS;
     const S* ptr[NV]; int tid;
-    vec_t r[1 + SCFGP_PREFETCH2][NV];
+    vec_t r[1][NV];
     __device__ __forceinline__ TrLoader(const S* b, int64_t l, int t) : tid(t) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
@@ -182,9 +179,6 @@ struct TrLoader {
     }
 };
 
-// ---------------------------------------------------------------------------
-// main loop: accumulates nkt k-tiles into acc[TM][TN]; smem = 2*(SA+SB) elements
-// ---------------------------------------------------------------------------
 // ---------------------------------------------------------------------------
 // ZbarLoader: B operand of X~^T Zbar, formed on the fly from the resident Phi and Phibar:
 //   s[k=n][x=j] = Phi[n][j] * Phibar[n][J+j] - Phi[n][J+j] * Phibar[n][j]      (0 for j >= J)
@@ -260,54 +254,6 @@ __device__ __forceinline__ void tile_compute(const typename Cfg::T* sA, const ty
     }
 }
 
-#ifndef SCFGP_INTERLEAVE
-#define SCFGP_INTERLEAVE 0       // >0: ask the scheduler to spread staging instructions between MFMAs
-#endif
-
-// scheduling hint: after every MFMA allow one DS read / VALU / VMEM / DS write to issue, so the
-// staging work of the next k-tile hides in the MFMA shadows instead of clustering at the ends
-template <int NMFMA>
-__device__ __forceinline__ void interleave_hint() {
-#if SCFGP_INTERLEAVE
-#pragma unroll
-    for (int i = 0; i < NMFMA; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 DS read
-        __builtin_amdgcn_sched_group_barrier(0x002, SCFGP_INTERLEAVE, 0);      // VALU
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // 1 VMEM read
-        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // 1 DS write
-    }
-#endif
-}
-
-// one pipeline step.  PREFETCH2: k-tile kt is in LDS buffer PAR, k-tile kt+1 in register set 1-PAR
-// (requested a whole step ago), k-tile kt+2 is requested now into set PAR.  Otherwise: k-tile kt+1
-// is requested now into set 0 and stored after the MFMAs.
-template <class Cfg, int PAR, class LA, class LB>
-__device__ __forceinline__ void tile_step(LA& la, LB& lb, int kt, int nkt,
-                                          typename Cfg::MTr::acc_t (&acc)[Cfg::TM][Cfg::TN], typename Cfg::T* sA,
-                                          typename Cfg::T* sB) {
-#if SCFGP_DRY_LOOP == 1 || SCFGP_DRY_LOOP == 2     // diagnostic builds (results are wrong):
-    const bool st1 = false, st2 = false;            //   1: no staging, no barrier   2: no staging, barrier kept
-#else                                               //   3: staging kept, no barrier
-    const bool st1 = kt + 1 < nkt, st2 = kt + 2 < nkt;
-#endif
-#if SCFGP_PREFETCH2
-    if (st2) { la.template load<PAR>(kt + 2); lb.template load<PAR>(kt + 2); }
-    tile_compute<Cfg>(sA + PAR * Cfg::SA, sB + PAR * Cfg::SB, acc);
-    if (st1) { la.template store<1 - PAR>(sA + (1 - PAR) * Cfg::SA); lb.template store<1 - PAR>(sB + (1 - PAR) * Cfg::SB); }
-#else
-    (void)st2;
-    if (st1) { la.template load<0>(kt + 1); lb.template load<0>(kt + 1); }
-    tile_compute<Cfg>(sA + PAR * Cfg::SA, sB + PAR * Cfg::SB, acc);
-    if (st1) { la.template store<0>(sA + (1 - PAR) * Cfg::SA); lb.template store<0>(sB + (1 - PAR) * Cfg::SB); }
-#endif
-    interleave_hint<Cfg::TM * Cfg::TN * (Cfg::BK / Cfg::MTr::KS)>();
-#if SCFGP_DRY_LOOP != 1 && SCFGP_DRY_LOOP != 3
-    __syncthreads();
-#endif
-}
-
 // ---------------------------------------------------------------------------
 // main loop: accumulates nkt k-tiles into acc[TM][TN]; smem = 2*(SA+SB) elements.
 // LDS is double buffered (buffer = k-tile parity), one barrier per k-tile.
@@ -320,37 +266,25 @@ __device__ __forceinline__ void tile_mainloop(LA& la, LB& lb, int nkt,
     T* sA = smem;
     T* sB = smem + 2 * Cfg::SA;
     la.template load<0>(0); lb.template load<0>(0);
-#if SCFGP_PREFETCH2
-    if (nkt > 1) { la.template load<1>(1); lb.template load<1>(1); }
-#endif
     la.template store<0>(sA); lb.template store<0>(sB);
     __syncthreads();
-#if SCFGP_PREFETCH2
-    int kt = 0;
-    for (; kt + 1 < nkt; kt += 2) {
-        tile_step<Cfg, 0>(la, lb, kt, nkt, acc, sA, sB);
-        tile_step<Cfg, 1>(la, lb, kt + 1, nkt, acc, sA, sB);
-    }
-    if (kt < nkt) tile_step<Cfg, 0>(la, lb, kt, nkt, acc, sA, sB);
-#else
-    // rolled loop with a run-time buffer index: smaller code and fewer live registers than the
-    // parity-unrolled form (which cost the fp32 apply kernel an occupancy step)
+    // Rolled loop, run-time buffer index.  Measured alternatives that were equal or slower on MI355X
+    // (profiles/r01_tuning.md): global loads two k-tiles ahead with two register sets, LDS stores
+    // placed mid-tile, scheduler interleave hints, BK = 32, parity-unrolled body.
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
-#if SCFGP_DRY_LOOP == 1 || SCFGP_DRY_LOOP == 2
-        const bool stage = false;
-#else
+#if SCFGP_DRY_LOOP == 1 || SCFGP_DRY_LOOP == 2     // diagnostic builds (results are wrong):
+        const bool stage = false;                    //   1: no staging, no barrier   2: no staging, barrier kept
+#else                                                //   3: staging kept, no barrier
         const bool stage = kt + 1 < nkt;
 #endif
         if (stage) { la.template load<0>(kt + 1); lb.template load<0>(kt + 1); }
         tile_compute<Cfg>(sA + cur * Cfg::SA, sB + cur * Cfg::SB, acc);
         if (stage) { la.template store<0>(sA + (cur ^ 1) * Cfg::SA); lb.template store<0>(sB + (cur ^ 1) * Cfg::SB); }
-        interleave_hint<Cfg::TM * Cfg::TN * (Cfg::BK / Cfg::MTr::KS)>();
 #if SCFGP_DRY_LOOP != 1 && SCFGP_DRY_LOOP != 3
         __syncthreads();
 #endif
     }
-#endif
 }
 
 template <class Cfg>

@@ -238,6 +238,18 @@ def test_headline_size_fp32_properties():
     A = G + (np.exp(2 * params[0]) + 1e-6) * np.eye(K)
     assert rel(A @ alpha.ravel(), g) < 1e-7
     eng.close()
+    # the fp64 mode (oracle-exact at every size the oracle can reach) on the SAME 1e6 rows:
+    # fp32 mode must stay within its stated tolerances of it at full size
+    e64 = HipEngine(D, S, M, dtype='f64')
+    e64.set_params(params); e64.set_data(X, y)
+    c64, g64, a64, L64 = e64.eval(want_grad=True)
+    e64.close()
+    assert abs(float(cost) - float(c64)) < 1e-5 * max(1.0, abs(float(c64)))
+    for u, v in zip(grad_blocks(grad, D, S, M), grad_blocks(g64, D, S, M)):
+        assert rel(u, v) < 1e-3
+    assert rel(alpha, a64) < 1e-2 and rel(Li, L64) < 1e-3
+    print('\nheadline fp32 vs fp64: cost %.2e grad %.2e alpha %.2e Li %.2e' % (
+        abs(float(cost) - float(c64)) / abs(float(c64)), rel(grad, g64), rel(alpha, a64), rel(Li, L64)))
 
 
 # ---------------------------------------------------------------------------------------------
