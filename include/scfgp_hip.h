@@ -95,9 +95,9 @@ int scfgp_predict(scfgp_ctx* ctx, const double* Xs, int64_t T, const double* alp
  * over ranks each sweep ends in one sum over ranks.  The host framework (torch.distributed
  * over RCCL) performs that sum in place on the device buffer scfgp_exchange() exposes:
  *
- *   scfgp_pass1   -> exchange 1 = [G (Kp*Kp) | Phi^T y (Kp) | y^T y ...]
+ *   scfgp_pass1   -> exchange 1 = [G, packed lower 128x128 tiles | Phi^T y (Kp) | y^T y ...]
  *   scfgp_factor     (replicated: Cholesky, Li, alpha, log det)
- *   scfgp_pass2   -> exchange 2 = [W (Kp*Kp) | Phi^T p (Kp) | T2, kbar ...]
+ *   scfgp_pass2   -> exchange 2 = [W, packed lower tiles | Phi^T p (Kp) | T2, kbar ...]
  *   scfgp_adjoint    (replicated: Abar)                      [want_grad only]
  *   scfgp_pass3   -> exchange 3 = [X~^T Zbar | bbar ...]     [want_grad only]
  *   scfgp_finish  -> outputs on the host

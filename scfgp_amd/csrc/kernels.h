@@ -43,12 +43,14 @@ template <typename T> struct SweepKernels {
 };
 
 // ---- reductions ------------------------------------------------------------
-// out (ldo) = sum over splits of lower-tile slabs, mirrored into the upper triangle
-void reduce_tri_tiles(const double* slabs, int nsplit, int nts, int tile, double* out, int64_t ldo, hipStream_t st);
+// packed lower tiles = sum over splits of the per-split lower-tile slabs (tile t = ti(ti+1)/2+tj, row-major)
+void reduce_tri_tiles(const double* slabs, int nsplit, int nts, int tile, double* packed, hipStream_t st);
+// packed lower tiles -> full symmetric Kp x Kp matrix
+void unpack_tri_tiles(const double* packed, int nts, int tile, double* full, int64_t ld, hipStream_t st);
 // out (ldo) = sum over splits of a full ntm x ntn tile grid of slabs
 void reduce_full_tiles(const double* slabs, int nsplit, int ntm, int ntn, double* out, int64_t ldo, hipStream_t st);
-// dst[j<K] = x[row][j], then zero rows/cols K, K+1 of the Kp x Kp matrix x (augmented Gram -> plain)
-void extract_aug(double* x, int K, int Kp, int row, double* dst, hipStream_t st);
+// vec[j<K] = M[row][j], then zero rows/cols K, K+1 of the packed symmetric matrix (augmented Gram -> plain)
+void extract_aug(double* packed, int K, int Kp, int tile, int row, double* vec, hipStream_t st);
 // out[i] = sum_s partial[s][i], i < n
 void reduce_rows(const double* partial, int nsplit, int64_t n, double* out, hipStream_t st);
 // scalars[slot0 + k] = sum_b partial[b*width + k], k < width

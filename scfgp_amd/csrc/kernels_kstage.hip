@@ -95,57 +95,87 @@ __global__ __launch_bounds__(KCfg::THREADS) void trinv_level_kernel(const double
 }
 
 // ---------------------------------------------------------------------------
-// 64 x 64 diagonal block: Cholesky + triangular inverse by ONE wave, matrix in registers.
-//   lane i owns row i of L (64 fp64 values, static register indices: both loops are fully
-//   unrolled); the pivot column is broadcast with v_readlane, so there is no LDS traffic and no
-//   barrier in the 64 dependent steps.  The inverse is column-per-lane forward substitution
-//   with L[i][k] again read by v_readlane.  ~4x faster than the LDS/barrier version it replaced
-//   (the 34 sequential calls were 4.2 ms of a 5.7 ms K-stage at K = 2112).
+// 64 x 64 diagonal block: Cholesky and triangular inverse by one 4-wave workgroup in LDS.
+//   Cholesky: left-to-right in four 16-column panels; inside a panel each pivot step only updates the
+//   panel's own remaining columns (<= 15 x 64 elements over 256 threads), the rest of the matrix gets
+//   one rank-16 update per panel: 2 barriers per column instead of a full trailing sweep per column.
+//   Inverse: the two 32 x 32 diagonal blocks are inverted concurrently (one thread per column, forward
+//   substitution), the off-diagonal block is X21 = -X22 (L21 X11) by all threads.
+//   This kernel sits 34 times on the critical path of the K-stage at K = 2112.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ double readlane_f64(double v, int lane) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_readlane(lo, lane);
-    hi = __builtin_amdgcn_readlane(hi, lane);
-    return __hiloint2double(hi, lo);
-}
-
-__global__ __launch_bounds__(64) void potrf_diag_kernel(double* A, double* Li, int64_t ld, int p, int* flag) {
-    constexpr int NB = 64;
-    __shared__ double sT[NB * (NB + 1)];
+__global__ __launch_bounds__(256) void potrf_diag_kernel(double* A, double* Li, int64_t ld, int p, int* flag) {
+    constexpr int NB = 64, LD = NB + 1, PB = 16;
+    __shared__ double sL[NB * LD];
+    __shared__ double sI[NB * LD];
+    __shared__ double sT[32 * 33];
     double* a = A + (int64_t)p * NB * ld + p * NB;
     double* li = Li + (int64_t)p * NB * ld + p * NB;
-    const int i = threadIdx.x;
-    double L[NB], X[NB];
-    // the block is symmetric on entry, so row i == column i: coalesced loads
-#pragma unroll
-    for (int k = 0; k < NB; ++k) L[k] = a[(int64_t)k * ld + i];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < NB * NB; e += 256) sL[(e / NB) * LD + e % NB] = a[(int64_t)(e / NB) * ld + e % NB];
     bool bad = false;
+    for (int pb = 0; pb < NB; pb += PB) {
+        const int pend = pb + PB;
+        for (int j = pb; j < pend; ++j) {
+            __syncthreads();
+            const double d = sL[j * LD + j];
+            bad |= !(d > 0.0);
+            const double sq = sqrt(d), inv = 1.0 / sq;
+            __syncthreads();                                           // everyone has read the pivot
+            if (tid < NB && tid >= j) sL[tid * LD + j] = tid == j ? sq : sL[tid * LD + j] * inv;
+            __syncthreads();
+            // columns (j, pend) of the panel: L[i][k] -= L[i][j] L[k][j],  i >= k
+            const int nc = pend - 1 - j;
+            for (int e = tid; e < nc * NB; e += 256) {
+                const int k = j + 1 + e / NB, i = e % NB;
+                if (i >= k) sL[i * LD + k] -= sL[i * LD + j] * sL[k * LD + j];
+            }
+        }
+        __syncthreads();
+        // rank-16 update of everything right of the panel: L[i][k] -= sum_c L[i][c] L[k][c], i >= k >= pend
+        const int rem = NB - pend;
+        for (int e = tid; e < rem * rem; e += 256) {
+            const int k = pend + e / rem, i = pend + e % rem;
+            if (i >= k) {
+                double s = 0;
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        const double d = readlane_f64(L[j], j);
-        bad |= !(d > 0.0);
-        const double sq = sqrt(d), inv = 1.0 / sq;
-        L[j] = i == j ? sq : L[j] * inv;                               // column j scaled (rows < j are dead)
-#pragma unroll
-        for (int k = j + 1; k < NB; ++k) L[k] -= L[j] * readlane_f64(L[j], k);   // L[i][k] -= L[i][j] L[k][j]
+                for (int c = 0; c < PB; ++c) s += sL[i * LD + pb + c] * sL[k * LD + pb + c];
+                sL[i * LD + k] -= s;
+            }
+        }
     }
-    if (bad && i == 0) *flag = 1;                                      // not positive definite (or NaN)
-    // X = column i of L^{-1}: x_r = (delta_ri - sum_{k<r} L[r][k] x_k) / L[r][r]; x_k = 0 for k < i
-#pragma unroll
-    for (int r = 0; r < NB; ++r) {
-        double s = r == i ? 1.0 : 0.0;
-#pragma unroll
-        for (int k = 0; k < r; ++k) s -= readlane_f64(L[k], r) * X[k];
-        X[r] = r < i ? 0.0 : s / readlane_f64(L[r], r);
-    }
-    // L: transpose through LDS for coalesced stores; zero above the diagonal
-#pragma unroll
-    for (int k = 0; k < NB; ++k) sT[i * (NB + 1) + k] = k <= i ? L[k] : 0.0;
+    if (bad && tid == 0) *flag = 1;                                    // not positive definite (or NaN)
     __syncthreads();
-#pragma unroll
-    for (int r = 0; r < NB; ++r) {
-        a[(int64_t)r * ld + i] = sT[r * (NB + 1) + i];
-        li[(int64_t)r * ld + i] = X[r];
+    // ---- inverse: two independent 32 x 32 triangles, one thread per column
+    for (int e = tid; e < NB * NB; e += 256) sI[(e / NB) * LD + e % NB] = 0.0;
+    __syncthreads();
+    if (tid < NB) {
+        const int c = tid, o = c < 32 ? 0 : 32, hi = o + 32;           // column c of block [o, hi)
+        for (int r = c; r < hi; ++r) {
+            double s = r == c ? 1.0 : 0.0;
+            for (int k = c; k < r; ++k) s -= sL[r * LD + k] * sI[k * LD + c];
+            sI[r * LD + c] = s / sL[r * LD + r];
+        }
+    }
+    __syncthreads();
+    // T = L21 X11 (32 x 32), then X21 = -X22 T
+    for (int e = tid; e < 32 * 32; e += 256) {
+        const int r = e / 32, c = e % 32;
+        double s = 0;
+        for (int k = c; k < 32; ++k) s += sL[(32 + r) * LD + k] * sI[k * LD + c];     // X11 lower: k >= c
+        sT[r * 33 + c] = s;
+    }
+    __syncthreads();
+    for (int e = tid; e < 32 * 32; e += 256) {
+        const int r = e / 32, c = e % 32;
+        double s = 0;
+        for (int k = 0; k <= r; ++k) s += sI[(32 + r) * LD + 32 + k] * sT[k * 33 + c];  // X22 lower: k <= r
+        sI[(32 + r) * LD + c] = -s;
+    }
+    __syncthreads();
+    for (int e = tid; e < NB * NB; e += 256) {
+        const int i = e / NB, k = e % NB;
+        a[(int64_t)i * ld + k] = k <= i ? sL[i * LD + k] : 0.0;
+        li[(int64_t)i * ld + k] = sI[i * LD + k];
     }
 }
 
@@ -169,20 +199,6 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const double* __restrict
     for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
     if (lane == 0) out[i] = s;
 }
-// out[i] = sum_k M[k][i] v[k]      thread per column, 4 k-phases per block
-__global__ __launch_bounds__(256) void gemv_cols_kernel(const double* __restrict__ M, int64_t ld, const double* __restrict__ v,
-                                                        double* __restrict__ out, int n) {
-    __shared__ double red[4][64];
-    const int lane = threadIdx.x & 63, ph = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + lane;
-    double s = 0;
-    if (i < n)
-        for (int k = ph; k < n; k += 4) s += M[(int64_t)k * ld + i] * v[k];
-    red[ph][lane] = s;
-    __syncthreads();
-    if (ph == 0 && i < n) out[i] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
-}
-
 // scalars: logdet = 2 sum_{i<K} log L_ii ; g.alpha
 __global__ __launch_bounds__(256) void factor_scalars_kernel(const double* __restrict__ L, int64_t ld, int K,
                                                              const double* __restrict__ g, const double* __restrict__ alpha,
@@ -237,7 +253,7 @@ static void cholesky_inplace(const KStage& k, hipStream_t st) {
     const int Kp = k.Kp, nb = Kp / 64;
     const int64_t ld = Kp;
     for (int p = 0; p < nb; ++p) {
-        hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(64), 0, st, k.A, k.Li, ld, p, k.flag);
+        hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, st, k.A, k.Li, ld, p, k.flag);
         const int rem = Kp - (p + 1) * 64;
         if (rem <= 0) break;
         double* A21 = k.A + (int64_t)(p + 1) * 64 * ld + p * 64;
@@ -273,8 +289,8 @@ void kstage_factor(const KStage& k, const Scal* sc, hipStream_t st) {
     cholesky_inplace(k, st);
     trinv(k, st);
     kstage_gram_li(k, st);
-    hipLaunchKernelGGL(gemv_rows_kernel, dim3((Kp + 3) / 4), dim3(256), 0, st, k.Li, ld, k.g, k.beta, Kp);      // beta = Li g
-    hipLaunchKernelGGL(gemv_cols_kernel, dim3((Kp + 63) / 64), dim3(256), 0, st, k.Li, ld, k.beta, k.alpha, Kp); // alpha = Li^T beta
+    // alpha = Li^T (Li g) = B g  (SCFGP.py:108-110); B is symmetric, so one coalesced row-dot GEMV
+    hipLaunchKernelGGL(gemv_rows_kernel, dim3((Kp + 3) / 4), dim3(256), 0, st, k.B, ld, k.g, k.alpha, Kp);
     hipLaunchKernelGGL(factor_scalars_kernel, dim3(1), dim3(256), 0, st, k.A, ld, k.K, k.g, k.alpha, k.scalars);
 }
 

@@ -457,24 +457,57 @@ template struct SweepKernels<float>;
 // --------------------------------------------------------------------------
 // reductions (deterministic: fixed order over splits)
 // --------------------------------------------------------------------------
+// packed lower-tile layout of a symmetric Kp x Kp matrix: tile (ti >= tj) number t = ti(ti+1)/2 + tj holds
+// its B x B elements row-major at [t*B*B, (t+1)*B*B) -- what the all-reduce of a sharded run moves
+// (K^2/2 instead of K^2 doubles).
 __global__ __launch_bounds__(256) void reduce_tri_kernel(const double* __restrict__ slabs, int nsplit, int ntiles, int B,
-                                                         double* __restrict__ out, int64_t ldo) {
+                                                         double* __restrict__ packed) {
+    const int t = blockIdx.x;
+    for (int e = blockIdx.y * 256 + threadIdx.x; e < B * B; e += gridDim.y * 256) {
+        double s = 0;
+        for (int sp = 0; sp < nsplit; ++sp) s += slabs[((int64_t)sp * ntiles + t) * (B * B) + e];
+        packed[(int64_t)t * B * B + e] = s;
+    }
+}
+void reduce_tri_tiles(const double* slabs, int nsplit, int nts, int tile, double* packed, hipStream_t st) {
+    const int ntiles = nts * (nts + 1) / 2;
+    hipLaunchKernelGGL(reduce_tri_kernel, dim3(ntiles, 16), dim3(256), 0, st, slabs, nsplit, ntiles, tile, packed);
+}
+// slot of element (i, j): off-diagonal tiles exist only below the diagonal, diagonal tiles hold both triangles
+__device__ __forceinline__ int64_t packed_index(int i, int j, int B) {
+    int ti = i / B, tj = j / B, r = i % B, c = j % B;
+    if (ti < tj) { int t = ti; ti = tj; tj = t; t = r; r = c; c = t; }
+    return ((int64_t)(ti * (ti + 1) / 2 + tj) * B + r) * B + c;
+}
+// vec[j<K] = M[row][j]; then the augmented rows/columns K, K+1 are cleared in every slot that holds them
+__global__ void extract_aug_kernel(double* __restrict__ packed, int K, int Kp, int B, int row, double* __restrict__ vec) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= Kp) return;
+    vec[j] = j < K ? packed[packed_index(row, j, B)] : 0.0;
+    for (int a = K; a < K + 2; ++a) {
+        packed[packed_index(a, j, B)] = 0.0;
+        packed[packed_index(j, a, B)] = 0.0;          // the other triangle's slot when (a, j) share a diagonal tile
+    }
+}
+void extract_aug(double* packed, int K, int Kp, int tile, int row, double* vec, hipStream_t st) {
+    hipLaunchKernelGGL(extract_aug_kernel, dim3((Kp + 255) / 256), dim3(256), 0, st, packed, K, Kp, tile, row, vec);
+}
+// full symmetric matrix (ld = Kp) from the packed lower tiles; diagonal tiles carry both triangles
+__global__ __launch_bounds__(256) void unpack_tri_kernel(const double* __restrict__ packed, int B, double* __restrict__ full, int64_t ld) {
     const int t = blockIdx.x;
     int ti = (int)((sqrtf(8.0f * t + 1.0f) - 1.0f) * 0.5f);
     while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
     while (ti * (ti + 1) / 2 > t) --ti;
     const int tj = t - ti * (ti + 1) / 2;
     for (int e = blockIdx.y * 256 + threadIdx.x; e < B * B; e += gridDim.y * 256) {
-        double s = 0;
-        for (int sp = 0; sp < nsplit; ++sp) s += slabs[((int64_t)sp * ntiles + t) * (B * B) + e];
+        const double v = packed[(int64_t)t * B * B + e];
         const int i = ti * B + e / B, j = tj * B + e % B;
-        out[(int64_t)i * ldo + j] = s;
-        if (ti != tj) out[(int64_t)j * ldo + i] = s;
+        full[(int64_t)i * ld + j] = v;
+        if (ti != tj) full[(int64_t)j * ld + i] = v;
     }
 }
-void reduce_tri_tiles(const double* slabs, int nsplit, int nts, int tile, double* out, int64_t ldo, hipStream_t st) {
-    const int ntiles = nts * (nts + 1) / 2;
-    hipLaunchKernelGGL(reduce_tri_kernel, dim3(ntiles, 16), dim3(256), 0, st, slabs, nsplit, ntiles, tile, out, ldo);
+void unpack_tri_tiles(const double* packed, int nts, int tile, double* full, int64_t ld, hipStream_t st) {
+    hipLaunchKernelGGL(unpack_tri_kernel, dim3(nts * (nts + 1) / 2, 16), dim3(256), 0, st, packed, tile, full, ld);
 }
 
 __global__ __launch_bounds__(256) void reduce_full_kernel(const double* __restrict__ slabs, int nsplit, int ntiles, int ntn,
@@ -569,15 +602,4 @@ __global__ void pad_square_kernel(const double* __restrict__ src, int K, int Kp,
 }
 void pad_square(const double* src, int K, int Kp, double* dst, hipStream_t st) {
     hipLaunchKernelGGL(pad_square_kernel, dim3(1024), dim3(256), 0, st, src, K, Kp, dst);
-}
-
-// dst[j] = x[row][j] (j < K), then clear the augmented rows/columns K, K+1 of the Kp x Kp matrix x
-__global__ void extract_aug_kernel(double* __restrict__ x, int K, int Kp, int row, double* __restrict__ dst) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= Kp) return;
-    dst[j] = j < K ? x[(int64_t)row * Kp + j] : 0.0;
-    for (int a = K; a < K + 2; ++a) { x[(int64_t)a * Kp + j] = 0.0; x[(int64_t)j * Kp + a] = 0.0; }
-}
-void extract_aug(double* x, int K, int Kp, int row, double* dst, hipStream_t st) {
-    hipLaunchKernelGGL(extract_aug_kernel, dim3((Kp + 255) / 256), dim3(256), 0, st, x, K, Kp, row, dst);
 }

@@ -44,6 +44,9 @@ struct scfgp_ctx {
     double *d_Xt = nullptr, *d_y = nullptr, *d_p = nullptr, *d_q = nullptr, *d_vpart = nullptr;
     void *d_Phi = nullptr, *d_V = nullptr; double* d_bpart = nullptr;
     // exchange buffers and K-stage
+    // exchange buffers xp1/xp2 = [packed lower tiles | vector Kp | 8 scalars], x3 = [X~^T Zbar | 8 scalars];
+    // x1/x2 = the same matrices unpacked to full Kp x Kp (+ vector) for the K x K stage
+    double *d_xp1 = nullptr, *d_xp2 = nullptr; int64_t n_xp = 0, n_pk = 0;
     double *d_x1 = nullptr, *d_x2 = nullptr, *d_x3 = nullptr; int64_t n_x1 = 0, n_x2 = 0, n_x3 = 0; int Dpp = 0;
     double *d_Li = nullptr, *d_B = nullptr, *d_T1 = nullptr, *d_T2 = nullptr, *d_Abar = nullptr;
     void *d_BT = nullptr, *d_AbarT = nullptr;
@@ -180,11 +183,16 @@ extern "C" int scfgp_create(scfgp_ctx** out, int D, int S, int M, int dtype, int
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_factor, hipEventDisableTiming));
     const int64_t Kp = g.Kp, K2 = Kp * Kp;
     c->n_x1 = K2 + Kp + 8; c->n_x2 = K2 + Kp + 8; c->n_x3 = (int64_t)c->Dpp * g.Jp + 8;
+    { const int64_t nts = Kp / g.tile; c->n_pk = nts * (nts + 1) / 2 * g.tile * g.tile; c->n_xp = c->n_pk + Kp + 8; }
     int rc;
     if ((rc = dmalloc(c, &c->d_params, sizeof(double) * g.P))) return rc;
     if ((rc = dmalloc(c, &c->d_F, sizeof(double) * D * M))) return rc;
     if ((rc = dmalloc(c, &c->d_Fall, sizeof(double) * g.Dp * g.Jp))) return rc;
     if ((rc = dmalloc(c, &c->d_sc, sizeof(Scal)))) return rc;
+    if ((rc = dmalloc(c, &c->d_xp1, sizeof(double) * c->n_xp))) return rc;
+    if ((rc = dmalloc(c, &c->d_xp2, sizeof(double) * c->n_xp))) return rc;
+    HIPCHK(c, hipMemsetAsync(c->d_xp1, 0, sizeof(double) * c->n_xp, c->st));
+    HIPCHK(c, hipMemsetAsync(c->d_xp2, 0, sizeof(double) * c->n_xp, c->st));
     if ((rc = dmalloc(c, &c->d_x1, sizeof(double) * c->n_x1))) return rc;
     if ((rc = dmalloc(c, &c->d_x2, sizeof(double) * c->n_x2))) return rc;
     if ((rc = dmalloc(c, &c->d_x3, sizeof(double) * c->n_x3))) return rc;
@@ -219,7 +227,7 @@ extern "C" void scfgp_destroy(scfgp_ctx* c) {
     free_rows(c);
     dfree(c->d_Xraw); dfree(c->d_yraw); dfree(c->d_idx);
     dfree(c->d_params); dfree(c->d_F); dfree(c->d_Fall); dfree(c->d_sc);
-    dfree(c->d_x1); dfree(c->d_x2); dfree(c->d_x3); dfree(c->d_Li); dfree(c->d_B); dfree(c->d_T1); dfree(c->d_T2);
+    dfree(c->d_xp1); dfree(c->d_xp2); dfree(c->d_x1); dfree(c->d_x2); dfree(c->d_x3); dfree(c->d_Li); dfree(c->d_B); dfree(c->d_T1); dfree(c->d_T2);
     dfree(c->d_Abar); dfree(c->d_BT); dfree(c->d_AbarT); dfree(c->d_vecs); dfree(c->d_scalars); dfree(c->d_yy);
     dfree(c->d_flag); dfree(c->d_partial); dfree(c->d_work); dfree(c->d_grad);
     dfree(c->p_Xt); dfree(c->p_vpart); dfree(c->p_mu); dfree(c->p_sd); dfree(c->p_Phi); dfree(c->p_V);
@@ -287,6 +295,13 @@ extern "C" int scfgp_set_data(scfgp_ctx* c, const double* X, const double* y, in
 // ----------------------------------------------------------------------------------------------
 // staged evaluation
 // ----------------------------------------------------------------------------------------------
+// summed exchange buffer [packed | vec | scalars] -> full symmetric matrix + vector for the K x K stage
+static void unpack_exchange(scfgp_ctx* c, const double* xp, double* x) {
+    const Geom& g = c->g;
+    unpack_tri_tiles(xp, g.Kp / g.tile, g.tile, x, g.Kp, c->st);
+    hipMemcpyAsync(x + (int64_t)g.Kp * g.Kp, xp + c->n_pk, sizeof(double) * (g.Kp + 8), hipMemcpyDeviceToDevice, c->st);
+}
+
 template <typename T> struct Impl {
     typedef SweepKernels<T> SK;
     static const T* BT(scfgp_ctx* c) { return (const T*)c->d_BT; }
@@ -300,43 +315,41 @@ template <typename T> struct Impl {
         const int gs = c->gram_nsplit > 0 ? (int)std::min<int64_t>(c->gram_nsplit, g.Np / 256) : default_split(ntiles, g.Np);
         { ProfScope ps(c, name);
           SK::gram(g, (const T*)c->d_Phi, w, gs, c->dtype == SCFGP_F32 ? c->gram_chunk : 0, c->d_slabs, c->st); }
-        { ProfScope ps(c, "reduce_tiles"); reduce_tri_tiles(c->d_slabs, gs, nts, g.tile, out, g.Kp, c->st);
-          extract_aug(out, g.K, g.Kp, row, out + (int64_t)g.Kp * g.Kp, c->st); }
+        { ProfScope ps(c, "reduce_tiles"); reduce_tri_tiles(c->d_slabs, gs, nts, g.tile, out, c->st);
+          extract_aug(out, g.K, g.Kp, g.tile, row, out + c->n_pk, c->st); }
     }
     static int pass1(scfgp_ctx* c) {
         const Geom& g = c->g;
-        const int64_t K2 = (int64_t)g.Kp * g.Kp;
         if (!c->in_train) HIPCHK(c, hipMemsetAsync(c->d_flag, 0, sizeof(int) * 4, c->st));
         { ProfScope ps(c, "featuremap"); SK::featuremap(g, c->d_Xt, c->d_Fall, c->d_sc, (T*)c->d_Phi, c->st); }
-        gram_to(c, nullptr, c->d_x1, g.K, "gram");
-        HIPCHK(c, hipMemcpyAsync(c->d_x1 + K2 + g.Kp, c->d_yy, sizeof(double), hipMemcpyDeviceToDevice, c->st));
+        gram_to(c, nullptr, c->d_xp1, g.K, "gram");
+        HIPCHK(c, hipMemcpyAsync(c->d_xp1 + c->n_pk + g.Kp, c->d_yy, sizeof(double), hipMemcpyDeviceToDevice, c->st));
         HIPCHK(c, hipGetLastError());
         return SCFGP_OK;
     }
     static int factor(scfgp_ctx* c) {
         const Geom& g = c->g;
-        { ProfScope ps(c, "kstage_factor"); kstage_factor(c->kstage(), c->d_sc, c->st); }
+        { ProfScope ps(c, "kstage_factor"); unpack_exchange(c, c->d_xp1, c->d_x1); kstage_factor(c->kstage(), c->d_sc, c->st); }
         SK::convert(c->d_B, (T*)c->d_BT, g.K, g.Kp, c->st);
         HIPCHK(c, hipGetLastError());
         return SCFGP_OK;
     }
     static int pass2(scfgp_ctx* c, int want_grad) {
         const Geom& g = c->g;
-        const int64_t K2 = (int64_t)g.Kp * g.Kp;
         { ProfScope ps(c, "apply_v"); SK::apply_v(g, (const T*)c->d_Phi, BT(c), (T*)c->d_V, c->d_vpart, c->st); }
         const int nb = (int)std::min<int64_t>(g.Np / 4, 2048);
         { ProfScope ps(c, "rowstats");
           SK::rowstats(g, (T*)c->d_Phi, c->alpha(), c->d_vpart, c->d_y, c->d_sc, c->d_p, c->d_q, c->d_partial, nb, c->st);
-          reduce_scalars(c->d_partial, nb, 2, c->d_x2 + K2 + g.Kp, 0, c->st); }
+          reduce_scalars(c->d_partial, nb, 2, c->d_xp2 + c->n_pk + g.Kp, 0, c->st); }
         if (want_grad) {
-            gram_to(c, c->d_q, c->d_x2, g.K + 1, "gram_w");
+            gram_to(c, c->d_q, c->d_xp2, g.K + 1, "gram_w");
         }
         HIPCHK(c, hipGetLastError());
         return SCFGP_OK;
     }
     static int adjoint(scfgp_ctx* c) {
         const Geom& g = c->g;
-        { ProfScope ps(c, "kstage_adjoint"); kstage_adjoint(c->kstage(), c->d_x2, c->d_Abar, c->d_sc, c->st); }
+        { ProfScope ps(c, "kstage_adjoint"); unpack_exchange(c, c->d_xp2, c->d_x2); kstage_adjoint(c->kstage(), c->d_x2, c->d_Abar, c->d_sc, c->st); }
         SK::convert(c->d_Abar, (T*)c->d_AbarT, g.K, g.Kp, c->st);
         HIPCHK(c, hipGetLastError());
         return SCFGP_OK;
@@ -407,11 +420,10 @@ extern "C" int scfgp_pass3(scfgp_ctx* c) {
 
 extern "C" int scfgp_exchange(scfgp_ctx* c, int stage, void** dev_ptr, int64_t* count) {
     if (!c || !dev_ptr || !count) return SCFGP_EARG;
-    const int64_t K2 = (int64_t)c->g.Kp * c->g.Kp;
-    if (stage == 1) { *dev_ptr = c->d_x1; *count = c->n_x1; }
+    if (stage == 1) { *dev_ptr = c->d_xp1; *count = c->n_xp; }
     else if (stage == 2) {
-        if (c->last_want_grad) { *dev_ptr = c->d_x2; *count = c->n_x2; }
-        else { *dev_ptr = c->d_x2 + K2 + c->g.Kp; *count = 8; }          // forward only: just (T2, kbar)
+        if (c->last_want_grad) { *dev_ptr = c->d_xp2; *count = c->n_xp; }
+        else { *dev_ptr = c->d_xp2 + c->n_pk + c->g.Kp; *count = 8; }    // forward only: just (T2, kbar)
     }
     else if (stage == 3) { *dev_ptr = c->d_x3; *count = c->n_x3; }
     else return SCFGP_EARG;
@@ -434,10 +446,9 @@ extern "C" int scfgp_fetch_factors(scfgp_ctx* c, double* alpha, double* Li) {
 
 static void enqueue_epilogue(scfgp_ctx* c, int want_grad) {
     const Geom& g = c->g;
-    const int64_t K2 = (int64_t)g.Kp * g.Kp;
     ProfScope ps(c, "epilogue");
     grad_epilogue(g, c->d_params, c->d_F, c->d_x3, g.Jp, c->d_work, c->d_scalars, c->Nglobal, want_grad ? c->d_grad : nullptr, c->st);
-    finalize_cost(g, c->d_sc, c->d_scalars, c->d_x1 + K2 + g.Kp, c->d_x2 + K2 + g.Kp, c->d_x3 + (int64_t)c->Dpp * g.Jp,
+    finalize_cost(g, c->d_sc, c->d_scalars, c->d_xp1 + c->n_pk + g.Kp, c->d_xp2 + c->n_pk + g.Kp, c->d_x3 + (int64_t)c->Dpp * g.Jp,
                   c->Nglobal, c->d_grad, want_grad, c->st);
 }
 
@@ -445,7 +456,6 @@ extern "C" int scfgp_finish(scfgp_ctx* c, int want_grad, double* cost, double* g
     if (int rc = ready(c)) return rc;
     if ((want_grad && c->stage != 5) || (!want_grad && c->stage != 3)) { c->err = "finish: evaluation incomplete"; return SCFGP_EARG; }
     const Geom& g = c->g;
-    const int64_t K2 = (int64_t)g.Kp * g.Kp;
     enqueue_epilogue(c, want_grad);
     double h_cost = 0; int h_flag[4] = {0, 0, 0, 0};
     {
@@ -517,7 +527,7 @@ extern "C" int scfgp_predict(scfgp_ctx* c, const double* Xs, int64_t T, const do
     if (!c->have_params) { c->err = "predict: parameters not set"; return SCFGP_EARG; }
     HIPCHK(c, hipSetDevice(c->device));
     const Geom& g0 = c->g;
-    const int64_t Kp = g0.Kp, K2 = Kp * Kp;
+    const int64_t Kp = g0.Kp;
     const size_t ts = c->tsize();
     int rc;
     if (!c->p_Xt) {
@@ -710,8 +720,8 @@ extern "C" int64_t scfgp_debug_read(scfgp_ctx* c, const char* name, void* host, 
     const void* src = nullptr; int64_t bytes = 0;
     if (s == "Phi") { src = c->d_Phi; bytes = ts * g.Np * g.Kp; }
     else if (s == "V") { src = c->d_V; bytes = ts * g.Np * g.Kp; }
-    else if (s == "G") { src = c->d_x1; bytes = 8 * c->n_x1; }
-    else if (s == "W") { src = c->d_x2; bytes = 8 * c->n_x2; }
+    else if (s == "G") { if (c->stage == 1) unpack_exchange(c, c->d_xp1, c->d_x1); src = c->d_x1; bytes = 8 * c->n_x1; }
+    else if (s == "W") { if (c->stage == 3) unpack_exchange(c, c->d_xp2, c->d_x2); src = c->d_x2; bytes = 8 * c->n_x2; }
     else if (s == "XZ") { src = c->d_x3; bytes = 8 * c->n_x3; }
     else if (s == "Li") { src = c->d_Li; bytes = 8 * K2; }
     else if (s == "B") { src = c->d_B; bytes = 8 * K2; }
