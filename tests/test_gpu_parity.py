@@ -383,3 +383,56 @@ def test_index_list_minibatches_on_resident_rows():
     model.set_data(X * 3 - 1, np.sin(X[:, :1] * 5) + 0.1 * y)
     model.optimize(None, None, max_iter=6, nbatches=3, batchsize=120)
     assert len(model.evals['COST'][1]) == 7 and np.all(np.isfinite(model.evals['COST'][1]))
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('N,D,S,M,dtype', [(3000, 8, 32, 1024, 'f32'),      # C3 shape (K = 2112), reduced N
+                                           (2500, 64, 32, 1024, 'f64'),     # C4 / headline shape
+                                           (1500, 512, 64, 2048, 'f32')])   # C5 shape (K = 4224)
+def test_baseline_config_shapes_against_oracle(N, D, S, M, dtype):
+    """The K, D, S, M of BASELINE.json's large configs at an N the CPU oracle finishes in seconds."""
+    from scfgp_amd.engine import HipEngine
+    seed = 0x5CF60300 + D
+    X = synth.make_X(seed, N, D)
+    params = synth.make_params(seed + 0x0202, D, S, M, abc=(-1.0, 0.0, -1.0))
+    eng = HipEngine(D, S, M, dtype=dtype)
+    y = _teacher_targets(eng, X, D, S, M, seed)
+    eng.set_params(params); eng.set_data(X, y)
+    cost, grad, alpha, Li = eng.eval(want_grad=True)
+    c0, g0, a0, L0 = O.value_and_grad(X, y, params, S, M, chunk=1024)
+    if dtype == 'f64':
+        assert abs(float(cost) - c0) < 1e-10 * abs(c0) and rel(grad, g0) < 1e-8 and rel(alpha, a0) < 1e-7 and rel(Li, L0) < 1e-8
+    else:
+        assert abs(float(cost) - c0) < 1e-5 * max(1.0, abs(c0))
+        for u, v in zip(grad_blocks(grad, D, S, M), grad_blocks(g0, D, S, M)):
+            assert rel(u, v) < 1e-3
+        assert rel(Li, L0) < 1e-3
+    eng.close()
+
+
+def test_predict_in_chunks_and_call_order_errors():
+    """T larger than the library's internal predict chunk; staged calls out of order are refused."""
+    from scfgp_amd.engine import HipEngine
+    name = 'kin8nm_like'
+    N, D, S, M, T, seed = CASES[name]
+    X, y, params, _ = case_inputs(name)
+    eng = HipEngine(D, S, M); eng.set_params(params); eng.set_data(X, y)
+    c, g, alpha, Li = eng.eval(want_grad=True)
+    Tbig = 70001
+    Xs = synth.make_X(seed + 99, Tbig, D)
+    mu, sd = eng.predict(Xs, alpha, Li)
+    sel = np.r_[0:50, 32760:32780, Tbig - 50:Tbig]
+    mu0, sd0 = O.predict(Xs[sel], alpha, Li, params, S, M)
+    assert rel(mu[sel], mu0) < 1e-9 and rel(sd[sel], sd0) < 1e-10
+    # training data survived the predict call
+    c2, g2, _, _ = eng.eval(want_grad=True)
+    assert float(c2) == float(c) and np.array_equal(g2, g)
+    for bad in (eng.factor, eng.adjoint, eng.pass3, lambda: eng.pass2(True), lambda: eng.finish(True)):
+        with pytest.raises(ValueError):
+            bad()
+    eng.pass1(); eng.factor(); eng.pass2(False)
+    with pytest.raises(ValueError):
+        eng.adjoint()                                   # forward-only pass 2 cannot feed the adjoint
+    c3, _, _, _ = eng.finish(False)
+    assert abs(float(c3) - float(c)) < 1e-13 * abs(float(c))
+    eng.close()
