@@ -246,18 +246,22 @@ __global__ __launch_bounds__(Cfg::THREADS) void apply_kernel(
     const typename Cfg::T* __restrict__ Phi, const typename Cfg::T* __restrict__ Bm, typename Cfg::T* V,
     double* __restrict__ vpart, const double* __restrict__ p, const double* __restrict__ q, const double* __restrict__ y,
     const double* __restrict__ alpha, const double* __restrict__ ut, int K, int Kp, int64_t Np, int njt,
-    double* __restrict__ bpart) {
+    double* __restrict__ bpart, int col0, int jt0) {
+    // this launch covers columns [col0, col0 + njt*BN); jt0 = index of its first tile in vpart
     typedef typename Cfg::T T;
     SMEM_DECL;
     T* smem = reinterpret_cast<T*>(smem_raw);
     const unsigned wid = xcd_remap(blockIdx.x, gridDim.x);
     const int jt = wid % njt;
     const int64_t rb = wid / njt;
+    const int cbase = col0 + jt * Cfg::BN;
     TrLoader<T, T, Cfg::BM, Cfg::BK, Cfg::LDA, Cfg::THREADS> la(Phi + rb * Cfg::BM * Kp, Kp, threadIdx.x);
-    NatLoader<T, T, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS, false, false> lb(Bm + jt * Cfg::BN, Kp, threadIdx.x);
+    NatLoader<T, T, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS, false, false> lb(Bm + cbase, Kp, threadIdx.x);
     typename Cfg::MTr::acc_t acc[Cfg::TM][Cfg::TN];
     acc_zero<Cfg>(acc);
-    tile_mainloop<Cfg>(la, lb, Kp / Cfg::BK, acc, smem);
+    // rows >= K of the operand matrix are zero (padding and the y, p columns of Phi~ are masked out of
+    // the sweep operands), so the contraction stops at K rounded up to the k-tile
+    tile_mainloop<Cfg>(la, lb, (K + Cfg::BK - 1) / Cfg::BK, acc, smem);
     AccCoord<Cfg> co;
     if (EPI == 0) {
         double* red = reinterpret_cast<double*>(smem_raw);          // [WGN][BM]; main loop ended with a barrier
@@ -267,13 +271,13 @@ __global__ __launch_bounds__(Cfg::THREADS) void apply_kernel(
 #pragma unroll
             for (int r = 0; r < Cfg::MTr::NACC; ++r) {
                 const int row = co.row(tm, r);
-                const int64_t off = (rb * Cfg::BM + row) * Kp + (int64_t)jt * Cfg::BN;
+                const int64_t off = (rb * Cfg::BM + row) * Kp + cbase;
                 double part = 0;
 #pragma unroll
                 for (int tn = 0; tn < Cfg::TN; ++tn) {
                     const T c = acc[tm][tn][r];
                     V[off + co.col(tn)] = c;
-                    if (jt * Cfg::BN + co.col(tn) < K) part += (double)Phi[off + co.col(tn)] * (double)c;   // not the y, p columns
+                    if (cbase + co.col(tn) < K) part += (double)Phi[off + co.col(tn)] * (double)c;   // not the y, p columns
                 }
 #pragma unroll
                 for (int m = 1; m < Cfg::MS; m <<= 1) part += __shfl_xor(part, m);      // lanes of one MFMA row group
@@ -284,7 +288,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void apply_kernel(
             double s = 0;
 #pragma unroll
             for (int k = 0; k < Cfg::WGN; ++k) s += red[k * Cfg::BM + threadIdx.x];
-            vpart[(int64_t)jt * Np + rb * Cfg::BM + threadIdx.x] = s;
+            vpart[(int64_t)(jt0 + jt) * Np + rb * Cfg::BM + threadIdx.x] = s;
         }
     } else {
         double bb = 0;                                                  // bbar = sum Phibar o Phi  (d cost / d b)
@@ -293,11 +297,11 @@ __global__ __launch_bounds__(Cfg::THREADS) void apply_kernel(
 #pragma unroll
             for (int r = 0; r < Cfg::MTr::NACC; ++r) {
                 const int64_t n = rb * Cfg::BM + co.row(tm, r);
-                const int64_t off = n * Kp + (int64_t)jt * Cfg::BN;
+                const int64_t off = n * Kp + cbase;
                 const double qn = 2.0 * q[n], pn = p[n], yn = y[n];
 #pragma unroll
                 for (int tn = 0; tn < Cfg::TN; ++tn) {
-                    const int j = jt * Cfg::BN + co.col(tn);
+                    const int j = cbase + co.col(tn);
                     const double v = 2.0 * (double)acc[tm][tn][r] + qn * (double)V[off + co.col(tn)] + pn * alpha[j] + yn * ut[j];
                     V[off + co.col(tn)] = (T)v;
                     if (j < K) bb += v * (double)Phi[off + co.col(tn)];
@@ -316,22 +320,39 @@ __global__ __launch_bounds__(Cfg::THREADS) void apply_kernel(
     }
 }
 
+// Columns [0, K) of the output are covered by full TILE-wide tiles plus, for the ragged remainder, 64-wide
+// tiles (K = 2112: 16 x 128 + 1 x 64), so no workgroup multiplies a half-empty tile; columns >= K of the
+// output buffer are never written and stay zero.
+template <typename T, int TILE> static int apply_ntiles(const Geom& g) {
+    const int nfull = g.K / TILE, rem = g.K - nfull * TILE;
+    return nfull + (rem + 63) / 64;
+}
+template <class Cfg, int EPI, typename T>
+static int apply_launch_cfg(const Geom& g, int njt, int col0, int jt0, int boff, const T* Phi, const T* Bm, T* V, double* vpart,
+                            const double* p, const double* q, const double* y, const double* alpha, const double* ut,
+                            double* bpart, hipStream_t st) {
+    if (njt <= 0) return 0;
+    const int64_t nrb = g.Np / Cfg::BM;
+    allow_big_lds(apply_kernel<Cfg, EPI>, Cfg::LDS_BYTES);
+    hipLaunchKernelGGL((apply_kernel<Cfg, EPI>), dim3((unsigned)(njt * nrb)), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st,
+                       Phi, Bm, V, vpart, p, q, y, alpha, ut, g.K, g.Kp, g.Np, njt, bpart ? bpart + boff : nullptr, col0, jt0);
+    return (int)(njt * nrb);
+}
 template <typename T, int TILE>
 static int apply_launch(int epi, const Geom& g, const T* Phi, const T* Bm, T* V, double* vpart, const double* p, const double* q,
                         const double* y, const double* alpha, const double* ut, double* bpart, hipStream_t st) {
     typedef typename ApplyCfg<T, TILE>::type Cfg;
-    const int njt = g.Kp / Cfg::BN;
-    const int64_t nrb = g.Np / Cfg::BM;
+    typedef typename ApplyCfg<T, 64>::type CfgR;
+    const int nfull = g.K / TILE, rem = g.K - nfull * TILE, nrem = (rem + 63) / 64;
+    int nb = 0;
     if (epi == 0) {
-        allow_big_lds(apply_kernel<Cfg, 0>, Cfg::LDS_BYTES);
-        hipLaunchKernelGGL((apply_kernel<Cfg, 0>), dim3((unsigned)(njt * nrb)), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st,
-                           Phi, Bm, V, vpart, p, q, y, alpha, ut, g.K, g.Kp, g.Np, njt, bpart);
+        nb += apply_launch_cfg<Cfg, 0, T>(g, nfull, 0, 0, nb, Phi, Bm, V, vpart, p, q, y, alpha, ut, bpart, st);
+        nb += apply_launch_cfg<CfgR, 0, T>(g, nrem, nfull * TILE, nfull, nb, Phi, Bm, V, vpart, p, q, y, alpha, ut, bpart, st);
     } else {
-        allow_big_lds(apply_kernel<Cfg, 1>, Cfg::LDS_BYTES);
-        hipLaunchKernelGGL((apply_kernel<Cfg, 1>), dim3((unsigned)(njt * nrb)), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st,
-                           Phi, Bm, V, vpart, p, q, y, alpha, ut, g.K, g.Kp, g.Np, njt, bpart);
+        nb += apply_launch_cfg<Cfg, 1, T>(g, nfull, 0, 0, nb, Phi, Bm, V, vpart, p, q, y, alpha, ut, bpart, st);
+        nb += apply_launch_cfg<CfgR, 1, T>(g, nrem, nfull * TILE, nfull, nb, Phi, Bm, V, vpart, p, q, y, alpha, ut, bpart, st);
     }
-    return (int)(njt * nrb);
+    return nb;
 }
 template <typename T>
 void SweepKernels<T>::apply_v(const Geom& g, const T* Phi, const T* Bm, T* V, double* vpart, hipStream_t st) {
@@ -344,14 +365,13 @@ int SweepKernels<T>::apply_phibar(const Geom& g, const T* Phi, const T* Abar, T*
     if (g.tile == 192) return apply_launch<T, 192>(1, g, Phi, Abar, V, nullptr, p, q, y, alpha, ut, bpart, st);
     return apply_launch<T, 128>(1, g, Phi, Abar, V, nullptr, p, q, y, alpha, ut, bpart, st);
 }
+// number of column tiles of the apply kernel (vpart leading count)
+template <typename T> static int apply_njt(const Geom& g) { return g.tile == 192 ? apply_ntiles<T, 192>(g) : apply_ntiles<T, 128>(g); }
 template <typename T>
 int SweepKernels<T>::apply_blocks(const Geom& g) {
-    const int bm = g.tile == 192 ? ApplyCfg<T, 192>::type::BM : ApplyCfg<T, 128>::type::BM;
-    return (int)((g.Kp / g.tile) * (g.Np / bm));
+    return (int)(apply_njt<T>(g) * (g.Np / ApplyCfg<T, 128>::type::BM));
 }
 
-// number of column tiles of the apply kernel (vpart leading count)
-template <typename T> static int apply_njt(const Geom& g) { return g.Kp / g.tile; }
 
 // --------------------------------------------------------------------------
 // per-row statistics: one wave per row (grid-stride).

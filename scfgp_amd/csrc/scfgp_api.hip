@@ -154,11 +154,12 @@ static int ensure_rows(scfgp_ctx* c, int64_t N) {
     if ((rc = dmalloc(c, &c->d_y, sizeof(double) * Np))) return rc;
     if ((rc = dmalloc(c, &c->d_p, sizeof(double) * Np))) return rc;
     if ((rc = dmalloc(c, &c->d_q, sizeof(double) * Np))) return rc;
-    if ((rc = dmalloc(c, &c->d_vpart, sizeof(double) * Np * (g.Kp / g.tile)))) return rc;
+    if ((rc = dmalloc(c, &c->d_vpart, sizeof(double) * Np * (g.Kp / 64)))) return rc;          // <= one entry per 64 columns
     if ((rc = dmalloc(c, &c->d_Phi, ts * Np * g.Kp))) return rc;
     if ((rc = dmalloc(c, &c->d_V, ts * Np * g.Kp))) return rc;
-    if ((rc = dmalloc(c, &c->d_bpart, sizeof(double) * (g.Kp / g.tile) * (Np / 128)))) return rc;
+    if ((rc = dmalloc(c, &c->d_bpart, sizeof(double) * (g.Kp / 64) * (Np / 128)))) return rc;
     HIPCHK(c, hipMemsetAsync(c->d_Phi, 0, ts * Np * g.Kp, c->st));       // padding columns >= K+2 stay zero forever
+    HIPCHK(c, hipMemsetAsync(c->d_V, 0, ts * Np * g.Kp, c->st));         // columns >= K are never written
     c->Ncap = Np;
     return SCFGP_OK;
 }
@@ -532,12 +533,13 @@ extern "C" int scfgp_predict(scfgp_ctx* c, const double* Xs, int64_t T, const do
     int rc;
     if (!c->p_Xt) {
         if ((rc = dmalloc(c, &c->p_Xt, sizeof(double) * PRED_ROWS * g0.Dp))) return rc;
-        if ((rc = dmalloc(c, &c->p_vpart, sizeof(double) * PRED_ROWS * (Kp / g0.tile)))) return rc;
+        if ((rc = dmalloc(c, &c->p_vpart, sizeof(double) * PRED_ROWS * (Kp / 64)))) return rc;
         if ((rc = dmalloc(c, &c->p_mu, sizeof(double) * PRED_ROWS))) return rc;
         if ((rc = dmalloc(c, &c->p_sd, sizeof(double) * PRED_ROWS))) return rc;
         if ((rc = dmalloc(c, &c->p_Phi, ts * PRED_ROWS * Kp))) return rc;
         if ((rc = dmalloc(c, &c->p_V, ts * PRED_ROWS * Kp))) return rc;
         HIPCHK(c, hipMemsetAsync(c->p_Phi, 0, ts * PRED_ROWS * Kp, c->st));
+        HIPCHK(c, hipMemsetAsync(c->p_V, 0, ts * PRED_ROWS * Kp, c->st));
     }
     // Li (K x K host) -> T1 (Kp x Kp, identity padding); B = Li^T Li -> T2; typed copy -> AbarT scratch
     double* raw = nullptr;
