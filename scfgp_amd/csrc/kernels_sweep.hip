@@ -32,7 +32,10 @@ template <typename T, int TILE> struct GramCfg {
 template <typename T, int TILE> struct ApplyCfg {
     typedef TileCfg<T, Tune<T>::APPLY_BM, TILE, SCFGP_BK, Tune<T>::APPLY_WGM, Tune<T>::APPLY_WGN, Tune<T>::MS> type;
 };
-typedef TileCfg<double, 128, 64, 16, 2, 2> FmapCfg;
+#ifndef SCFGP_FMAP_WGM
+#define SCFGP_FMAP_WGM 4     // 8 waves: one wave's fp64 sincos overlaps another's projection MFMAs
+#endif
+typedef TileCfg<double, 128, 64, 16, SCFGP_FMAP_WGM, 2> FmapCfg;
 template <typename T> struct XtzCfg { typedef TileCfg<T, 128, 128, 16, 4, 2, Tune<T>::MS> type; };
 
 // --------------------------------------------------------------------------
