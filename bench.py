@@ -151,7 +151,9 @@ def main():
                        "rows_per_gpu": hi - lo, "parallelism": "row-sharded dp%d, 3 all-reduces/eval" % world,
                        "F_alg_per_eval": falg, "F_alg_TFLOPs": falg / (dt / a.steps) / 1e12},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "apply_kernel (Phi.B / Phi.Abar, 2*N*K^2 flops per launch)",
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "apply_kernel (Phi.B / Phi.Abar): one N x K x K product = 2*N*K^2 flops, issued as a 256x128-tile launch "
+                                   "for the full column tiles plus a 256x64-tile launch for the ragged remainder; "
+                                   "avg_launch_ms is the hipEvent time of that pair (rocprof: sum of the two kernels)",
                          "avg_launch_ms": ap_ms},
             "stages_ms": {k: float(np.mean(v)) for k, v in per_kernel.items()},
             "cost": float(cost),
