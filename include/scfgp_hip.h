@@ -90,6 +90,17 @@ int scfgp_eval_rows(scfgp_ctx* ctx, const int64_t* idx, int64_t n, int want_grad
 int scfgp_predict(scfgp_ctx* ctx, const double* Xs, int64_t T, const double* alpha, const double* Li,
                   double* mu, double* std);
 
+/* ---- predict on unscaled inputs (input side) -------------------------------
+ * SCFGP.predict applies X_scaler.forward_transform on the host before pred_func
+ * (SCFGP/SCFGP.py:279, SCFGP/Scaler.py:99-116): min-max, Box-Cox, z-score / normal CDF per column.
+ * With the fitted per-column parameters registered once (D doubles each; NULL = unused by `mode`:
+ * 0 none, 1 min-max, 2 normal, 3 inv-normal, 4 auto-normal, 5 auto-inv-normal) scfgp_predict_raw
+ * takes the column-selected raw Xs and applies the transform inside its packing kernel. */
+int scfgp_set_x_scaler(scfgp_ctx* ctx, int mode, const double* min, const double* max, const double* boxcox,
+                       const double* mu, const double* std);
+int scfgp_predict_raw(scfgp_ctx* ctx, const double* Xs_raw, int64_t T, const double* alpha, const double* Li,
+                      double* mu, double* std);
+
 /* ---- staged evaluation for row-sharded data parallelism ---------------------------------
  * The objective needs three row sweeps separated by two K x K stages; with rows sharded
  * over ranks each sweep ends in one sum over ranks.  The host framework (torch.distributed

@@ -66,7 +66,9 @@ void grad_epilogue(const Geom& g, const double* params, const double* F, const d
 void finalize_cost(const Geom& g, const Scal* sc, double* scalars, const double* yy, const double* t2kb, const double* bbar,
                    int64_t Nglobal, double* grad, int want_grad, hipStream_t st);
 // Xt (Np x Dp) = [X[idx] | 1 | 0], zero rows >= N; y padded with zeros; idx == NULL: rows in order
-void pack_data(const Geom& g, const double* Xraw, const double* yraw, const int64_t* idx, double* Xt, double* y, hipStream_t st);
+// mode/sp: optional per-column input scaling (SCFGP/Scaler.py forward_transform) applied on the fly
+void pack_data(const Geom& g, const double* Xraw, const double* yraw, const int64_t* idx, double* Xt, double* y, hipStream_t st,
+               int mode = 0, const double* sp = nullptr);
 // square K x K host-layout matrix (ld K) -> Kp x Kp with identity padding, and back
 void pad_square(const double* src, int K, int Kp, double* dst, hipStream_t st);
 

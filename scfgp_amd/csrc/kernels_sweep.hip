@@ -600,21 +600,37 @@ void sum_squares(const double* y, int64_t n, double* scalars, int slot, double* 
 // --------------------------------------------------------------------------
 // data staging
 // --------------------------------------------------------------------------
+// per-column input scaling of SCFGP/Scaler.py:99-116 applied while packing (predict on raw inputs):
+//   mode 0 none | 1 min-max | 2 normal | 3 inv-normal | 4 auto-normal | 5 auto-inv-normal
+//   sp = [min | max | boxcox | mu | std], D doubles each
+__device__ __forceinline__ double scale_x(double x, int mode, const double* __restrict__ sp, int D, int d) {
+    if (mode == 0) return x;
+    const double mn = sp[d], mx = sp[D + d], lm = sp[2 * D + d], mu = sp[3 * D + d], sd = sp[4 * D + d];
+    if (mode == 1) return (x - mn) / (mx - mn);
+    if (mode == 2) return (x - mu) / sd;
+    if (mode == 3) return 0.5 * erfc(-((x - mu) / sd) * 0.70710678118654752440);
+    const double t = (x - mn) / (mx - mn);
+    const double bc = ((t < 0 ? -1.0 : (t > 0 ? 1.0 : 0.0)) * pow(fabs(t), lm) - 1.0) / lm;       // sign(t)|t|^lm
+    const double z = (bc - mu) / sd;
+    return mode == 4 ? z : 0.5 * erfc(-z * 0.70710678118654752440);
+}
 __global__ void pack_data_kernel(const double* __restrict__ Xraw, const double* __restrict__ yraw, const int64_t* __restrict__ idx,
-                                 double* __restrict__ Xt, double* __restrict__ y, int D, int Dp, int64_t N, int64_t Np) {
+                                 double* __restrict__ Xt, double* __restrict__ y, int D, int Dp, int64_t N, int64_t Np,
+                                 int mode, const double* __restrict__ sp) {
     const int64_t total = Np * Dp;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t n = i / Dp;
         const int d = (int)(i - n * Dp);
         const int64_t src = (n < N && idx) ? idx[n] : n;           // row gather for index-list minibatches
         double v = 0;
-        if (n < N) v = d < D ? Xraw[src * D + d] : (d == D ? 1.0 : 0.0);
+        if (n < N) v = d < D ? scale_x(Xraw[src * D + d], mode, sp, D, d) : (d == D ? 1.0 : 0.0);
         Xt[i] = v;
         if (d == 0 && y) y[n] = (n < N && yraw) ? yraw[src] : 0.0;
     }
 }
-void pack_data(const Geom& g, const double* Xraw, const double* yraw, const int64_t* idx, double* Xt, double* y, hipStream_t st) {
-    hipLaunchKernelGGL(pack_data_kernel, dim3(4096), dim3(256), 0, st, Xraw, yraw, idx, Xt, y, g.D, g.Dp, g.N, g.Np);
+void pack_data(const Geom& g, const double* Xraw, const double* yraw, const int64_t* idx, double* Xt, double* y, hipStream_t st,
+               int mode, const double* sp) {
+    hipLaunchKernelGGL(pack_data_kernel, dim3(4096), dim3(256), 0, st, Xraw, yraw, idx, Xt, y, g.D, g.Dp, g.N, g.Np, mode, sp);
 }
 __global__ void pad_square_kernel(const double* __restrict__ src, int K, int Kp, double* __restrict__ dst) {
     const int64_t total = (int64_t)Kp * Kp;

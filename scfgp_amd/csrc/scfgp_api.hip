@@ -55,6 +55,7 @@ struct scfgp_ctx {
     double *d_slabs = nullptr; size_t slabs_bytes = 0;
     double *d_partial = nullptr; int64_t n_partial = 0;
     double *d_work = nullptr, *d_grad = nullptr;
+    int xs_mode = 0; double* d_xscale = nullptr;                 // X scaler for scfgp_predict_raw (5*D doubles)
     // predict chunk buffers
     double *p_Xt = nullptr, *p_vpart = nullptr, *p_mu = nullptr, *p_sd = nullptr; void *p_Phi = nullptr, *p_V = nullptr;
     // on-device optimiser + captured training iteration
@@ -226,7 +227,7 @@ extern "C" void scfgp_destroy(scfgp_ctx* c) {
     hipSetDevice(c->device);
     if (c->st) hipStreamSynchronize(c->st);
     free_rows(c);
-    dfree(c->d_Xraw); dfree(c->d_yraw); dfree(c->d_idx);
+    dfree(c->d_Xraw); dfree(c->d_yraw); dfree(c->d_idx); dfree(c->d_xscale);
     dfree(c->d_params); dfree(c->d_F); dfree(c->d_Fall); dfree(c->d_sc);
     dfree(c->d_xp1); dfree(c->d_xp2); dfree(c->d_x1); dfree(c->d_x2); dfree(c->d_x3); dfree(c->d_Li); dfree(c->d_B); dfree(c->d_T1); dfree(c->d_T2);
     dfree(c->d_Abar); dfree(c->d_BT); dfree(c->d_AbarT); dfree(c->d_vecs); dfree(c->d_scalars); dfree(c->d_yy);
@@ -522,8 +523,8 @@ extern "C" int scfgp_eval_rows(scfgp_ctx* c, const int64_t* idx, int64_t n, int 
     return run_eval(c, want_grad, cost, grad, alpha, Li);
 }
 
-extern "C" int scfgp_predict(scfgp_ctx* c, const double* Xs, int64_t T, const double* alpha, const double* Li,
-                             double* mu, double* sd) {
+static int predict_impl(scfgp_ctx* c, const double* Xs, int64_t T, const double* alpha, const double* Li,
+                        double* mu, double* sd, int raw_mode) {
     if (!c || !Xs || !alpha || !Li || !mu || !sd || T < 1) { if (c) c->err = "predict: bad arguments"; return SCFGP_EARG; }
     if (!c->have_params) { c->err = "predict: parameters not set"; return SCFGP_EARG; }
     HIPCHK(c, hipSetDevice(c->device));
@@ -558,7 +559,7 @@ extern "C" int scfgp_predict(scfgp_ctx* c, const double* Xs, int64_t T, const do
         Geom g = g0;
         g.N = std::min<int64_t>(PRED_ROWS, T - t0); g.Np = round_up(g.N, 256);
         HIPCHK(c, hipMemcpyAsync(raw, Xs + t0 * g.D, sizeof(double) * g.N * g.D, hipMemcpyHostToDevice, c->st));
-        pack_data(g, raw, nullptr, nullptr, c->p_Xt, nullptr, c->st);
+        pack_data(g, raw, nullptr, nullptr, c->p_Xt, nullptr, c->st, raw_mode ? c->xs_mode : 0, c->d_xscale);
         rc = c->dtype == SCFGP_F32 ? Impl<float>::predict_chunk(c, g, (const float*)Bt) : Impl<double>::predict_chunk(c, g, (const double*)Bt);
         if (rc) { dfree(raw); return rc; }
         HIPCHK(c, hipMemcpyAsync(mu + t0, c->p_mu, sizeof(double) * g.N, hipMemcpyDeviceToHost, c->st));
@@ -568,6 +569,33 @@ extern "C" int scfgp_predict(scfgp_ctx* c, const double* Xs, int64_t T, const do
     dfree(raw);
     HIPCHK(c, hipGetLastError());
     return SCFGP_OK;
+}
+
+extern "C" int scfgp_predict(scfgp_ctx* c, const double* Xs, int64_t T, const double* alpha, const double* Li,
+                             double* mu, double* sd) {
+    return predict_impl(c, Xs, T, alpha, Li, mu, sd, 0);
+}
+
+// SCFGP.predict feeds pred_func with X_scaler.forward_transform(Xs) (SCFGP/SCFGP.py:279); for large test
+// sets that element-wise host pass dominates, so the same transform can run inside the packing kernel.
+extern "C" int scfgp_set_x_scaler(scfgp_ctx* c, int mode, const double* mn, const double* mx, const double* boxcox,
+                                  const double* mu, const double* sd) {
+    if (!c || mode < 0 || mode > 5) return SCFGP_EARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int D = c->g.D;
+    std::vector<double> h(5 * D, 0.0);
+    const double* src[5] = {mn, mx, boxcox, mu, sd};
+    for (int k = 0; k < 5; ++k)
+        if (src[k]) std::copy(src[k], src[k] + D, h.begin() + k * D);
+    if (!c->d_xscale) { if (int rc = dmalloc(c, &c->d_xscale, sizeof(double) * 5 * D)) return rc; }
+    HIPCHK(c, hipMemcpy(c->d_xscale, h.data(), sizeof(double) * 5 * D, hipMemcpyHostToDevice));
+    c->xs_mode = mode;
+    return SCFGP_OK;
+}
+extern "C" int scfgp_predict_raw(scfgp_ctx* c, const double* Xs, int64_t T, const double* alpha, const double* Li,
+                                 double* mu, double* sd) {
+    if (c && c->xs_mode && !c->d_xscale) { c->err = "predict_raw: no scaler set"; return SCFGP_EARG; }
+    return predict_impl(c, Xs, T, alpha, Li, mu, sd, 1);
 }
 
 // ----------------------------------------------------------------------------------------------

@@ -137,6 +137,30 @@ class HipEngine(object):
         self._check(self.lib.scfgp_predict(self.ctx, dptr(Xs), T, dptr(alpha), dptr(Li), dptr(mu), dptr(sd)), 'predict')
         return mu, sd
 
+    SCALER_MODES = {'min-max': 1, 'normal': 2, 'inv-normal': 3, 'auto-normal': 4, 'auto-inv-normal': 5}
+
+    def set_x_scaler(self, scaler):
+        """Register a fitted scfgp_amd.scaler.Scaler so predict_raw can transform inputs on the device."""
+        d = scaler.data
+        arr = lambda k: np.ascontiguousarray(d[k], dtype=np.float64) if k in d and np.ndim(d[k]) else None
+        bufs = [arr(k) for k in ('min', 'max', 'boxcox', 'mu', 'std')]
+        for b in bufs:
+            if b is not None and b.size != self.D:
+                raise ValueError('scaler was fitted on %d columns, engine has D=%d' % (b.size, self.D))
+        self._check(self.lib.scfgp_set_x_scaler(self.ctx, self.SCALER_MODES[scaler.algo], *[dptr(b) for b in bufs]),
+                    'set_x_scaler')
+        self._xcols = list(d['cols'])
+
+    def predict_raw(self, Xs_raw, alpha, Li):
+        """pred_func on UNSCALED inputs: column selection here, the element-wise transform on the GPU."""
+        Xs = np.ascontiguousarray(np.asarray(Xs_raw, dtype=np.float64)[:, self._xcols])
+        alpha = np.ascontiguousarray(alpha, dtype=np.float64).reshape(-1)
+        Li = np.ascontiguousarray(Li, dtype=np.float64)
+        T = Xs.shape[0]
+        mu = np.empty((T, 1)); sd = np.empty(T)
+        self._check(self.lib.scfgp_predict_raw(self.ctx, dptr(Xs), T, dptr(alpha), dptr(Li), dptr(mu), dptr(sd)), 'predict_raw')
+        return mu, sd
+
     # -- staged evaluation (row-sharded data parallelism) --------------------------------------
     def pass1(self):
         self._check(self.lib.scfgp_pass1(self.ctx), 'pass1')

@@ -140,6 +140,14 @@ class CompiledFuncs(object):
         mu, sd = self.engine.predict(Xs, alpha, Li)
         return [mu, sd]
 
+    def pred_raw(self, Xs_raw, x_scaler, alpha, Li):
+        """pred_func on unscaled inputs: the X scaler's element-wise transform runs on the GPU."""
+        self._sync_params()
+        if getattr(self, '_scaler_id', None) is not x_scaler:
+            self.engine.set_x_scaler(x_scaler)
+            self._scaler_id = x_scaler
+        return self.engine.predict_raw(Xs_raw, alpha, Li)
+
     def value_and_grad(self, X, y):
         """cost, grad, alpha, Li at the current parameters without touching them."""
         return self._evaluate(X, y, True)

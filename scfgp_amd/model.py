@@ -49,7 +49,7 @@ class SCFGP(object):
 
     def __init__(self, sparsity=20, nfeats=18, evals=None,
                  X_scaling_method='auto-inv-normal', y_scaling_method='auto-normal', verbose=False,
-                 dtype='f64', device=0, compat_noop_restore=False, device_optimizer=False):
+                 dtype='f64', device=0, compat_noop_restore=False, device_optimizer=False, device_scaler=False):
         self.S = sparsity
         self.M = nfeats
         self.X_scaler = Scaler(X_scaling_method)
@@ -59,6 +59,7 @@ class SCFGP(object):
         self.dtype, self.device = dtype, device
         self.compat_noop_restore = compat_noop_restore
         self.device_optimizer = device_optimizer
+        self.device_scaler = device_scaler          # predict(): X scaling inside the GPU packing kernel
         self.generate_ID()
 
     def message(self, *arg):
@@ -227,8 +228,12 @@ class SCFGP(object):
     # -- prediction ---------------------------------------------------------------------------------
     def predict(self, Xs, ys=None):
         """SCFGP/SCFGP.py:278-294."""
-        self.Xs = np.ascontiguousarray(self.X_scaler.forward_transform(Xs), dtype=np.float64)
-        mu_f, std_f = self.pred_func(self.Xs, self.alpha, self.Li)
+        owner = getattr(self.pred_func, '__self__', None)
+        if self.device_scaler and isinstance(owner, CompiledFuncs):
+            mu_f, std_f = owner.pred_raw(Xs, self.X_scaler, self.alpha, self.Li)
+        else:
+            self.Xs = np.ascontiguousarray(self.X_scaler.forward_transform(Xs), dtype=np.float64)
+            mu_f, std_f = self.pred_func(self.Xs, self.alpha, self.Li)
         mu_y = self.y_scaler.backward_transform(mu_f)
         up_bnd_y = self.y_scaler.backward_transform(mu_f + std_f[:, None])
         dn_bnd_y = self.y_scaler.backward_transform(mu_f - std_f[:, None])

@@ -315,6 +315,10 @@ def test_facade_fit_predict_save_load(tmp_path):
     mu, sd = model.predict(X[240:])
     assert mu.shape == (60, 1) and sd.shape == (60, 1) and np.all(sd > 0)
     assert model.evals['NMSE'][1][-1] < 0.5
+    model.device_scaler = True                                # same prediction with the X scaler on the GPU
+    mu_d, sd_d = model.predict(X[240:])
+    assert np.allclose(mu_d, mu, rtol=1e-9) and np.allclose(sd_d, sd, rtol=1e-9)
+    model.device_scaler = False
     path = os.path.join(str(tmp_path), 'm.npz')
     model.save(path)
     m2 = SCFGP(sparsity=1, nfeats=1); m2.load(path)
@@ -435,4 +439,25 @@ def test_predict_in_chunks_and_call_order_errors():
         eng.adjoint()                                   # forward-only pass 2 cannot feed the adjoint
     c3, _, _, _ = eng.finish(False)
     assert abs(float(c3) - float(c)) < 1e-13 * abs(float(c))
+    eng.close()
+
+
+@pytest.mark.parametrize('algo', ['min-max', 'normal', 'inv-normal', 'auto-normal', 'auto-inv-normal'])
+def test_predict_raw_applies_the_x_scaler_on_the_device(algo):
+    """scfgp_predict_raw == pred_func(X_scaler.forward_transform(Xs)) for every scaler mode (SCFGP.py:279)."""
+    from scfgp_amd.engine import HipEngine
+    from scfgp_amd.scaler import Scaler
+    rng = np.random.default_rng(12)
+    Xraw = np.exp(rng.standard_normal((400, 6))); Xraw[:, 3] = 2.5                  # one constant column is dropped
+    sc = Scaler(algo); sc.fit(Xraw)
+    D, S, M = 5, 3, 8
+    params = O.init_params(D, S, M, rng); params[:3] = (-0.5, 0.0, -0.8)
+    Xt = np.ascontiguousarray(sc.forward_transform(Xraw)); y = rng.standard_normal((400, 1))
+    eng = HipEngine(D, S, M); eng.set_params(params); eng.set_data(Xt, y)
+    c, g, alpha, Li = eng.eval(want_grad=True)
+    Xs_raw = np.exp(rng.standard_normal((333, 6))); Xs_raw[:, 3] = 2.5
+    eng.set_x_scaler(sc)
+    mu_r, sd_r = eng.predict_raw(Xs_raw, alpha, Li)
+    mu_h, sd_h = eng.predict(np.ascontiguousarray(sc.forward_transform(Xs_raw)), alpha, Li)
+    assert rel(mu_r, mu_h) < 1e-11 and rel(sd_r, sd_h) < 1e-11
     eng.close()
