@@ -151,8 +151,8 @@ int scfgp_get_dims(scfgp_ctx* ctx, int64_t* out, int n);
  * (name, milliseconds) pairs.  Returns the number of stages recorded. */
 int scfgp_set_profiling(scfgp_ctx* ctx, int enable);
 int scfgp_get_timings(scfgp_ctx* ctx, double* ms, const char** names, int n);
-/* copy an internal device buffer to the host for tests ("Phi","G","Li","B","V","Zbar","XZ",
- * "W","Abar","p","q","alpha","scalars"); returns the number of bytes copied or <0 */
+/* copy an internal device buffer to the host for tests ("Phi","V","G","W","XZ","Li","B","Abar",
+ * "p","q","vecs","Fall","Xt","scalars"); returns the number of bytes copied or <0 */
 int64_t scfgp_debug_read(scfgp_ctx* ctx, const char* name, void* host, int64_t max_bytes);
 /* tuning knobs: "gram_nsplit", "gram_chunk" (fp32 flush interval in rows), "xtz_nsplit", "use_graph" */
 int scfgp_set_option(scfgp_ctx* ctx, const char* name, int64_t value);
