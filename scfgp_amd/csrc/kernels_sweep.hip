@@ -23,14 +23,23 @@
 #ifndef SCFGP_F32_MS
 #define SCFGP_F32_MS 16          // fp32 MFMA shape: 16 -> 16x16x4, 32 -> 32x32x2
 #endif
+#ifndef SCFGP_APPLY_BN_F32
+#define SCFGP_APPLY_BN_F32 128
+#endif
 template <typename T> struct Tune;
-template <> struct Tune<float>  { static constexpr int MS = SCFGP_F32_MS, GRAM_WGM = 4, GRAM_WGN = 2, APPLY_BM = 256, APPLY_WGM = 4, APPLY_WGN = 2; };
-template <> struct Tune<double> { static constexpr int MS = 16,           GRAM_WGM = 4, GRAM_WGN = 2, APPLY_BM = 256, APPLY_WGM = 4, APPLY_WGN = 4; };
+template <> struct Tune<float>  {
+    static constexpr int MS = SCFGP_F32_MS, GRAM_WGM = 4, GRAM_WGN = 2, APPLY_BM = 256, APPLY_BN = SCFGP_APPLY_BN_F32, APPLY_WGM = 4;
+    static constexpr int apply_wgn(int bn) { return bn >= 256 ? 4 : 2; }
+};
+template <> struct Tune<double> {
+    static constexpr int MS = 16, GRAM_WGM = 4, GRAM_WGN = 2, APPLY_BM = 256, APPLY_BN = 128, APPLY_WGM = 4;
+    static constexpr int apply_wgn(int) { return 4; }
+};
 template <typename T, int TILE> struct GramCfg {
     typedef TileCfg<T, TILE, TILE, SCFGP_BK, Tune<T>::GRAM_WGM, Tune<T>::GRAM_WGN, Tune<T>::MS> type;
 };
 template <typename T, int TILE> struct ApplyCfg {
-    typedef TileCfg<T, Tune<T>::APPLY_BM, TILE, SCFGP_BK, Tune<T>::APPLY_WGM, Tune<T>::APPLY_WGN, Tune<T>::MS> type;
+    typedef TileCfg<T, Tune<T>::APPLY_BM, TILE, SCFGP_BK, Tune<T>::APPLY_WGM, Tune<T>::apply_wgn(TILE), Tune<T>::MS> type;
 };
 #ifndef SCFGP_FMAP_WGM
 #define SCFGP_FMAP_WGM 4     // 8 waves: one wave's fp64 sincos overlaps another's projection MFMAs
@@ -213,6 +222,9 @@ static void gram_launch(const Geom& g, const T* Phi, const double* w, int nsplit
     chunk = round_up(chunk, Cfg::BK);
     allow_big_lds(gram_kernel<Cfg, true>, Cfg::LDS_BYTES);
     allow_big_lds(gram_kernel<Cfg, false>, Cfg::LDS_BYTES);
+#ifdef SCFGP_DIAG_PLAIN_W
+    w = nullptr;                                               // timing diagnostic only: wrong numbers
+#endif
     if (w)
         hipLaunchKernelGGL((gram_kernel<Cfg, true>), dim3(ntiles * nsplit), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st,
                            Phi, (int64_t)g.Kp, w, g.Np, rps, chunk, nts, g.K + 1, slabs);
@@ -323,13 +335,26 @@ __global__ __launch_bounds__(Cfg::THREADS) void apply_kernel(
     }
 }
 
-// Columns [0, K) of the output are covered by full TILE-wide tiles plus, for the ragged remainder, 64-wide
-// tiles (K = 2112: 16 x 128 + 1 x 64), so no workgroup multiplies a half-empty tile; columns >= K of the
-// output buffer are never written and stay zero.
-template <typename T, int TILE> static int apply_ntiles(const Geom& g) {
-    const int nfull = g.K / TILE, rem = g.K - nfull * TILE;
-    return nfull + (rem + 63) / 64;
-}
+// Columns [0, K) of the output are covered by a cascade of launches of decreasing tile width
+// (APPLY_BN, then 128, then 64-wide tiles for the ragged remainder; K = 2112 with 128-wide tiles:
+// 16 x 128 + 1 x 64), so no workgroup multiplies a half-empty tile; columns >= K of the output buffer are
+// never written and stay zero.
+template <typename T> struct ApplyPlan {
+    static constexpr int NW = 3;
+    int width[NW], count[NW], col0[NW], jt0[NW], total;
+    explicit ApplyPlan(int K) {
+        const int w[NW] = {Tune<T>::APPLY_BN, 128, 64};
+        int col = 0, jt = 0;
+        for (int i = 0; i < NW; ++i) {
+            width[i] = w[i];
+            const bool last = i == NW - 1, dup = i > 0 && w[i] >= w[i - 1];
+            count[i] = dup ? 0 : (last ? (K - col + w[i] - 1) / w[i] : (K - col) / w[i]);
+            col0[i] = col; jt0[i] = jt;
+            col += count[i] * w[i]; jt += count[i];
+        }
+        total = jt;
+    }
+};
 template <class Cfg, int EPI, typename T>
 static int apply_launch_cfg(const Geom& g, int njt, int col0, int jt0, int boff, const T* Phi, const T* Bm, T* V, double* vpart,
                             const double* p, const double* q, const double* y, const double* alpha, const double* ut,
@@ -341,38 +366,30 @@ static int apply_launch_cfg(const Geom& g, int njt, int col0, int jt0, int boff,
                        Phi, Bm, V, vpart, p, q, y, alpha, ut, g.K, g.Kp, g.Np, njt, bpart ? bpart + boff : nullptr, col0, jt0);
     return (int)(njt * nrb);
 }
-template <typename T, int TILE>
-static int apply_launch(int epi, const Geom& g, const T* Phi, const T* Bm, T* V, double* vpart, const double* p, const double* q,
+template <typename T, int EPI>
+static int apply_launch(const Geom& g, const T* Phi, const T* Bm, T* V, double* vpart, const double* p, const double* q,
                         const double* y, const double* alpha, const double* ut, double* bpart, hipStream_t st) {
-    typedef typename ApplyCfg<T, TILE>::type Cfg;
-    typedef typename ApplyCfg<T, 64>::type CfgR;
-    const int nfull = g.K / TILE, rem = g.K - nfull * TILE, nrem = (rem + 63) / 64;
+    const ApplyPlan<T> pl(g.K);
     int nb = 0;
-    if (epi == 0) {
-        nb += apply_launch_cfg<Cfg, 0, T>(g, nfull, 0, 0, nb, Phi, Bm, V, vpart, p, q, y, alpha, ut, bpart, st);
-        nb += apply_launch_cfg<CfgR, 0, T>(g, nrem, nfull * TILE, nfull, nb, Phi, Bm, V, vpart, p, q, y, alpha, ut, bpart, st);
-    } else {
-        nb += apply_launch_cfg<Cfg, 1, T>(g, nfull, 0, 0, nb, Phi, Bm, V, vpart, p, q, y, alpha, ut, bpart, st);
-        nb += apply_launch_cfg<CfgR, 1, T>(g, nrem, nfull * TILE, nfull, nb, Phi, Bm, V, vpart, p, q, y, alpha, ut, bpart, st);
-    }
+    nb += apply_launch_cfg<typename ApplyCfg<T, Tune<T>::APPLY_BN>::type, EPI, T>(g, pl.count[0], pl.col0[0], pl.jt0[0], nb, Phi, Bm, V, vpart, p, q, y, alpha, ut, bpart, st);
+    nb += apply_launch_cfg<typename ApplyCfg<T, 128>::type, EPI, T>(g, pl.count[1], pl.col0[1], pl.jt0[1], nb, Phi, Bm, V, vpart, p, q, y, alpha, ut, bpart, st);
+    nb += apply_launch_cfg<typename ApplyCfg<T, 64>::type, EPI, T>(g, pl.count[2], pl.col0[2], pl.jt0[2], nb, Phi, Bm, V, vpart, p, q, y, alpha, ut, bpart, st);
     return nb;
 }
 template <typename T>
 void SweepKernels<T>::apply_v(const Geom& g, const T* Phi, const T* Bm, T* V, double* vpart, hipStream_t st) {
-    if (g.tile == 192) apply_launch<T, 192>(0, g, Phi, Bm, V, vpart, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, st);
-    else apply_launch<T, 128>(0, g, Phi, Bm, V, vpart, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, st);
+    apply_launch<T, 0>(g, Phi, Bm, V, vpart, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, st);
 }
 template <typename T>
 int SweepKernels<T>::apply_phibar(const Geom& g, const T* Phi, const T* Abar, T* V, const double* p, const double* q,
                                   const double* y, const double* alpha, const double* ut, double* bpart, hipStream_t st) {
-    if (g.tile == 192) return apply_launch<T, 192>(1, g, Phi, Abar, V, nullptr, p, q, y, alpha, ut, bpart, st);
-    return apply_launch<T, 128>(1, g, Phi, Abar, V, nullptr, p, q, y, alpha, ut, bpart, st);
+    return apply_launch<T, 1>(g, Phi, Abar, V, nullptr, p, q, y, alpha, ut, bpart, st);
 }
 // number of column tiles of the apply kernel (vpart leading count)
-template <typename T> static int apply_njt(const Geom& g) { return g.tile == 192 ? apply_ntiles<T, 192>(g) : apply_ntiles<T, 128>(g); }
+template <typename T> static int apply_njt(const Geom& g) { return ApplyPlan<T>(g.K).total; }
 template <typename T>
 int SweepKernels<T>::apply_blocks(const Geom& g) {
-    return (int)(apply_njt<T>(g) * (g.Np / ApplyCfg<T, 128>::type::BM));
+    return (int)(apply_njt<T>(g) * (g.Np / Tune<T>::APPLY_BM));
 }
 
 

@@ -84,8 +84,8 @@ struct NatLoader {
     // that advances by BK rows per call, so the loop carries no 64-bit multiplies.
     const S* ptr[NV]; const double* wptr[NV]; int64_t step; int xlim;     // xlim: first invalid x (GUARD)
     int xplain = -1;                                          // WEIGHT: this x is stored unweighted
-    vec_t r[1][NV]; T wr[1][NV];
-    int tid;
+    vec_t r[1][NV]; double wr[1][NV];                         // weights stay raw until store(): converting in
+    int tid;                                                  // load() would wait on the fetch before the MFMAs
     __device__ __forceinline__ NatLoader(const S* b, int64_t l, int t, const double* w_ = nullptr, int xl = 0)
         : step((int64_t)BK * l), xlim(xl), tid(t) {
 #pragma unroll
@@ -108,7 +108,7 @@ struct NatLoader {
             for (int e = 0; e < VS; ++e) val[e] = 0;
             if (ok && (!GUARD || xv * VS < xlim)) val = *reinterpret_cast<const vec_t*>(ptr[i]);
             r[SET][i] = val;
-            if (WEIGHT) { wr[SET][i] = ok ? (T)*wptr[i] : (T)0; wptr[i] += BK; }
+            if (WEIGHT) { wr[SET][i] = ok ? *wptr[i] : 0.0; wptr[i] += BK; }
             ptr[i] += step;
         }
     }
@@ -122,12 +122,13 @@ struct NatLoader {
             T* d = s + k * LD + xv * VS;
             constexpr int TV = 16 / (int)sizeof(T) < VS ? 16 / (int)sizeof(T) : VS;   // elements per LDS store
             typedef T tv_t __attribute__((ext_vector_type(TV)));
+            const T wt = WEIGHT ? (T)wr[SET][i] : (T)1;
 #pragma unroll
             for (int e0 = 0; e0 < VS; e0 += TV) {
                 tv_t o;
 #pragma unroll
                 for (int e = 0; e < TV; ++e)
-                    o[e] = (WEIGHT && xv * VS + e0 + e != xplain) ? (T)r[SET][i][e0 + e] * wr[SET][i] : (T)r[SET][i][e0 + e];
+                    o[e] = (WEIGHT && xv * VS + e0 + e != xplain) ? (T)r[SET][i][e0 + e] * wt : (T)r[SET][i][e0 + e];
                 *reinterpret_cast<tv_t*>(d + e0) = o;
             }
         }
@@ -190,12 +191,12 @@ struct ZbarLoader {
     static constexpr int VPR = BX / VS;
     static constexpr int NV = (BK * VPR + THREADS - 1) / THREADS;
     const S* phi; const S* pb; int64_t ld; int J, j0, tid; bool vec; int kt = 0;   // consecutive k-tiles
-    T r[1][NV][VS];
+    typedef typename Vec16<S>::type vec_t;
+    vec_t raw[NV][4];                                         // fc, fs, bc, bs: combined in store(), after the MFMAs
     __device__ __forceinline__ ZbarLoader(const S* phi_, const S* pb_, int64_t ld_, int J_, int j0_, int t)
         : phi(phi_), pb(pb_), ld(ld_), J(J_), j0(j0_), tid(t), vec(J_ % VS == 0) {}
     template <int SET = 0>
     __device__ __forceinline__ void load(int) {
-        typedef typename Vec16<S>::type vec_t;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int v = tid + i * THREADS;
@@ -204,14 +205,15 @@ struct ZbarLoader {
             const S* f = phi + (int64_t)(kt * BK + k) * ld;
             const S* b = pb + (int64_t)(kt * BK + k) * ld;
             if (ok && vec && j + VS <= J) {
-                const vec_t fc = *reinterpret_cast<const vec_t*>(f + j), fs = *reinterpret_cast<const vec_t*>(f + J + j);
-                const vec_t bc = *reinterpret_cast<const vec_t*>(b + j), bs = *reinterpret_cast<const vec_t*>(b + J + j);
-#pragma unroll
-                for (int e = 0; e < VS; ++e) r[0][i][e] = (T)fc[e] * (T)bs[e] - (T)fs[e] * (T)bc[e];
+                raw[i][0] = *reinterpret_cast<const vec_t*>(f + j); raw[i][1] = *reinterpret_cast<const vec_t*>(f + J + j);
+                raw[i][2] = *reinterpret_cast<const vec_t*>(b + j); raw[i][3] = *reinterpret_cast<const vec_t*>(b + J + j);
             } else {
 #pragma unroll
-                for (int e = 0; e < VS; ++e)
-                    r[0][i][e] = (ok && j + e < J) ? (T)f[j + e] * (T)b[J + j + e] - (T)f[J + j + e] * (T)b[j + e] : (T)0;
+                for (int e = 0; e < VS; ++e) {
+                    const bool in = ok && j + e < J;
+                    raw[i][0][e] = in ? f[j + e] : (S)0; raw[i][1][e] = in ? f[J + j + e] : (S)0;
+                    raw[i][2][e] = in ? b[j + e] : (S)0; raw[i][3][e] = in ? b[J + j + e] : (S)0;
+                }
             }
         }
         ++kt;
@@ -224,7 +226,7 @@ struct ZbarLoader {
             if ((BK * VPR) % THREADS != 0 && v >= BK * VPR) continue;
             T* d = s + (v / VPR) * LD + (v % VPR) * VS;
 #pragma unroll
-            for (int e = 0; e < VS; ++e) d[e] = r[0][i][e];
+            for (int e = 0; e < VS; ++e) d[e] = (T)raw[i][0][e] * (T)raw[i][3][e] - (T)raw[i][1][e] * (T)raw[i][2][e];
         }
     }
 };
