@@ -87,7 +87,8 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', 0)) % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     allreduce = None
-    if world > 1:
+    use_dist = world > 1 or 'TORCHELASTIC_RUN_ID' in os.environ     # under torchrun even one rank goes through RCCL
+    if use_dist:
         import torch.distributed as dist
         if a.backend == 'nccl':
             dist.init_process_group('nccl', device_id=torch.device('cuda', local))
@@ -105,7 +106,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -122,7 +123,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], device='cuda' if a.backend == 'nccl' else 'cpu')
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
@@ -161,7 +162,7 @@ def main():
         if not a.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(X, y, params, S, M, N, a.cpu_rows)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     eng.close()
