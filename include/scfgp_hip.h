@@ -100,6 +100,14 @@ int scfgp_set_x_scaler(scfgp_ctx* ctx, int mode, const double* min, const double
                        const double* mu, const double* std);
 int scfgp_predict_raw(scfgp_ctx* ctx, const double* Xs_raw, int64_t T, const double* alpha, const double* Li,
                       double* mu, double* std);
+/* The rest of SCFGP.predict on the device (SCFGP/SCFGP.py:281-293, SCFGP/Scaler.py:118-135): with the
+ * fitted single-column y scaler registered (same mode numbers), scfgp_predict_y returns
+ * mu_y = backward(mu_f) and std_y = (backward(mu_f + std_f) - backward(mu_f - std_f)) / 2 (T doubles each)
+ * and, when raw targets ys (T) are given, metrics[6] = MAE, NMAE, MSE, NMSE, MNLP, SCORE.  The X scaler
+ * registered with scfgp_set_x_scaler (or none) is applied to Xs_raw as in scfgp_predict_raw. */
+int scfgp_set_y_scaler(scfgp_ctx* ctx, int mode, double min, double max, double boxcox, double mu, double std);
+int scfgp_predict_y(scfgp_ctx* ctx, const double* Xs_raw, int64_t T, const double* alpha, const double* Li,
+                    const double* ys, double* mu_y, double* std_y, double* metrics);
 
 /* ---- staged evaluation for row-sharded data parallelism ---------------------------------
  * The objective needs three row sweeps separated by two K x K stages; with rows sharded

@@ -32,6 +32,9 @@ SIGNATURES = {
     'scfgp_predict': (C.c_int, [C.c_void_p, _c_double_p, C.c_int64, _c_double_p, _c_double_p, _c_double_p, _c_double_p]),
     'scfgp_set_x_scaler': (C.c_int, [C.c_void_p, C.c_int, _c_double_p, _c_double_p, _c_double_p, _c_double_p, _c_double_p]),
     'scfgp_predict_raw': (C.c_int, [C.c_void_p, _c_double_p, C.c_int64, _c_double_p, _c_double_p, _c_double_p, _c_double_p]),
+    'scfgp_set_y_scaler': (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double]),
+    'scfgp_predict_y': (C.c_int, [C.c_void_p, _c_double_p, C.c_int64, _c_double_p, _c_double_p, _c_double_p, _c_double_p, _c_double_p,
+                                  _c_double_p]),
     'scfgp_pass1': (C.c_int, [C.c_void_p]),
     'scfgp_factor': (C.c_int, [C.c_void_p]),
     'scfgp_pass2': (C.c_int, [C.c_void_p, C.c_int]),

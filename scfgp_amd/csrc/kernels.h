@@ -72,6 +72,17 @@ void pack_data(const Geom& g, const double* Xraw, const double* yraw, const int6
 // square K x K host-layout matrix (ld K) -> Kp x Kp with identity padding, and back
 void pad_square(const double* src, int K, int Kp, double* dst, hipStream_t st);
 
+// ---- prediction post-processing (SCFGP/SCFGP.py:281-293, SCFGP/Scaler.py:118-135) -------------
+constexpr int YPOST_BLOCKS = 64;
+// out[0] = mean(ys)
+void ypost_mean(const double* ys, int64_t n, double* out, hipStream_t st);
+// mu, sd (n) <- y-scaler backward transform of the mean and half the transformed +-1 std band, in place;
+// ys != NULL: part[YPOST_BLOCKS][4] = block partials of the metric sums of this chunk
+void ypost_chunk(double* mu, double* sd, const double* ys, int64_t n, int mode, const double* sp, const double* ymean,
+                 double* part, hipStream_t st);
+// out[6] = MAE, NMAE, MSE, NMSE, MNLP, SCORE from nparts x 4 partial sums over n targets
+void ypost_metrics(const double* part, int nparts, int64_t n, double* out, hipStream_t st);
+
 // ---- on-device update rules (SCFGP/Optimizer.py) --------------------------------------------
 struct OptHyper { double lr, b1, b2, eps, momentum; };   // b1 doubles as rho for rmsprop/adadelta; momentum < 0: no Nesterov
 // theta <- rule(theta, grad); st = [s1 | s2 | velocity]; tctr[0] = step counter, tctr[1] = index into hist

@@ -224,3 +224,122 @@ void opt_update(int algo, const OptHyper& h, int P, double* theta, const double*
     hipLaunchKernelGGL(opt_update_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, algo, h, P, theta, grad, st, tctr);
     hipLaunchKernelGGL(opt_tick_kernel, dim3(1), dim3(64), 0, stream, tctr, scalars, hist, hist_cap);
 }
+
+// ----------------------------------------------------------------------------------------------
+// Prediction post-processing (SCFGP/SCFGP.py:281-293, SCFGP/Scaler.py:118-135): y-scaler backward
+// transform of mu and of the mu +- std bounds, and the six validation metrics, so that predict on a
+// large test set returns from the GPU with nothing left to do on the host.
+// ----------------------------------------------------------------------------------------------
+// inverse normal CDF, Wichura's algorithm AS 241 (PPND16, relative accuracy ~1e-16); scipy's
+// norm.ppf conventions at the ends: ppf(0) = -inf, ppf(1) = +inf, NaN outside [0, 1]
+__device__ double norm_ppf(double p) {
+    if (!(p >= 0.0 && p <= 1.0)) return __builtin_nan("");
+    if (p == 0.0) return -__builtin_inf();
+    if (p == 1.0) return __builtin_inf();
+    const double q = p - 0.5;
+    if (fabs(q) <= 0.425) {
+        const double r = 0.180625 - q * q;
+        const double num = (((((((2.5090809287301226727e3 * r + 3.3430575583588128105e4) * r + 6.7265770927008700853e4) * r
+                                + 4.5921953931549871457e4) * r + 1.3731693765509461125e4) * r + 1.9715909503065514427e3) * r
+                             + 1.3314166789178437745e2) * r + 3.3871328727963666080e0);
+        const double den = (((((((5.2264952788528545610e3 * r + 2.8729085735721942674e4) * r + 3.9307895800092710610e4) * r
+                                + 2.1213794301586595867e4) * r + 5.3941960214247511077e3) * r + 6.8718700749205790830e2) * r
+                             + 4.2313330701600911252e1) * r + 1.0);
+        return q * num / den;
+    }
+    double r = sqrt(-log(q < 0 ? p : 1.0 - p));
+    double v;
+    if (r <= 5.0) {
+        r -= 1.6;
+        const double num = (((((((7.74545014278341407640e-4 * r + 2.27238449892691845833e-2) * r + 2.41780725177450611770e-1) * r
+                                + 1.27045825245236838258e0) * r + 3.64784832476320460504e0) * r + 5.76949722146069140550e0) * r
+                             + 4.63033784615654529590e0) * r + 1.42343711074968357734e0);
+        const double den = (((((((1.05075007164441684324e-9 * r + 5.47593808499534494600e-4) * r + 1.51986665636164571966e-2) * r
+                                + 1.48103976427480074590e-1) * r + 6.89767334985100004550e-1) * r + 1.67638483018380384940e0) * r
+                             + 2.05319162663775882187e0) * r + 1.0);
+        v = num / den;
+    } else {
+        r -= 5.0;
+        const double num = (((((((2.01033439929228813265e-7 * r + 2.71155556874348757815e-5) * r + 1.24266094738807843860e-3) * r
+                                + 2.65321895265761230930e-2) * r + 2.96560571828504891230e-1) * r + 1.78482653991729133580e0) * r
+                             + 5.46378491116411436990e0) * r + 6.65790464350110377720e0);
+        const double den = (((((((2.04426310338993978564e-15 * r + 1.42151175831644588870e-7) * r + 1.84631831751005468180e-5) * r
+                                + 7.86869131145613259100e-4) * r + 1.48753612908506148525e-2) * r + 1.36929880922735805310e-1) * r
+                             + 5.99832206555887937690e-1) * r + 1.0);
+        v = num / den;
+    }
+    return q < 0 ? -v : v;
+}
+// Scaler.backward_transform for one column; sp = [min, max, boxcox, mu, std]; modes as scale_x.
+// Mode 3 is the reference's expression (ppf(x) - mu) / std, which is not the inverse of its forward map.
+__device__ __forceinline__ double y_backward(double x, int mode, const double* __restrict__ sp) {
+    const double mn = sp[0], mx = sp[1], lm = sp[2], mu = sp[3], sd = sp[4];
+    if (mode == 0) return x;
+    if (mode == 1) return x * (mx - mn) + mn;
+    if (mode == 2) return x * sd + mu;
+    if (mode == 3) return (norm_ppf(x) - mu) / sd;
+    const double t = mode == 4 ? x * sd + mu : norm_ppf(x) * sd + mu;
+    const double u = t * lm + 1.0;
+    const double ib = (u < 0 ? -1.0 : (u > 0 ? 1.0 : 0.0)) * pow(fabs(u), 1.0 / lm);
+    return ib * (mx - mn) + mn;
+}
+__global__ __launch_bounds__(1024) void ymean_kernel(const double* __restrict__ ys, int64_t n, double* __restrict__ out) {
+    __shared__ double red[1024];
+    double s = 0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) s += ys[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 512; w >= 1; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0] / (double)n;
+}
+// in place: mu <- mu_y, sd <- std_y = (back(mu+sd) - back(mu-sd)) / 2; with targets, block partials of
+// [sum |e|, sum e^2, sum (e/std_y)^2 + log(2 pi std_y^2), sum (ys - mean)^2]
+__global__ __launch_bounds__(256) void ypost_kernel(double* __restrict__ mu, double* __restrict__ sd, const double* __restrict__ ys,
+                                                    int64_t n, int mode, const double* __restrict__ sp,
+                                                    const double* __restrict__ ymean, double* __restrict__ part) {
+    __shared__ double red[4][256];
+    double acc[4] = {0, 0, 0, 0};
+    const double ym = ys ? ymean[0] : 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const double m = mu[i], s = sd[i];
+        const double my = y_backward(m, mode, sp);
+        const double sy = 0.5 * (y_backward(m + s, mode, sp) - y_backward(m - s, mode, sp));
+        mu[i] = my; sd[i] = sy;
+        if (ys) {
+            const double e = my - ys[i], z = e / sy, c = ys[i] - ym;
+            acc[0] += fabs(e); acc[1] += e * e; acc[2] += z * z + log(2.0 * M_PI * sy * sy); acc[3] += c * c;
+        }
+    }
+    if (!ys) return;
+    for (int k = 0; k < 4; ++k) red[k][threadIdx.x] = acc[k];
+    __syncthreads();
+    for (int w = 128; w >= 1; w >>= 1) {
+        if ((int)threadIdx.x < w)
+            for (int k = 0; k < 4; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x < 4) part[blockIdx.x * 4 + threadIdx.x] = red[threadIdx.x][0];
+}
+// out = [MAE, NMAE, MSE, NMSE, MNLP, SCORE]                      (SCFGP/SCFGP.py:286-293)
+__global__ void ymetrics_kernel(const double* __restrict__ part, int nparts, int64_t n, double* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double s[4] = {0, 0, 0, 0};
+    for (int b = 0; b < nparts; ++b)
+        for (int k = 0; k < 4; ++k) s[k] += part[b * 4 + k];
+    const double mae = s[0] / n, mse = s[1] / n, mnlp = 0.5 * s[2] / n, var = s[3] / n;
+    const double nmse = mse / var;
+    out[0] = mae; out[1] = mae / sqrt(var); out[2] = mse; out[3] = nmse; out[4] = mnlp; out[5] = nmse / (1.0 + exp(-mnlp));
+}
+void ypost_mean(const double* ys, int64_t n, double* out, hipStream_t st) {
+    hipLaunchKernelGGL(ymean_kernel, dim3(1), dim3(1024), 0, st, ys, n, out);
+}
+void ypost_chunk(double* mu, double* sd, const double* ys, int64_t n, int mode, const double* sp, const double* ymean,
+                 double* part, hipStream_t st) {
+    hipLaunchKernelGGL(ypost_kernel, dim3(YPOST_BLOCKS), dim3(256), 0, st, mu, sd, ys, n, mode, sp, ymean, part);
+}
+void ypost_metrics(const double* part, int nparts, int64_t n, double* out, hipStream_t st) {
+    hipLaunchKernelGGL(ymetrics_kernel, dim3(1), dim3(64), 0, st, part, nparts, n, out);
+}

@@ -56,6 +56,7 @@ struct scfgp_ctx {
     double *d_partial = nullptr; int64_t n_partial = 0;
     double *d_work = nullptr, *d_grad = nullptr;
     int xs_mode = 0; double* d_xscale = nullptr;                 // X scaler for scfgp_predict_raw (5*D doubles)
+    int ys_mode = 0; double* d_yscale = nullptr;                 // y scaler for scfgp_predict_y (5 doubles)
     // predict chunk buffers
     double *p_Xt = nullptr, *p_vpart = nullptr, *p_mu = nullptr, *p_sd = nullptr; void *p_Phi = nullptr, *p_V = nullptr;
     // on-device optimiser + captured training iteration
@@ -227,7 +228,7 @@ extern "C" void scfgp_destroy(scfgp_ctx* c) {
     hipSetDevice(c->device);
     if (c->st) hipStreamSynchronize(c->st);
     free_rows(c);
-    dfree(c->d_Xraw); dfree(c->d_yraw); dfree(c->d_idx); dfree(c->d_xscale);
+    dfree(c->d_Xraw); dfree(c->d_yraw); dfree(c->d_idx); dfree(c->d_xscale); dfree(c->d_yscale);
     dfree(c->d_params); dfree(c->d_F); dfree(c->d_Fall); dfree(c->d_sc);
     dfree(c->d_xp1); dfree(c->d_xp2); dfree(c->d_x1); dfree(c->d_x2); dfree(c->d_x3); dfree(c->d_Li); dfree(c->d_B); dfree(c->d_T1); dfree(c->d_T2);
     dfree(c->d_Abar); dfree(c->d_BT); dfree(c->d_AbarT); dfree(c->d_vecs); dfree(c->d_scalars); dfree(c->d_yy);
@@ -523,8 +524,11 @@ extern "C" int scfgp_eval_rows(scfgp_ctx* c, const int64_t* idx, int64_t n, int 
     return run_eval(c, want_grad, cost, grad, alpha, Li);
 }
 
+// raw_mode: apply the registered X scaler while packing; post: y-scaler backward transform of the outputs on
+// the device and, with targets ys, the six validation metrics
 static int predict_impl(scfgp_ctx* c, const double* Xs, int64_t T, const double* alpha, const double* Li,
-                        double* mu, double* sd, int raw_mode) {
+                        double* mu, double* sd, int raw_mode, int post = 0, const double* ys = nullptr,
+                        double* metrics = nullptr) {
     if (!c || !Xs || !alpha || !Li || !mu || !sd || T < 1) { if (c) c->err = "predict: bad arguments"; return SCFGP_EARG; }
     if (!c->have_params) { c->err = "predict: parameters not set"; return SCFGP_EARG; }
     HIPCHK(c, hipSetDevice(c->device));
@@ -555,18 +559,35 @@ static int predict_impl(scfgp_ctx* c, const double* Xs, int64_t T, const double*
     if (c->dtype == SCFGP_F32) SweepKernels<float>::convert(c->d_T2, (float*)c->d_AbarT, g0.K, g0.Kp, c->st);
     else SweepKernels<double>::convert(c->d_T2, (double*)c->d_AbarT, g0.K, g0.Kp, c->st);
     HIPCHK(c, hipStreamSynchronize(c->st));                     // raw is reused below
+    const int nchunks = (int)((T + PRED_ROWS - 1) / PRED_ROWS);
+    double *d_ys = nullptr, *d_part = nullptr;                   // targets | [mean, metrics(6)] | chunk partials
+    if (post && ys) {
+        if ((rc = dmalloc(c, &d_ys, sizeof(double) * (T + 8)))) { dfree(raw); return rc; }
+        if ((rc = dmalloc(c, &d_part, sizeof(double) * 4 * YPOST_BLOCKS * nchunks))) { dfree(raw); dfree(d_ys); return rc; }
+        hipMemcpyAsync(d_ys, ys, sizeof(double) * T, hipMemcpyHostToDevice, c->st);
+        ypost_mean(d_ys, T, d_ys + T, c->st);
+    }
+    auto cleanup = [&]() { dfree(raw); dfree(d_ys); dfree(d_part); };
     for (int64_t t0 = 0; t0 < T; t0 += PRED_ROWS) {
         Geom g = g0;
         g.N = std::min<int64_t>(PRED_ROWS, T - t0); g.Np = round_up(g.N, 256);
         HIPCHK(c, hipMemcpyAsync(raw, Xs + t0 * g.D, sizeof(double) * g.N * g.D, hipMemcpyHostToDevice, c->st));
         pack_data(g, raw, nullptr, nullptr, c->p_Xt, nullptr, c->st, raw_mode ? c->xs_mode : 0, c->d_xscale);
         rc = c->dtype == SCFGP_F32 ? Impl<float>::predict_chunk(c, g, (const float*)Bt) : Impl<double>::predict_chunk(c, g, (const double*)Bt);
-        if (rc) { dfree(raw); return rc; }
+        if (rc) { cleanup(); return rc; }
+        if (post)
+            ypost_chunk(c->p_mu, c->p_sd, d_ys ? d_ys + t0 : nullptr, g.N, c->ys_mode, c->d_yscale, d_ys ? d_ys + T : nullptr,
+                        d_part ? d_part + 4 * YPOST_BLOCKS * (t0 / PRED_ROWS) : nullptr, c->st);
         HIPCHK(c, hipMemcpyAsync(mu + t0, c->p_mu, sizeof(double) * g.N, hipMemcpyDeviceToHost, c->st));
         HIPCHK(c, hipMemcpyAsync(sd + t0, c->p_sd, sizeof(double) * g.N, hipMemcpyDeviceToHost, c->st));
         HIPCHK(c, hipStreamSynchronize(c->st));
     }
-    dfree(raw);
+    if (post && ys) {
+        ypost_metrics(d_part, YPOST_BLOCKS * nchunks, T, d_ys + T + 1, c->st);
+        hipMemcpyAsync(metrics, d_ys + T + 1, sizeof(double) * 6, hipMemcpyDeviceToHost, c->st);
+        hipStreamSynchronize(c->st);
+    }
+    cleanup();
     HIPCHK(c, hipGetLastError());
     return SCFGP_OK;
 }
@@ -596,6 +617,24 @@ extern "C" int scfgp_predict_raw(scfgp_ctx* c, const double* Xs, int64_t T, cons
                                  double* mu, double* sd) {
     if (c && c->xs_mode && !c->d_xscale) { c->err = "predict_raw: no scaler set"; return SCFGP_EARG; }
     return predict_impl(c, Xs, T, alpha, Li, mu, sd, 1);
+}
+
+// The rest of SCFGP.predict (SCFGP/SCFGP.py:281-293): y_scaler.backward_transform of mu and of the mu +- std
+// band, std_y = half the transformed band, and with targets the metrics MAE, NMAE, MSE, NMSE, MNLP, SCORE.
+extern "C" int scfgp_set_y_scaler(scfgp_ctx* c, int mode, double mn, double mx, double boxcox, double mu, double sd) {
+    if (!c || mode < 0 || mode > 5) return SCFGP_EARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    const double h[5] = {mn, mx, boxcox, mu, sd};
+    if (!c->d_yscale) { if (int rc = dmalloc(c, &c->d_yscale, sizeof(double) * 5)) return rc; }
+    HIPCHK(c, hipMemcpy(c->d_yscale, h, sizeof(h), hipMemcpyHostToDevice));
+    c->ys_mode = mode;
+    return SCFGP_OK;
+}
+extern "C" int scfgp_predict_y(scfgp_ctx* c, const double* Xs, int64_t T, const double* alpha, const double* Li,
+                               const double* ys, double* mu_y, double* std_y, double* metrics) {
+    if (c && ((c->xs_mode && !c->d_xscale) || !c->d_yscale)) { c->err = "predict_y: scalers not set"; return SCFGP_EARG; }
+    if (c && ys && !metrics) { c->err = "predict_y: targets given without a metrics buffer"; return SCFGP_EARG; }
+    return predict_impl(c, Xs, T, alpha, Li, mu_y, std_y, 1, 1, ys, metrics);
 }
 
 // ----------------------------------------------------------------------------------------------

@@ -161,6 +161,37 @@ class HipEngine(object):
         self._check(self.lib.scfgp_predict_raw(self.ctx, dptr(Xs), T, dptr(alpha), dptr(Li), dptr(mu), dptr(sd)), 'predict_raw')
         return mu, sd
 
+    METRICS = ('MAE', 'NMAE', 'MSE', 'NMSE', 'MNLP', 'SCORE')
+
+    def set_y_scaler(self, scaler):
+        """Register the fitted single-column target scaler for predict_y."""
+        d = scaler.data
+        val = lambda k: float(np.asarray(d[k]).reshape(-1)[0]) if k in d and np.size(d[k]) else 0.0
+        if len(d['cols']) != 1:
+            raise ValueError('the y scaler must have exactly one column')
+        self._check(self.lib.scfgp_set_y_scaler(self.ctx, self.SCALER_MODES[scaler.algo],
+                                                *[val(k) for k in ('min', 'max', 'boxcox', 'mu', 'std')]), 'set_y_scaler')
+
+    def predict_y(self, Xs_raw, alpha, Li, ys=None):
+        """SCFGP.predict (SCFGP/SCFGP.py:278-294) entirely on the device: X scaling, pred_func, y-scaler backward
+        transform of the mean and of the +-1 std band and, with raw targets ys, the six metrics.
+        Returns mu_y (T,1), std_y (T,1), metrics dict or None."""
+        Xs = np.asarray(Xs_raw, dtype=np.float64)
+        if getattr(self, '_xcols', None) is not None:
+            Xs = Xs[:, self._xcols]
+        Xs = np.ascontiguousarray(Xs)
+        alpha = np.ascontiguousarray(alpha, dtype=np.float64).reshape(-1)
+        Li = np.ascontiguousarray(Li, dtype=np.float64)
+        T = Xs.shape[0]
+        mu = np.empty((T, 1)); sd = np.empty((T, 1)); met = np.empty(6)
+        if ys is not None:
+            ys = np.ascontiguousarray(ys, dtype=np.float64).reshape(-1)
+            if ys.size != T:
+                raise ValueError('ys has %d entries for %d test rows' % (ys.size, T))
+        self._check(self.lib.scfgp_predict_y(self.ctx, dptr(Xs), T, dptr(alpha), dptr(Li), dptr(ys), dptr(mu), dptr(sd),
+                                             dptr(met) if ys is not None else None), 'predict_y')
+        return mu, sd, (dict(zip(self.METRICS, met.tolist())) if ys is not None else None)
+
     # -- staged evaluation (row-sharded data parallelism) --------------------------------------
     def pass1(self):
         self._check(self.lib.scfgp_pass1(self.ctx), 'pass1')

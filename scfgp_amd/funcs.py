@@ -148,6 +148,17 @@ class CompiledFuncs(object):
             self._scaler_id = x_scaler
         return self.engine.predict_raw(Xs_raw, alpha, Li)
 
+    def pred_y(self, Xs_raw, x_scaler, y_scaler, alpha, Li, ys=None):
+        """All of SCFGP.predict on the GPU: mu_y, std_y (T,1) and the metric dict (None without targets)."""
+        self._sync_params()
+        if getattr(self, '_scaler_id', None) is not x_scaler:
+            self.engine.set_x_scaler(x_scaler)
+            self._scaler_id = x_scaler
+        if getattr(self, '_yscaler_id', None) is not y_scaler:
+            self.engine.set_y_scaler(y_scaler)
+            self._yscaler_id = y_scaler
+        return self.engine.predict_y(Xs_raw, alpha, Li, ys)
+
     def value_and_grad(self, X, y):
         """cost, grad, alpha, Li at the current parameters without touching them."""
         return self._evaluate(X, y, True)

@@ -230,7 +230,12 @@ class SCFGP(object):
         """SCFGP/SCFGP.py:278-294."""
         owner = getattr(self.pred_func, '__self__', None)
         if self.device_scaler and isinstance(owner, CompiledFuncs):
-            mu_f, std_f = owner.pred_raw(Xs, self.X_scaler, self.alpha, self.Li)
+            # scaling, pred_func, back-transform and metrics in one device call (SURVEY 8(f) rank 4)
+            mu_y, std_y, met = owner.pred_y(Xs, self.X_scaler, self.y_scaler, self.alpha, self.Li, ys)
+            if met is not None:
+                for k in met:
+                    self.evals[k][1].append(met[k])
+            return mu_y, std_y
         else:
             self.Xs = np.ascontiguousarray(self.X_scaler.forward_transform(Xs), dtype=np.float64)
             mu_f, std_f = self.pred_func(self.Xs, self.alpha, self.Li)

@@ -315,9 +315,13 @@ def test_facade_fit_predict_save_load(tmp_path):
     mu, sd = model.predict(X[240:])
     assert mu.shape == (60, 1) and sd.shape == (60, 1) and np.all(sd > 0)
     assert model.evals['NMSE'][1][-1] < 0.5
-    model.device_scaler = True                                # same prediction with the X scaler on the GPU
-    mu_d, sd_d = model.predict(X[240:])
+    model.predict(X[240:], y[240:])
+    host_metrics = {k: model.evals[k][1][-1] for k in ('MAE', 'NMAE', 'MSE', 'NMSE', 'MNLP', 'SCORE')}
+    model.device_scaler = True                                # same prediction, scalers and metrics on the GPU
+    mu_d, sd_d = model.predict(X[240:], y[240:])
     assert np.allclose(mu_d, mu, rtol=1e-9) and np.allclose(sd_d, sd, rtol=1e-9)
+    for k, v in host_metrics.items():
+        assert abs(model.evals[k][1][-1] - v) <= 1e-9 * max(1.0, abs(v)), k
     model.device_scaler = False
     path = os.path.join(str(tmp_path), 'm.npz')
     model.save(path)
@@ -460,4 +464,49 @@ def test_predict_raw_applies_the_x_scaler_on_the_device(algo):
     mu_r, sd_r = eng.predict_raw(Xs_raw, alpha, Li)
     mu_h, sd_h = eng.predict(np.ascontiguousarray(sc.forward_transform(Xs_raw)), alpha, Li)
     assert rel(mu_r, mu_h) < 1e-11 and rel(sd_r, sd_h) < 1e-11
+    eng.close()
+
+
+@pytest.mark.parametrize('xalgo,yalgo,T', [('auto-inv-normal', 'auto-normal', 333), ('min-max', 'min-max', 500),
+                                           ('normal', 'normal', 40000), ('inv-normal', 'inv-normal', 257),
+                                           ('auto-normal', 'auto-inv-normal', 1000)])
+def test_predict_y_back_transform_and_metrics_on_the_device(xalgo, yalgo, T):
+    """scfgp_predict_y == the host tail of SCFGP.predict (SCFGP.py:281-293): y_scaler.backward_transform of mu and of the
+    mu +- std band, std_y, and the six metrics -- for every scaler mode, one and several predict chunks."""
+    from scfgp_amd.engine import HipEngine
+    from scfgp_amd.scaler import Scaler
+    rng = np.random.default_rng(21)
+    n, D, S, M = 400, 4, 3, 10
+    Xraw = np.exp(0.5 * rng.standard_normal((n, D)))
+    yraw = np.exp(0.3 * np.sin(Xraw[:, :1]) + 0.1 * rng.standard_normal((n, 1)))
+    xs, ys_ = Scaler(xalgo), Scaler(yalgo)
+    xs.fit(Xraw); ys_.fit(yraw)
+    Xt = np.ascontiguousarray(xs.forward_transform(Xraw)); yt = np.ascontiguousarray(ys_.forward_transform(yraw))
+    params = O.init_params(D, S, M, rng); params[:3] = (-1.0, 0.0, -1.5)
+    eng = HipEngine(D, S, M); eng.set_params(params); eng.set_data(Xt, yt)
+    _, _, alpha, Li = eng.eval(want_grad=True)
+    Xs_raw = np.exp(0.5 * rng.standard_normal((T, D)))
+    ys_raw = np.exp(0.3 * np.sin(Xs_raw[:, :1]) + 0.1 * rng.standard_normal((T, 1)))
+    eng.set_x_scaler(xs); eng.set_y_scaler(ys_)
+    mu_y, sd_y, met = eng.predict_y(Xs_raw, alpha, Li, ys_raw)
+    # host tail, as model.predict writes it
+    mu_f, sd_f = eng.predict(np.ascontiguousarray(xs.forward_transform(Xs_raw)), alpha, Li)
+    with np.errstate(all='ignore'):
+        mu_h = ys_.backward_transform(mu_f)
+        sd_h = 0.5 * (ys_.backward_transform(mu_f + sd_f[:, None]) - ys_.backward_transform(mu_f - sd_f[:, None]))
+        err = mu_h - ys_raw
+        mae, mse = np.mean(np.abs(err)), np.mean(err ** 2.)
+        mnlp = 0.5 * np.mean((err / sd_h) ** 2 + np.log(2 * np.pi * sd_h ** 2))
+        nmse = mse / np.var(ys_raw)
+        ref = dict(MAE=mae, NMAE=mae / np.std(ys_raw), MSE=mse, NMSE=nmse, MNLP=mnlp, SCORE=nmse / (1 + np.exp(-mnlp)))
+    assert mu_y.shape == (T, 1) and sd_y.shape == (T, 1)
+    assert np.array_equal(np.isnan(mu_y), np.isnan(mu_h)) and np.array_equal(np.isnan(sd_y), np.isnan(sd_h))
+    ok = ~(np.isnan(mu_h) | np.isnan(sd_h))
+    assert ok.mean() > 0.1                                   # inv-normal targets: mu +- std outside (0, 1) is NaN on both sides
+    assert np.allclose(mu_y[ok], mu_h[ok], rtol=1e-9, atol=1e-12) and np.allclose(sd_y[ok], sd_h[ok], rtol=1e-8, atol=1e-12)
+    for k in ref:
+        assert (np.isnan(ref[k]) and np.isnan(met[k])) or abs(met[k] - ref[k]) <= 1e-8 * max(1.0, abs(ref[k])), (k, met[k], ref[k])
+    # without targets: same moments, no metrics
+    mu2, sd2, met2 = eng.predict_y(Xs_raw, alpha, Li)
+    assert met2 is None and np.array_equal(mu2, mu_y, equal_nan=True) and np.array_equal(sd2, sd_y, equal_nan=True)
     eng.close()
