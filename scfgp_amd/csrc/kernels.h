@@ -8,8 +8,10 @@ struct Geom {
     int D, S, M, J, K, P;
     int Dp;      // round_up(D+1,16): X~ = [X | 1 | 0..]   (ones column carries the phase offsets)
     int Jp;      // round_up(J,128)
-    int Kp;      // round_up(K+2,tile): columns K and K+1 of Phi hold y and p (augmented Gram)
-    int tile;    // 128 or 192: column tile of the Gram / apply kernels, chosen to minimise Kp
+    int Kp;      // round_up(K,tile): leading dimension of Phi and of every K x K matrix
+    int tile;    // 128: square tile of the Gram products and of the packed exchange layout
+    int gfull;   // Gram tile grid: gfull rows of square tiles ...
+    int gstrip;  // ... plus, for an odd number of 64-column blocks in K, one 64-high strip below them
     int64_t N;   // valid local rows
     int64_t Np;  // round_up(N,256)
 };
@@ -18,7 +20,9 @@ template <typename T> struct SweepKernels {
     // Phi = s*[cos Z, sin Z], Z = X~ . Fall                      (SCFGP.py:98-102 / :139-142)
     static void featuremap(const Geom& g, const double* Xt, const double* Fall, const Scal* sc, T* Phi, hipStream_t st);
     // lower tiles of  Phi^T diag(w) Phi  into per-split fp64 slabs (SCFGP.py:104; weighted: backward of :111-113)
-    static void gram(const Geom& g, const T* Phi, const double* w, int nsplit, int64_t chunk, double* slabs, hipStream_t st);
+    // and, from the diagonal tiles, sidepart[split][Kp] = partials of Phi^T side (side = y: SCFGP.py:108)
+    static void gram(const Geom& g, const T* Phi, const double* w, const double* side, int nsplit, int64_t chunk, double* slabs,
+                     double* sidepart, hipStream_t st);
     // V = Phi . Bm, vpart[jt][n] = sum_{j in tile} Phi[n][j] V[n][j]    (SCFGP.py:112)
     static void apply_v(const Geom& g, const T* Phi, const T* Bm, T* V, double* vpart, hipStream_t st);
     // Phibar = 2 Phi.Abar + 2 q V + p alpha^T + y ut^T  (in place over V); bpart[block] = partial of
@@ -27,7 +31,7 @@ template <typename T> struct SweepKernels {
                             const double* y, const double* alpha, const double* ut, double* bpart, hipStream_t st);
     static int apply_blocks(const Geom& g);
     // per-row moments and adjoint scalars; block partials of (T2, kbar)  (SCFGP.py:111-113,121-124)
-    static void rowstats(const Geom& g, T* Phi, const double* alpha, const double* vpart, const double* y,
+    static void rowstats(const Geom& g, const T* Phi, const double* alpha, const double* vpart, const double* y,
                          const Scal* sc, double* p, double* q, double* partial, int nblocks, hipStream_t st);
     // predictive mean / std                                          (SCFGP.py:143-144)
     static void rowpredict(const Geom& g, const T* Phi, const double* alpha, const double* vpart, const Scal* sc,
@@ -38,8 +42,6 @@ template <typename T> struct SweepKernels {
                     hipStream_t st);
     // fp64 Kp x Kp matrix -> sweep operand (type T, rows/cols >= K zeroed)
     static void convert(const double* src, T* dst, int K, int Kp, hipStream_t st);
-    // Phi[:, col] = src  (augmented columns)
-    static void set_col(const Geom& g, T* Phi, int col, const double* src, hipStream_t st);
 };
 
 // ---- reductions ------------------------------------------------------------
@@ -49,8 +51,8 @@ void reduce_tri_tiles(const double* slabs, int nsplit, int nts, int tile, double
 void unpack_tri_tiles(const double* packed, int nts, int tile, double* full, int64_t ld, hipStream_t st);
 // out (ldo) = sum over splits of a full ntm x ntn tile grid of slabs
 void reduce_full_tiles(const double* slabs, int nsplit, int ntm, int ntn, double* out, int64_t ldo, hipStream_t st);
-// vec[j<K] = M[row][j], then zero rows/cols K, K+1 of the packed symmetric matrix (augmented Gram -> plain)
-void extract_aug(double* packed, int K, int Kp, int tile, int row, double* vec, hipStream_t st);
+// vec[j < ncov] = sum over splits of sidepart[split][j] (ld Kp), vec[ncov..Kp) = 0
+void reduce_side(const double* sidepart, int nsplit, int Kp, int ncov, double* vec, hipStream_t st);
 // out[i] = sum_s partial[s][i], i < n
 void reduce_rows(const double* partial, int nsplit, int64_t n, double* out, hipStream_t st);
 // scalars[slot0 + k] = sum_b partial[b*width + k], k < width

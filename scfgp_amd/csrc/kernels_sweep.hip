@@ -8,15 +8,13 @@
 // --------------------------------------------------------------------------
 // tile configurations (tuning knobs)
 // --------------------------------------------------------------------------
-// Gram: square TILE x TILE output tiles; apply: 128 rows x TILE columns.
-// TILE = 192 (3 x 64) fits K = 2112 / 4224 exactly; fp64 needs 8 waves there to stay in registers.
+// Gram: square 128 x 128 output tiles plus a 64 x 128 strip; apply: 256 rows x {128, 64} columns.
 // Measured on MI355X (N = 5e5..1e6, K = 2112; tests/gpu_tune.py, profiles/r01_tuning.md):
 //   * 8-wave workgroups (2 waves per SIMD inside one workgroup) beat 4-wave ones for both dtypes;
 //     fp64 apply gains again with 16 waves (4 per SIMD): the 64-cycle fp64 MFMA leaves room
 //     for every other wave's LDS / global traffic and the barrier bubbles overlap.
 //   * BK = 32 (fewer barriers, lower occupancy) and the 32x32x2 fp32 MFMA shape are slower.
-//   * TILE = 192 removes the padding of K = 2112 but its 96 x 96 wave tile costs occupancy;
-//     it only pays when it shrinks Kp by >= 8 % (see scfgp_create).
+//   * 192- and 256-wide tiles (96 x 96 / 128 x 64 wave tiles) cost occupancy or spill and are slower.
 #ifndef SCFGP_BK
 #define SCFGP_BK 16
 #endif
@@ -37,6 +35,10 @@ template <> struct Tune<double> {
 };
 template <typename T, int TILE> struct GramCfg {
     typedef TileCfg<T, TILE, TILE, SCFGP_BK, Tune<T>::GRAM_WGM, Tune<T>::GRAM_WGN, Tune<T>::MS> type;
+};
+// the 64-high strip below the square tiles: same workgroup size (one launch), 32 x 32 wave tiles
+template <typename T> struct GramStripCfg {
+    typedef TileCfg<T, 64, 128, SCFGP_BK, Tune<T>::GRAM_WGM / 2, Tune<T>::GRAM_WGN * 2, Tune<T>::MS> type;
 };
 template <typename T, int TILE> struct ApplyCfg {
     typedef TileCfg<T, Tune<T>::APPLY_BM, TILE, SCFGP_BK, Tune<T>::APPLY_WGM, Tune<T>::apply_wgn(TILE), Tune<T>::MS> type;
@@ -127,8 +129,8 @@ void SweepKernels<T>::featuremap(const Geom& g, const double* Xt, const double* 
 
 // --------------------------------------------------------------------------
 // TN products (contraction over rows), one workgroup per (output tile, row split):
-//   gram_kernel  lower tiles of  Phi~^T diag(w) Phi~   (Phi~ = [Phi | y | p]: the augmented
-//                columns K, K+1 make Phi^T y and Phi^T p fall out of the same MFMA stream)
+//   gram_kernel  lower tiles of  Phi^T diag(w) Phi; its diagonal tiles also form Phi^T y / Phi^T p in
+//                fp64 from the rows they stage anyway
 //   xtz_kernel   X~^T Zbar with Zbar formed on the fly (ZbarLoader)
 // fp32 accumulators are flushed into the workgroup's private fp64 slab every `chunk` rows
 // (one fp32 chain stays ~sqrt(chunk)*2^-24); fp64 runs one chunk.
@@ -149,39 +151,71 @@ __device__ __forceinline__ void slab_flush(const typename Cfg::MTr::acc_t (&acc)
         }
 }
 
-template <class Cfg, bool WEIGHT>
-__global__ __launch_bounds__(Cfg::THREADS) void gram_kernel(
-    const typename Cfg::T* __restrict__ Phi, int64_t ld, const double* __restrict__ w, int64_t Np, int64_t rows_per_split,
-    int64_t chunk, int nts, int xplain_col, double* __restrict__ slabs) {
+// Tile grid of the Gram products: `nfull` rows of square tiles (lower triangle) and, when the 64-column blocks of K
+// do not pair up, one 64-high STRIP of nfull+1 tiles (64 x 128) below them whose results occupy the upper halves of
+// the slabs of tile row nfull.  Diagonal tiles also produce the side vector sum_n s_n Phi[n][col] (s = y: Phi^T y,
+// s = p: Phi^T p) for their columns from the rows they stream anyway: sidepart[split][col].
+// One launch covers everything, longest jobs first (a workgroup lives for milliseconds, so the order in which the
+// hardware hands them out decides the tail): diagonal tiles, then off-diagonal tiles, then the half-size strip tiles.
+template <class Cfg, bool WEIGHT, bool STRIP>
+__device__ __forceinline__ void gram_body(
+    const typename Cfg::T* __restrict__ Phi, int64_t ld, const double* __restrict__ w, const double* __restrict__ side,
+    int64_t r0, int64_t r1, int64_t chunk, int acol, int bcol, bool diag, double* __restrict__ sideout,
+    double* __restrict__ slab, char* smem_raw) {
     typedef typename Cfg::T T;
-    SMEM_DECL;
     T* smem = reinterpret_cast<T*>(smem_raw);
-    const unsigned wid = xcd_remap(blockIdx.x, gridDim.x);
-    const int ntile = nts * (nts + 1) / 2;
-    const int t = (int)(wid % ntile), split = (int)(wid / ntile);
-    int ti = (int)((sqrtf(8.0f * t + 1.0f) - 1.0f) * 0.5f);
-    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-    while (ti * (ti + 1) / 2 > t) --ti;
-    const int tj = t - ti * (ti + 1) / 2;
-    const int64_t r0 = (int64_t)split * rows_per_split;
-    const int64_t r1 = r0 + rows_per_split < Np ? r0 + rows_per_split : Np;
-    double* slab = slabs + ((int64_t)split * ntile + t) * (Cfg::BM * Cfg::BN);
     typename Cfg::MTr::acc_t acc[Cfg::TM][Cfg::TN];
+    // consecutive chunks are consecutive k-tiles, so one pair of loaders walks the whole row range
+    NatLoader<T, T, Cfg::BM, Cfg::BK, Cfg::LDA, Cfg::THREADS, WEIGHT, false, true> la(
+        Phi + r0 * ld + acol, ld, threadIdx.x, WEIGHT ? w + r0 : nullptr, 0, diag ? side + r0 : nullptr);
+    NatLoader<T, T, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS, false, false> lb(Phi + r0 * ld + bcol, ld, threadIdx.x);
     bool first = true;
     for (int64_t c0 = r0; c0 < r1 || first; c0 += chunk) {
         const int64_t c1 = c0 + chunk < r1 ? c0 + chunk : r1;
         acc_zero<Cfg>(acc);
-        if (c0 < r1) {
-            NatLoader<T, T, Cfg::BM, Cfg::BK, Cfg::LDA, Cfg::THREADS, WEIGHT, false> la(
-                Phi + c0 * ld + (int64_t)ti * Cfg::BM, ld, threadIdx.x, WEIGHT ? w + c0 : nullptr);
-            la.xplain = xplain_col - ti * Cfg::BM;             // the p column enters the weighted Gram unweighted
-            NatLoader<T, T, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS, false, false> lb(
-                Phi + c0 * ld + (int64_t)tj * Cfg::BN, ld, threadIdx.x);
-            tile_mainloop<Cfg>(la, lb, (int)((c1 - c0) / Cfg::BK), acc, smem);
-        }
+        if (c0 < r1) tile_mainloop<Cfg>(la, lb, (int)((c1 - c0) / Cfg::BK), acc, smem);
         slab_flush<Cfg>(acc, slab, first);
         first = false;
     }
+    if (STRIP) {                                               // lower half of the 128 x 128 slab: rows the strip does not have
+        for (int e = threadIdx.x; e < (Cfg::BN - Cfg::BM) * Cfg::BN; e += Cfg::THREADS) slab[Cfg::BM * Cfg::BN + e] = 0.0;
+    }
+    if (diag) la.side_reduce(reinterpret_cast<double*>(smem_raw), sideout);
+}
+
+template <class Cfg, class SCfg, bool WEIGHT>
+__global__ __launch_bounds__(Cfg::THREADS) void gram_kernel(
+    const typename Cfg::T* __restrict__ Phi, int64_t ld, const double* __restrict__ w, const double* __restrict__ side,
+    int64_t Np, int64_t rows_per_split, int64_t chunk, int nfull, int nstrip, int nsplit, double* __restrict__ sidepart,
+    double* __restrict__ slabs) {
+    static_assert(Cfg::THREADS == SCfg::THREADS && Cfg::BN == SCfg::BN && Cfg::BM == Cfg::BN, "one launch, two tile shapes");
+    SMEM_DECL;
+    const int nall = nfull + nstrip, ntile_all = nall * (nall + 1) / 2;
+    const int ndiag = nfull * nsplit, noff = nfull * (nfull - 1) / 2 * nsplit;
+    int j = blockIdx.x, split, acol, bcol, slab_t; bool diag = false, strip = false;
+    if (j < ndiag) {                                           // diagonal tiles (they also carry the side vector)
+        const int ti = j % nfull; split = j / nfull;
+        acol = bcol = ti * Cfg::BM; slab_t = ti * (ti + 1) / 2 + ti; diag = side != nullptr;
+    } else if (j < ndiag + noff) {                             // strictly lower tiles: u = (ti-1) ti / 2 + tj
+        j -= ndiag;
+        const int cnt = nfull * (nfull - 1) / 2, u = j % cnt; split = j / cnt;
+        int tq = (int)((sqrtf(8.0f * u + 1.0f) - 1.0f) * 0.5f);
+        while ((tq + 1) * (tq + 2) / 2 <= u) ++tq;
+        while (tq * (tq + 1) / 2 > u) --tq;
+        const int ti = tq + 1, tj = u - tq * (tq + 1) / 2;
+        acol = ti * Cfg::BM; bcol = tj * Cfg::BN; slab_t = ti * (ti + 1) / 2 + tj;
+    } else {                                                   // strip tiles
+        j -= ndiag + noff;
+        const int tj = j % (nfull + 1); split = j / (nfull + 1);
+        acol = nfull * Cfg::BN; bcol = tj * Cfg::BN; slab_t = nfull * (nfull + 1) / 2 + tj;
+        strip = true; diag = side != nullptr && tj == nfull;
+    }
+    const int64_t r0 = (int64_t)split * rows_per_split;
+    const int64_t r1 = r0 + rows_per_split < Np ? r0 + rows_per_split : Np;
+    double* slab = slabs + ((int64_t)split * ntile_all + slab_t) * (Cfg::BN * Cfg::BN);
+    double* sideout = sidepart + (int64_t)split * ld + acol;
+    if (strip) gram_body<SCfg, WEIGHT, true>(Phi, ld, w, side, r0, r1, chunk, acol, bcol, diag, sideout, slab, smem_raw);
+    else gram_body<Cfg, WEIGHT, false>(Phi, ld, w, side, r0, r1, chunk, acol, bcol, diag, sideout, slab, smem_raw);
 }
 
 template <class Cfg, typename S>
@@ -213,29 +247,30 @@ __global__ __launch_bounds__(Cfg::THREADS) void xtz_kernel(
     }
 }
 
-template <typename T, int TILE>
-static void gram_launch(const Geom& g, const T* Phi, const double* w, int nsplit, int64_t chunk, double* slabs, hipStream_t st) {
-    typedef typename GramCfg<T, TILE>::type Cfg;
-    const int nts = g.Kp / Cfg::BM, ntiles = nts * (nts + 1) / 2;
+template <typename T>
+void SweepKernels<T>::gram(const Geom& g, const T* Phi, const double* w, const double* side, int nsplit, int64_t chunk, double* slabs,
+                           double* sidepart, hipStream_t st) {
+    typedef typename GramCfg<T, 128>::type Cfg;
+    typedef typename GramStripCfg<T>::type SCfg;
+    const int njobs = (g.gfull * (g.gfull + 1) / 2 + g.gstrip * (g.gfull + 1)) * nsplit;
     const int64_t rps = round_up((g.Np + nsplit - 1) / nsplit, 256);
     if (chunk <= 0 || chunk > rps) chunk = rps;
     chunk = round_up(chunk, Cfg::BK);
-    allow_big_lds(gram_kernel<Cfg, true>, Cfg::LDS_BYTES);
-    allow_big_lds(gram_kernel<Cfg, false>, Cfg::LDS_BYTES);
 #ifdef SCFGP_DIAG_PLAIN_W
     w = nullptr;                                               // timing diagnostic only: wrong numbers
 #endif
+#ifdef SCFGP_DIAG_NOSIDE
+    side = nullptr;                                            // timing diagnostic only: wrong numbers
+#endif
+    constexpr int LDS = Cfg::LDS_BYTES > SCfg::LDS_BYTES ? Cfg::LDS_BYTES : SCfg::LDS_BYTES;
+    allow_big_lds(gram_kernel<Cfg, SCfg, true>, LDS);
+    allow_big_lds(gram_kernel<Cfg, SCfg, false>, LDS);
     if (w)
-        hipLaunchKernelGGL((gram_kernel<Cfg, true>), dim3(ntiles * nsplit), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st,
-                           Phi, (int64_t)g.Kp, w, g.Np, rps, chunk, nts, g.K + 1, slabs);
+        hipLaunchKernelGGL((gram_kernel<Cfg, SCfg, true>), dim3(njobs), dim3(Cfg::THREADS), LDS, st,
+                           Phi, (int64_t)g.Kp, w, side, g.Np, rps, chunk, g.gfull, g.gstrip, nsplit, sidepart, slabs);
     else
-        hipLaunchKernelGGL((gram_kernel<Cfg, false>), dim3(ntiles * nsplit), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st,
-                           Phi, (int64_t)g.Kp, w, g.Np, rps, chunk, nts, -1, slabs);
-}
-template <typename T>
-void SweepKernels<T>::gram(const Geom& g, const T* Phi, const double* w, int nsplit, int64_t chunk, double* slabs, hipStream_t st) {
-    if (g.tile == 192) gram_launch<T, 192>(g, Phi, w, nsplit, chunk, slabs, st);
-    else gram_launch<T, 128>(g, Phi, w, nsplit, chunk, slabs, st);
+        hipLaunchKernelGGL((gram_kernel<Cfg, SCfg, false>), dim3(njobs), dim3(Cfg::THREADS), LDS, st,
+                           Phi, (int64_t)g.Kp, w, side, g.Np, rps, chunk, g.gfull, g.gstrip, nsplit, sidepart, slabs);
 }
 
 template <typename T>
@@ -274,8 +309,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void apply_kernel(
     NatLoader<T, T, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS, false, false> lb(Bm + cbase, Kp, threadIdx.x);
     typename Cfg::MTr::acc_t acc[Cfg::TM][Cfg::TN];
     acc_zero<Cfg>(acc);
-    // rows >= K of the operand matrix are zero (padding and the y, p columns of Phi~ are masked out of
-    // the sweep operands), so the contraction stops at K rounded up to the k-tile
+    // rows >= K of the operand matrix are zero padding, so the contraction stops at K rounded up to the k-tile
     tile_mainloop<Cfg>(la, lb, (K + Cfg::BK - 1) / Cfg::BK, acc, smem);
     AccCoord<Cfg> co;
     if (EPI == 0) {
@@ -292,7 +326,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void apply_kernel(
                 for (int tn = 0; tn < Cfg::TN; ++tn) {
                     const T c = acc[tm][tn][r];
                     V[off + co.col(tn)] = c;
-                    if (cbase + co.col(tn) < K) part += (double)Phi[off + co.col(tn)] * (double)c;   // not the y, p columns
+                    if (cbase + co.col(tn) < K) part += (double)Phi[off + co.col(tn)] * (double)c;
                 }
 #pragma unroll
                 for (int m = 1; m < Cfg::MS; m <<= 1) part += __shfl_xor(part, m);      // lanes of one MFMA row group
@@ -401,7 +435,7 @@ int SweepKernels<T>::apply_blocks(const Geom& g) {
 //   MODE 1 (predict): mu, sd = sqrt(kappa (1+v))
 // --------------------------------------------------------------------------
 template <typename T, int MODE>
-__global__ __launch_bounds__(256) void rowstats_kernel(T* Phi, int pcol, const double* __restrict__ alpha,
+__global__ __launch_bounds__(256) void rowstats_kernel(const T* __restrict__ Phi, const double* __restrict__ alpha,
                                                        const double* __restrict__ vpart, int njt, const double* __restrict__ y,
                                                        const Scal* __restrict__ sc, double* __restrict__ o1, double* __restrict__ o2,
                                                        double* __restrict__ partial, int Kp, int64_t N, int64_t Np) {
@@ -437,7 +471,6 @@ __global__ __launch_bounds__(256) void rowstats_kernel(T* Phi, int pcol, const d
                     kb += e * (v + 1.0);
                 }
                 o1[n] = pn; o2[n] = qn;
-                Phi[n * Kp + pcol] = (T)pn;                          // augmented column for Phi^T p (weighted Gram)
             } else if (n < N) {
                 o1[n] = mu; o2[n] = sqrt(d);
             }
@@ -452,9 +485,9 @@ __global__ __launch_bounds__(256) void rowstats_kernel(T* Phi, int pcol, const d
 }
 
 template <typename T>
-void SweepKernels<T>::rowstats(const Geom& g, T* Phi, const double* alpha, const double* vpart, const double* y,
+void SweepKernels<T>::rowstats(const Geom& g, const T* Phi, const double* alpha, const double* vpart, const double* y,
                                const Scal* sc, double* p, double* q, double* partial, int nblocks, hipStream_t st) {
-    hipLaunchKernelGGL((rowstats_kernel<T, 0>), dim3(nblocks), dim3(256), 0, st, Phi, g.K + 1, alpha, vpart, apply_njt<T>(g), y, sc, p, q,
+    hipLaunchKernelGGL((rowstats_kernel<T, 0>), dim3(nblocks), dim3(256), 0, st, Phi, alpha, vpart, apply_njt<T>(g), y, sc, p, q,
                        partial, g.Kp, g.N, g.Np);
 }
 
@@ -462,13 +495,12 @@ template <typename T>
 void SweepKernels<T>::rowpredict(const Geom& g, const T* Phi, const double* alpha, const double* vpart, const Scal* sc,
                                  double* mu, double* sd, hipStream_t st) {
     int nblocks = (int)((g.Np / 4) < 4096 ? (g.Np / 4) : 4096);
-    hipLaunchKernelGGL((rowstats_kernel<T, 1>), dim3(nblocks), dim3(256), 0, st, const_cast<T*>(Phi), 0, alpha, vpart, apply_njt<T>(g),
+    hipLaunchKernelGGL((rowstats_kernel<T, 1>), dim3(nblocks), dim3(256), 0, st, Phi, alpha, vpart, apply_njt<T>(g),
                        (const double*)nullptr, sc, mu, sd, (double*)nullptr, g.Kp, g.N, g.Np);
 }
 
 // --------------------------------------------------------------------------
-// fp64 Kp x Kp matrix -> sweep operand of type T with rows/columns >= K zeroed (the augmented
-// columns of Phi~ must not leak into Phi.B), optionally with column K := vec (unused: 0)
+// fp64 Kp x Kp matrix -> sweep operand of type T with the padding rows/columns >= K zeroed
 template <typename T>
 __global__ void convert_kernel(const double* __restrict__ src, T* __restrict__ dst, int K, int Kp) {
     const int64_t n = (int64_t)Kp * Kp;
@@ -481,16 +513,6 @@ template <typename T>
 void SweepKernels<T>::convert(const double* src, T* dst, int K, int Kp, hipStream_t st) {
     hipLaunchKernelGGL(convert_kernel<T>, dim3(2048), dim3(256), 0, st, src, dst, K, Kp);
 }
-template <typename T>
-__global__ void set_col_kernel(T* __restrict__ Phi, int Kp, int col, const double* __restrict__ src, int64_t Np) {
-    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < Np; n += (int64_t)gridDim.x * blockDim.x)
-        Phi[n * Kp + col] = (T)src[n];
-}
-template <typename T>
-void SweepKernels<T>::set_col(const Geom& g, T* Phi, int col, const double* src, hipStream_t st) {
-    hipLaunchKernelGGL(set_col_kernel<T>, dim3(1024), dim3(256), 0, st, Phi, g.Kp, col, src, g.Np);
-}
-
 template struct SweepKernels<double>;
 template struct SweepKernels<float>;
 
@@ -513,24 +535,17 @@ void reduce_tri_tiles(const double* slabs, int nsplit, int nts, int tile, double
     const int ntiles = nts * (nts + 1) / 2;
     hipLaunchKernelGGL(reduce_tri_kernel, dim3(ntiles, 16), dim3(256), 0, st, slabs, nsplit, ntiles, tile, packed);
 }
-// slot of element (i, j): off-diagonal tiles exist only below the diagonal, diagonal tiles hold both triangles
-__device__ __forceinline__ int64_t packed_index(int i, int j, int B) {
-    int ti = i / B, tj = j / B, r = i % B, c = j % B;
-    if (ti < tj) { int t = ti; ti = tj; tj = t; t = r; r = c; c = t; }
-    return ((int64_t)(ti * (ti + 1) / 2 + tj) * B + r) * B + c;
-}
-// vec[j<K] = M[row][j]; then the augmented rows/columns K, K+1 are cleared in every slot that holds them
-__global__ void extract_aug_kernel(double* __restrict__ packed, int K, int Kp, int B, int row, double* __restrict__ vec) {
+// vec[j] = sum over splits of the Gram's side partials for j < ncov (columns covered by diagonal tiles), 0 beyond
+__global__ void reduce_side_kernel(const double* __restrict__ sidepart, int nsplit, int Kp, int ncov, double* __restrict__ vec) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= Kp) return;
-    vec[j] = j < K ? packed[packed_index(row, j, B)] : 0.0;
-    for (int a = K; a < K + 2; ++a) {
-        packed[packed_index(a, j, B)] = 0.0;
-        packed[packed_index(j, a, B)] = 0.0;          // the other triangle's slot when (a, j) share a diagonal tile
-    }
+    double s = 0;
+    if (j < ncov)
+        for (int sp = 0; sp < nsplit; ++sp) s += sidepart[(int64_t)sp * Kp + j];
+    vec[j] = s;
 }
-void extract_aug(double* packed, int K, int Kp, int tile, int row, double* vec, hipStream_t st) {
-    hipLaunchKernelGGL(extract_aug_kernel, dim3((Kp + 255) / 256), dim3(256), 0, st, packed, K, Kp, tile, row, vec);
+void reduce_side(const double* sidepart, int nsplit, int Kp, int ncov, double* vec, hipStream_t st) {
+    hipLaunchKernelGGL(reduce_side_kernel, dim3((Kp + 255) / 256), dim3(256), 0, st, sidepart, nsplit, Kp, ncov, vec);
 }
 // full symmetric matrix (ld = Kp) from the packed lower tiles; diagonal tiles carry both triangles
 __global__ __launch_bounds__(256) void unpack_tri_kernel(const double* __restrict__ packed, int B, double* __restrict__ full, int64_t ld) {

@@ -140,7 +140,8 @@ static int ensure_rows(scfgp_ctx* c, int64_t N) {
     const int ntx = ((g.Dp + XT - 1) / XT) * (g.Jp / XT);
     const int gs = c->gram_nsplit > 0 ? (int)std::min<int64_t>(c->gram_nsplit, Np / 256) : default_split(ntiles, Np);
     const int xs = c->xtz_nsplit > 0 ? (int)std::min<int64_t>(c->xtz_nsplit, Np / 256) : xtz_split(ntx, Np);
-    const size_t need = sizeof(double) * std::max<size_t>((size_t)gs * ntiles * g.tile * g.tile, (size_t)xs * ntx * XT * XT);
+    // Gram slabs are followed by the per-split side-vector partials (gs x Kp)
+    const size_t need = sizeof(double) * std::max<size_t>((size_t)gs * ntiles * g.tile * g.tile + (size_t)gs * g.Kp, (size_t)xs * ntx * XT * XT);
     if (need > c->slabs_bytes) {
         dfree(c->d_slabs);
         if (int rc = dmalloc(c, &c->d_slabs, need)) return rc;
@@ -160,7 +161,7 @@ static int ensure_rows(scfgp_ctx* c, int64_t N) {
     if ((rc = dmalloc(c, &c->d_Phi, ts * Np * g.Kp))) return rc;
     if ((rc = dmalloc(c, &c->d_V, ts * Np * g.Kp))) return rc;
     if ((rc = dmalloc(c, &c->d_bpart, sizeof(double) * (g.Kp / 64) * (Np / 128)))) return rc;
-    HIPCHK(c, hipMemsetAsync(c->d_Phi, 0, ts * Np * g.Kp, c->st));       // padding columns >= K+2 stay zero forever
+    HIPCHK(c, hipMemsetAsync(c->d_Phi, 0, ts * Np * g.Kp, c->st));       // padding columns >= K stay zero forever
     HIPCHK(c, hipMemsetAsync(c->d_V, 0, ts * Np * g.Kp, c->st));         // columns >= K are never written
     c->Ncap = Np;
     return SCFGP_OK;
@@ -174,10 +175,11 @@ extern "C" int scfgp_create(scfgp_ctx** out, int D, int S, int M, int dtype, int
     Geom& g = c->g;
     g.D = D; g.S = S; g.M = M; g.J = S + M; g.K = 2 * g.J; g.P = 3 + D * S + M * S + S + M;
     g.Dp = (int)round_up(D + 1, 16); g.Jp = (int)round_up(g.J, XT);
-    // 192-wide tiles only when they cut the padded size by >= 8 % (their wave tile costs occupancy)
-    g.tile = round_up(g.K + 2, 192) * 100 <= round_up(g.K + 2, 128) * 92 ? 192 : 128;
-    if (const char* e = getenv("SCFGP_TILE")) { const int t = atoi(e); if (t == 128 || t == 192) g.tile = t; }   // tuning override
-    g.Kp = (int)round_up(g.K + 2, g.tile);          // + the two augmented columns (y, p) of Phi~
+    // Gram tile grid: 128-wide tiles cover K in 64-column blocks; an odd block count ends in a 64-high strip
+    g.tile = 128;
+    g.gfull = (int)(round_up(g.K, 64) / 128);
+    g.gstrip = (int)(round_up(g.K, 64) / 64 % 2);
+    g.Kp = (g.gfull + g.gstrip) * g.tile;
     c->Dpp = (int)round_up(g.Dp, XT);
     HIPCHK(c, hipSetDevice(device));
     if (stream) c->st = (hipStream_t)stream;
@@ -269,8 +271,6 @@ static int load_working_set(scfgp_ctx* c, const int64_t* d_idx, int64_t n, int64
     c->Nglobal = n_global > 0 ? n_global : n;
     pack_data(c->g, c->d_Xraw, c->d_yraw, d_idx, c->d_Xt, c->d_y, c->st);
     sum_squares(c->d_y, c->g.Np, c->d_yy, 0, c->d_partial, c->st);
-    if (c->dtype == SCFGP_F32) SweepKernels<float>::set_col(c->g, (float*)c->d_Phi, c->g.K, c->d_y, c->st);
-    else SweepKernels<double>::set_col(c->g, (double*)c->d_Phi, c->g.K, c->d_y, c->st);
     HIPCHK(c, hipGetLastError());
     c->work_full = d_idx == nullptr;
     c->have_data = true; c->stage = 0;
@@ -310,22 +310,22 @@ template <typename T> struct Impl {
     static const T* BT(scfgp_ctx* c) { return (const T*)c->d_BT; }
     static const T* AbarT(scfgp_ctx* c) { return (const T*)c->d_AbarT; }
 
-    // augmented Gram of Phi~ = [Phi | y | p] -> out = [Kp x Kp matrix | vector]; `row` is the augmented
-    // row that carries the wanted vector (K: Phi^T y, K+1: Phi^T p)
-    static void gram_to(scfgp_ctx* c, const double* w, double* out, int row, const char* name) {
+    // out = [packed lower tiles of Phi^T diag(w) Phi | Phi^T side (Kp)]
+    static void gram_to(scfgp_ctx* c, const double* w, const double* side, double* out, const char* name) {
         const Geom& g = c->g;
         const int nts = g.Kp / g.tile, ntiles = nts * (nts + 1) / 2;
         const int gs = c->gram_nsplit > 0 ? (int)std::min<int64_t>(c->gram_nsplit, g.Np / 256) : default_split(ntiles, g.Np);
+        double* sidepart = c->d_slabs + (size_t)gs * ntiles * g.tile * g.tile;
         { ProfScope ps(c, name);
-          SK::gram(g, (const T*)c->d_Phi, w, gs, c->dtype == SCFGP_F32 ? c->gram_chunk : 0, c->d_slabs, c->st); }
+          SK::gram(g, (const T*)c->d_Phi, w, side, gs, c->dtype == SCFGP_F32 ? c->gram_chunk : 0, c->d_slabs, sidepart, c->st); }
         { ProfScope ps(c, "reduce_tiles"); reduce_tri_tiles(c->d_slabs, gs, nts, g.tile, out, c->st);
-          extract_aug(out, g.K, g.Kp, g.tile, row, out + c->n_pk, c->st); }
+          reduce_side(sidepart, gs, g.Kp, g.gfull * g.tile + g.gstrip * 64, out + c->n_pk, c->st); }
     }
     static int pass1(scfgp_ctx* c) {
         const Geom& g = c->g;
         if (!c->in_train) HIPCHK(c, hipMemsetAsync(c->d_flag, 0, sizeof(int) * 4, c->st));
         { ProfScope ps(c, "featuremap"); SK::featuremap(g, c->d_Xt, c->d_Fall, c->d_sc, (T*)c->d_Phi, c->st); }
-        gram_to(c, nullptr, c->d_xp1, g.K, "gram");
+        gram_to(c, nullptr, c->d_y, c->d_xp1, "gram");
         HIPCHK(c, hipMemcpyAsync(c->d_xp1 + c->n_pk + g.Kp, c->d_yy, sizeof(double), hipMemcpyDeviceToDevice, c->st));
         HIPCHK(c, hipGetLastError());
         return SCFGP_OK;
@@ -342,10 +342,10 @@ template <typename T> struct Impl {
         { ProfScope ps(c, "apply_v"); SK::apply_v(g, (const T*)c->d_Phi, BT(c), (T*)c->d_V, c->d_vpart, c->st); }
         const int nb = (int)std::min<int64_t>(g.Np / 4, 2048);
         { ProfScope ps(c, "rowstats");
-          SK::rowstats(g, (T*)c->d_Phi, c->alpha(), c->d_vpart, c->d_y, c->d_sc, c->d_p, c->d_q, c->d_partial, nb, c->st);
+          SK::rowstats(g, (const T*)c->d_Phi, c->alpha(), c->d_vpart, c->d_y, c->d_sc, c->d_p, c->d_q, c->d_partial, nb, c->st);
           reduce_scalars(c->d_partial, nb, 2, c->d_xp2 + c->n_pk + g.Kp, 0, c->st); }
         if (want_grad) {
-            gram_to(c, c->d_q, c->d_xp2, g.K + 1, "gram_w");
+            gram_to(c, c->d_q, c->d_p, c->d_xp2, "gram_w");
         }
         HIPCHK(c, hipGetLastError());
         return SCFGP_OK;

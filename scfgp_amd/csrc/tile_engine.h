@@ -72,9 +72,11 @@ template <> struct Vec16<float> { typedef v4f type; static constexpr int N = 4; 
 // ---------------------------------------------------------------------------
 // NatLoader: source S[k][x] (row-major, leading dimension ld, x contiguous).
 //   tile kt = rows [kt*BK, kt*BK+BK), columns [0, BX) relative to `base`.
-//   Optional per-k-row weight w[k] (Gram with row weights) and x-limit guard.
+//   Optional per-k-row weight w[k] (Gram with row weights), x-limit guard, and a "side" product:
+//   with SIDE and side_on the loader also accumulates, in fp64 and from the unweighted values it
+//   stages anyway, side[x] = sum_k s[k] * S[k][x] (Phi^T y, Phi^T p on the Gram's diagonal tiles).
 // ---------------------------------------------------------------------------
-template <typename S, typename T, int BX, int BK, int LD, int THREADS, bool WEIGHT, bool GUARD>
+template <typename S, typename T, int BX, int BK, int LD, int THREADS, bool WEIGHT, bool GUARD, bool SIDE = false>
 struct NatLoader {
     typedef typename Vec16<S>::type vec_t;
     static constexpr int VS = Vec16<S>::N;
@@ -83,17 +85,23 @@ struct NatLoader {
     // Loads are issued for consecutive k-tiles (0, 1, 2, ...): each vector keeps a running pointer
     // that advances by BK rows per call, so the loop carries no 64-bit multiplies.
     const S* ptr[NV]; const double* wptr[NV]; int64_t step; int xlim;     // xlim: first invalid x (GUARD)
-    int xplain = -1;                                          // WEIGHT: this x is stored unweighted
     vec_t r[1][NV]; double wr[1][NV];                         // weights stay raw until store(): converting in
     int tid;                                                  // load() would wait on the fetch before the MFMAs
-    __device__ __forceinline__ NatLoader(const S* b, int64_t l, int t, const double* w_ = nullptr, int xl = 0)
+    const double* sptr[NV]; double sr[NV]; double sacc[NV][VS]; bool side_on = false;
+    __device__ __forceinline__ NatLoader(const S* b, int64_t l, int t, const double* w_ = nullptr, int xl = 0,
+                                         const double* s_ = nullptr)
         : step((int64_t)BK * l), xlim(xl), tid(t) {
+        side_on = SIDE && s_ != nullptr;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int v = tid + i * THREADS;
             const int k = v / VPR, xv = v % VPR;
             ptr[i] = b + (int64_t)k * l + xv * VS;
             wptr[i] = WEIGHT ? w_ + k : nullptr;
+            sptr[i] = side_on ? s_ + k : nullptr;
+            sr[i] = 0;
+#pragma unroll
+            for (int e = 0; e < VS; ++e) sacc[i][e] = 0;
         }
     }
     template <int SET = 0>
@@ -109,11 +117,12 @@ struct NatLoader {
             if (ok && (!GUARD || xv * VS < xlim)) val = *reinterpret_cast<const vec_t*>(ptr[i]);
             r[SET][i] = val;
             if (WEIGHT) { wr[SET][i] = ok ? *wptr[i] : 0.0; wptr[i] += BK; }
+            if (SIDE && side_on) { sr[i] = ok ? *sptr[i] : 0.0; sptr[i] += BK; }
             ptr[i] += step;
         }
     }
     template <int SET = 0>
-    __device__ __forceinline__ void store(T* s) const {
+    __device__ __forceinline__ void store(T* s) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int v = tid + i * THREADS;
@@ -127,11 +136,34 @@ struct NatLoader {
             for (int e0 = 0; e0 < VS; e0 += TV) {
                 tv_t o;
 #pragma unroll
-                for (int e = 0; e < TV; ++e)
-                    o[e] = (WEIGHT && xv * VS + e0 + e != xplain) ? (T)r[SET][i][e0 + e] * wt : (T)r[SET][i][e0 + e];
+                for (int e = 0; e < TV; ++e) o[e] = WEIGHT ? (T)r[SET][i][e0 + e] * wt : (T)r[SET][i][e0 + e];
                 *reinterpret_cast<tv_t*>(d + e0) = o;
             }
+            if (SIDE && side_on) {
+#pragma unroll
+                for (int e = 0; e < VS; ++e) sacc[i][e] = fma(sr[i], (double)r[SET][i][e], sacc[i][e]);
+            }
         }
+    }
+    // out[x] = side[x], x < BX, summed over this workgroup's BK row groups through lds (BK*BX doubles).
+    // Every thread of the workgroup must call; lds must not be in use by the main loop any more.
+    __device__ __forceinline__ void side_reduce(double* lds, double* __restrict__ out) const {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int v = tid + i * THREADS;
+            if ((BK * VPR) % THREADS != 0 && v >= BK * VPR) continue;
+            const int k = v / VPR, xv = v % VPR;
+#pragma unroll
+            for (int e = 0; e < VS; ++e) lds[k * BX + xv * VS + e] = sacc[i][e];
+        }
+        __syncthreads();
+        for (int x = tid; x < BX; x += THREADS) {
+            double sum = 0;
+#pragma unroll
+            for (int k = 0; k < BK; ++k) sum += lds[k * BX + x];
+            out[x] = sum;
+        }
+        __syncthreads();
     }
 };
 

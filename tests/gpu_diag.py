@@ -40,7 +40,7 @@ def stages(name, dtype):
     eng.pass1(); ora.pass1()
     Phi = eng.debug_read('Phi', (Np, Kp), tdt).astype(np.float64)
     out.append(('Phi', rel(Phi[:N, :K], ora.Ph)))
-    out.append(('Phi_pad', float(np.abs(Phi[N:]).max() if Np > N else 0) + float(np.abs(Phi[:, K + 1:]).max())))
+    out.append(('Phi_pad', float(np.abs(Phi[N:]).max() if Np > N else 0) + float(np.abs(Phi[:, K:]).max())))
     x1 = eng.debug_read('G', (Kp * Kp + Kp + 8,))
     G = x1[:Kp * Kp].reshape(Kp, Kp)
     out.append(('G', rel(G[:K, :K], ora.x1[:K * K].reshape(K, K))))
