@@ -73,8 +73,9 @@ template <> struct Vec16<float> { typedef v4f type; static constexpr int N = 4; 
 // NatLoader: source S[k][x] (row-major, leading dimension ld, x contiguous).
 //   tile kt = rows [kt*BK, kt*BK+BK), columns [0, BX) relative to `base`.
 //   Optional per-k-row weight w[k] (Gram with row weights), x-limit guard, and a "side" product:
-//   with SIDE and side_on the loader also accumulates, in fp64 and from the unweighted values it
-//   stages anyway, side[x] = sum_k s[k] * S[k][x] (Phi^T y, Phi^T p on the Gram's diagonal tiles).
+//   with SIDE and side_on the loader also accumulates, from the unweighted values it stages anyway,
+//   side[x] = sum_k s[k] * S[k][x] (Phi^T y, Phi^T p on the Gram's diagonal tiles): in the compute type
+//   per thread between side_flush() calls (one row in BK: a chain 1/BK as long as the MFMA's), fp64 across.
 // ---------------------------------------------------------------------------
 template <typename S, typename T, int BX, int BK, int LD, int THREADS, bool WEIGHT, bool GUARD, bool SIDE = false>
 struct NatLoader {
@@ -87,7 +88,7 @@ struct NatLoader {
     const S* ptr[NV]; const double* wptr[NV]; int64_t step; int xlim;     // xlim: first invalid x (GUARD)
     vec_t r[1][NV]; double wr[1][NV];                         // weights stay raw until store(): converting in
     int tid;                                                  // load() would wait on the fetch before the MFMAs
-    const double* sptr[NV]; double sr[NV]; double sacc[NV][VS]; bool side_on = false;
+    const double* sptr[NV]; double sr[NV]; T sacc[NV][VS]; double stot[NV][VS]; bool side_on = false;
     __device__ __forceinline__ NatLoader(const S* b, int64_t l, int t, const double* w_ = nullptr, int xl = 0,
                                          const double* s_ = nullptr)
         : step((int64_t)BK * l), xlim(xl), tid(t) {
@@ -101,7 +102,7 @@ struct NatLoader {
             sptr[i] = side_on ? s_ + k : nullptr;
             sr[i] = 0;
 #pragma unroll
-            for (int e = 0; e < VS; ++e) sacc[i][e] = 0;
+            for (int e = 0; e < VS; ++e) { sacc[i][e] = 0; stot[i][e] = 0; }
         }
     }
     template <int SET = 0>
@@ -140,10 +141,17 @@ struct NatLoader {
                 *reinterpret_cast<tv_t*>(d + e0) = o;
             }
             if (SIDE && side_on) {
+                const T sv = (T)sr[i];
 #pragma unroll
-                for (int e = 0; e < VS; ++e) sacc[i][e] = fma(sr[i], (double)r[SET][i][e], sacc[i][e]);
+                for (int e = 0; e < VS; ++e) sacc[i][e] += sv * (T)r[SET][i][e];
             }
         }
+    }
+    __device__ __forceinline__ void side_flush() {
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int e = 0; e < VS; ++e) { stot[i][e] += (double)sacc[i][e]; sacc[i][e] = 0; }
     }
     // out[x] = side[x], x < BX, summed over this workgroup's BK row groups through lds (BK*BX doubles).
     // Every thread of the workgroup must call; lds must not be in use by the main loop any more.
@@ -154,7 +162,7 @@ struct NatLoader {
             if ((BK * VPR) % THREADS != 0 && v >= BK * VPR) continue;
             const int k = v / VPR, xv = v % VPR;
 #pragma unroll
-            for (int e = 0; e < VS; ++e) lds[k * BX + xv * VS + e] = sacc[i][e];
+            for (int e = 0; e < VS; ++e) lds[k * BX + xv * VS + e] = stot[i][e];
         }
         __syncthreads();
         for (int x = tid; x < BX; x += THREADS) {
