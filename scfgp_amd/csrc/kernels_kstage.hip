@@ -95,12 +95,13 @@ __global__ __launch_bounds__(KCfg::THREADS) void trinv_level_kernel(const double
 }
 
 // ---------------------------------------------------------------------------
-// 64 x 64 diagonal block: Cholesky and triangular inverse by one 4-wave workgroup in LDS.
-//   Cholesky: left-to-right in four 16-column panels; inside a panel each pivot step only updates the
-//   panel's own remaining columns (<= 15 x 64 elements over 256 threads), the rest of the matrix gets
-//   one rank-16 update per panel: 2 barriers per column instead of a full trailing sweep per column.
-//   Inverse: the two 32 x 32 diagonal blocks are inverted concurrently (one thread per column, forward
-//   substitution), the off-diagonal block is X21 = -X22 (L21 X11) by all threads.
+// 64 x 64 diagonal block: Cholesky and triangular inverse by one 4-wave workgroup.
+//   Cholesky: left-to-right in four 16-column panels.  A panel (rows pb..63 x 16 columns) is factored by
+//   wave 0 alone with one matrix row per lane in registers: the pivot and the multipliers L[k][j] reach the
+//   other lanes by lane broadcasts, so the 16 sequential column steps need neither LDS nor barriers.  The
+//   rest of the matrix then gets one rank-16 update by all four waves: 2 barriers per panel.
+//   Inverse: the four 16 x 16 diagonal blocks by forward substitution in registers (one column per thread,
+//   chains of <= 120 FMAs), then two doubling levels X21 = -X22 (L21 X11) by all threads.
 //   This kernel sits 34 times on the critical path of the K-stage at K = 2112.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void potrf_diag_kernel(double* A, double* Li, int64_t ld, int p, int* flag) {
@@ -108,27 +109,40 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* A, double* Li, 
     __shared__ double sL[NB * LD];
     __shared__ double sI[NB * LD];
     __shared__ double sT[32 * 33];
+    __shared__ double sD[NB];                                          // 1 / L[j][j]
     double* a = A + (int64_t)p * NB * ld + p * NB;
     double* li = Li + (int64_t)p * NB * ld + p * NB;
-    const int tid = threadIdx.x;
-    for (int e = tid; e < NB * NB; e += 256) sL[(e / NB) * LD + e % NB] = a[(int64_t)(e / NB) * ld + e % NB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int e = tid; e < NB * NB; e += 256) {
+        sL[(e / NB) * LD + e % NB] = a[(int64_t)(e / NB) * ld + e % NB];
+        sI[(e / NB) * LD + e % NB] = 0.0;
+    }
     bool bad = false;
     for (int pb = 0; pb < NB; pb += PB) {
         const int pend = pb + PB;
-        for (int j = pb; j < pend; ++j) {
-            __syncthreads();
-            const double d = sL[j * LD + j];
-            bad |= !(d > 0.0);
-            const double sq = sqrt(d), inv = 1.0 / sq;
-            __syncthreads();                                           // everyone has read the pivot
-            if (tid < NB && tid >= j) sL[tid * LD + j] = tid == j ? sq : sL[tid * LD + j] * inv;
-            __syncthreads();
-            // columns (j, pend) of the panel: L[i][k] -= L[i][j] L[k][j],  i >= k
-            const int nc = pend - 1 - j;
-            for (int e = tid; e < nc * NB; e += 256) {
-                const int k = j + 1 + e / NB, i = e % NB;
-                if (i >= k) sL[i * LD + k] -= sL[i * LD + j] * sL[k * LD + j];
+        __syncthreads();
+        if (wave == 0) {
+            const int row = pb + lane;                                 // lanes past the last row idle along
+            double v[PB];
+#pragma unroll
+            for (int c = 0; c < PB; ++c) v[c] = row < NB ? sL[row * LD + pb + c] : 0.0;
+#pragma unroll
+            for (int j = 0; j < PB; ++j) {
+                const double d = __shfl(v[j], j);                      // pivot: row pb+j is lane j
+                bad |= !(d > 0.0);
+                // 1/sqrt(d): hardware estimate + two Newton steps (the library sqrt and divide are ~450 dependent
+                // cycles per column on this 64-step critical path)
+                double inv = __builtin_amdgcn_rsq(d);
+                inv = fma(0.5 * inv, fma(-d * inv, inv, 1.0), inv);
+                inv = fma(0.5 * inv, fma(-d * inv, inv, 1.0), inv);
+                if (lane == j) sD[pb + j] = inv;
+                v[j] = lane == j ? d * inv : v[j] * inv;               // entries above the diagonal are never used
+#pragma unroll
+                for (int k = j + 1; k < PB; ++k) v[k] -= v[j] * __shfl(v[j], k);    // L[pb+k][pb+j] lives in lane k
             }
+#pragma unroll
+            for (int c = 0; c < PB; ++c)
+                if (row < NB) sL[row * LD + pb + c] = v[c];
         }
         __syncthreads();
         // rank-16 update of everything right of the panel: L[i][k] -= sum_c L[i][c] L[k][c], i >= k >= pend
@@ -145,33 +159,38 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* A, double* Li, 
     }
     if (bad && tid == 0) *flag = 1;                                    // not positive definite (or NaN)
     __syncthreads();
-    // ---- inverse: two independent 32 x 32 triangles, one thread per column
-    for (int e = tid; e < NB * NB; e += 256) sI[(e / NB) * LD + e % NB] = 0.0;
-    __syncthreads();
+    // ---- inverse, level 0: the four 16 x 16 diagonal blocks, thread = (block, column)
     if (tid < NB) {
-        const int c = tid, o = c < 32 ? 0 : 32, hi = o + 32;           // column c of block [o, hi)
-        for (int r = c; r < hi; ++r) {
+        const int o = (tid / PB) * PB, c = tid % PB;
+        double x[PB];
+#pragma unroll
+        for (int r = 0; r < PB; ++r) {
             double s = r == c ? 1.0 : 0.0;
-            for (int k = c; k < r; ++k) s -= sL[r * LD + k] * sI[k * LD + c];
-            sI[r * LD + c] = s / sL[r * LD + r];
+#pragma unroll
+            for (int k = 0; k < r; ++k) s -= sL[(o + r) * LD + o + k] * x[k];      // x[k] = 0 for k < c
+            x[r] = r >= c ? s * sD[o + r] : 0.0;
+            sI[(o + r) * LD + o + c] = x[r];
         }
     }
     __syncthreads();
-    // T = L21 X11 (32 x 32), then X21 = -X22 T
-    for (int e = tid; e < 32 * 32; e += 256) {
-        const int r = e / 32, c = e % 32;
-        double s = 0;
-        for (int k = c; k < 32; ++k) s += sL[(32 + r) * LD + k] * sI[k * LD + c];     // X11 lower: k >= c
-        sT[r * 33 + c] = s;
+    // ---- doubling levels h = 16, 32: for each pair of diagonal blocks T = L21 X11, X21 = -X22 T
+    for (int h = PB; h < NB; h *= 2) {
+        const int npair = NB / (2 * h), per = h * h;
+        for (int e = tid; e < npair * per; e += 256) {
+            const int q = e / per, r = (e % per) / h, c = e % h, o = q * 2 * h;
+            double s = 0;
+            for (int k = c; k < h; ++k) s += sL[(o + h + r) * LD + o + k] * sI[(o + k) * LD + o + c];      // X11 lower: k >= c
+            sT[q * 16 * 17 + r * (h + 1) + c] = s;
+        }
+        __syncthreads();
+        for (int e = tid; e < npair * per; e += 256) {
+            const int q = e / per, r = (e % per) / h, c = e % h, o = q * 2 * h;
+            double s = 0;
+            for (int k = 0; k <= r; ++k) s += sI[(o + h + r) * LD + o + h + k] * sT[q * 16 * 17 + k * (h + 1) + c];  // X22 lower
+            sI[(o + h + r) * LD + o + c] = -s;
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    for (int e = tid; e < 32 * 32; e += 256) {
-        const int r = e / 32, c = e % 32;
-        double s = 0;
-        for (int k = 0; k <= r; ++k) s += sI[(32 + r) * LD + 32 + k] * sT[k * 33 + c];  // X22 lower: k <= r
-        sI[(32 + r) * LD + c] = -s;
-    }
-    __syncthreads();
     for (int e = tid; e < NB * NB; e += 256) {
         const int i = e / NB, k = e % NB;
         a[(int64_t)i * ld + k] = k <= i ? sL[i * LD + k] : 0.0;
