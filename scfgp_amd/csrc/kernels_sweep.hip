@@ -298,7 +298,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void apply_kernel(
     const typename Cfg::T* __restrict__ Phi, const typename Cfg::T* __restrict__ Bm, typename Cfg::T* V,
     double* __restrict__ vpart, const double* __restrict__ p, const double* __restrict__ q, const double* __restrict__ y,
     const double* __restrict__ alpha, const double* __restrict__ ut, int K, int Kp, int64_t Np, int njt,
-    double* __restrict__ bpart, int col0, int jt0) {
+    double* __restrict__ bpart, int col0, int jt0, double* __restrict__ mu) {
     // this launch covers columns [col0, col0 + njt*BN); jt0 = index of its first tile in vpart
     typedef typename Cfg::T T;
     SMEM_DECL;
@@ -307,7 +307,10 @@ __global__ __launch_bounds__(Cfg::THREADS) void apply_kernel(
     const int jt = wid % njt;
     const int64_t rb = wid / njt;
     const int cbase = col0 + jt * Cfg::BN;
-    TrLoader<T, T, Cfg::BM, Cfg::BK, Cfg::LDA, Cfg::THREADS> la(Phi + rb * Cfg::BM * Kp, Kp, threadIdx.x);
+    // EPI 0: the workgroups of the first column tile also form mu = Phi.alpha for their rows
+    const bool want_mu = EPI == 0 && mu != nullptr && jt0 + jt == 0;
+    TrLoader<T, T, Cfg::BM, Cfg::BK, Cfg::LDA, Cfg::THREADS, EPI == 0> la(Phi + rb * Cfg::BM * Kp, Kp, threadIdx.x,
+                                                                        want_mu ? alpha : nullptr);
     NatLoader<T, T, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS, false, false> lb(Bm + cbase, Kp, threadIdx.x);
     typename Cfg::MTr::acc_t acc[Cfg::TM][Cfg::TN];
     acc_zero<Cfg>(acc);
@@ -315,6 +318,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void apply_kernel(
     tile_mainloop<Cfg>(la, lb, (K + Cfg::BK - 1) / Cfg::BK, acc, smem);
     AccCoord<Cfg> co;
     if (EPI == 0) {
+        if (want_mu) la.dot_reduce(mu + rb * Cfg::BM);
         double* red = reinterpret_cast<double*>(smem_raw);          // [WGN][BM]; main loop ended with a barrier
         const int wn = (threadIdx.x >> 6) % Cfg::WGN;
 #pragma unroll
@@ -394,32 +398,36 @@ template <typename T> struct ApplyPlan {
 template <class Cfg, int EPI, typename T>
 static int apply_launch_cfg(const Geom& g, int njt, int col0, int jt0, int boff, const T* Phi, const T* Bm, T* V, double* vpart,
                             const double* p, const double* q, const double* y, const double* alpha, const double* ut,
-                            double* bpart, hipStream_t st) {
+                            double* bpart, double* mu, hipStream_t st) {
     if (njt <= 0) return 0;
     const int64_t nrb = g.Np / Cfg::BM;
     allow_big_lds(apply_kernel<Cfg, EPI>, Cfg::LDS_BYTES);
     hipLaunchKernelGGL((apply_kernel<Cfg, EPI>), dim3((unsigned)(njt * nrb)), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st,
-                       Phi, Bm, V, vpart, p, q, y, alpha, ut, g.K, g.Kp, g.Np, njt, bpart ? bpart + boff : nullptr, col0, jt0);
+                       Phi, Bm, V, vpart, p, q, y, alpha, ut, g.K, g.Kp, g.Np, njt, bpart ? bpart + boff : nullptr, col0, jt0, mu);
     return (int)(njt * nrb);
 }
 template <typename T, int EPI>
 static int apply_launch(const Geom& g, const T* Phi, const T* Bm, T* V, double* vpart, const double* p, const double* q,
-                        const double* y, const double* alpha, const double* ut, double* bpart, hipStream_t st) {
+                        const double* y, const double* alpha, const double* ut, double* bpart, double* mu, hipStream_t st) {
     const ApplyPlan<T> pl(g.K);
     int nb = 0;
-    nb += apply_launch_cfg<typename ApplyCfg<T, Tune<T>::APPLY_BN>::type, EPI, T>(g, pl.count[0], pl.col0[0], pl.jt0[0], nb, Phi, Bm, V, vpart, p, q, y, alpha, ut, bpart, st);
-    nb += apply_launch_cfg<typename ApplyCfg<T, 128>::type, EPI, T>(g, pl.count[1], pl.col0[1], pl.jt0[1], nb, Phi, Bm, V, vpart, p, q, y, alpha, ut, bpart, st);
-    nb += apply_launch_cfg<typename ApplyCfg<T, 64>::type, EPI, T>(g, pl.count[2], pl.col0[2], pl.jt0[2], nb, Phi, Bm, V, vpart, p, q, y, alpha, ut, bpart, st);
+    nb += apply_launch_cfg<typename ApplyCfg<T, Tune<T>::APPLY_BN>::type, EPI, T>(g, pl.count[0], pl.col0[0], pl.jt0[0], nb, Phi, Bm, V, vpart, p, q, y, alpha, ut, bpart, mu, st);
+    nb += apply_launch_cfg<typename ApplyCfg<T, 128>::type, EPI, T>(g, pl.count[1], pl.col0[1], pl.jt0[1], nb, Phi, Bm, V, vpart, p, q, y, alpha, ut, bpart, mu, st);
+    nb += apply_launch_cfg<typename ApplyCfg<T, 64>::type, EPI, T>(g, pl.count[2], pl.col0[2], pl.jt0[2], nb, Phi, Bm, V, vpart, p, q, y, alpha, ut, bpart, mu, st);
     return nb;
 }
 template <typename T>
-void SweepKernels<T>::apply_v(const Geom& g, const T* Phi, const T* Bm, T* V, double* vpart, hipStream_t st) {
-    apply_launch<T, 0>(g, Phi, Bm, V, vpart, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, st);
+void SweepKernels<T>::apply_v(const Geom& g, const T* Phi, const T* Bm, T* V, double* vpart, const double* alpha, double* mu,
+                              hipStream_t st) {
+#ifdef SCFGP_DIAG_NOMU
+    mu = nullptr;                                              // timing diagnostic only: wrong numbers
+#endif
+    apply_launch<T, 0>(g, Phi, Bm, V, vpart, nullptr, nullptr, nullptr, alpha, nullptr, nullptr, mu, st);
 }
 template <typename T>
 int SweepKernels<T>::apply_phibar(const Geom& g, const T* Phi, const T* Abar, T* V, const double* p, const double* q,
                                   const double* y, const double* alpha, const double* ut, double* bpart, hipStream_t st) {
-    return apply_launch<T, 1>(g, Phi, Abar, V, nullptr, p, q, y, alpha, ut, bpart, st);
+    return apply_launch<T, 1>(g, Phi, Abar, V, nullptr, p, q, y, alpha, ut, bpart, nullptr, st);
 }
 // number of column tiles of the apply kernel (vpart leading count)
 template <typename T> static int apply_njt(const Geom& g) { return ApplyPlan<T>(g.K).total; }
@@ -430,75 +438,63 @@ int SweepKernels<T>::apply_blocks(const Geom& g) {
 
 
 // --------------------------------------------------------------------------
-// per-row statistics: one wave per row (grid-stride).
-//   mu = phi.alpha, v = sum_jt vpart, d = kappa (v+1), r = mu - y
-//   MODE 0 (train): p = 2r/d, e = 1/d - (r^2+v)/d^2, q = 1/d + kappa e; partial sums of
+// per-row statistics from mu (apply_v's by-product) and the per-tile row dots: one thread per row.
+//   v = sum_jt vpart, d = kappa (v+1), r = mu - y
+//   MODE 0 (train): p = 2r/d, e = 1/d - (r^2+v)/d^2, q = 1/d + kappa e; block partials of
 //                   T2 = (r^2+v)/d + log(2 pi d) and kbar = e (v+1)
-//   MODE 1 (predict): mu, sd = sqrt(kappa (1+v))
+//   MODE 1 (predict): sd = sqrt(kappa (1+v))      (mu is already in place)
 // --------------------------------------------------------------------------
-template <typename T, int MODE>
-__global__ __launch_bounds__(256) void rowstats_kernel(const T* __restrict__ Phi, const double* __restrict__ alpha,
-                                                       const double* __restrict__ vpart, int njt, const double* __restrict__ y,
-                                                       const Scal* __restrict__ sc, double* __restrict__ o1, double* __restrict__ o2,
-                                                       double* __restrict__ partial, int Kp, int64_t N, int64_t Np) {
-    constexpr int VS = Vec16<T>::N;
-    typedef typename Vec16<T>::type vec_t;
-    __shared__ double red[4][2];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+template <int MODE>
+__global__ __launch_bounds__(256) void rowstats_kernel(const double* __restrict__ mu, const double* __restrict__ vpart, int njt,
+                                                       const double* __restrict__ y, const Scal* __restrict__ sc,
+                                                       double* __restrict__ o1, double* __restrict__ o2,
+                                                       double* __restrict__ partial, int64_t N, int64_t Np) {
+    __shared__ double red[2][256];
     const double kappa = sc->kappa;
     double t2 = 0, kb = 0;
-    const int64_t nw = (int64_t)gridDim.x * 4;
-    for (int64_t n = (int64_t)blockIdx.x * 4 + wave; n < Np; n += nw) {
-        double mu = 0;
-        for (int c = lane * VS; c < Kp; c += 64 * VS) {
-            const vec_t v = *reinterpret_cast<const vec_t*>(Phi + n * Kp + c);
-#pragma unroll
-            for (int e = 0; e < VS; ++e) mu += (double)v[e] * alpha[c + e];
-        }
+    for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < Np; n += (int64_t)gridDim.x * 256) {
         double v = 0;
-        for (int t = lane; t < njt; t += 64) v += vpart[(int64_t)t * Np + n];
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) { mu += __shfl_xor(mu, m); v += __shfl_xor(v, m); }
-        if (lane == 0) {
-            const double d = kappa * (v + 1.0);
-            if (MODE == 0) {
-                double pn = 0, qn = 0;
-                if (n < N) {
-                    const double r = mu - y[n];
-                    const double rv = r * r + v;
-                    const double e = 1.0 / d - rv / (d * d);
-                    pn = 2.0 * r / d;
-                    qn = 1.0 / d + kappa * e;
-                    t2 += rv / d + log(2.0 * M_PI * d);
-                    kb += e * (v + 1.0);
-                }
-                o1[n] = pn; o2[n] = qn;
-            } else if (n < N) {
-                o1[n] = mu; o2[n] = sqrt(d);
+        for (int t = 0; t < njt; ++t) v += vpart[(int64_t)t * Np + n];
+        const double d = kappa * (v + 1.0);
+        if (MODE == 0) {
+            double pn = 0, qn = 0;
+            if (n < N) {
+                const double r = mu[n] - y[n];
+                const double rv = r * r + v;
+                const double e = 1.0 / d - rv / (d * d);
+                pn = 2.0 * r / d;
+                qn = 1.0 / d + kappa * e;
+                t2 += rv / d + log(2.0 * M_PI * d);
+                kb += e * (v + 1.0);
             }
+            o1[n] = pn; o2[n] = qn;
+        } else if (n < N) {
+            o2[n] = sqrt(d);
         }
     }
     if (MODE == 0) {
-        if (lane == 0) { red[wave][0] = t2; red[wave][1] = kb; }
+        red[0][threadIdx.x] = t2; red[1][threadIdx.x] = kb;
         __syncthreads();
-        if (threadIdx.x < 2)
-            partial[blockIdx.x * 2 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        for (int w = 128; w >= 1; w >>= 1) {
+            if ((int)threadIdx.x < w) { red[0][threadIdx.x] += red[0][threadIdx.x + w]; red[1][threadIdx.x] += red[1][threadIdx.x + w]; }
+            __syncthreads();
+        }
+        if (threadIdx.x < 2) partial[blockIdx.x * 2 + threadIdx.x] = red[threadIdx.x][0];
     }
 }
 
 template <typename T>
-void SweepKernels<T>::rowstats(const Geom& g, const T* Phi, const double* alpha, const double* vpart, const double* y,
+void SweepKernels<T>::rowstats(const Geom& g, const double* mu, const double* vpart, const double* y,
                                const Scal* sc, double* p, double* q, double* partial, int nblocks, hipStream_t st) {
-    hipLaunchKernelGGL((rowstats_kernel<T, 0>), dim3(nblocks), dim3(256), 0, st, Phi, alpha, vpart, apply_njt<T>(g), y, sc, p, q,
-                       partial, g.Kp, g.N, g.Np);
+    hipLaunchKernelGGL((rowstats_kernel<0>), dim3(nblocks), dim3(256), 0, st, mu, vpart, apply_njt<T>(g), y, sc, p, q,
+                       partial, g.N, g.Np);
 }
 
 template <typename T>
-void SweepKernels<T>::rowpredict(const Geom& g, const T* Phi, const double* alpha, const double* vpart, const Scal* sc,
-                                 double* mu, double* sd, hipStream_t st) {
-    int nblocks = (int)((g.Np / 4) < 4096 ? (g.Np / 4) : 4096);
-    hipLaunchKernelGGL((rowstats_kernel<T, 1>), dim3(nblocks), dim3(256), 0, st, Phi, alpha, vpart, apply_njt<T>(g),
-                       (const double*)nullptr, sc, mu, sd, (double*)nullptr, g.Kp, g.N, g.Np);
+void SweepKernels<T>::rowpredict(const Geom& g, const double* vpart, const Scal* sc, double* mu, double* sd, hipStream_t st) {
+    const int nblocks = (int)((g.Np + 255) / 256 < 1024 ? (g.Np + 255) / 256 : 1024);
+    hipLaunchKernelGGL((rowstats_kernel<1>), dim3(nblocks), dim3(256), 0, st, mu, vpart, apply_njt<T>(g),
+                       (const double*)nullptr, sc, mu, sd, (double*)nullptr, g.N, g.Np);
 }
 
 // --------------------------------------------------------------------------

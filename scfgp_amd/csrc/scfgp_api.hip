@@ -41,7 +41,7 @@ struct scfgp_ctx {
     double *d_Xraw = nullptr, *d_yraw = nullptr; int64_t Nstore = 0, store_cap = 0; bool work_full = false;
     int64_t* d_idx = nullptr; int64_t idx_cap = 0;
     // rows
-    double *d_Xt = nullptr, *d_y = nullptr, *d_p = nullptr, *d_q = nullptr, *d_vpart = nullptr;
+    double *d_Xt = nullptr, *d_y = nullptr, *d_p = nullptr, *d_q = nullptr, *d_mu = nullptr, *d_vpart = nullptr;
     void *d_Phi = nullptr, *d_V = nullptr; double* d_bpart = nullptr;
     // exchange buffers and K-stage
     // exchange buffers xp1/xp2 = [packed lower tiles | vector Kp | 8 scalars], x3 = [X~^T Zbar | 8 scalars];
@@ -124,7 +124,7 @@ static int xtz_split(int ntiles, int64_t Np) {          // the X~^T Zbar grid ha
 }
 
 static void free_rows(scfgp_ctx* c) {
-    dfree(c->d_Xt); dfree(c->d_y); dfree(c->d_p); dfree(c->d_q); dfree(c->d_vpart);
+    dfree(c->d_Xt); dfree(c->d_y); dfree(c->d_p); dfree(c->d_q); dfree(c->d_mu); dfree(c->d_vpart);
     dfree(c->d_Phi); dfree(c->d_V); dfree(c->d_bpart); dfree(c->d_slabs);
     c->Ncap = 0; c->slabs_bytes = 0;
 }
@@ -148,7 +148,7 @@ static int ensure_rows(scfgp_ctx* c, int64_t N) {
         c->slabs_bytes = need;
     }
     if (Np <= c->Ncap) return SCFGP_OK;
-    dfree(c->d_Xt); dfree(c->d_y); dfree(c->d_p); dfree(c->d_q); dfree(c->d_vpart);
+    dfree(c->d_Xt); dfree(c->d_y); dfree(c->d_p); dfree(c->d_q); dfree(c->d_mu); dfree(c->d_vpart);
     dfree(c->d_Phi); dfree(c->d_V); dfree(c->d_bpart);
     c->Ncap = 0;
     const size_t ts = c->tsize();
@@ -157,6 +157,7 @@ static int ensure_rows(scfgp_ctx* c, int64_t N) {
     if ((rc = dmalloc(c, &c->d_y, sizeof(double) * Np))) return rc;
     if ((rc = dmalloc(c, &c->d_p, sizeof(double) * Np))) return rc;
     if ((rc = dmalloc(c, &c->d_q, sizeof(double) * Np))) return rc;
+    if ((rc = dmalloc(c, &c->d_mu, sizeof(double) * Np))) return rc;
     if ((rc = dmalloc(c, &c->d_vpart, sizeof(double) * Np * (g.Kp / 64)))) return rc;          // <= one entry per 64 columns
     if ((rc = dmalloc(c, &c->d_Phi, ts * Np * g.Kp))) return rc;
     if ((rc = dmalloc(c, &c->d_V, ts * Np * g.Kp))) return rc;
@@ -339,10 +340,10 @@ template <typename T> struct Impl {
     }
     static int pass2(scfgp_ctx* c, int want_grad) {
         const Geom& g = c->g;
-        { ProfScope ps(c, "apply_v"); SK::apply_v(g, (const T*)c->d_Phi, BT(c), (T*)c->d_V, c->d_vpart, c->st); }
+        { ProfScope ps(c, "apply_v"); SK::apply_v(g, (const T*)c->d_Phi, BT(c), (T*)c->d_V, c->d_vpart, c->alpha(), c->d_mu, c->st); }
         const int nb = (int)std::min<int64_t>(g.Np / 4, 2048);
         { ProfScope ps(c, "rowstats");
-          SK::rowstats(g, (const T*)c->d_Phi, c->alpha(), c->d_vpart, c->d_y, c->d_sc, c->d_p, c->d_q, c->d_partial, nb, c->st);
+          SK::rowstats(g, c->d_mu, c->d_vpart, c->d_y, c->d_sc, c->d_p, c->d_q, c->d_partial, nb, c->st);
           reduce_scalars(c->d_partial, nb, 2, c->d_xp2 + c->n_pk + g.Kp, 0, c->st); }
         if (want_grad) {
             gram_to(c, c->d_q, c->d_p, c->d_xp2, "gram_w");
@@ -373,8 +374,8 @@ template <typename T> struct Impl {
     }
     static int predict_chunk(scfgp_ctx* c, const Geom& g, const T* Bt) {
         SK::featuremap(g, c->p_Xt, c->d_Fall, c->d_sc, (T*)c->p_Phi, c->st);
-        SK::apply_v(g, (const T*)c->p_Phi, Bt, (T*)c->p_V, c->p_vpart, c->st);
-        SK::rowpredict(g, (const T*)c->p_Phi, c->alpha_pred(), c->p_vpart, c->d_sc, c->p_mu, c->p_sd, c->st);
+        SK::apply_v(g, (const T*)c->p_Phi, Bt, (T*)c->p_V, c->p_vpart, c->alpha_pred(), c->p_mu, c->st);
+        SK::rowpredict(g, c->p_vpart, c->d_sc, c->p_mu, c->p_sd, c->st);
         HIPCHK(c, hipGetLastError());
         return SCFGP_OK;
     }

@@ -177,20 +177,27 @@ struct NatLoader {
 
 // ---------------------------------------------------------------------------
 // TrLoader: source S[x][k] (row-major, k contiguous); transposes into s[k][x].
+//   With DOT and a vector d the loader also forms, in fp64 and from the values it stages anyway, the row
+//   dots dot[x] = sum_k S[x][k] d[k]  (mu = Phi.alpha rides along with the first column tile of Phi.B).
 // ---------------------------------------------------------------------------
-template <typename S, typename T, int BX, int BK, int LD, int THREADS>
+template <typename S, typename T, int BX, int BK, int LD, int THREADS, bool DOT = false>
 struct TrLoader {
     typedef typename Vec16<S>::type vec_t;
     static constexpr int VS = Vec16<S>::N;
     static constexpr int VPR = BK / VS;                       // vectors per x row
     static constexpr int NV = (BX * VPR + THREADS - 1) / THREADS;
+    static_assert(!DOT || (THREADS % VPR == 0 && (VPR & (VPR - 1)) == 0 && VPR <= 64), "DOT: a row's vectors sit in adjacent lanes");
     const S* ptr[NV]; int tid;
     vec_t r[1][NV];
-    __device__ __forceinline__ TrLoader(const S* b, int64_t l, int t) : tid(t) {
+    const double* dptr = nullptr; double dv[VS]; double dacc[NV]; bool dot_on = false;
+    __device__ __forceinline__ TrLoader(const S* b, int64_t l, int t, const double* d_ = nullptr) : tid(t) {
+        dot_on = DOT && d_ != nullptr;
+        if (dot_on) dptr = d_ + (t % VPR) * VS;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int v = tid + i * THREADS;
             ptr[i] = b + (int64_t)(v / VPR) * l + (v % VPR) * VS;
+            dacc[i] = 0;
         }
     }
     template <int SET = 0>
@@ -206,9 +213,14 @@ struct TrLoader {
             r[SET][i] = val;
             ptr[i] += BK;
         }
+        if (DOT && dot_on) {
+#pragma unroll
+            for (int e = 0; e < VS; ++e) dv[e] = dptr[e];
+            dptr += BK;
+        }
     }
     template <int SET = 0>
-    __device__ __forceinline__ void store(T* s) const {
+    __device__ __forceinline__ void store(T* s) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int v = tid + i * THREADS;
@@ -216,6 +228,21 @@ struct TrLoader {
             const int x = v / VPR, kv = v % VPR;
 #pragma unroll
             for (int e = 0; e < VS; ++e) s[(kv * VS + e) * LD + x] = (T)r[SET][i][e];
+            if (DOT && dot_on) {
+#pragma unroll
+                for (int e = 0; e < VS; ++e) dacc[i] = fma((double)r[SET][i][e], dv[e], dacc[i]);
+            }
+        }
+    }
+    // out[x] = dot[x] for the BX rows of this tile (all threads call)
+    __device__ __forceinline__ void dot_reduce(double* __restrict__ out) const {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            double s = dacc[i];
+#pragma unroll
+            for (int m = 1; m < VPR; m <<= 1) s += __shfl_xor(s, m);
+            const int v = tid + i * THREADS;
+            if (((BX * VPR) % THREADS == 0 || v < BX * VPR) && v % VPR == 0) out[v / VPR] = s;
         }
     }
 };
