@@ -129,8 +129,10 @@ int scfgp_pass2(scfgp_ctx* ctx, int want_grad);
 int scfgp_adjoint(scfgp_ctx* ctx);
 int scfgp_pass3(scfgp_ctx* ctx);
 int scfgp_finish(scfgp_ctx* ctx, int want_grad, double* cost, double* grad, double* alpha, double* Li);
-/* optional, any time after scfgp_factor: start copying alpha (K) and Li (K*K) to the host on a second
- * stream so the transfer overlaps passes 2 and 3; scfgp_finish waits for it (then pass NULL there). */
+/* optional, any time after scfgp_factor, best after the remaining stages are queued: copies alpha (K) and
+ * Li (K*K) to the host on a second stream through pinned staging and returns once they are in the caller's
+ * arrays.  It waits for the factor stage only, so the transfer and the host-side copy overlap passes 2 and 3
+ * (then pass NULL for both to scfgp_finish). */
 int scfgp_fetch_factors(scfgp_ctx* ctx, double* alpha, double* Li);
 /* device pointer + length (in doubles) of exchange buffer `stage` (1..3) */
 int scfgp_exchange(scfgp_ctx* ctx, int stage, void** dev_ptr, int64_t* count);

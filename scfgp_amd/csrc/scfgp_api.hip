@@ -30,7 +30,8 @@ struct scfgp_ctx {
     Geom g{};
     int dtype = 0, device = 0;
     hipStream_t st = nullptr; bool own_stream = false;
-    hipStream_t copy_st = nullptr; hipEvent_t ev_factor = nullptr; bool fetch_pending = false;   // alpha/Li D2H beside pass 2/3
+    hipStream_t copy_st = nullptr; hipEvent_t ev_factor = nullptr;          // alpha/Li D2H beside pass 2/3 ...
+    double* h_pin = nullptr;                                                // ... through pinned staging (K*K + K doubles)
     int64_t Ncap = 0, Nglobal = 0;
     bool have_params = false, have_data = false;
     int stage = 0, last_want_grad = 0;
@@ -243,6 +244,7 @@ extern "C" void scfgp_destroy(scfgp_ctx* c) {
     for (hipEvent_t e : c->pool) hipEventDestroy(e);
     if (c->copy_st) { hipStreamSynchronize(c->copy_st); hipStreamDestroy(c->copy_st); }
     if (c->ev_factor) hipEventDestroy(c->ev_factor);
+    if (c->h_pin) hipHostFree(c->h_pin);
     if (c->own_stream && c->st) hipStreamDestroy(c->st);
     delete c;
 }
@@ -440,11 +442,18 @@ extern "C" int scfgp_fetch_factors(scfgp_ctx* c, double* alpha, double* Li) {
     if (int rc = ready(c)) return rc;
     if (c->stage < 2) { c->err = "fetch_factors: call factor first"; return SCFGP_EARG; }
     const Geom& g = c->g;
+    // The factors are final once the factor stage is done.  They cross PCIe on the copy stream into pinned memory
+    // while the sweeps already queued behind the factor stage keep the GPU busy, and the host moves them on into the
+    // caller's (pageable) arrays during those sweeps instead of after the last one.
+    const size_t K = (size_t)g.K;
+    if (!c->h_pin) HIPCHK(c, hipHostMalloc((void**)&c->h_pin, sizeof(double) * (K * K + K), hipHostMallocDefault));
     HIPCHK(c, hipStreamWaitEvent(c->copy_st, c->ev_factor, 0));
-    if (alpha) HIPCHK(c, hipMemcpyAsync(alpha, c->alpha(), sizeof(double) * g.K, hipMemcpyDeviceToHost, c->copy_st));
-    if (Li) HIPCHK(c, hipMemcpy2DAsync(Li, sizeof(double) * g.K, c->d_Li, sizeof(double) * g.Kp, sizeof(double) * g.K, g.K,
+    if (alpha) HIPCHK(c, hipMemcpyAsync(c->h_pin + K * K, c->alpha(), sizeof(double) * K, hipMemcpyDeviceToHost, c->copy_st));
+    if (Li) HIPCHK(c, hipMemcpy2DAsync(c->h_pin, sizeof(double) * K, c->d_Li, sizeof(double) * g.Kp, sizeof(double) * K, K,
                                        hipMemcpyDeviceToHost, c->copy_st));
-    c->fetch_pending = true;
+    HIPCHK(c, hipStreamSynchronize(c->copy_st));
+    if (alpha) memcpy(alpha, c->h_pin + K * K, sizeof(double) * K);
+    if (Li) memcpy(Li, c->h_pin, sizeof(double) * K * K);
     return SCFGP_OK;
 }
 
@@ -472,7 +481,6 @@ extern "C" int scfgp_finish(scfgp_ctx* c, int want_grad, double* cost, double* g
                                            hipMemcpyDeviceToHost, c->st));
     }
     HIPCHK(c, hipStreamSynchronize(c->st));
-    if (c->fetch_pending) { HIPCHK(c, hipStreamSynchronize(c->copy_st)); c->fetch_pending = false; }
     HIPCHK(c, hipGetLastError());
     c->stage = 0; c->warm = true;
     if (cost) *cost = h_cost;

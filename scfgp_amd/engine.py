@@ -201,7 +201,7 @@ class HipEngine(object):
         self._early = None
 
     def fetch_factors(self):
-        """Start the alpha / Li device-to-host copy now (overlaps passes 2 and 3); finish() returns them."""
+        """Fetch alpha / Li as soon as the factor stage is done (overlaps the sweeps already queued); finish() returns them."""
         alpha = np.empty((self.K, 1)); Li = np.empty((self.K, self.K))
         self._check(self.lib.scfgp_fetch_factors(self.ctx, dptr(alpha), dptr(Li)), 'fetch_factors')
         self._early = (alpha, Li)

@@ -61,11 +61,10 @@ class ShardedEvaluator(object):
         e = self.engine
         e.pass1(); self._sum(1)
         e.factor()
-        e.pass2(want_grad)
-        if hasattr(e, 'fetch_factors'):
-            e.fetch_factors()               # alpha / Li travel to the host beside the remaining sweeps
-        self._sum(2)
+        e.pass2(want_grad); self._sum(2)
         if want_grad:
             e.adjoint()
             e.pass3(); self._sum(3)
+        if hasattr(e, 'fetch_factors'):
+            e.fetch_factors()               # everything is queued: alpha / Li reach the host beside the remaining sweeps
         return e.finish(want_grad)
