@@ -155,8 +155,7 @@ __device__ __forceinline__ void slab_flush(const typename Cfg::MTr::acc_t (&acc)
 // do not pair up, one 64-high STRIP of nfull+1 tiles (64 x 128) below them whose results occupy the upper halves of
 // the slabs of tile row nfull.  Diagonal tiles also produce the side vector sum_n s_n Phi[n][col] (s = y: Phi^T y,
 // s = p: Phi^T p) for their columns from the rows they stream anyway: sidepart[split][col].
-// One launch covers everything, longest jobs first (a workgroup lives for milliseconds, so the order in which the
-// hardware hands them out decides the tail): diagonal tiles, then off-diagonal tiles, then the half-size strip tiles.
+// One launch covers everything; the job order is described at the decode in gram_kernel.
 template <class Cfg, bool WEIGHT, bool STRIP>
 __device__ __forceinline__ void gram_body(
     const typename Cfg::T* __restrict__ Phi, int64_t ld, const double* __restrict__ w, const double* __restrict__ side,
@@ -192,23 +191,25 @@ __global__ __launch_bounds__(Cfg::THREADS) void gram_kernel(
     static_assert(Cfg::THREADS == SCfg::THREADS && Cfg::BN == SCfg::BN && Cfg::BM == Cfg::BN, "one launch, two tile shapes");
     SMEM_DECL;
     const int nall = nfull + nstrip, ntile_all = nall * (nall + 1) / 2;
-    const int ndiag = nfull * nsplit, noff = nfull * (nfull - 1) / 2 * nsplit;
-    int j = blockIdx.x;            // no XCD remap here: it would put a whole job class on one XCD (measured +8 %)
-    int split, acol, bcol, slab_t; bool diag = false, strip = false;
-    if (j < ndiag) {                                           // diagonal tiles (they also carry the side vector)
-        const int ti = j % nfull; split = j / nfull;
-        acol = bcol = ti * Cfg::BM; slab_t = ti * (ti + 1) / 2 + ti; diag = side != nullptr;
-    } else if (j < ndiag + noff) {                             // strictly lower tiles: u = (ti-1) ti / 2 + tj
-        j -= ndiag;
-        const int cnt = nfull * (nfull - 1) / 2, u = j % cnt; split = j / cnt;
+    // job id -> (split, tile): split-major, and inside a split the diagonal tiles, then the strictly lower tiles
+    // row by row, then the strip tiles.  The XCD map hands each XCD a contiguous range of job ids (whole splits),
+    // so the workgroups running together on one L2 work on the same rows and share operand panels, and every
+    // XCD's list ends with short strip jobs.
+    const int noff = nfull * (nfull - 1) / 2, per_split = nfull + noff + nstrip * (nfull + 1);
+    const int j = (int)xcd_remap(blockIdx.x, gridDim.x);
+    const int split = j / per_split;
+    int u = j % per_split, acol, bcol, slab_t; bool diag = false, strip = false;
+    if (u < nfull) {                                           // diagonal tiles (they also carry the side vector)
+        acol = bcol = u * Cfg::BM; slab_t = u * (u + 1) / 2 + u; diag = side != nullptr;
+    } else if (u < nfull + noff) {                             // strictly lower tiles: u = (ti-1) ti / 2 + tj
+        u -= nfull;
         int tq = (int)((sqrtf(8.0f * u + 1.0f) - 1.0f) * 0.5f);
         while ((tq + 1) * (tq + 2) / 2 <= u) ++tq;
         while (tq * (tq + 1) / 2 > u) --tq;
         const int ti = tq + 1, tj = u - tq * (tq + 1) / 2;
         acol = ti * Cfg::BM; bcol = tj * Cfg::BN; slab_t = ti * (ti + 1) / 2 + tj;
     } else {                                                   // strip tiles
-        j -= ndiag + noff;
-        const int tj = j % (nfull + 1); split = j / (nfull + 1);
+        const int tj = u - nfull - noff;
         acol = nfull * Cfg::BN; bcol = tj * Cfg::BN; slab_t = nfull * (nfull + 1) / 2 + tj;
         strip = true; diag = side != nullptr && tj == nfull;
     }

@@ -65,7 +65,7 @@ struct scfgp_ctx {
     hipGraph_t graph = nullptr; hipGraphExec_t gexec = nullptr; int64_t graph_N = -1; bool in_train = false, warm = false;
     int use_graph = 1;
     // options
-    int gram_nsplit = 0, xtz_nsplit = 0, cs_nsplit = 128; int64_t gram_chunk = 4096;
+    int gram_nsplit = 0, xtz_nsplit = 0; int64_t gram_chunk = 4096;
     // profiling
     bool prof = false; std::vector<ProfRec> recs; std::vector<hipEvent_t> pool; size_t pool_used = 0;
     std::string err;
@@ -214,7 +214,7 @@ extern "C" int scfgp_create(scfgp_ctx** out, int D, int S, int M, int dtype, int
     if ((rc = dmalloc(c, &c->d_scalars, sizeof(double) * 32))) return rc;
     if ((rc = dmalloc(c, &c->d_yy, sizeof(double) * 8))) return rc;
     if ((rc = dmalloc(c, &c->d_flag, sizeof(int) * 4))) return rc;
-    c->n_partial = std::max<int64_t>((int64_t)c->cs_nsplit * Kp, 16384);
+    c->n_partial = 16384;                                             // block partials of the scalar reductions
     if ((rc = dmalloc(c, &c->d_partial, sizeof(double) * c->n_partial))) return rc;
     if ((rc = dmalloc(c, &c->d_work, sizeof(double) * (4 * D + 4 + (int64_t)D * M)))) return rc;
     if ((rc = dmalloc(c, &c->d_grad, sizeof(double) * g.P))) return rc;
