@@ -41,7 +41,8 @@ template <typename T> struct GramStripCfg {
     typedef TileCfg<T, 64, 128, SCFGP_BK, Tune<T>::GRAM_WGM / 2, Tune<T>::GRAM_WGN * 2, Tune<T>::MS> type;
 };
 template <typename T, int TILE> struct ApplyCfg {
-    typedef TileCfg<T, Tune<T>::APPLY_BM, TILE, SCFGP_BK, Tune<T>::APPLY_WGM, Tune<T>::apply_wgn(TILE), Tune<T>::MS> type;
+    typedef TileCfg<T, Tune<T>::APPLY_BM, TILE, SCFGP_BK, Tune<T>::APPLY_WGM, Tune<T>::apply_wgn(TILE), Tune<T>::MS,
+                    sizeof(T) == 4 && SCFGP_BK == 16 && Tune<T>::MS == 16> type;
 };
 #ifndef SCFGP_FMAP_WGM
 #define SCFGP_FMAP_WGM 4     // 8 waves: one wave's fp64 sincos overlaps another's projection MFMAs
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void apply_kernel(
     const int cbase = col0 + jt * Cfg::BN;
     // EPI 0: the workgroups of the first column tile also form mu = Phi.alpha for their rows
     const bool want_mu = EPI == 0 && mu != nullptr && jt0 + jt == 0;
-    TrLoader<T, T, Cfg::BM, Cfg::BK, Cfg::LDA, Cfg::THREADS, EPI == 0> la(Phi + rb * Cfg::BM * Kp, Kp, threadIdx.x,
+    TrLoader<T, T, Cfg::BM, Cfg::BK, Cfg::LDA, Cfg::THREADS, EPI == 0, Cfg::SWZA> la(Phi + rb * Cfg::BM * Kp, Kp, threadIdx.x,
                                                                         want_mu ? alpha : nullptr);
     NatLoader<T, T, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS, false, false> lb(Bm + cbase, Kp, threadIdx.x);
     typename Cfg::MTr::acc_t acc[Cfg::TM][Cfg::TN];
