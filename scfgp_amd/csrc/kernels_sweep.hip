@@ -42,12 +42,12 @@ template <typename T> struct GramStripCfg {
 };
 template <typename T, int TILE> struct ApplyCfg {
     typedef TileCfg<T, Tune<T>::APPLY_BM, TILE, SCFGP_BK, Tune<T>::APPLY_WGM, Tune<T>::apply_wgn(TILE), Tune<T>::MS,
-                    sizeof(T) == 4 && SCFGP_BK == 16 && Tune<T>::MS == 16> type;
+                    SCFGP_BK == 16 && Tune<T>::MS == 16> type;                 // swizzled Phi image (TrLoader)
 };
 #ifndef SCFGP_FMAP_WGM
 #define SCFGP_FMAP_WGM 4     // 8 waves: one wave's fp64 sincos overlaps another's projection MFMAs
 #endif
-typedef TileCfg<double, 128, 64, 16, SCFGP_FMAP_WGM, 2> FmapCfg;
+typedef TileCfg<double, 128, 64, 16, SCFGP_FMAP_WGM, 2, 16, true> FmapCfg;    // swizzled X~ image (TrLoader)
 template <typename T> struct XtzCfg { typedef TileCfg<T, 128, 128, 16, 4, 2, Tune<T>::MS> type; };
 
 // --------------------------------------------------------------------------
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(FmapCfg::THREADS) void featuremap_kernel(
     double* smem = reinterpret_cast<double*>(smem_raw);
     const int jt = blockIdx.x % njt;
     const int64_t rb = blockIdx.x / njt;
-    TrLoader<double, double, Cfg::BM, Cfg::BK, Cfg::LDA, Cfg::THREADS> la(Xt + rb * Cfg::BM * Dp, Dp, threadIdx.x);
+    TrLoader<double, double, Cfg::BM, Cfg::BK, Cfg::LDA, Cfg::THREADS, false, Cfg::SWZA> la(Xt + rb * Cfg::BM * Dp, Dp, threadIdx.x);
     NatLoader<double, double, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS, false, false> lb(Fall + jt * Cfg::BN, Jp, threadIdx.x);
     typename Cfg::MTr::acc_t acc[Cfg::TM][Cfg::TN];
     acc_zero<Cfg>(acc);

@@ -50,14 +50,14 @@ template <> struct MT<float, 32> {
     static __device__ __forceinline__ int crow(int lane, int r) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 };
 
-// SWZA: the A image is written by a TrLoader<..., SWZ = true> (column index XOR 8*(k/4), see there)
+// SWZA: the A image is written by a TrLoader<..., SWZ = true> (column index XOR-swizzled, see there)
 template <typename T_, int BM_, int BN_, int BK_, int WGM_, int WGN_, int MS_ = 16, bool SWZA_ = false>
 struct TileCfg {
     typedef T_ T;
     typedef MT<T_, MS_> MTr;
     static constexpr int BM = BM_, BN = BN_, BK = BK_, WGM = WGM_, WGN = WGN_, MS = MS_;
     static constexpr bool SWZA = SWZA_;
-    static_assert(!SWZA_ || (sizeof(T_) == 4 && BK_ == 16 && MS_ == 16), "swizzle is laid out for fp32, BK = 16, 16x16x4");
+    static_assert(!SWZA_ || (BK_ == 16 && MS_ == 16), "swizzle is laid out for BK = 16 and the 16x16x4 shapes");
     static constexpr int THREADS = 64 * WGM * WGN;
     static constexpr int WM = BM / WGM, WN = BN / WGN;
     static constexpr int TM = WM / MS, TN = WN / MS;
@@ -183,10 +183,12 @@ struct NatLoader {
 //   With DOT and a vector d the loader also forms, in fp64 and from the values it stages anyway, the row
 //   dots dot[x] = sum_k S[x][k] d[k]  (mu = Phi.alpha rides along with the first column tile of Phi.B).
 // ---------------------------------------------------------------------------
-//   SWZ (fp32, BK = 16): element (k, x) is stored at column x ^ 8*(k/4).  A thread holds 4 consecutive k of
-//   one row, so the 4 threads of a row write k/4 = 0..3: without the swizzle their banks coincide (row stride
-//   == 16 mod 32) and every transposing store is a 4-way conflict; with it the 32 lanes of a store group hit
-//   32 banks.  Fragment reads of one k-step share k/4, so they stay 16 consecutive, conflict-free columns.
+//   SWZ (BK = 16): element (k, x) is stored at column x ^ SZ*(k/VS), SZ = 8 (fp32, VS = 4) or 2 (fp64, VS = 2).
+//   A thread holds VS consecutive k of one row, so the threads of a row write k/VS = 0, 1, ...: without the
+//   swizzle their banks coincide (the row stride is a multiple of 16 elements) and every transposing store is
+//   a 4-way (fp32) or 8-way (fp64) bank conflict; with it the lanes of a store group spread over all banks.
+//   Fragment reads XOR the same constant (tile_compute): within a 16-lane group it only permutes the group's 16
+//   columns, so reads stay conflict-free.
 template <typename S, typename T, int BX, int BK, int LD, int THREADS, bool DOT = false, bool SWZ = false>
 struct TrLoader {
     typedef typename Vec16<S>::type vec_t;
@@ -234,7 +236,7 @@ struct TrLoader {
             if ((BX * VPR) % THREADS != 0 && v >= BX * VPR) continue;
             const int x = v / VPR, kv = v % VPR;
 #pragma unroll
-            for (int e = 0; e < VS; ++e) s[(kv * VS + e) * LD + (SWZ ? x ^ (8 * kv) : x)] = (T)r[SET][i][e];
+            for (int e = 0; e < VS; ++e) s[(kv * VS + e) * LD + (SWZ ? x ^ ((sizeof(T) == 4 ? 8 : 2) * kv) : x)] = (T)r[SET][i][e];
             if (DOT && dot_on) {
 #pragma unroll
                 for (int e = 0; e < VS; ++e) dacc[i] = fma((double)r[SET][i][e], dv[e], dacc[i]);
@@ -315,15 +317,21 @@ __device__ __forceinline__ void tile_compute(const typename Cfg::T* sA, const ty
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm0 = (wave / Cfg::WGN) * Cfg::WM, wn0 = (wave % Cfg::WGN) * Cfg::WN;
     const T* a_s = sA + (lane / MS) * Cfg::LDA + wm0 + (lane % MS);
-    const T* a_x = sA + (lane / MS) * Cfg::LDA + wm0 + ((lane % MS) ^ 8);       // SWZA: column ^ 8 for odd k-steps
     const T* b_s = sB + (lane / MS) * Cfg::LDB + wn0 + (lane % MS);
+    // SWZA: lane (q = lane/16, i = lane%16) reads row k = 4 kk + q of k-step kk at column (..+i) ^ SZ*(k/VS):
+    //   fp32: 8 kk          -> i ^ 8 for odd kk, neighbouring 16-column group for kk >= 2
+    //   fp64: 4 kk + 2(q/2) -> stays inside the lane's own 16-column group
+    const int q = lane / MS;
+    const T* a_x = sA + q * Cfg::LDA + wm0 + ((lane % MS) ^ 8);                  // fp32, odd kk
 #pragma unroll
     for (int kk = 0; kk < Cfg::BK / KS; ++kk) {
         T a[Cfg::TM], b[Cfg::TN];
 #pragma unroll
-        for (int tm = 0; tm < Cfg::TM; ++tm)
-            a[tm] = Cfg::SWZA ? ((kk & 1) ? a_x : a_s)[kk * KS * Cfg::LDA + (tm ^ ((kk >> 1) & 1)) * MS]   // column ^ 8*kk
-                              : a_s[kk * KS * Cfg::LDA + tm * MS];
+        for (int tm = 0; tm < Cfg::TM; ++tm) {
+            if (!Cfg::SWZA) a[tm] = a_s[kk * KS * Cfg::LDA + tm * MS];
+            else if (sizeof(T) == 4) a[tm] = ((kk & 1) ? a_x : a_s)[kk * KS * Cfg::LDA + (tm ^ ((kk >> 1) & 1)) * MS];
+            else a[tm] = sA[(kk * KS + q) * Cfg::LDA + wm0 + tm * MS + (((lane % MS) ^ (2 * (q >> 1))) ^ (4 * kk))];
+        }
 #pragma unroll
         for (int tn = 0; tn < Cfg::TN; ++tn) b[tn] = b_s[kk * KS * Cfg::LDB + tn * MS];
 #pragma unroll
