@@ -18,6 +18,9 @@
 #ifndef SCFGP_BK
 #define SCFGP_BK 16
 #endif
+#ifndef SCFGP_GRAM_BK
+#define SCFGP_GRAM_BK SCFGP_BK
+#endif
 #ifndef SCFGP_F32_MS
 #define SCFGP_F32_MS 16          // fp32 MFMA shape: 16 -> 16x16x4, 32 -> 32x32x2
 #endif
@@ -34,11 +37,11 @@ template <> struct Tune<double> {
     static constexpr int apply_wgn(int) { return 4; }
 };
 template <typename T, int TILE> struct GramCfg {
-    typedef TileCfg<T, TILE, TILE, SCFGP_BK, Tune<T>::GRAM_WGM, Tune<T>::GRAM_WGN, Tune<T>::MS> type;
+    typedef TileCfg<T, TILE, TILE, SCFGP_GRAM_BK, Tune<T>::GRAM_WGM, Tune<T>::GRAM_WGN, Tune<T>::MS> type;
 };
 // the 64-high strip below the square tiles: same workgroup size (one launch), 32 x 32 wave tiles
 template <typename T> struct GramStripCfg {
-    typedef TileCfg<T, 64, 128, SCFGP_BK, Tune<T>::GRAM_WGM / 2, Tune<T>::GRAM_WGN * 2, Tune<T>::MS> type;
+    typedef TileCfg<T, 64, 128, SCFGP_GRAM_BK, Tune<T>::GRAM_WGM / 2, Tune<T>::GRAM_WGN * 2, Tune<T>::MS> type;
 };
 template <typename T, int TILE> struct ApplyCfg {
     typedef TileCfg<T, Tune<T>::APPLY_BM, TILE, SCFGP_BK, Tune<T>::APPLY_WGM, Tune<T>::apply_wgn(TILE), Tune<T>::MS,
