@@ -85,6 +85,22 @@ __device__ __forceinline__ void fast_sincos(double z, double& sn, double& cs) {
     cs = ((q + 1) & 2) ? -cc : cc;
 }
 
+// fp32 outputs: the same fp64 reduction (the phase itself needs it: |z| ~ 1e2 rad at 2^-24 would already be
+// 1e-5), then the reduced argument in fp32 with the cephes sinf / cosf kernel polynomials on [-pi/4, pi/4]
+// (~1 ulp of fp32, the precision Phi is stored in): a third of the VALU work of the fp64 kernels.
+__device__ __forceinline__ void fast_sincos(double z, float& sn, float& cs) {
+    const double fn = rint(z * 6.36619772367581382433e-01);
+    const double r = fma(-fn, 6.07710050650619224932e-11, fma(-fn, 1.57079632673412561417e+00, z));
+    const float x = (float)r, z2 = x * x;
+    const float s = fmaf(x * z2, fmaf(z2, fmaf(z2, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f), x);
+    const float c = fmaf(z2 * z2, fmaf(z2, fmaf(z2, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f),
+                         fmaf(-0.5f, z2, 1.0f));
+    const int q = (int)fn & 3;
+    const float ss = (q & 1) ? c : s, cc = (q & 1) ? s : c;
+    sn = (q & 2) ? -ss : ss;
+    cs = ((q + 1) & 2) ? -cc : cc;
+}
+
 // --------------------------------------------------------------------------
 // feature map:  Z = X~ . Fall  (fp64 MFMA, K-dim = Dp),  Phi = s [cos Z | sin Z]
 // --------------------------------------------------------------------------
@@ -103,6 +119,7 @@ __global__ __launch_bounds__(FmapCfg::THREADS) void featuremap_kernel(
     acc_zero<Cfg>(acc);
     tile_mainloop<Cfg>(la, lb, Dp / Cfg::BK, acc, smem);
     const double s = sc->s;
+    const T s_hi = (T)s, s_lo = (T)(s - (double)s_hi);
     AccCoord<Cfg> co;
 #pragma unroll
     for (int tm = 0; tm < Cfg::TM; ++tm)
@@ -113,11 +130,11 @@ __global__ __launch_bounds__(FmapCfg::THREADS) void featuremap_kernel(
 #pragma unroll
             for (int r = 0; r < Cfg::MTr::NACC; ++r) {
                 const int64_t n = rb * Cfg::BM + co.row(tm, r);
-                double sn, cs;
+                T sn, cs;                                          // fp64 or fp32 kernels by output type
                 fast_sincos(acc[tm][tn][r], sn, cs);
-                const double m = n < N ? s : 0.0;
-                Phi[n * Kp + j] = (T)(m * cs);
-                Phi[n * Kp + J + j] = (T)(m * sn);
+                // scale s = s_hi + s_lo in T: a rounded scale alone would bias every entry of Phi the same way
+                Phi[n * Kp + j] = n < N ? fma(cs, s_hi, cs * s_lo) : (T)0;
+                Phi[n * Kp + J + j] = n < N ? fma(sn, s_hi, sn * s_lo) : (T)0;
             }
         }
 }
