@@ -23,9 +23,9 @@ template <typename T> struct SweepKernels {
     // and, from the diagonal tiles, sidepart[split][Kp] = partials of Phi^T side (side = y: SCFGP.py:108)
     static void gram(const Geom& g, const T* Phi, const double* w, const double* side, int nsplit, int64_t chunk, double* slabs,
                      double* sidepart, hipStream_t st);
-    // V = Phi . Bm, vpart[jt][n] = sum_{j in tile} Phi[n][j] V[n][j]    (SCFGP.py:112); the first column tile's
-    // workgroups also form mu = Phi . alpha (SCFGP.py:111 / :143) from the rows they stage
-    static void apply_v(const Geom& g, const T* Phi, const T* Bm, T* V, double* vpart, const double* alpha, double* mu,
+    // V = Phi . Bm, vpart[jt][n] = sum_{j in tile} Phi[n][j] V[n][j]    (SCFGP.py:112); column tile jt also forms
+    // mupart[jt][n] = its slice of mu = Phi . alpha (SCFGP.py:111 / :143) from the rows it stages
+    static void apply_v(const Geom& g, const T* Phi, const T* Bm, T* V, double* vpart, const double* alpha, double* mupart,
                         hipStream_t st);
     // Phibar = 2 Phi.Abar + 2 q V + p alpha^T + y ut^T  (in place over V); bpart[block] = partial of
     // bbar = sum Phibar o Phi.  Returns the number of blocks (= partials written).
@@ -33,10 +33,11 @@ template <typename T> struct SweepKernels {
                             const double* y, const double* alpha, const double* ut, double* bpart, hipStream_t st);
     static int apply_blocks(const Geom& g);
     // per-row moments and adjoint scalars; block partials of (T2, kbar)  (SCFGP.py:111-113,121-124)
-    static void rowstats(const Geom& g, const double* mu, const double* vpart, const double* y,
+    static void rowstats(const Geom& g, const double* mupart, const double* vpart, const double* y,
                          const Scal* sc, double* p, double* q, double* partial, int nblocks, hipStream_t st);
     // predictive mean / std                                          (SCFGP.py:143-144)
-    static void rowpredict(const Geom& g, const double* vpart, const Scal* sc, double* mu, double* sd, hipStream_t st);
+    static void rowpredict(const Geom& g, const double* mupart, const double* vpart, const Scal* sc, double* mu, double* sd,
+                           hipStream_t st);
     // X~^T Zbar into per-split fp64 slabs, Zbar[n][j] = Phi[n][j] Phibar[n][J+j] - Phi[n][J+j] Phibar[n][j]
     // formed inside the operand loader
     static void xtz(const Geom& g, const double* Xt, const T* Phi, const T* Phibar, int nsplit, int64_t chunk, double* slabs,

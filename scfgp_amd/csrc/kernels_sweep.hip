@@ -320,7 +320,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void apply_kernel(
     const typename Cfg::T* __restrict__ Phi, const typename Cfg::T* __restrict__ Bm, typename Cfg::T* V,
     double* __restrict__ vpart, const double* __restrict__ p, const double* __restrict__ q, const double* __restrict__ y,
     const double* __restrict__ alpha, const double* __restrict__ ut, int K, int Kp, int64_t Np, int njt,
-    double* __restrict__ bpart, int col0, int jt0, double* __restrict__ mu) {
+    double* __restrict__ bpart, int col0, int jt0, double* __restrict__ mu, int ntot) {
     // this launch covers columns [col0, col0 + njt*BN); jt0 = index of its first tile in vpart
     typedef typename Cfg::T T;
     SMEM_DECL;
@@ -329,10 +329,10 @@ __global__ __launch_bounds__(Cfg::THREADS) void apply_kernel(
     const int jt = wid % njt;
     const int64_t rb = wid / njt;
     const int cbase = col0 + jt * Cfg::BN;
-    // EPI 0: the workgroups of the first column tile also form mu = Phi.alpha for their rows
-    const bool want_mu = EPI == 0 && mu != nullptr && jt0 + jt == 0;
+    // EPI 0: column tile t of ntot also forms the slice kt % ntot == t of mu = Phi.alpha for its rows
+    const bool want_mu = EPI == 0 && mu != nullptr;
     TrLoader<T, T, Cfg::BM, Cfg::BK, Cfg::LDA, Cfg::THREADS, EPI == 0, Cfg::SWZA> la(Phi + rb * Cfg::BM * Kp, Kp, threadIdx.x,
-                                                                        want_mu ? alpha : nullptr);
+                                                                        want_mu ? alpha : nullptr, jt0 + jt, ntot);
     NatLoader<T, T, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS, false, false> lb(Bm + cbase, Kp, threadIdx.x);
     typename Cfg::MTr::acc_t acc[Cfg::TM][Cfg::TN];
     acc_zero<Cfg>(acc);
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void apply_kernel(
     tile_mainloop<Cfg>(la, lb, (K + Cfg::BK - 1) / Cfg::BK, acc, smem);
     AccCoord<Cfg> co;
     if (EPI == 0) {
-        if (want_mu) la.dot_reduce(mu + rb * Cfg::BM);
+        if (want_mu) la.dot_reduce(mu + (int64_t)(jt0 + jt) * Np + rb * Cfg::BM);
         double* red = reinterpret_cast<double*>(smem_raw);          // [WGN][BM]; main loop ended with a barrier
         const int wn = (threadIdx.x >> 6) % Cfg::WGN;
 #pragma unroll
@@ -425,7 +425,7 @@ static int apply_launch_cfg(const Geom& g, int njt, int col0, int jt0, int boff,
     const int64_t nrb = g.Np / Cfg::BM;
     allow_big_lds(apply_kernel<Cfg, EPI>, Cfg::LDS_BYTES);
     hipLaunchKernelGGL((apply_kernel<Cfg, EPI>), dim3((unsigned)(njt * nrb)), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st,
-                       Phi, Bm, V, vpart, p, q, y, alpha, ut, g.K, g.Kp, g.Np, njt, bpart ? bpart + boff : nullptr, col0, jt0, mu);
+                       Phi, Bm, V, vpart, p, q, y, alpha, ut, g.K, g.Kp, g.Np, njt, bpart ? bpart + boff : nullptr, col0, jt0, mu, ApplyPlan<T>(g.K).total);
     return (int)(njt * nrb);
 }
 template <typename T, int EPI>
@@ -460,14 +460,14 @@ int SweepKernels<T>::apply_blocks(const Geom& g) {
 
 
 // --------------------------------------------------------------------------
-// per-row statistics from mu (apply_v's by-product) and the per-tile row dots: one thread per row.
-//   v = sum_jt vpart, d = kappa (v+1), r = mu - y
+// per-row statistics from apply_v's per-tile by-products: one thread per row.
+//   mu = sum_jt mupart, v = sum_jt vpart, d = kappa (v+1), r = mu - y
 //   MODE 0 (train): p = 2r/d, e = 1/d - (r^2+v)/d^2, q = 1/d + kappa e; block partials of
 //                   T2 = (r^2+v)/d + log(2 pi d) and kbar = e (v+1)
-//   MODE 1 (predict): sd = sqrt(kappa (1+v))      (mu is already in place)
+//   MODE 1 (predict): mu, sd = sqrt(kappa (1+v))
 // --------------------------------------------------------------------------
 template <int MODE>
-__global__ __launch_bounds__(256) void rowstats_kernel(const double* __restrict__ mu, const double* __restrict__ vpart, int njt,
+__global__ __launch_bounds__(256) void rowstats_kernel(const double* __restrict__ mupart, const double* __restrict__ vpart, int njt,
                                                        const double* __restrict__ y, const Scal* __restrict__ sc,
                                                        double* __restrict__ o1, double* __restrict__ o2,
                                                        double* __restrict__ partial, int64_t N, int64_t Np) {
@@ -475,13 +475,13 @@ __global__ __launch_bounds__(256) void rowstats_kernel(const double* __restrict_
     const double kappa = sc->kappa;
     double t2 = 0, kb = 0;
     for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < Np; n += (int64_t)gridDim.x * 256) {
-        double v = 0;
-        for (int t = 0; t < njt; ++t) v += vpart[(int64_t)t * Np + n];
+        double v = 0, mu = 0;
+        for (int t = 0; t < njt; ++t) { v += vpart[(int64_t)t * Np + n]; mu += mupart[(int64_t)t * Np + n]; }
         const double d = kappa * (v + 1.0);
         if (MODE == 0) {
             double pn = 0, qn = 0;
             if (n < N) {
-                const double r = mu[n] - y[n];
+                const double r = mu - y[n];
                 const double rv = r * r + v;
                 const double e = 1.0 / d - rv / (d * d);
                 pn = 2.0 * r / d;
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(256) void rowstats_kernel(const double* __restrict_
             }
             o1[n] = pn; o2[n] = qn;
         } else if (n < N) {
-            o2[n] = sqrt(d);
+            o1[n] = mu; o2[n] = sqrt(d);
         }
     }
     if (MODE == 0) {
@@ -506,16 +506,17 @@ __global__ __launch_bounds__(256) void rowstats_kernel(const double* __restrict_
 }
 
 template <typename T>
-void SweepKernels<T>::rowstats(const Geom& g, const double* mu, const double* vpart, const double* y,
+void SweepKernels<T>::rowstats(const Geom& g, const double* mupart, const double* vpart, const double* y,
                                const Scal* sc, double* p, double* q, double* partial, int nblocks, hipStream_t st) {
-    hipLaunchKernelGGL((rowstats_kernel<0>), dim3(nblocks), dim3(256), 0, st, mu, vpart, apply_njt<T>(g), y, sc, p, q,
+    hipLaunchKernelGGL((rowstats_kernel<0>), dim3(nblocks), dim3(256), 0, st, mupart, vpart, apply_njt<T>(g), y, sc, p, q,
                        partial, g.N, g.Np);
 }
 
 template <typename T>
-void SweepKernels<T>::rowpredict(const Geom& g, const double* vpart, const Scal* sc, double* mu, double* sd, hipStream_t st) {
+void SweepKernels<T>::rowpredict(const Geom& g, const double* mupart, const double* vpart, const Scal* sc, double* mu, double* sd,
+                                 hipStream_t st) {
     const int nblocks = (int)((g.Np + 255) / 256 < 1024 ? (g.Np + 255) / 256 : 1024);
-    hipLaunchKernelGGL((rowstats_kernel<1>), dim3(nblocks), dim3(256), 0, st, mu, vpart, apply_njt<T>(g),
+    hipLaunchKernelGGL((rowstats_kernel<1>), dim3(nblocks), dim3(256), 0, st, mupart, vpart, apply_njt<T>(g),
                        (const double*)nullptr, sc, mu, sd, (double*)nullptr, g.N, g.Np);
 }
 

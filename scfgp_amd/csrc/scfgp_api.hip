@@ -59,7 +59,7 @@ struct scfgp_ctx {
     int xs_mode = 0; double* d_xscale = nullptr;                 // X scaler for scfgp_predict_raw (5*D doubles)
     int ys_mode = 0; double* d_yscale = nullptr;                 // y scaler for scfgp_predict_y (5 doubles)
     // predict chunk buffers
-    double *p_Xt = nullptr, *p_vpart = nullptr, *p_mu = nullptr, *p_sd = nullptr; void *p_Phi = nullptr, *p_V = nullptr;
+    double *p_Xt = nullptr, *p_vpart = nullptr, *p_mupart = nullptr, *p_mu = nullptr, *p_sd = nullptr; void *p_Phi = nullptr, *p_V = nullptr;
     // on-device optimiser + captured training iteration
     int opt_algo = -1; OptHyper opt_h{}; double *d_opt = nullptr, *d_tctr = nullptr, *d_hist = nullptr; int hist_cap = 0;
     hipGraph_t graph = nullptr; hipGraphExec_t gexec = nullptr; int64_t graph_N = -1; bool in_train = false, warm = false;
@@ -158,7 +158,7 @@ static int ensure_rows(scfgp_ctx* c, int64_t N) {
     if ((rc = dmalloc(c, &c->d_y, sizeof(double) * Np))) return rc;
     if ((rc = dmalloc(c, &c->d_p, sizeof(double) * Np))) return rc;
     if ((rc = dmalloc(c, &c->d_q, sizeof(double) * Np))) return rc;
-    if ((rc = dmalloc(c, &c->d_mu, sizeof(double) * Np))) return rc;
+    if ((rc = dmalloc(c, &c->d_mu, sizeof(double) * Np * (g.Kp / 64)))) return rc;           // mupart, like vpart
     if ((rc = dmalloc(c, &c->d_vpart, sizeof(double) * Np * (g.Kp / 64)))) return rc;          // <= one entry per 64 columns
     if ((rc = dmalloc(c, &c->d_Phi, ts * Np * g.Kp))) return rc;
     if ((rc = dmalloc(c, &c->d_V, ts * Np * g.Kp))) return rc;
@@ -237,7 +237,7 @@ extern "C" void scfgp_destroy(scfgp_ctx* c) {
     dfree(c->d_xp1); dfree(c->d_xp2); dfree(c->d_x1); dfree(c->d_x2); dfree(c->d_x3); dfree(c->d_Li); dfree(c->d_B); dfree(c->d_T1); dfree(c->d_T2);
     dfree(c->d_Abar); dfree(c->d_BT); dfree(c->d_AbarT); dfree(c->d_vecs); dfree(c->d_scalars); dfree(c->d_yy);
     dfree(c->d_flag); dfree(c->d_partial); dfree(c->d_work); dfree(c->d_grad);
-    dfree(c->p_Xt); dfree(c->p_vpart); dfree(c->p_mu); dfree(c->p_sd); dfree(c->p_Phi); dfree(c->p_V);
+    dfree(c->p_Xt); dfree(c->p_vpart); dfree(c->p_mupart); dfree(c->p_mu); dfree(c->p_sd); dfree(c->p_Phi); dfree(c->p_V);
     if (c->gexec) hipGraphExecDestroy(c->gexec);
     if (c->graph) hipGraphDestroy(c->graph);
     dfree(c->d_opt); dfree(c->d_tctr); dfree(c->d_hist);
@@ -376,8 +376,8 @@ template <typename T> struct Impl {
     }
     static int predict_chunk(scfgp_ctx* c, const Geom& g, const T* Bt) {
         SK::featuremap(g, c->p_Xt, c->d_Fall, c->d_sc, (T*)c->p_Phi, c->st);
-        SK::apply_v(g, (const T*)c->p_Phi, Bt, (T*)c->p_V, c->p_vpart, c->alpha_pred(), c->p_mu, c->st);
-        SK::rowpredict(g, c->p_vpart, c->d_sc, c->p_mu, c->p_sd, c->st);
+        SK::apply_v(g, (const T*)c->p_Phi, Bt, (T*)c->p_V, c->p_vpart, c->alpha_pred(), c->p_mupart, c->st);
+        SK::rowpredict(g, c->p_mupart, c->p_vpart, c->d_sc, c->p_mu, c->p_sd, c->st);
         HIPCHK(c, hipGetLastError());
         return SCFGP_OK;
     }
@@ -548,6 +548,7 @@ static int predict_impl(scfgp_ctx* c, const double* Xs, int64_t T, const double*
     if (!c->p_Xt) {
         if ((rc = dmalloc(c, &c->p_Xt, sizeof(double) * PRED_ROWS * g0.Dp))) return rc;
         if ((rc = dmalloc(c, &c->p_vpart, sizeof(double) * PRED_ROWS * (Kp / 64)))) return rc;
+        if ((rc = dmalloc(c, &c->p_mupart, sizeof(double) * PRED_ROWS * (Kp / 64)))) return rc;
         if ((rc = dmalloc(c, &c->p_mu, sizeof(double) * PRED_ROWS))) return rc;
         if ((rc = dmalloc(c, &c->p_sd, sizeof(double) * PRED_ROWS))) return rc;
         if ((rc = dmalloc(c, &c->p_Phi, ts * PRED_ROWS * Kp))) return rc;

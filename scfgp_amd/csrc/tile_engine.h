@@ -180,8 +180,10 @@ struct NatLoader {
 
 // ---------------------------------------------------------------------------
 // TrLoader: source S[x][k] (row-major, k contiguous); transposes into s[k][x].
-//   With DOT and a vector d the loader also forms, in fp64 and from the values it stages anyway, the row
-//   dots dot[x] = sum_k S[x][k] d[k]  (mu = Phi.alpha rides along with the first column tile of Phi.B).
+//   With DOT and a vector d the loader also forms, in fp64 and from the values it stages anyway, its share of
+//   the row dots dot[x] = sum_k S[x][k] d[k]: k-tiles kt with kt % nparts == part (mu = Phi.alpha rides along
+//   with Phi.B, one slice per column tile -- equal work in every workgroup keeps the workgroups that share an
+//   operand panel in step, which is what makes them share it in L2).
 // ---------------------------------------------------------------------------
 //   SWZ (BK = 16): element (k, x) is stored at column x ^ SZ*(k/VS), SZ = 8 (fp32, VS = 4) or 2 (fp64, VS = 2).
 //   A thread holds VS consecutive k of one row, so the threads of a row write k/VS = 0, 1, ...: without the
@@ -198,8 +200,10 @@ struct TrLoader {
     static_assert(!DOT || (THREADS % VPR == 0 && (VPR & (VPR - 1)) == 0 && VPR <= 64), "DOT: a row's vectors sit in adjacent lanes");
     const S* ptr[NV]; int tid;
     vec_t r[1][NV];
-    const double* dptr = nullptr; double dv[VS]; double dacc[NV]; bool dot_on = false;
-    __device__ __forceinline__ TrLoader(const S* b, int64_t l, int t, const double* d_ = nullptr) : tid(t) {
+    const double* dptr = nullptr; double dv[VS]; double dacc[NV]; bool dot_on = false, dot_now = false;
+    int dpart = 0, dnparts = 1, dphase = 0;                     // dphase: (index of the k-tile being loaded) % dnparts
+    __device__ __forceinline__ TrLoader(const S* b, int64_t l, int t, const double* d_ = nullptr, int part = 0, int nparts = 1)
+        : tid(t), dpart(part), dnparts(nparts) {
         dot_on = DOT && d_ != nullptr;
         if (dot_on) dptr = d_ + (t % VPR) * VS;
 #pragma unroll
@@ -223,9 +227,13 @@ struct TrLoader {
             ptr[i] += BK;
         }
         if (DOT && dot_on) {
+            dot_now = dphase == dpart;
+            if (dot_now) {
 #pragma unroll
-            for (int e = 0; e < VS; ++e) dv[e] = dptr[e];
+                for (int e = 0; e < VS; ++e) dv[e] = dptr[e];
+            }
             dptr += BK;
+            dphase = dphase + 1 == dnparts ? 0 : dphase + 1;
         }
     }
     template <int SET = 0>
@@ -237,7 +245,7 @@ struct TrLoader {
             const int x = v / VPR, kv = v % VPR;
 #pragma unroll
             for (int e = 0; e < VS; ++e) s[(kv * VS + e) * LD + (SWZ ? x ^ ((sizeof(T) == 4 ? 8 : 2) * kv) : x)] = (T)r[SET][i][e];
-            if (DOT && dot_on) {
+            if (DOT && dot_on && dot_now) {
 #pragma unroll
                 for (int e = 0; e < VS; ++e) dacc[i] = fma((double)r[SET][i][e], dv[e], dacc[i]);
             }
