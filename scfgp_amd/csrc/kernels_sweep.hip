@@ -18,8 +18,8 @@
 #ifndef SCFGP_BK
 #define SCFGP_BK 16
 #endif
-#ifndef SCFGP_GRAM_BK
-#define SCFGP_GRAM_BK SCFGP_BK
+#ifndef SCFGP_GRAM_BK_F32
+#define SCFGP_GRAM_BK_F32 32       // one barrier per 64 MFMAs per wave; fits 128 VGPRs only in fp32
 #endif
 #ifndef SCFGP_F32_MS
 #define SCFGP_F32_MS 16          // fp32 MFMA shape: 16 -> 16x16x4, 32 -> 32x32x2
@@ -29,19 +29,19 @@
 #endif
 template <typename T> struct Tune;
 template <> struct Tune<float>  {
-    static constexpr int MS = SCFGP_F32_MS, GRAM_WGM = 4, GRAM_WGN = 2, APPLY_BM = 256, APPLY_BN = SCFGP_APPLY_BN_F32, APPLY_WGM = 4;
+    static constexpr int MS = SCFGP_F32_MS, GRAM_WGM = 4, GRAM_WGN = 2, GRAM_BK = SCFGP_GRAM_BK_F32, APPLY_BM = 256, APPLY_BN = SCFGP_APPLY_BN_F32, APPLY_WGM = 4;
     static constexpr int apply_wgn(int bn) { return bn >= 256 ? 4 : 2; }
 };
 template <> struct Tune<double> {
-    static constexpr int MS = 16, GRAM_WGM = 4, GRAM_WGN = 2, APPLY_BM = 256, APPLY_BN = 128, APPLY_WGM = 4;
+    static constexpr int MS = 16, GRAM_WGM = 4, GRAM_WGN = 2, GRAM_BK = SCFGP_BK, APPLY_BM = 256, APPLY_BN = 128, APPLY_WGM = 4;
     static constexpr int apply_wgn(int) { return 4; }
 };
 template <typename T, int TILE> struct GramCfg {
-    typedef TileCfg<T, TILE, TILE, SCFGP_GRAM_BK, Tune<T>::GRAM_WGM, Tune<T>::GRAM_WGN, Tune<T>::MS> type;
+    typedef TileCfg<T, TILE, TILE, Tune<T>::GRAM_BK, Tune<T>::GRAM_WGM, Tune<T>::GRAM_WGN, Tune<T>::MS> type;
 };
 // the 64-high strip below the square tiles: same workgroup size (one launch), 32 x 32 wave tiles
 template <typename T> struct GramStripCfg {
-    typedef TileCfg<T, 64, 128, SCFGP_GRAM_BK, Tune<T>::GRAM_WGM / 2, Tune<T>::GRAM_WGN * 2, Tune<T>::MS> type;
+    typedef TileCfg<T, 64, 128, Tune<T>::GRAM_BK, Tune<T>::GRAM_WGM / 2, Tune<T>::GRAM_WGN * 2, Tune<T>::MS> type;
 };
 template <typename T, int TILE> struct ApplyCfg {
     typedef TileCfg<T, Tune<T>::APPLY_BM, TILE, SCFGP_BK, Tune<T>::APPLY_WGM, Tune<T>::apply_wgn(TILE), Tune<T>::MS,
@@ -205,7 +205,9 @@ __device__ __forceinline__ void gram_body(
 }
 
 template <class Cfg, class SCfg, bool WEIGHT>
-__global__ __launch_bounds__(Cfg::THREADS) void gram_kernel(
+__global__ __launch_bounds__(Cfg::THREADS)
+__attribute__((amdgpu_waves_per_eu(4, 4)))       // two 8-wave workgroups per CU: the compiler would take up to 256 VGPRs
+void gram_kernel(
     const typename Cfg::T* __restrict__ Phi, int64_t ld, const double* __restrict__ w, const double* __restrict__ side,
     int64_t Np, int64_t rows_per_split, int64_t chunk, int nfull, int nstrip, int nsplit, double* __restrict__ sidepart,
     double* __restrict__ slabs) {

@@ -91,7 +91,10 @@ struct NatLoader {
     const S* ptr[NV]; const double* wptr[NV]; int64_t step; int xlim;     // xlim: first invalid x (GUARD)
     vec_t r[1][NV]; double wr[1][NV];                         // weights stay raw until store(): converting in
     int tid;                                                  // load() would wait on the fetch before the MFMAs
-    const double* sptr[NV]; double sr[NV]; T sacc[NV][VS]; double stot[NV][VS]; bool side_on = false;
+    // side accumulators: when THREADS is a multiple of VPR every vector of a thread has the same columns -> one set
+    static constexpr bool SAMEX = THREADS % VPR == 0;
+    static constexpr int NS = SAMEX ? 1 : NV;
+    const double* sptr[NV]; double sr[NV]; T sacc[NS][VS]; double stot[NS][VS]; bool side_on = false;
     __device__ __forceinline__ NatLoader(const S* b, int64_t l, int t, const double* w_ = nullptr, int xl = 0,
                                          const double* s_ = nullptr)
         : step((int64_t)BK * l), xlim(xl), tid(t) {
@@ -104,9 +107,11 @@ struct NatLoader {
             wptr[i] = WEIGHT ? w_ + k : nullptr;
             sptr[i] = side_on ? s_ + k : nullptr;
             sr[i] = 0;
+        }
+#pragma unroll
+        for (int i = 0; i < NS; ++i)
 #pragma unroll
             for (int e = 0; e < VS; ++e) { sacc[i][e] = 0; stot[i][e] = 0; }
-        }
     }
     template <int SET = 0>
     __device__ __forceinline__ void load(int) {
@@ -146,23 +151,24 @@ struct NatLoader {
             if (SIDE && side_on) {
                 const T sv = (T)sr[i];
 #pragma unroll
-                for (int e = 0; e < VS; ++e) sacc[i][e] += sv * (T)r[SET][i][e];
+                for (int e = 0; e < VS; ++e) sacc[SAMEX ? 0 : i][e] += sv * (T)r[SET][i][e];
             }
         }
     }
     __device__ __forceinline__ void side_flush() {
 #pragma unroll
-        for (int i = 0; i < NV; ++i)
+        for (int i = 0; i < NS; ++i)
 #pragma unroll
             for (int e = 0; e < VS; ++e) { stot[i][e] += (double)sacc[i][e]; sacc[i][e] = 0; }
     }
     // out[x] = side[x], x < BX, summed over this workgroup's BK row groups through lds (BK*BX doubles).
     // Every thread of the workgroup must call; lds must not be in use by the main loop any more.
     __device__ __forceinline__ void side_reduce(double* lds, double* __restrict__ out) const {
+        constexpr int ROWS = SAMEX ? (THREADS / VPR < BK ? THREADS / VPR : BK) : BK;      // partial sums per column
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
+        for (int i = 0; i < NS; ++i) {
             const int v = tid + i * THREADS;
-            if ((BK * VPR) % THREADS != 0 && v >= BK * VPR) continue;
+            if (v >= ROWS * VPR) continue;
             const int k = v / VPR, xv = v % VPR;
 #pragma unroll
             for (int e = 0; e < VS; ++e) lds[k * BX + xv * VS + e] = stot[i][e];
@@ -171,7 +177,7 @@ struct NatLoader {
         for (int x = tid; x < BX; x += THREADS) {
             double sum = 0;
 #pragma unroll
-            for (int k = 0; k < BK; ++k) sum += lds[k * BX + x];
+            for (int k = 0; k < ROWS; ++k) sum += lds[k * BX + x];
             out[x] = sum;
         }
         __syncthreads();
