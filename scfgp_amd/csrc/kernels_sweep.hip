@@ -43,6 +43,10 @@ template <typename T, int TILE> struct GramCfg {
 template <typename T> struct GramStripCfg {
     typedef TileCfg<T, 64, 128, Tune<T>::GRAM_BK, Tune<T>::GRAM_WGM / 2, Tune<T>::GRAM_WGN * 2, Tune<T>::MS> type;
 };
+// fp32 only: the tall Gram tile (64 x 64 wave tiles); fp64 would need 16 waves for the same tile
+template <typename T> struct GramBigCfg {
+    typedef TileCfg<T, 256, 128, SCFGP_BK, Tune<T>::GRAM_WGM, Tune<T>::GRAM_WGN, Tune<T>::MS> type;
+};
 template <typename T, int TILE> struct ApplyCfg {
     typedef TileCfg<T, Tune<T>::APPLY_BM, TILE, SCFGP_BK, Tune<T>::APPLY_WGM, Tune<T>::apply_wgn(TILE), Tune<T>::MS,
                     SCFGP_BK == 16 && Tune<T>::MS == 16> type;                 // swizzled Phi image (TrLoader)
@@ -156,9 +160,12 @@ void SweepKernels<T>::featuremap(const Geom& g, const double* Xt, const double* 
 // fp32 accumulators are flushed into the workgroup's private fp64 slab every `chunk` rows
 // (one fp32 chain stays ~sqrt(chunk)*2^-24); fp64 runs one chunk.
 // --------------------------------------------------------------------------
+// slab_hi: for 256-row tiles, the slab of rows 128..255 (the two 128 x 128 slabs of a tall tile are not adjacent)
 template <class Cfg>
-__device__ __forceinline__ void slab_flush(const typename Cfg::MTr::acc_t (&acc)[Cfg::TM][Cfg::TN], double* slab, bool first) {
+__device__ __forceinline__ void slab_flush(const typename Cfg::MTr::acc_t (&acc)[Cfg::TM][Cfg::TN], double* slab, bool first,
+                                           double* slab_hi = nullptr) {
     AccCoord<Cfg> co;
+    if (Cfg::BM > 128 && co.wm0 >= 128) slab = slab_hi - 128 * Cfg::BN;          // a wave's rows lie in one half
 #pragma unroll
     for (int tm = 0; tm < Cfg::TM; ++tm)
 #pragma unroll
@@ -181,7 +188,7 @@ template <class Cfg, bool WEIGHT, bool STRIP>
 __device__ __forceinline__ void gram_body(
     const typename Cfg::T* __restrict__ Phi, int64_t ld, const double* __restrict__ w, const double* __restrict__ side,
     int64_t r0, int64_t r1, int64_t chunk, int acol, int bcol, bool diag, double* __restrict__ sideout,
-    double* __restrict__ slab, char* smem_raw) {
+    double* __restrict__ slab, double* __restrict__ slab_hi, char* smem_raw) {
     typedef typename Cfg::T T;
     T* smem = reinterpret_cast<T*>(smem_raw);
     typename Cfg::MTr::acc_t acc[Cfg::TM][Cfg::TN];
@@ -194,7 +201,7 @@ __device__ __forceinline__ void gram_body(
         const int64_t c1 = c0 + chunk < r1 ? c0 + chunk : r1;
         acc_zero<Cfg>(acc);
         if (c0 < r1) tile_mainloop<Cfg>(la, lb, (int)((c1 - c0) / Cfg::BK), acc, smem);
-        slab_flush<Cfg>(acc, slab, first);
+        slab_flush<Cfg>(acc, slab, first, slab_hi);
         if (diag) la.side_flush();
         first = false;
     }
@@ -204,44 +211,82 @@ __device__ __forceinline__ void gram_body(
     if (diag) la.side_reduce(reinterpret_cast<double*>(smem_raw), sideout);
 }
 
-template <class Cfg, class SCfg, bool WEIGHT>
+// Job list of one row split (all kernels of the launch have 8 waves):
+//   !BIG  diagonal 128 x 128 tiles, strictly lower tiles row by row, strip tiles
+//    BIG  (fp32) pairs of 128-row blocks are covered by 256 x 128 tiles (64 x 64 wave tiles, the shape of the apply
+//         product): tile (a, b), b <= 2a, is blocks (2a, b) and (2a+1, b); the diagonal blocks (2a+1, 2a+1), an
+//         unpaired last block row and the strip stay 128- / 64-row tiles.  Tall tiles with b == 2a hold the diagonal
+//         block of both of their column blocks' rows and carry the side vector for all 256 columns.
+// Jobs are split-major and the XCD map hands each XCD a contiguous range of them (whole splits), so the workgroups
+// running together on one L2 work on the same rows and share operand panels; inside a split the longest jobs come
+// first and the short strip jobs last.
+template <bool BIG> __host__ __device__ inline int gram_jobs_per_split(int nfull, int nstrip) {
+    if (!BIG) return nfull * (nfull + 1) / 2 + nstrip * (nfull + 1);
+    const int R = nfull / 2, odd = nfull & 1;
+    return R * R + R + odd * nfull + nstrip * (nfull + 1);
+}
+template <class Cfg, class SCfg, class BCfg, bool WEIGHT, bool BIG>
 __global__ __launch_bounds__(Cfg::THREADS)
 __attribute__((amdgpu_waves_per_eu(4, 4)))       // two 8-wave workgroups per CU: the compiler would take up to 256 VGPRs
 void gram_kernel(
     const typename Cfg::T* __restrict__ Phi, int64_t ld, const double* __restrict__ w, const double* __restrict__ side,
     int64_t Np, int64_t rows_per_split, int64_t chunk, int nfull, int nstrip, int nsplit, double* __restrict__ sidepart,
     double* __restrict__ slabs) {
-    static_assert(Cfg::THREADS == SCfg::THREADS && Cfg::BN == SCfg::BN && Cfg::BM == Cfg::BN, "one launch, two tile shapes");
+    static_assert(Cfg::THREADS == SCfg::THREADS && Cfg::THREADS == BCfg::THREADS && Cfg::BN == SCfg::BN && Cfg::BN == BCfg::BN &&
+                  Cfg::BM == Cfg::BN, "one launch, three tile shapes");
     SMEM_DECL;
+    constexpr int B = Cfg::BN;
     const int nall = nfull + nstrip, ntile_all = nall * (nall + 1) / 2;
-    // job id -> (split, tile): split-major, and inside a split the diagonal tiles, then the strictly lower tiles
-    // row by row, then the strip tiles.  The XCD map hands each XCD a contiguous range of job ids (whole splits),
-    // so the workgroups running together on one L2 work on the same rows and share operand panels, and every
-    // XCD's list ends with short strip jobs.
-    const int noff = nfull * (nfull - 1) / 2, per_split = nfull + noff + nstrip * (nfull + 1);
+    const int per_split = gram_jobs_per_split<BIG>(nfull, nstrip);
     const int j = (int)xcd_remap(blockIdx.x, gridDim.x);
     const int split = j / per_split;
-    int u = j % per_split, acol, bcol, slab_t; bool diag = false, strip = false;
-    if (u < nfull) {                                           // diagonal tiles (they also carry the side vector)
-        acol = bcol = u * Cfg::BM; slab_t = u * (u + 1) / 2 + u; diag = side != nullptr;
-    } else if (u < nfull + noff) {                             // strictly lower tiles: u = (ti-1) ti / 2 + tj
-        u -= nfull;
-        int tq = (int)((sqrtf(8.0f * u + 1.0f) - 1.0f) * 0.5f);
-        while ((tq + 1) * (tq + 2) / 2 <= u) ++tq;
-        while (tq * (tq + 1) / 2 > u) --tq;
-        const int ti = tq + 1, tj = u - tq * (tq + 1) / 2;
-        acol = ti * Cfg::BM; bcol = tj * Cfg::BN; slab_t = ti * (ti + 1) / 2 + tj;
-    } else {                                                   // strip tiles
-        const int tj = u - nfull - noff;
-        acol = nfull * Cfg::BN; bcol = tj * Cfg::BN; slab_t = nfull * (nfull + 1) / 2 + tj;
-        strip = true; diag = side != nullptr && tj == nfull;
+    int u = j % per_split, acol, bcol, slab_t, slab_t2 = 0, kind = 0;     // kind 0: 128-row tile, 1: strip, 2: 256-row tile
+    bool diag = false;
+    const auto tri = [](int ti, int tj) { return ti * (ti + 1) / 2 + tj; };
+    if (BIG) {
+        const int R = nfull / 2, nbig = R * R, nsmall = R + (nfull & 1) * nfull;
+        if (u < nbig) {                                        // tall tile (a, b), u = a^2 + b
+            int a = (int)sqrtf((float)u);
+            while ((a + 1) * (a + 1) <= u) ++a;
+            while (a * a > u) --a;
+            const int b = u - a * a;
+            acol = 2 * a * B; bcol = b * B; slab_t = tri(2 * a, b); slab_t2 = tri(2 * a + 1, b); kind = 2;
+            diag = side != nullptr && b == 2 * a;
+        } else if (u < nbig + R) {                             // diagonal block of the second row of a pair
+            const int i = 2 * (u - nbig) + 1;
+            acol = bcol = i * B; slab_t = tri(i, i);
+        } else if (u < nbig + nsmall) {                        // unpaired last block row
+            const int i = nfull - 1, b = u - nbig - R;
+            acol = i * B; bcol = b * B; slab_t = tri(i, b); diag = side != nullptr && b == i;
+        } else {
+            const int tj = u - nbig - nsmall;
+            acol = nfull * B; bcol = tj * B; slab_t = tri(nfull, tj); kind = 1; diag = side != nullptr && tj == nfull;
+        }
+    } else {
+        const int noff = nfull * (nfull - 1) / 2;
+        if (u < nfull) {                                       // diagonal tiles (they also carry the side vector)
+            acol = bcol = u * B; slab_t = tri(u, u); diag = side != nullptr;
+        } else if (u < nfull + noff) {                         // strictly lower tiles: u = (ti-1) ti / 2 + tj
+            u -= nfull;
+            int tq = (int)((sqrtf(8.0f * u + 1.0f) - 1.0f) * 0.5f);
+            while ((tq + 1) * (tq + 2) / 2 <= u) ++tq;
+            while (tq * (tq + 1) / 2 > u) --tq;
+            const int ti = tq + 1, tj = u - tq * (tq + 1) / 2;
+            acol = ti * B; bcol = tj * B; slab_t = tri(ti, tj);
+        } else {                                               // strip tiles
+            const int tj = u - nfull - noff;
+            acol = nfull * B; bcol = tj * B; slab_t = tri(nfull, tj); kind = 1; diag = side != nullptr && tj == nfull;
+        }
     }
     const int64_t r0 = (int64_t)split * rows_per_split;
     const int64_t r1 = r0 + rows_per_split < Np ? r0 + rows_per_split : Np;
-    double* slab = slabs + ((int64_t)split * ntile_all + slab_t) * (Cfg::BN * Cfg::BN);
+    double* slab = slabs + ((int64_t)split * ntile_all + slab_t) * (B * B);
+    double* slab2 = slabs + ((int64_t)split * ntile_all + slab_t2) * (B * B);
     double* sideout = sidepart + (int64_t)split * ld + acol;
-    if (strip) gram_body<SCfg, WEIGHT, true>(Phi, ld, w, side, r0, r1, chunk, acol, bcol, diag, sideout, slab, smem_raw);
-    else gram_body<Cfg, WEIGHT, false>(Phi, ld, w, side, r0, r1, chunk, acol, bcol, diag, sideout, slab, smem_raw);
+    if (kind == 1) { gram_body<SCfg, WEIGHT, true>(Phi, ld, w, side, r0, r1, chunk, acol, bcol, diag, sideout, slab, nullptr, smem_raw); return; }
+    if constexpr (BIG)
+        if (kind == 2) { gram_body<BCfg, WEIGHT, false>(Phi, ld, w, side, r0, r1, chunk, acol, bcol, diag, sideout, slab, slab2, smem_raw); return; }
+    gram_body<Cfg, WEIGHT, false>(Phi, ld, w, side, r0, r1, chunk, acol, bcol, diag, sideout, slab, nullptr, smem_raw);
 }
 
 template <class Cfg, typename S>
@@ -274,28 +319,33 @@ __global__ __launch_bounds__(Cfg::THREADS) void xtz_kernel(
 }
 
 template <typename T>
+int SweepKernels<T>::gram_jobs(const Geom& g) { return gram_jobs_per_split<sizeof(T) == 4>(g.gfull, g.gstrip); }
+template <typename T>
 void SweepKernels<T>::gram(const Geom& g, const T* Phi, const double* w, const double* side, int nsplit, int64_t chunk, double* slabs,
                            double* sidepart, hipStream_t st) {
     typedef typename GramCfg<T, 128>::type Cfg;
     typedef typename GramStripCfg<T>::type SCfg;
-    const int njobs = (g.gfull * (g.gfull + 1) / 2 + g.gstrip * (g.gfull + 1)) * nsplit;
+    typedef typename GramBigCfg<T>::type BCfg;
+    constexpr bool BIG = sizeof(T) == 4;
+    const int njobs = gram_jobs(g) * nsplit;
     const int64_t rps = round_up((g.Np + nsplit - 1) / nsplit, 256);
     if (chunk <= 0 || chunk > rps) chunk = rps;
-    chunk = round_up(chunk, Cfg::BK);
+    chunk = round_up(chunk, Cfg::BK > BCfg::BK ? Cfg::BK : BCfg::BK);
 #ifdef SCFGP_DIAG_PLAIN_W
     w = nullptr;                                               // timing diagnostic only: wrong numbers
 #endif
 #ifdef SCFGP_DIAG_NOSIDE
     side = nullptr;                                            // timing diagnostic only: wrong numbers
 #endif
-    constexpr int LDS = Cfg::LDS_BYTES > SCfg::LDS_BYTES ? Cfg::LDS_BYTES : SCfg::LDS_BYTES;
-    allow_big_lds(gram_kernel<Cfg, SCfg, true>, LDS);
-    allow_big_lds(gram_kernel<Cfg, SCfg, false>, LDS);
+    constexpr int L1 = Cfg::LDS_BYTES > SCfg::LDS_BYTES ? Cfg::LDS_BYTES : SCfg::LDS_BYTES;
+    constexpr int LDS = BIG && BCfg::LDS_BYTES > L1 ? BCfg::LDS_BYTES : L1;
+    allow_big_lds(gram_kernel<Cfg, SCfg, BCfg, true, BIG>, LDS);
+    allow_big_lds(gram_kernel<Cfg, SCfg, BCfg, false, BIG>, LDS);
     if (w)
-        hipLaunchKernelGGL((gram_kernel<Cfg, SCfg, true>), dim3(njobs), dim3(Cfg::THREADS), LDS, st,
+        hipLaunchKernelGGL((gram_kernel<Cfg, SCfg, BCfg, true, BIG>), dim3(njobs), dim3(Cfg::THREADS), LDS, st,
                            Phi, (int64_t)g.Kp, w, side, g.Np, rps, chunk, g.gfull, g.gstrip, nsplit, sidepart, slabs);
     else
-        hipLaunchKernelGGL((gram_kernel<Cfg, SCfg, false>), dim3(njobs), dim3(Cfg::THREADS), LDS, st,
+        hipLaunchKernelGGL((gram_kernel<Cfg, SCfg, BCfg, false, BIG>), dim3(njobs), dim3(Cfg::THREADS), LDS, st,
                            Phi, (int64_t)g.Kp, w, side, g.Np, rps, chunk, g.gfull, g.gstrip, nsplit, sidepart, slabs);
 }
 

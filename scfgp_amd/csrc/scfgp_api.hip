@@ -139,7 +139,8 @@ static int ensure_rows(scfgp_ctx* c, int64_t N) {
     g.N = N; g.Np = Np;
     const int nts = g.Kp / g.tile, ntiles = nts * (nts + 1) / 2;
     const int ntx = ((g.Dp + XT - 1) / XT) * (g.Jp / XT);
-    const int gs = c->gram_nsplit > 0 ? (int)std::min<int64_t>(c->gram_nsplit, Np / 256) : default_split(ntiles, Np);
+    const int gjobs = c->dtype == SCFGP_F32 ? SweepKernels<float>::gram_jobs(g) : SweepKernels<double>::gram_jobs(g);
+    const int gs = c->gram_nsplit > 0 ? (int)std::min<int64_t>(c->gram_nsplit, Np / 256) : default_split(gjobs, Np);
     const int xs = c->xtz_nsplit > 0 ? (int)std::min<int64_t>(c->xtz_nsplit, Np / 256) : xtz_split(ntx, Np);
     // Gram slabs are followed by the per-split side-vector partials (gs x Kp)
     const size_t need = sizeof(double) * std::max<size_t>((size_t)gs * ntiles * g.tile * g.tile + (size_t)gs * g.Kp, (size_t)xs * ntx * XT * XT);
@@ -317,7 +318,7 @@ template <typename T> struct Impl {
     static void gram_to(scfgp_ctx* c, const double* w, const double* side, double* out, const char* name) {
         const Geom& g = c->g;
         const int nts = g.Kp / g.tile, ntiles = nts * (nts + 1) / 2;
-        const int gs = c->gram_nsplit > 0 ? (int)std::min<int64_t>(c->gram_nsplit, g.Np / 256) : default_split(ntiles, g.Np);
+        const int gs = c->gram_nsplit > 0 ? (int)std::min<int64_t>(c->gram_nsplit, g.Np / 256) : default_split(SK::gram_jobs(g), g.Np);
         double* sidepart = c->d_slabs + (size_t)gs * ntiles * g.tile * g.tile;
         { ProfScope ps(c, name);
           SK::gram(g, (const T*)c->d_Phi, w, side, gs, c->dtype == SCFGP_F32 ? c->gram_chunk : 0, c->d_slabs, sidepart, c->st); }
