@@ -116,7 +116,7 @@ int scfgp_predict_y(scfgp_ctx* ctx, const double* Xs_raw, int64_t T, const doubl
  *
  *   scfgp_pass1   -> exchange 1 = [G, packed lower 128x128 tiles | Phi^T y (Kp) | y^T y ...]
  *   scfgp_factor     (replicated: Cholesky, Li, alpha, log det)
- *   scfgp_pass2   -> exchange 2 = [W, packed lower tiles | Phi^T p (Kp) | T2, kbar ...]
+ *   scfgp_pass2   -> exchange 2 = [B W B = V^T diag(q) V, packed lower tiles | B Phi^T p = V^T p (Kp) | T2, kbar ...]
  *   scfgp_adjoint    (replicated: Abar)                      [want_grad only]
  *   scfgp_pass3   -> exchange 3 = [X~^T Zbar | bbar ...]     [want_grad only]
  *   scfgp_finish  -> outputs on the host

@@ -294,16 +294,17 @@ class OracleEngine(object):
         self.q = 1 / d + kappa * e; self.p = 2 * r / d
         kbar = (e * (v + 1)).sum()
         K = self.K
-        W = Ph.T @ (self.q[:, None] * Ph) if want_grad else np.zeros((K, K))
-        self.x2 = np.concatenate((W.ravel(), Ph.T @ self.p, [T2, kbar]))
+        # second exchange: B W B = V^T diag(q) V and u = B Phi^T p = V^T p with V = Phi B (row sums, like W and Phi^T p)
+        V = Ph @ self.B
+        BWB = V.T @ (self.q[:, None] * V) if want_grad else np.zeros((K, K))
+        self.x2 = np.concatenate((BWB.ravel(), V.T @ self.p, [T2, kbar]))
 
     def adjoint(self):
         K = self.K; a = self.params[0]
-        W = self.x2[:K * K].reshape(K, K); h = self.x2[K * K:K * K + K]
+        BWB = self.x2[:K * K].reshape(K, K); u = self.x2[K * K:K * K + K]
         self.T2, self.kbar = self.x2[-2], self.x2[-1]
         em2a = np.exp(-2 * a); B = self.B; al = self.alpha
-        u = B @ h
-        self.Abar = B - B @ W @ B - 0.5 * (np.outer(u, al) + np.outer(al, u)) + em2a * np.outer(al, al)
+        self.Abar = B - BWB - 0.5 * (np.outer(u, al) + np.outer(al, u)) + em2a * np.outer(al, al)
         self.ut = u - 2 * em2a * al
 
     def pass3(self):

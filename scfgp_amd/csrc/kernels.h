@@ -105,5 +105,5 @@ struct KStage {
     double *scalars; int* flag;
 };
 void kstage_factor(const KStage& k, const Scal* sc, hipStream_t st);          // SCFGP.py:105-110,125
-void kstage_adjoint(const KStage& k, const double* W, double* Abar, const Scal* sc, hipStream_t st);
+void kstage_adjoint(const KStage& k, const double* BWB, double* Abar, const Scal* sc, hipStream_t st);
 void kstage_gram_li(const KStage& k, hipStream_t st);                         // B = Li^T Li only (predict)

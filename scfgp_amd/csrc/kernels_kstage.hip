@@ -313,14 +313,11 @@ void kstage_factor(const KStage& k, const Scal* sc, hipStream_t st) {
     hipLaunchKernelGGL(factor_scalars_kernel, dim3(1), dim3(256), 0, st, k.A, ld, k.K, k.g, k.alpha, k.scalars);
 }
 
-void kstage_adjoint(const KStage& k, const double* W, double* Abar, const Scal* sc, hipStream_t st) {
+// BWB = V^T diag(q) V and u = B h = V^T p arrive ready from the row sweep (V = Phi B is resident), so the adjoint
+// of A needs no K^3 work: Abar = B - BWB - (u a^T + a u^T)/2 + e^{-2a} a a^T.   k.h holds u.
+void kstage_adjoint(const KStage& k, const double* BWB, double* Abar, const Scal* sc, hipStream_t st) {
     const int Kp = k.Kp;
     const int64_t ld = Kp;
-    hipLaunchKernelGGL(gemv_rows_kernel, dim3((Kp + 3) / 4), dim3(256), 0, st, k.B, ld, k.h, k.u, Kp);           // u = B h
-    GemmArgs g1 = {W, k.B, k.T1, ld, ld, ld, Kp, Kp, Kp, 1.0, 0.0, 0, 0};
-    gemm64<false, false>(g1, st);                                     // T1 = W B   (W symmetric)
-    GemmArgs g2 = {k.B, k.T1, k.T2, ld, ld, ld, Kp, Kp, Kp, 1.0, 0.0, 0, 0};
-    gemm64<false, false>(g2, st);                                     // T2 = B W B
-    hipLaunchKernelGGL(abar_kernel, dim3(1024), dim3(256), 0, st, k.B, k.T2, Abar, k.u, k.alpha, Kp, sc);
-    hipLaunchKernelGGL(adjoint_vec_kernel, dim3(1), dim3(256), 0, st, Abar, ld, k.K, Kp, k.u, k.alpha, k.ut, sc, k.scalars);
+    hipLaunchKernelGGL(abar_kernel, dim3(1024), dim3(256), 0, st, k.B, BWB, Abar, k.h, k.alpha, Kp, sc);
+    hipLaunchKernelGGL(adjoint_vec_kernel, dim3(1), dim3(256), 0, st, Abar, ld, k.K, Kp, k.h, k.alpha, k.ut, sc, k.scalars);
 }

@@ -314,14 +314,14 @@ template <typename T> struct Impl {
     static const T* BT(scfgp_ctx* c) { return (const T*)c->d_BT; }
     static const T* AbarT(scfgp_ctx* c) { return (const T*)c->d_AbarT; }
 
-    // out = [packed lower tiles of Phi^T diag(w) Phi | Phi^T side (Kp)]
-    static void gram_to(scfgp_ctx* c, const double* w, const double* side, double* out, const char* name) {
+    // out = [packed lower tiles of M^T diag(w) M | M^T side (Kp)],  M = Phi (pass 1) or V = Phi B (pass 2)
+    static void gram_to(scfgp_ctx* c, const T* Mx, const double* w, const double* side, double* out, const char* name) {
         const Geom& g = c->g;
         const int nts = g.Kp / g.tile, ntiles = nts * (nts + 1) / 2;
         const int gs = c->gram_nsplit > 0 ? (int)std::min<int64_t>(c->gram_nsplit, g.Np / 256) : default_split(SK::gram_jobs(g), g.Np);
         double* sidepart = c->d_slabs + (size_t)gs * ntiles * g.tile * g.tile;
         { ProfScope ps(c, name);
-          SK::gram(g, (const T*)c->d_Phi, w, side, gs, c->dtype == SCFGP_F32 ? c->gram_chunk : 0, c->d_slabs, sidepart, c->st); }
+          SK::gram(g, Mx, w, side, gs, c->dtype == SCFGP_F32 ? c->gram_chunk : 0, c->d_slabs, sidepart, c->st); }
         { ProfScope ps(c, "reduce_tiles"); reduce_tri_tiles(c->d_slabs, gs, nts, g.tile, out, c->st);
           reduce_side(sidepart, gs, g.Kp, g.gfull * g.tile + g.gstrip * 64, out + c->n_pk, c->st); }
     }
@@ -329,7 +329,7 @@ template <typename T> struct Impl {
         const Geom& g = c->g;
         if (!c->in_train) HIPCHK(c, hipMemsetAsync(c->d_flag, 0, sizeof(int) * 4, c->st));
         { ProfScope ps(c, "featuremap"); SK::featuremap(g, c->d_Xt, c->d_Fall, c->d_sc, (T*)c->d_Phi, c->st); }
-        gram_to(c, nullptr, c->d_y, c->d_xp1, "gram");
+        gram_to(c, (const T*)c->d_Phi, nullptr, c->d_y, c->d_xp1, "gram");
         HIPCHK(c, hipMemcpyAsync(c->d_xp1 + c->n_pk + g.Kp, c->d_yy, sizeof(double), hipMemcpyDeviceToDevice, c->st));
         HIPCHK(c, hipGetLastError());
         return SCFGP_OK;
@@ -349,7 +349,7 @@ template <typename T> struct Impl {
           SK::rowstats(g, c->d_mu, c->d_vpart, c->d_y, c->d_sc, c->d_p, c->d_q, c->d_partial, nb, c->st);
           reduce_scalars(c->d_partial, nb, 2, c->d_xp2 + c->n_pk + g.Kp, 0, c->st); }
         if (want_grad) {
-            gram_to(c, c->d_q, c->d_p, c->d_xp2, "gram_w");
+            gram_to(c, (const T*)c->d_V, c->d_q, c->d_p, c->d_xp2, "gram_w");      // V^T diag(q) V = B W B, V^T p = B Phi^T p
         }
         HIPCHK(c, hipGetLastError());
         return SCFGP_OK;
