@@ -8,6 +8,8 @@ struct Geom {
     int D, S, M, J, K, P;
     int Dp;      // round_up(D+1,16): X~ = [X | 1 | 0..]   (ones column carries the phase offsets)
     int Jp;      // round_up(J,128)
+    int Sp;      // round_up(S+1,16): T~ = [X l_F | 1 | 0..] (N x Sp), the rank-S form of the projection
+    int lowrank; // 1: Z = (X~ Lall) Rall = T~ Rall (chosen when Sp < Dp); 0: Z = X~ Fall
     int Kp;      // round_up(K,tile): leading dimension of Phi and of every K x K matrix
     int tile;    // 128: square tile of the Gram products and of the packed exchange layout
     int gfull;   // Gram tile grid: gfull rows of square tiles ...
@@ -16,9 +18,14 @@ struct Geom {
     int64_t Np;  // round_up(N,256)
 };
 
+// operands of the phase projection: Fall (Dp x Jp); Lall (Dp x round_up(Sp,64)) = [l_F | e_D], Rall (Sp x Jp) =
+// [[I_S | r_F^T]; phase offsets], Tt (Np x Sp) scratch for T~
+struct Projection { const double* Fall; const double* Lall; const double* Rall; double* Tt; };
+
 template <typename T> struct SweepKernels {
-    // Phi = s*[cos Z, sin Z], Z = X~ . Fall                      (SCFGP.py:98-102 / :139-142)
-    static void featuremap(const Geom& g, const double* Xt, const double* Fall, const Scal* sc, T* Phi, hipStream_t st);
+    // Phi = s*[cos Z, sin Z], Z = X~ . Fall  or, F = l_F r_F^T being rank S (SCFGP.py:83), Z = (X~ . Lall) . Rall
+    //                                                            (SCFGP.py:98-102 / :139-142)
+    static void featuremap(const Geom& g, const double* Xt, const Projection& pr, const Scal* sc, T* Phi, hipStream_t st);
     // lower tiles of  Phi^T diag(w) Phi  into per-split fp64 slabs (SCFGP.py:104; weighted: backward of :111-113)
     // and, from the diagonal tiles, sidepart[split][Kp] = partials of Phi^T side (side = y: SCFGP.py:108)
     static void gram(const Geom& g, const T* Phi, const double* w, const double* side, int nsplit, int64_t chunk, double* slabs,
@@ -64,7 +71,7 @@ void reduce_scalars(const double* partial, int nblocks, int width, double* scala
 void sum_squares(const double* y, int64_t n, double* scalars, int slot, double* scratch, hipStream_t st);
 
 // ---- parameter unpack / gradient epilogue -----------------------------------
-void unpack_params(const Geom& g, const double* params, double* F, double* Fall, Scal* sc, hipStream_t st);
+void unpack_params(const Geom& g, const double* params, double* F, double* Fall, double* Lall, double* Rall, Scal* sc, hipStream_t st);
 void grad_epilogue(const Geom& g, const double* params, const double* F, const double* XZ, int64_t ldxz,
                    double* work, double* scalars, int64_t Nglobal, double* grad, hipStream_t st);
 // yy -> y^T y, t2kb -> (T2, kbar), bbar -> bbar: device scalars living in the exchange buffers

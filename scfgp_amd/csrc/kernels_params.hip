@@ -54,11 +54,37 @@ __global__ void fall_kernel(const double* __restrict__ params, const double* __r
     Fall[i] = v;
 }
 
-void unpack_params(const Geom& g, const double* params, double* F, double* Fall, Scal* sc, hipStream_t st) {
+// rank-S form of the same projection: X~ Fall = (X~ Lall) Rall with
+//   Lall (Dp x Spp) = [l_F | e_D | 0]     -> T~ = X~ Lall = [X l_F | 1 | 0]
+//   Rall (Sp x Jp): rows s < S = [e_s | r_F[:, s]^T], row S = the phase offsets (row D of Fall)
+__global__ void lowrank_kernel(const double* __restrict__ params, const double* __restrict__ Fall, int D, int S, int M, int Dp,
+                               int Sp, int Spp, int Jp, double* __restrict__ Lall, double* __restrict__ Rall) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nl = (int64_t)Dp * Spp, nr = (int64_t)Sp * Jp;
+    if (i < nl) {
+        const int d = (int)(i / Spp), c = (int)(i % Spp);
+        Lall[i] = (c < S && d < D) ? params[3 + (int64_t)d * S + c] : ((c == S && d == D) ? 1.0 : 0.0);
+    } else if (i < nl + nr) {
+        const int64_t e = i - nl;
+        const int s = (int)(e / Jp), j = (int)(e % Jp);
+        double v = 0;
+        if (s < S) v = j < S ? (s == j ? 1.0 : 0.0) : (j < S + M ? params[3 + (int64_t)D * S + (int64_t)(j - S) * S + s] : 0.0);
+        else if (s == S) v = Fall[(int64_t)D * Jp + j];
+        Rall[e] = v;
+    }
+}
+
+void unpack_params(const Geom& g, const double* params, double* F, double* Fall, double* Lall, double* Rall, Scal* sc, hipStream_t st) {
     hipLaunchKernelGGL(scal_kernel, dim3(1), dim3(64), 0, st, params, g.M, sc);
     const int64_t nf = (int64_t)g.D * g.M, nfa = (int64_t)g.Dp * g.Jp;
     hipLaunchKernelGGL(f_kernel, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, st, params, g.D, g.S, g.M, F);
     hipLaunchKernelGGL(fall_kernel, dim3((unsigned)((nfa + 255) / 256)), dim3(256), 0, st, params, F, g.D, g.S, g.M, g.Dp, g.Jp, Fall);
+    if (g.lowrank) {
+        const int Spp = (int)round_up(g.Sp, 64);
+        const int64_t n = (int64_t)g.Dp * Spp + (int64_t)g.Sp * g.Jp;
+        hipLaunchKernelGGL(lowrank_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, params, Fall, g.D, g.S, g.M, g.Dp, g.Sp,
+                           Spp, g.Jp, Lall, Rall);
+    }
 }
 
 // ---------------------------------------------------------------------------

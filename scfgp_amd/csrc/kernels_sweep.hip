@@ -143,13 +143,47 @@ __global__ __launch_bounds__(FmapCfg::THREADS) void featuremap_kernel(
         }
 }
 
+// T~ = X~ . Lall (fp64 MFMA), the first factor of the rank-S projection
+__global__ __launch_bounds__(FmapCfg::THREADS) void project_kernel(
+    const double* __restrict__ Xt, const double* __restrict__ Lall, double* __restrict__ Tt, int Dp, int Sp, int Spp, int njt) {
+    typedef FmapCfg Cfg;
+    SMEM_DECL;
+    double* smem = reinterpret_cast<double*>(smem_raw);
+    const int jt = blockIdx.x % njt;
+    const int64_t rb = blockIdx.x / njt;
+    TrLoader<double, double, Cfg::BM, Cfg::BK, Cfg::LDA, Cfg::THREADS, false, Cfg::SWZA> la(Xt + rb * Cfg::BM * Dp, Dp, threadIdx.x);
+    NatLoader<double, double, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS, false, false> lb(Lall + jt * Cfg::BN, Spp, threadIdx.x);
+    typename Cfg::MTr::acc_t acc[Cfg::TM][Cfg::TN];
+    acc_zero<Cfg>(acc);
+    tile_mainloop<Cfg>(la, lb, Dp / Cfg::BK, acc, smem);
+    AccCoord<Cfg> co;
+#pragma unroll
+    for (int tm = 0; tm < Cfg::TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < Cfg::TN; ++tn) {
+            const int j = jt * Cfg::BN + co.col(tn);
+            if (j >= Sp) continue;
+#pragma unroll
+            for (int r = 0; r < Cfg::MTr::NACC; ++r) Tt[(rb * Cfg::BM + co.row(tm, r)) * Sp + j] = acc[tm][tn][r];
+        }
+}
+
 template <typename T>
-void SweepKernels<T>::featuremap(const Geom& g, const double* Xt, const double* Fall, const Scal* sc, T* Phi, hipStream_t st) {
+void SweepKernels<T>::featuremap(const Geom& g, const double* Xt, const Projection& pr, const Scal* sc, T* Phi, hipStream_t st) {
     const int njt = g.Jp / FmapCfg::BN;
     const int64_t nrb = g.Np / FmapCfg::BM;
     allow_big_lds(featuremap_kernel<T>, FmapCfg::LDS_BYTES);
-    hipLaunchKernelGGL(featuremap_kernel<T>, dim3((unsigned)(njt * nrb)), dim3(FmapCfg::THREADS), FmapCfg::LDS_BYTES, st,
-                       Xt, Fall, sc, Phi, g.Dp, g.Jp, g.Kp, g.J, g.N, njt);
+    if (g.lowrank) {
+        const int Spp = (int)round_up(g.Sp, FmapCfg::BN), njs = Spp / FmapCfg::BN;
+        allow_big_lds(project_kernel, FmapCfg::LDS_BYTES);
+        hipLaunchKernelGGL(project_kernel, dim3((unsigned)(njs * nrb)), dim3(FmapCfg::THREADS), FmapCfg::LDS_BYTES, st,
+                           Xt, pr.Lall, pr.Tt, g.Dp, g.Sp, Spp, njs);
+        hipLaunchKernelGGL(featuremap_kernel<T>, dim3((unsigned)(njt * nrb)), dim3(FmapCfg::THREADS), FmapCfg::LDS_BYTES, st,
+                           pr.Tt, pr.Rall, sc, Phi, g.Sp, g.Jp, g.Kp, g.J, g.N, njt);
+    } else {
+        hipLaunchKernelGGL(featuremap_kernel<T>, dim3((unsigned)(njt * nrb)), dim3(FmapCfg::THREADS), FmapCfg::LDS_BYTES, st,
+                           Xt, pr.Fall, sc, Phi, g.Dp, g.Jp, g.Kp, g.J, g.N, njt);
+    }
 }
 
 // --------------------------------------------------------------------------

@@ -37,7 +37,8 @@ struct scfgp_ctx {
     int stage = 0, last_want_grad = 0;
     std::vector<double> h_params;
     // parameters
-    double *d_params = nullptr, *d_F = nullptr, *d_Fall = nullptr; Scal* d_sc = nullptr;
+    double *d_params = nullptr, *d_F = nullptr, *d_Fall = nullptr, *d_Lall = nullptr, *d_Rall = nullptr; Scal* d_sc = nullptr;
+    double *d_Tt = nullptr, *p_Tt = nullptr;                     // T~ = X~ Lall of the rank-S projection (rows / predict chunk)
     // dataset store (raw rows as uploaded) and the working set the sweeps run on
     double *d_Xraw = nullptr, *d_yraw = nullptr; int64_t Nstore = 0, store_cap = 0; bool work_full = false;
     int64_t* d_idx = nullptr; int64_t idx_cap = 0;
@@ -125,7 +126,7 @@ static int xtz_split(int ntiles, int64_t Np) {          // the X~^T Zbar grid ha
 }
 
 static void free_rows(scfgp_ctx* c) {
-    dfree(c->d_Xt); dfree(c->d_y); dfree(c->d_p); dfree(c->d_q); dfree(c->d_mu); dfree(c->d_vpart);
+    dfree(c->d_Xt); dfree(c->d_y); dfree(c->d_p); dfree(c->d_q); dfree(c->d_mu); dfree(c->d_vpart); dfree(c->d_Tt);
     dfree(c->d_Phi); dfree(c->d_V); dfree(c->d_bpart); dfree(c->d_slabs);
     c->Ncap = 0; c->slabs_bytes = 0;
 }
@@ -150,12 +151,13 @@ static int ensure_rows(scfgp_ctx* c, int64_t N) {
         c->slabs_bytes = need;
     }
     if (Np <= c->Ncap) return SCFGP_OK;
-    dfree(c->d_Xt); dfree(c->d_y); dfree(c->d_p); dfree(c->d_q); dfree(c->d_mu); dfree(c->d_vpart);
+    dfree(c->d_Xt); dfree(c->d_y); dfree(c->d_p); dfree(c->d_q); dfree(c->d_mu); dfree(c->d_vpart); dfree(c->d_Tt);
     dfree(c->d_Phi); dfree(c->d_V); dfree(c->d_bpart);
     c->Ncap = 0;
     const size_t ts = c->tsize();
     int rc;
     if ((rc = dmalloc(c, &c->d_Xt, sizeof(double) * Np * g.Dp))) return rc;
+    if (g.lowrank && (rc = dmalloc(c, &c->d_Tt, sizeof(double) * Np * g.Sp))) return rc;
     if ((rc = dmalloc(c, &c->d_y, sizeof(double) * Np))) return rc;
     if ((rc = dmalloc(c, &c->d_p, sizeof(double) * Np))) return rc;
     if ((rc = dmalloc(c, &c->d_q, sizeof(double) * Np))) return rc;
@@ -178,6 +180,8 @@ extern "C" int scfgp_create(scfgp_ctx** out, int D, int S, int M, int dtype, int
     Geom& g = c->g;
     g.D = D; g.S = S; g.M = M; g.J = S + M; g.K = 2 * g.J; g.P = 3 + D * S + M * S + S + M;
     g.Dp = (int)round_up(D + 1, 16); g.Jp = (int)round_up(g.J, XT);
+    g.Sp = (int)round_up(S + 1, 16); g.lowrank = g.Sp < g.Dp;     // F = l_F r_F^T: project through the S columns when that is narrower
+    if (const char* e = getenv("SCFGP_LOWRANK")) g.lowrank = atoi(e) != 0;                       // tuning override
     // Gram tile grid: 128-wide tiles cover K in 64-column blocks; an odd block count ends in a 64-high strip
     g.tile = 128;
     g.gfull = (int)(round_up(g.K, 64) / 128);
@@ -196,6 +200,8 @@ extern "C" int scfgp_create(scfgp_ctx** out, int D, int S, int M, int dtype, int
     if ((rc = dmalloc(c, &c->d_params, sizeof(double) * g.P))) return rc;
     if ((rc = dmalloc(c, &c->d_F, sizeof(double) * D * M))) return rc;
     if ((rc = dmalloc(c, &c->d_Fall, sizeof(double) * g.Dp * g.Jp))) return rc;
+    if ((rc = dmalloc(c, &c->d_Lall, sizeof(double) * g.Dp * round_up(g.Sp, 64)))) return rc;
+    if ((rc = dmalloc(c, &c->d_Rall, sizeof(double) * g.Sp * g.Jp))) return rc;
     if ((rc = dmalloc(c, &c->d_sc, sizeof(Scal)))) return rc;
     if ((rc = dmalloc(c, &c->d_xp1, sizeof(double) * c->n_xp))) return rc;
     if ((rc = dmalloc(c, &c->d_xp2, sizeof(double) * c->n_xp))) return rc;
@@ -234,7 +240,7 @@ extern "C" void scfgp_destroy(scfgp_ctx* c) {
     if (c->st) hipStreamSynchronize(c->st);
     free_rows(c);
     dfree(c->d_Xraw); dfree(c->d_yraw); dfree(c->d_idx); dfree(c->d_xscale); dfree(c->d_yscale);
-    dfree(c->d_params); dfree(c->d_F); dfree(c->d_Fall); dfree(c->d_sc);
+    dfree(c->d_params); dfree(c->d_F); dfree(c->d_Fall); dfree(c->d_Lall); dfree(c->d_Rall); dfree(c->d_sc); dfree(c->p_Tt);
     dfree(c->d_xp1); dfree(c->d_xp2); dfree(c->d_x1); dfree(c->d_x2); dfree(c->d_x3); dfree(c->d_Li); dfree(c->d_B); dfree(c->d_T1); dfree(c->d_T2);
     dfree(c->d_Abar); dfree(c->d_BT); dfree(c->d_AbarT); dfree(c->d_vecs); dfree(c->d_scalars); dfree(c->d_yy);
     dfree(c->d_flag); dfree(c->d_partial); dfree(c->d_work); dfree(c->d_grad);
@@ -257,7 +263,7 @@ extern "C" int scfgp_set_params(scfgp_ctx* c, const double* params, int P) {
     HIPCHK(c, hipSetDevice(c->device));
     c->h_params.assign(params, params + P);
     HIPCHK(c, hipMemcpyAsync(c->d_params, c->h_params.data(), sizeof(double) * P, hipMemcpyHostToDevice, c->st));
-    unpack_params(c->g, c->d_params, c->d_F, c->d_Fall, c->d_sc, c->st);
+    unpack_params(c->g, c->d_params, c->d_F, c->d_Fall, c->d_Lall, c->d_Rall, c->d_sc, c->st);
     HIPCHK(c, hipGetLastError());
     c->have_params = true;
     return SCFGP_OK;
@@ -328,7 +334,7 @@ template <typename T> struct Impl {
     static int pass1(scfgp_ctx* c) {
         const Geom& g = c->g;
         if (!c->in_train) HIPCHK(c, hipMemsetAsync(c->d_flag, 0, sizeof(int) * 4, c->st));
-        { ProfScope ps(c, "featuremap"); SK::featuremap(g, c->d_Xt, c->d_Fall, c->d_sc, (T*)c->d_Phi, c->st); }
+        { ProfScope ps(c, "featuremap"); SK::featuremap(g, c->d_Xt, Projection{c->d_Fall, c->d_Lall, c->d_Rall, c->d_Tt}, c->d_sc, (T*)c->d_Phi, c->st); }
         gram_to(c, (const T*)c->d_Phi, nullptr, c->d_y, c->d_xp1, "gram");
         HIPCHK(c, hipMemcpyAsync(c->d_xp1 + c->n_pk + g.Kp, c->d_yy, sizeof(double), hipMemcpyDeviceToDevice, c->st));
         HIPCHK(c, hipGetLastError());
@@ -376,7 +382,7 @@ template <typename T> struct Impl {
         return SCFGP_OK;
     }
     static int predict_chunk(scfgp_ctx* c, const Geom& g, const T* Bt) {
-        SK::featuremap(g, c->p_Xt, c->d_Fall, c->d_sc, (T*)c->p_Phi, c->st);
+        SK::featuremap(g, c->p_Xt, Projection{c->d_Fall, c->d_Lall, c->d_Rall, c->p_Tt}, c->d_sc, (T*)c->p_Phi, c->st);
         SK::apply_v(g, (const T*)c->p_Phi, Bt, (T*)c->p_V, c->p_vpart, c->alpha_pred(), c->p_mupart, c->st);
         SK::rowpredict(g, c->p_mupart, c->p_vpart, c->d_sc, c->p_mu, c->p_sd, c->st);
         HIPCHK(c, hipGetLastError());
@@ -548,6 +554,7 @@ static int predict_impl(scfgp_ctx* c, const double* Xs, int64_t T, const double*
     int rc;
     if (!c->p_Xt) {
         if ((rc = dmalloc(c, &c->p_Xt, sizeof(double) * PRED_ROWS * g0.Dp))) return rc;
+        if (g0.lowrank && (rc = dmalloc(c, &c->p_Tt, sizeof(double) * PRED_ROWS * g0.Sp))) return rc;
         if ((rc = dmalloc(c, &c->p_vpart, sizeof(double) * PRED_ROWS * (Kp / 64)))) return rc;
         if ((rc = dmalloc(c, &c->p_mupart, sizeof(double) * PRED_ROWS * (Kp / 64)))) return rc;
         if ((rc = dmalloc(c, &c->p_mu, sizeof(double) * PRED_ROWS))) return rc;
@@ -690,7 +697,7 @@ static int enqueue_train_iter(scfgp_ctx* c) {
     if ((rc = DISPATCH(c, pass3, c))) return rc;
     enqueue_epilogue(c, 1);
     opt_update(c->opt_algo, c->opt_h, c->g.P, c->d_params, c->d_grad, c->d_opt, c->d_tctr, c->d_scalars, c->d_hist, c->hist_cap, c->st);
-    unpack_params(c->g, c->d_params, c->d_F, c->d_Fall, c->d_sc, c->st);
+    unpack_params(c->g, c->d_params, c->d_F, c->d_Fall, c->d_Lall, c->d_Rall, c->d_sc, c->st);
     HIPCHK(c, hipGetLastError());
     return SCFGP_OK;
 }
