@@ -141,16 +141,9 @@ __global__ void grad_tail_kernel(const double* __restrict__ params, const double
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t nDS = (int64_t)D * S, nMS = (int64_t)M * S;
     const double* lF = params + 3;
-    const double* rF = params + 3 + nDS;
     const double* Fbar = work + 4 * D + 4;
     if (i < nDS) {
-        const int d = (int)(i / S), s = (int)(i % S);
-        const double mu_l = work[4 * D + 2], sig_l = work[4 * D + 3];
-        const double wgt = (double)S / (S + M);
-        double v = XZ[(int64_t)d * ldxz + s] - XZ[(int64_t)D * ldxz + s] / D
-                 + wgt * ((1.0 - 1.0 / sig_l) * (lF[i] - work[2 * D + d]) / (S * work[3 * D + d]) + 2.0 * mu_l / S);
-        for (int m = 0; m < M; ++m) v += Fbar[(int64_t)d * M + m] * rF[(int64_t)m * S + s];
-        grad[3 + i] = v * invN;
+        return;                                                       // lbar_F: lbar_kernel (one wave per entry)
     } else if (i < nDS + nMS) {
         const int64_t t = i - nDS;
         const int m = (int)(t / S), s = (int)(t % S);
@@ -163,6 +156,28 @@ __global__ void grad_tail_kernel(const double* __restrict__ params, const double
     }
 }
 
+// lbar_F[d][s] = direct term + penalty + sum_m Fbar[d][m] r_F[m][s]: one wave per entry (the sum over M is the long one)
+__global__ __launch_bounds__(256) void lbar_kernel(const double* __restrict__ params, const double* __restrict__ XZ, int64_t ldxz, int D,
+                                                   int S, int M, const double* __restrict__ work, double invN,
+                                                   double* __restrict__ grad) {
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= (int64_t)D * S) return;
+    const int lane = threadIdx.x & 63, d = (int)(i / S), s = (int)(i % S);
+    const double* rF = params + 3 + (int64_t)D * S;
+    const double* Fbar = work + 4 * D + 4;
+    double v = 0;
+    for (int m = lane; m < M; m += 64) v += Fbar[(int64_t)d * M + m] * rF[(int64_t)m * S + s];
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) v += __shfl_xor(v, k);
+    if (lane == 0) {
+        const double mu_l = work[4 * D + 2], sig_l = work[4 * D + 3];
+        const double wgt = (double)S / (S + M);
+        v += XZ[(int64_t)d * ldxz + s] - XZ[(int64_t)D * ldxz + s] / D
+           + wgt * ((1.0 - 1.0 / sig_l) * (params[3 + i] - work[2 * D + d]) / (S * work[3 * D + d]) + 2.0 * mu_l / S);
+        grad[3 + i] = v * invN;
+    }
+}
+
 void grad_epilogue(const Geom& g, const double* params, const double* F, const double* XZ, int64_t ldxz, double* work,
                    double* scalars, int64_t Nglobal, double* grad, hipStream_t st) {
     const int D = g.D, S = g.S, M = g.M;
@@ -172,6 +187,8 @@ void grad_epilogue(const Geom& g, const double* params, const double* F, const d
     const int64_t nf = (int64_t)D * M, nt = (int64_t)g.P - 3;
     hipLaunchKernelGGL(fbar_kernel, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, st, F, XZ, ldxz, D, S, M, work);
     hipLaunchKernelGGL(grad_tail_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, params, XZ, ldxz, D, S, M, work,
+                       1.0 / (double)Nglobal, grad);
+    hipLaunchKernelGGL(lbar_kernel, dim3((unsigned)(((int64_t)D * S + 3) / 4)), dim3(256), 0, st, params, XZ, ldxz, D, S, M, work,
                        1.0 / (double)Nglobal, grad);
 }
 
