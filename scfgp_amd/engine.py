@@ -31,6 +31,7 @@ class HipEngine(object):
         self.K = 2 * self.J
         self.P = num_params(D, S, M)
         self.dtype = _DTYPES[dtype]
+        self.device = int(device)
         self.ctx = C.c_void_p()
         rc = self.lib.scfgp_create(C.byref(self.ctx), self.D, self.S, self.M, self.dtype, int(device),
                                    C.c_void_p(stream) if stream else None)
@@ -240,7 +241,8 @@ class HipEngine(object):
 
         class _Alias(object):
             __cuda_array_interface__ = {'shape': (n,), 'typestr': '<f8', 'data': (ptr, False), 'version': 2}
-        return torch.as_tensor(_Alias(), device='cuda')
+        # name the engine's own GPU: a bare 'cuda' is torch's CURRENT device and as_tensor would silently copy
+        return torch.as_tensor(_Alias(), device=torch.device('cuda', self.device))
 
     # -- on-device optimiser ------------------------------------------------------------------------
     ALGOS = {'sgd': 0, 'adagrad': 1, 'rmsprop': 2, 'adadelta': 3, 'adam': 4, 'adamax': 5}
