@@ -105,6 +105,12 @@ template <typename P> static int dmalloc(scfgp_ctx* c, P** p, size_t bytes) {
     return SCFGP_OK;
 }
 template <typename P> static void dfree(P*& p) { if (p) { hipFree((void*)p); p = nullptr; } }
+// call-scoped device buffer: released on every return path
+struct DevTmp {
+    double* p = nullptr;
+    ~DevTmp() { if (p) hipFree(p); }
+    operator double*() const { return p; }
+};
 
 // row splits of the Gram products: enough workgroups (>> 768 resident) that the tail does not
 // quantise, but at least 2048 rows per split so the slab traffic (nsplit x K^2/2 x 8 B written and
@@ -565,8 +571,8 @@ static int predict_impl(scfgp_ctx* c, const double* Xs, int64_t T, const double*
         HIPCHK(c, hipMemsetAsync(c->p_V, 0, ts * PRED_ROWS * Kp, c->st));
     }
     // Li (K x K host) -> T1 (Kp x Kp, identity padding); B = Li^T Li -> T2; typed copy -> AbarT scratch
-    double* raw = nullptr;
-    if ((rc = dmalloc(c, &raw, sizeof(double) * std::max<int64_t>((int64_t)g0.K * g0.K, PRED_ROWS * g0.D)))) return rc;
+    DevTmp raw, d_ys, d_part;                                     // Li / chunk of Xs | targets, mean, metrics | chunk partials
+    if ((rc = dmalloc(c, &raw.p, sizeof(double) * std::max<int64_t>((int64_t)g0.K * g0.K, PRED_ROWS * g0.D)))) return rc;
     HIPCHK(c, hipMemcpyAsync(raw, Li, sizeof(double) * g0.K * g0.K, hipMemcpyHostToDevice, c->st));
     pad_square(raw, g0.K, g0.Kp, c->d_T1, c->st);
     HIPCHK(c, hipMemsetAsync(c->alpha_pred(), 0, sizeof(double) * Kp, c->st));
@@ -578,34 +584,31 @@ static int predict_impl(scfgp_ctx* c, const double* Xs, int64_t T, const double*
     else SweepKernels<double>::convert(c->d_T2, (double*)c->d_AbarT, g0.K, g0.Kp, c->st);
     HIPCHK(c, hipStreamSynchronize(c->st));                     // raw is reused below
     const int nchunks = (int)((T + PRED_ROWS - 1) / PRED_ROWS);
-    double *d_ys = nullptr, *d_part = nullptr;                   // targets | [mean, metrics(6)] | chunk partials
     if (post && ys) {
-        if ((rc = dmalloc(c, &d_ys, sizeof(double) * (T + 8)))) { dfree(raw); return rc; }
-        if ((rc = dmalloc(c, &d_part, sizeof(double) * 4 * YPOST_BLOCKS * nchunks))) { dfree(raw); dfree(d_ys); return rc; }
-        hipMemcpyAsync(d_ys, ys, sizeof(double) * T, hipMemcpyHostToDevice, c->st);
+        if ((rc = dmalloc(c, &d_ys.p, sizeof(double) * (T + 8)))) return rc;
+        if ((rc = dmalloc(c, &d_part.p, sizeof(double) * 4 * YPOST_BLOCKS * nchunks))) return rc;
+        HIPCHK(c, hipMemcpyAsync(d_ys, ys, sizeof(double) * T, hipMemcpyHostToDevice, c->st));
         ypost_mean(d_ys, T, d_ys + T, c->st);
     }
-    auto cleanup = [&]() { dfree(raw); dfree(d_ys); dfree(d_part); };
     for (int64_t t0 = 0; t0 < T; t0 += PRED_ROWS) {
         Geom g = g0;
         g.N = std::min<int64_t>(PRED_ROWS, T - t0); g.Np = round_up(g.N, 256);
         HIPCHK(c, hipMemcpyAsync(raw, Xs + t0 * g.D, sizeof(double) * g.N * g.D, hipMemcpyHostToDevice, c->st));
         pack_data(g, raw, nullptr, nullptr, c->p_Xt, nullptr, c->st, raw_mode ? c->xs_mode : 0, c->d_xscale);
         rc = c->dtype == SCFGP_F32 ? Impl<float>::predict_chunk(c, g, (const float*)Bt) : Impl<double>::predict_chunk(c, g, (const double*)Bt);
-        if (rc) { cleanup(); return rc; }
+        if (rc) return rc;
         if (post)
-            ypost_chunk(c->p_mu, c->p_sd, d_ys ? d_ys + t0 : nullptr, g.N, c->ys_mode, c->d_yscale, d_ys ? d_ys + T : nullptr,
-                        d_part ? d_part + 4 * YPOST_BLOCKS * (t0 / PRED_ROWS) : nullptr, c->st);
+            ypost_chunk(c->p_mu, c->p_sd, d_ys.p ? d_ys + t0 : nullptr, g.N, c->ys_mode, c->d_yscale, d_ys.p ? d_ys + T : nullptr,
+                        d_part.p ? d_part + 4 * YPOST_BLOCKS * (t0 / PRED_ROWS) : nullptr, c->st);
         HIPCHK(c, hipMemcpyAsync(mu + t0, c->p_mu, sizeof(double) * g.N, hipMemcpyDeviceToHost, c->st));
         HIPCHK(c, hipMemcpyAsync(sd + t0, c->p_sd, sizeof(double) * g.N, hipMemcpyDeviceToHost, c->st));
         HIPCHK(c, hipStreamSynchronize(c->st));
     }
     if (post && ys) {
         ypost_metrics(d_part, YPOST_BLOCKS * nchunks, T, d_ys + T + 1, c->st);
-        hipMemcpyAsync(metrics, d_ys + T + 1, sizeof(double) * 6, hipMemcpyDeviceToHost, c->st);
-        hipStreamSynchronize(c->st);
+        HIPCHK(c, hipMemcpyAsync(metrics, d_ys + T + 1, sizeof(double) * 6, hipMemcpyDeviceToHost, c->st));
+        HIPCHK(c, hipStreamSynchronize(c->st));
     }
-    cleanup();
     HIPCHK(c, hipGetLastError());
     return SCFGP_OK;
 }

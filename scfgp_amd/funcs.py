@@ -36,6 +36,9 @@ class _GradSlot(object):
 
 
 def _fingerprint(X, y):
+    """Identity of a data set for the residency check: object ids, buffer addresses, shapes and a strided sample
+    of 257 values of each array.  An in-place edit that misses every sampled element is not seen -- callers that
+    mutate a resident array call CompiledFuncs.invalidate() (the reference re-reads its arguments on every call)."""
     flat = X.reshape(-1)
     step = max(1, flat.size // 257)
     return (id(X), id(y), X.shape, X.ctypes.data, y.ctypes.data,
@@ -91,6 +94,10 @@ class CompiledFuncs(object):
                 n_global = int(n[0])
             self.engine.set_data(X, y, n_global)
             self._resident = fp
+
+    def invalidate(self):
+        """Forget the resident data set: the next call uploads its X, y again."""
+        self._resident = None
 
     def _evaluate(self, X, y, want_grad):
         self._sync_params()

@@ -113,6 +113,22 @@ def test_error_behaviour_matches_reference():
         CompiledFuncs(D, S, M, params, algo='norm_constraint')
 
 
+def test_resident_data_is_re_uploaded_after_invalidate():
+    """X, y stay on the GPU while the caller keeps passing the same arrays; an in-place edit needs invalidate()."""
+    from scfgp_amd.funcs import CompiledFuncs
+    name = 'tiny_257x5'
+    N, D, S, M, T, seed = CASES[name]
+    X, y, params, _ = case_inputs(name)
+    cf = CompiledFuncs(D, S, M, params.copy())
+    c0 = float(cf.train_func(X, y)[0])
+    assert float(cf.train_func(X, y)[0]) == c0                      # second call: resident, same result
+    y[1::2] += 0.25                                                  # in-place edit (hits sampled elements or not)
+    cf.invalidate()
+    c1 = float(cf.train_func(X, y)[0])
+    c_ref = O.forward(X, y, params, S, M)[0]
+    assert abs(c1 - c_ref) < 1e-10 * abs(c_ref) and c1 != c0
+
+
 def test_minibatches_of_different_sizes():
     """N is per call (batch size enters 2(N-M)a and /N, SCFGP.py:126,128)."""
     from scfgp_amd.funcs import CompiledFuncs
