@@ -8,13 +8,13 @@
 // --------------------------------------------------------------------------
 // tile configurations (tuning knobs)
 // --------------------------------------------------------------------------
-// Gram: square 128 x 128 output tiles plus a 64 x 128 strip; apply: 256 rows x {128, 64} columns.
+// Gram: 256 x 128 (fp32) and 128 x 128 output tiles plus a 64 x 128 strip; apply: 256 rows x {128, 64} columns.
 // Measured on MI355X (N = 5e5..1e6, K = 2112; tests/gpu_tune.py, profiles/r01_tuning.md):
-//   * 8-wave workgroups (2 waves per SIMD inside one workgroup) beat 4-wave ones for both dtypes;
-//     fp64 apply gains again with 16 waves (4 per SIMD): the 64-cycle fp64 MFMA leaves room
-//     for every other wave's LDS / global traffic and the barrier bubbles overlap.
-//   * BK = 32 (fewer barriers, lower occupancy) and the 32x32x2 fp32 MFMA shape are slower.
-//   * 192- and 256-wide tiles (96 x 96 / 128 x 64 wave tiles) cost occupancy or spill and are slower.
+//   * every MFMA kernel wants two workgroups per CU: 8-wave workgroups within a 128-VGPR budget (the compiler
+//     takes up to 256 unless told: amdgpu_waves_per_eu on the Gram kernel); fp64 apply: one 16-wave workgroup;
+//   * 64 x 64 wave tiles and one barrier per 64 MFMAs per wave where the registers allow it (apply: BK = 16 on a
+//     256 x 128 tile; fp32 Gram: the same tall tile, BK = 32 on its 128 x 128 tiles);
+//   * the 32x32x2 fp32 MFMA shape, 192- / 256-wide square tiles and 16-wave 256 x 256 tiles are slower.
 #ifndef SCFGP_BK
 #define SCFGP_BK 16
 #endif
