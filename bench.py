@@ -162,6 +162,24 @@ def main():
             "stages_ms": {k: float(np.mean(v)) for k, v in per_kernel.items()},
             "cost": float(cost),
         }
+        # the two other figures the north star asks for: the feature map against the HBM roof (it writes Phi once:
+        # rows x K x element size, SURVEY 8(d) kernel K3) and the Gram build against the MFMA peak (executed flops:
+        # lower triangle in 64-column blocks, so about 1.06 x N K^2 rather than the algorithmic 2 N K^2)
+        esz = 4 if a.dtype == 'f32' else 8
+        fm_ms = float(np.mean(per_kernel.get('featuremap', [0])))
+        gr_ms = float(np.mean(per_kernel.get('gram', [0])))
+        b64 = -(-K // 64); nf = b64 // 2
+        gram_exec = 2.0 * (hi - lo) * ((nf * (nf + 1) // 2) * 128 * 128 + (b64 % 2) * (nf + 1) * 64 * 128)
+        out["secondary"] = {
+            "featuremap": {"bound": "hbm", "achieved": (hi - lo) * K * esz / (fm_ms * 1e-3) / 1e9 if fm_ms > 0 else 0.0,
+                           "peak": 8000.0, "unit": "GB/s", "avg_launch_ms": fm_ms,
+                           "note": "Phi written once / time of project+featuremap kernels; at D >= 32 the fp64 phase projection and "
+                                   "reduction, not HBM, set this time (D = 8: 3.4 TB/s, DESIGN.md)"},
+            "gram": {"bound": "mfma", "achieved": gram_exec / (gr_ms * 1e-3) / 1e12 if gr_ms > 0 else 0.0, "peak": peak,
+                     "unit": "TFLOP/s (executed)", "avg_launch_ms": gr_ms},
+        }
+        for v in out["secondary"].values():
+            v["frac"] = v["achieved"] / v["peak"]
         if not a.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(X, y, params, S, M, N, a.cpu_rows)
         print(json.dumps(out))
