@@ -112,12 +112,13 @@ struct DevTmp {
     operator double*() const { return p; }
 };
 
-// row splits of the Gram products: enough workgroups (>> 768 resident) that the tail does not
-// quantise, but at least 2048 rows per split so the slab traffic (nsplit x K^2/2 x 8 B written and
-// re-read by the reduction) stays far below the Phi traffic
-static int default_split(int ntiles, int64_t Np) {
-    int64_t s = (6144 + ntiles - 1) / ntiles;
-    const int64_t smax = std::max<int64_t>(Np / 2048, 1);
+// row splits of the Gram products: enough workgroups (>> 512 resident) that the tail does not quantise, but long
+// jobs -- at least 5120 rows per split -- so that the slab traffic (nsplit x K^2/2 x 8 B written and re-read by the
+// reduction) and the per-job prologue stay small.  Measured (profiles/r01_tuning.md): the fp32 job list (tall tiles,
+// 89 jobs per split at K = 2112) is fastest at 48 splits for N = 2.5e5..1e6 and at Np/5120 below that.
+static int default_split(int jobs, int64_t Np, bool f32) {
+    int64_t s = ((f32 ? 4224 : 6144) + jobs - 1) / jobs;
+    const int64_t smax = std::max<int64_t>(Np / (f32 ? 5120 : 2048), 1);
     if (s > smax) s = smax;
     if (s < 1) s = 1;
     return (int)s;
@@ -147,7 +148,7 @@ static int ensure_rows(scfgp_ctx* c, int64_t N) {
     const int nts = g.Kp / g.tile, ntiles = nts * (nts + 1) / 2;
     const int ntx = ((g.Dp + XT - 1) / XT) * (g.Jp / XT);
     const int gjobs = c->dtype == SCFGP_F32 ? SweepKernels<float>::gram_jobs(g) : SweepKernels<double>::gram_jobs(g);
-    const int gs = c->gram_nsplit > 0 ? (int)std::min<int64_t>(c->gram_nsplit, Np / 256) : default_split(gjobs, Np);
+    const int gs = c->gram_nsplit > 0 ? (int)std::min<int64_t>(c->gram_nsplit, Np / 256) : default_split(gjobs, Np, c->dtype == SCFGP_F32);
     const int xs = c->xtz_nsplit > 0 ? (int)std::min<int64_t>(c->xtz_nsplit, Np / 256) : xtz_split(ntx, Np);
     // Gram slabs are followed by the per-split side-vector partials (gs x Kp)
     const size_t need = sizeof(double) * std::max<size_t>((size_t)gs * ntiles * g.tile * g.tile + (size_t)gs * g.Kp, (size_t)xs * ntx * XT * XT);
@@ -330,7 +331,7 @@ template <typename T> struct Impl {
     static void gram_to(scfgp_ctx* c, const T* Mx, const double* w, const double* side, double* out, const char* name) {
         const Geom& g = c->g;
         const int nts = g.Kp / g.tile, ntiles = nts * (nts + 1) / 2;
-        const int gs = c->gram_nsplit > 0 ? (int)std::min<int64_t>(c->gram_nsplit, g.Np / 256) : default_split(SK::gram_jobs(g), g.Np);
+        const int gs = c->gram_nsplit > 0 ? (int)std::min<int64_t>(c->gram_nsplit, g.Np / 256) : default_split(SK::gram_jobs(g), g.Np, sizeof(T) == 4);
         double* sidepart = c->d_slabs + (size_t)gs * ntiles * g.tile * g.tile;
         { ProfScope ps(c, name);
           SK::gram(g, Mx, w, side, gs, c->dtype == SCFGP_F32 ? c->gram_chunk : 0, c->d_slabs, sidepart, c->st); }
