@@ -124,8 +124,8 @@ static int default_split(int jobs, int64_t Np, bool f32) {
     return (int)s;
 }
 
-static int xtz_split(int ntiles, int64_t Np) {          // the X~^T Zbar grid has few tiles: ~2048 workgroups suffice
-    int64_t s = (2048 + ntiles - 1) / ntiles;
+static int xtz_split(int ntiles, int64_t Np) {          // the X~^T Zbar grid has few tiles: ~1152 workgroups measured best
+    int64_t s = (1152 + ntiles - 1) / ntiles;
     const int64_t smax = std::max<int64_t>(Np / 2048, 1);
     if (s > smax) s = smax;
     if (s < 1) s = 1;
