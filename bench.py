@@ -2,19 +2,27 @@
 """
 bench.py -- NLML+grad evaluations/sec of the SCFGP hot path on MI355X.
 
-Workload (BASELINE.json `metric`): N=1e6, D=64, rank S=32, M=1024 (K=2112), fp32 compute
-mode, synthetic data; one "step" = one train_iter_func-equivalent evaluation with resident
-data: cost + full gradient + alpha + Li back on the host.
+Default workload (BASELINE.json `metric`, config "H"): N=1e6, D=64, rank S=32, M=1024 (K=2112), fp32
+compute mode, synthetic data; one "step" = one train_iter_func-equivalent evaluation with resident data:
+cost + full gradient + alpha + Li back on the host.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype f32|f64] [--rows N]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C1|C2|C3|C4|C5|H] [--dtype f32|f64] [--rows N]
 
-N>1 is launched by torch.distributed.run (one rank per GPU, RCCL): the N rows are sharded
-over the ranks (strong scaling -- total work fixed), three all-reduces per evaluation.
-Rank 0 prints ONE JSON line.
+--gpus N > 1 without a torchrun environment: this process (which touches no GPU) starts
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD, relays rank 0's JSON line
+and exits with the child's code.  Under torchrun (the driver's launch) every rank runs main() directly:
+one rank per GPU over RCCL, the N rows sharded over the ranks (strong scaling -- total work fixed, as
+the metric is quoted at fixed N), three all-reduces per evaluation.  Rank 0 prints ONE JSON line.
+
+In the default single-GPU run at config H the same process then also runs the fp64 engine (the
+reference's arithmetic, SCFGP/SCFGP.py:95-96,138) on the same rows: `secondary.f64` and the
+fp32-vs-fp64 `parity_at_size` block, and times the CPU restatements on a bounded sample (`cpu_baseline`).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,16 +31,70 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from scfgp_amd import synth                                   # noqa: E402
-from scfgp_amd.engine import HipEngine                        # noqa: E402
-from scfgp_amd.sharded import ShardedEvaluator, shard_rows, torch_allreduce   # noqa: E402
-
 SEED = 0x5CF600FF
 PEAK_TFLOPS = {'f32': 157.3, 'f64': 78.6}     # dense MFMA peaks, MI355X_MICROARCH.md / datasheet
+HBM_PEAK_GBS = 8000.0
+
+# BASELINE.json `configs` (C1..C5) and the headline metric (H): N, D, S (rank), M, compute dtype
+CONFIGS = {
+    'C1': (506, 13, 8, 64, 'f64', "Boston Housing shape (N=506, D=13), rank=8, M=64, fp64 -- plumbing/correctness"),
+    'C2': (100000, 32, 16, 256, 'f64', "Synthetic N=100k, D=32, rank=16, M=256, fp64, 1xMI355X"),
+    'C3': (1000000, 8, 32, 1024, 'f32', "kin8nm-shaped synthetic N=1e6, D=8, rank=32, M=1024, fp32 -- HBM-bound feature map"),
+    'C4': (4000000, 64, 32, 1024, 'f32', "Synthetic N=4e6, D=64, rank=32, M=1024, fp32, row-sharded with RCCL all-reduce"),
+    'C5': (1000000, 512, 64, 2048, 'f32', "High-dim synthetic N=1e6, D=512, rank=64, M=2048, fp32 -- MFMA-bound X.theta and Gram"),
+    'H': (1000000, 64, 32, 1024, 'f32', "headline metric: N=1e6, D=64, rank=32, M=1024, fp32"),
+}
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--config', default='H', choices=sorted(CONFIGS))
+    ap.add_argument('--dtype', default=None)
+    ap.add_argument('--rows', type=int, default=None)
+    ap.add_argument('--D', type=int, default=None)
+    ap.add_argument('--S', type=int, default=None)
+    ap.add_argument('--M', type=int, default=None)
+    ap.add_argument('--cpu-rows', type=int, default=100000)
+    ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the fp64 leg and the parity block')
+    ap.add_argument('--backend', default='nccl', help="'gloo' rehearses the multi-rank flow on one GPU")
+    a = ap.parse_args(argv)
+    N, D, S, M, dt, label = CONFIGS[a.config]
+    a.custom = any(v is not None for v in (a.rows, a.D, a.S, a.M))
+    a.rows = a.rows or N; a.D = a.D or D; a.S = a.S or S; a.M = a.M or M; a.dtype = a.dtype or dt
+    a.label = label if not a.custom else "custom shape derived from " + a.config
+    return a
+
+
+def spawn_ranks(a, argv):
+    """--gpus N > 1 outside torchrun: start the N ranks as a child process (this parent has made no GPU call)."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(a.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, universal_newlines=True)
+    line = None
+    for ln in p.stdout.splitlines():
+        if ln.startswith('{') and '"metric"' in ln:
+            line = ln
+        else:
+            sys.stderr.write(ln + '\n')
+    if p.returncode == 0 and line is not None:
+        out = json.loads(line)
+        assert out['n_gpus'] == a.gpus, 'asked for %d ranks, the job ran %d' % (a.gpus, out['n_gpus'])
+        print(line)
+    return p.returncode if p.returncode else (0 if line else 1)
 
 
 def build_problem(eng, N, D, S, M, lo, hi, allreduce):
     """Rows [lo,hi) of the synthetic problem; teacher response computed by the HIP predict path."""
+    from scfgp_amd import synth
     K = 2 * (S + M)
     X = synth.make_X(SEED, hi - lo, D, row0=lo)
     teacher = synth.make_params(SEED + 0x0101, D, S, M, abc=(-1.0, 0.0, -1.0))
@@ -48,44 +110,92 @@ def build_problem(eng, N, D, S, M, lo, hi, allreduce):
     return X, y, params
 
 
+def _blas_threads():
+    try:
+        import threadpoolctl
+        pools = threadpoolctl.threadpool_info()
+        mine = [p['num_threads'] for p in pools if 'numpy' in p.get('filepath', '')] or [p['num_threads'] for p in pools]
+        return int(max(mine or [os.cpu_count()]))
+    except Exception:
+        return int(os.cpu_count())
+
+
 def cpu_baseline(X, y, params, S, M, N_full, budget_rows):
-    """Times the CPU oracle (numpy/BLAS restatement of the same 3-sweep evaluation) on the first
-    `budget_rows` rows of the same workload and scales to evaluations/sec at N_full rows."""
+    """The reference's CPU path cannot run (Theano is absent), so its stand-ins are timed on the host cores of
+    this box on a bounded sample of the same workload (first `budget_rows` rows), scaled linearly in rows:
+      primary  torch-CPU float64 autograd of the LITERAL graph of SCFGP/SCFGP.py:92-129 (oracle/autograd_ref.py:
+               forward + reverse sweep as TT.grad would execute it, GH-30 tensor included), all torch threads
+      also     the numpy 3-sweep oracle (oracle/scfgp_oracle.py::value_and_grad), BLAS-threaded GEMMs"""
+    import torch
+    from oracle import autograd_ref as AR
     from oracle import scfgp_oracle as O
     n = min(budget_rows, X.shape[0])
     Xs, ys = np.ascontiguousarray(X[:n]), np.ascontiguousarray(y[:n])
     t0 = time.time()
-    O.value_and_grad(Xs, ys, params, S, M, chunk=n)             # one chunk: the fastest setting of the oracle on this host
-    dt = time.time() - t0
-    try:                                                        # threads of the BLAS numpy is linked against (the oracle's GEMMs)
-        import threadpoolctl
-        pools = threadpoolctl.threadpool_info()
-        mine = [p['num_threads'] for p in pools if 'numpy' in p.get('filepath', '')] or [p['num_threads'] for p in pools]
-        cores = max(mine or [os.cpu_count()])
-    except Exception:
-        cores = os.cpu_count()
-    return {"value": (n / float(N_full)) / dt, "unit": "evals/s", "cores": int(cores), "kind": "port",
-            "sample": "oracle.value_and_grad (numpy float64, 3-sweep; GEMMs on the BLAS threads counted in `cores`, element-wise "
-                      "numpy on one) on the first %d of %d rows, %.1f s; scaled linearly in rows (the K^3 stage is not "
-                      "scaled down)" % (n, N_full, dt)}
+    AR.value_and_grad(Xs, ys, params, S, M)
+    dt_ag = time.time() - t0
+    t0 = time.time()
+    O.value_and_grad(Xs, ys, params, S, M, chunk=n)             # one chunk: the oracle's fastest setting
+    dt_np = time.time() - t0
+    scale = n / float(N_full)
+    return {"value": scale / dt_ag, "unit": "evals/s", "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": "torch-CPU float64 autograd of the literal reference graph (oracle/autograd_ref.py, stand-in for Theano's "
+                      "compiled TT.grad, SCFGP/SCFGP.py:129) on the first %d of %d rows: %.1f s, scaled linearly in rows "
+                      "(the K^3 stage is not scaled down)" % (n, N_full, dt_ag),
+            "also": {"value": scale / dt_np, "unit": "evals/s", "cores": _blas_threads(), "kind": "port",
+                     "sample": "numpy 3-sweep oracle (oracle/scfgp_oracle.py value_and_grad; GEMMs on the BLAS threads in `cores`, "
+                               "element-wise numpy on one) on the same %d rows: %.1f s" % (n, dt_np)}}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--dtype', default='f32')
-    ap.add_argument('--rows', type=int, default=1000000)
-    ap.add_argument('--D', type=int, default=64)
-    ap.add_argument('--S', type=int, default=32)
-    ap.add_argument('--M', type=int, default=1024)
-    ap.add_argument('--cpu-rows', type=int, default=30000)
-    ap.add_argument('--no-cpu', action='store_true')
-    ap.add_argument('--backend', default='nccl', help="'gloo' rehearses the multi-rank flow on one GPU")
-    a = ap.parse_args()
+def rel(a, b):
+    return float(np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(np.asarray(b)), 1e-300))
 
+
+def f64_leg_and_parity(X, y, params, D, S, M, local, f32_out, f32_eng, steps=5, warmup=2):
+    """The reference's arithmetic is float64: run the fp64 engine on the SAME resident rows, time it, and report
+    how far the fp32-mode outputs are from it at this size (relative, norm-wise; gradient per block)."""
+    from scfgp_amd import synth
+    from scfgp_amd.engine import HipEngine
+    from scfgp_amd.sharded import ShardedEvaluator
+    N = X.shape[0]; J = S + M; K = 2 * J
+    eng = HipEngine(D, S, M, dtype='f64', device=local)
+    eng.set_params(params); eng.set_data(X, y, n_global=N)
+    ev = ShardedEvaluator(eng, None)
+    for _ in range(warmup):
+        ev.eval(True)
+    eng.set_profiling(True)
+    per_kernel, times = {}, []
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        c64, g64, a64, L64 = ev.eval(True)
+        times.append(time.perf_counter() - t0)
+        for name, ms in eng.timings():
+            per_kernel.setdefault(name, []).append(ms)
+    ms = float(np.median(times)) * 1e3
+    ap_ms = float(np.median(per_kernel.get('apply_v', [0]) + per_kernel.get('apply_phibar', [0])))
+    ach = 2.0 * N * K * K / (ap_ms * 1e-3) / 1e12 if ap_ms > 0 else 0.0
+    sec = {"evals_per_s": 1e3 / ms, "ms_per_step": ms, "steps": steps, "statistic": "median",
+           "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS['f64'], "unit": "TFLOP/s",
+                        "frac": ach / PEAK_TFLOPS['f64'], "kernel": "apply_kernel (fp64 MFMA 16x16x4)", "avg_launch_ms": ap_ms},
+           "stages_ms": {k: float(np.median(v)) for k, v in per_kernel.items()}, "cost": float(c64)}
+    c32, g32, a32, L32 = f32_out
+    o = 3 + D * S
+    Xs = synth.make_X(SEED + 0x0909, 4096, D)
+    mu64, sd64 = eng.predict(Xs, a64, L64)
+    mu32, sd32 = f32_eng.predict(Xs, a32, L32)
+    parity = {"what": "fp32 mode vs fp64 mode of this library on the same %d rows (fp64 mode equals the oracle to 1e-12 wherever "
+                      "the oracle is run: tests/test_gpu_parity.py); relative, norm-wise" % N,
+              "cost": abs(float(c32) - float(c64)) / abs(float(c64)),
+              "grad_abc": rel(g32[:3], g64[:3]), "grad_lF": rel(g32[3:o], g64[3:o]), "grad_rF": rel(g32[o:o + M * S], g64[o:o + M * S]),
+              "alpha": rel(a32, a64), "Li": rel(L32, L64), "mu": rel(mu32, mu64), "std": rel(sd32, sd64)}
+    eng.close()
+    return sec, parity
+
+
+def main(a):
     import torch
+    from scfgp_amd.engine import HipEngine
+    from scfgp_amd.sharded import ShardedEvaluator, shard_rows, torch_allreduce
     rank = int(os.environ.get('RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0)) % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
@@ -116,70 +226,85 @@ def main():
     for _ in range(a.warmup):
         ev.eval(True)
     eng.set_profiling(True)
-    per_kernel = {}
+    per_kernel, step_s = {}, []
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        cost, grad, alpha, Li = ev.eval(True)
+        t1 = time.perf_counter()
+        cost, grad, alpha, Li = ev.eval(True)                  # synchronous: results are on the host on return
+        step_s.append(time.perf_counter() - t1)
         for name, ms in eng.timings():
             per_kernel.setdefault(name, []).append(ms)
     barrier()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], device='cuda' if a.backend == 'nccl' else 'cpu')
+    tmax = torch.tensor([dt, float(np.median(step_s))], device='cuda' if a.backend == 'nccl' else 'cpu', dtype=torch.float64)
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    dt, med_s = float(tmax[0].item()), float(tmax[1].item())
 
     if rank == 0:
         ms_step = dt / a.steps * 1e3
+        med = lambda k: float(np.median(per_kernel.get(k, [0])))
         # dominant kernel: the N x K x K "apply" product (Phi.B and Phi.Abar use the same kernel);
         # algorithmic flops per launch = 2 * rows_on_this_rank * K^2   
-        ap_ms = np.mean(per_kernel.get('apply_v', [0]) + per_kernel.get('apply_phibar', [0]))
+        ap_ms = float(np.median(per_kernel.get('apply_v', [0]) + per_kernel.get('apply_phibar', [0])))
         flops = 2.0 * (hi - lo) * K * K
         ach = flops / (ap_ms * 1e-3) / 1e12 if ap_ms > 0 else 0.0
         peak = PEAK_TFLOPS[a.dtype]
         falg = 10.0 * N * K * K + 4.0 * N * D * J
-        traffic, traffic_src = None, None
-        tp = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
-        if os.path.exists(tp) and (N, D, S, M, a.dtype, world) == (1000000, 64, 32, 1024, 'f32', 1):
-            # HBM-side bytes per launch of the same kernel on the same workload, from rocprofv3 PMC passes
-            # (FETCH_SIZE x2 + WRITE_SIZE, one counter per pass): it cannot be collected inside this process
-            traffic = json.load(open(tp))['apply_kernel_mean_GB_per_launch'] * 1e9
-            traffic_src = 'profiles/r01_pmc_traffic.json'
+        traffic, traffic_src, pmc = None, None, {}
+        tp = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')
+        if os.path.exists(tp) and not a.custom and world == 1:
+            # HBM-side bytes per launch of the same kernels on the same workload, from rocprofv3 PMC passes
+            # (FETCH_SIZE x2 + WRITE_SIZE, one counter per pass): they cannot be collected inside this process
+            pmc = json.load(open(tp)).get(a.config + '_' + a.dtype, {})
+            if 'apply_kernel_mean_GB_per_launch' in pmc:
+                traffic = pmc['apply_kernel_mean_GB_per_launch'] * 1e9
+                traffic_src = 'profiles/r02_pmc_traffic.json'
         out = {
             "metric": "NLML+grad evals/sec", "value": a.steps / dt, "unit": "evals/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
+            "ms_per_step_median": med_s * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": "N=%d D=%d S=%d M=%d (K=%d), resident rows, cost+grad+alpha+Li to host" % (N, D, S, M, K),
+            "config": {"workload": "%s: %s -- N=%d D=%d S=%d M=%d (K=%d), resident rows, cost+grad+alpha+Li to host"
+                                   % (a.config, a.label, N, D, S, M, K),
                        "rows_per_gpu": hi - lo, "parallelism": "row-sharded dp%d, 3 all-reduces/eval" % world,
                        "F_alg_per_eval": falg, "F_alg_TFLOPs": falg / (dt / a.steps) / 1e12},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "apply_kernel (Phi.B / Phi.Abar): one N x K x K product = 2*N*K^2 flops, issued as a 256x128-tile launch "
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": "apply_kernel (Phi.B / Phi.Abar): one N x K x K product = 2*N*K^2 flops, issued as a 256x128-tile launch "
                                    "for the full column tiles plus a 256x64-tile launch for the ragged remainder; "
-                                   "avg_launch_ms is the hipEvent time of that pair (rocprof: sum of the two kernels)",
+                                   "avg_launch_ms is the median hipEvent time of that pair (rocprof: sum of the two kernels)",
                          "avg_launch_ms": ap_ms},
-            "stages_ms": {k: float(np.mean(v)) for k, v in per_kernel.items()},
+            "stages_ms": {k: float(np.median(v)) for k, v in per_kernel.items()},
+            "stages_statistic": "median over the timed steps",
             "cost": float(cost),
         }
         # the two other figures the north star asks for: the feature map against the HBM roof (it writes Phi once:
         # rows x K x element size, SURVEY 8(d) kernel K3) and the Gram build against the MFMA peak (executed flops:
         # lower triangle in 64-column blocks, so about 1.06 x N K^2 rather than the algorithmic 2 N K^2)
         esz = 4 if a.dtype == 'f32' else 8
-        fm_ms = float(np.mean(per_kernel.get('featuremap', [0])))
-        gr_ms = float(np.mean(per_kernel.get('gram', [0])))
+        fm_ms, gr_ms, xz_ms = med('featuremap'), med('gram'), med('xtz')
         b64 = -(-K // 64); nf = b64 // 2
         gram_exec = 2.0 * (hi - lo) * ((nf * (nf + 1) // 2) * 128 * 128 + (b64 % 2) * (nf + 1) * 64 * 128)
         out["secondary"] = {
             "featuremap": {"bound": "hbm", "achieved": (hi - lo) * K * esz / (fm_ms * 1e-3) / 1e9 if fm_ms > 0 else 0.0,
-                           "peak": 8000.0, "unit": "GB/s", "avg_launch_ms": fm_ms,
-                           "note": "Phi written once / time of project+featuremap kernels; at D >= 32 the fp64 phase projection and "
-                                   "reduction, not HBM, set this time (D = 8: 3.4 TB/s, DESIGN.md)"},
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "avg_launch_ms": fm_ms,
+                           "rocprof_WRITE_SIZE_GBs": pmc.get('featuremap_WRITE_SIZE_GBs'),
+                           "note": "Phi written once / time of project+featuremap kernels (hipEvents); rocprof_WRITE_SIZE_GBs is the "
+                                   "same quantity from the rocprofv3 WRITE_SIZE counter (profiles/r02_pmc_traffic.json)"},
             "gram": {"bound": "mfma", "achieved": gram_exec / (gr_ms * 1e-3) / 1e12 if gr_ms > 0 else 0.0, "peak": peak,
-                     "unit": "TFLOP/s (executed)", "avg_launch_ms": gr_ms},
+                     "unit": "TFLOP/s (executed)", "avg_launch_ms": gr_ms,
+                     "MFMA_BUSY": pmc.get('gram_MFMA_BUSY')},
+            "xtz": {"bound": "mfma", "achieved": 2.0 * (hi - lo) * (D + 1) * J / (xz_ms * 1e-3) / 1e12 if xz_ms > 0 else 0.0, "peak": peak,
+                    "unit": "TFLOP/s", "avg_launch_ms": xz_ms, "share_of_step": xz_ms / ms_step if ms_step > 0 else 0.0},
         }
         for v in out["secondary"].values():
             v["frac"] = v["achieved"] / v["peak"]
+        if world == 1 and a.config == 'H' and a.dtype == 'f32' and not a.custom and not a.no_secondary:
+            out["secondary"]["f64"], out["parity_at_size"] = f64_leg_and_parity(X, y, params, D, S, M, local,
+                                                                                   (cost, grad, alpha, Li), eng)
         if not a.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(X, y, params, S, M, N, a.cpu_rows)
         print(json.dumps(out))
@@ -190,4 +315,11 @@ def main():
 
 
 if __name__ == '__main__':
-    main()
+    args = parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(args, sys.argv[1:]))
+    if 'WORLD_SIZE' in os.environ and int(os.environ['WORLD_SIZE']) != args.gpus:
+        sys.stderr.write('bench.py: --gpus %d but WORLD_SIZE=%s; the launcher decides the rank count\n'
+                         % (args.gpus, os.environ['WORLD_SIZE']))
+        sys.exit(2)
+    main(args)

@@ -136,6 +136,15 @@ int scfgp_finish(scfgp_ctx* ctx, int want_grad, double* cost, double* grad, doub
 int scfgp_fetch_factors(scfgp_ctx* ctx, double* alpha, double* Li);
 /* device pointer + length (in doubles) of exchange buffer `stage` (1..3) */
 int scfgp_exchange(scfgp_ctx* ctx, int stage, void** dev_ptr, int64_t* count);
+/* Ordering contract for the sums.  The library enqueues on ITS stream: the one handed to scfgp_create, or a
+ * private one when that was NULL (torch's default stream is handle 0 == NULL, so a caller on torch's default
+ * stream always gets a private library stream).  A collective issued by the host framework on another stream
+ * must be fenced on both sides:
+ *     scfgp_stream_fence(ctx, peer, 0)   peer waits for the library's queued work   (before the all-reduce)
+ *     scfgp_stream_fence(ctx, peer, 1)   the library waits for peer's queued work   (after the all-reduce)
+ * peer = the hipStream_t the collective runs on (NULL = legacy default stream).  Event based, asynchronous,
+ * a no-op when peer is the library's own stream.  No reference counterpart (the reference is single-device). */
+int scfgp_stream_fence(scfgp_ctx* ctx, void* peer_stream, int direction);
 
 /* ---- on-device update rule and multi-iteration residency -------------
  * The arithmetic of SCFGP/Optimizer.py as a device kernel behind the evaluation, so a training

@@ -43,6 +43,7 @@ SIGNATURES = {
     'scfgp_finish': (C.c_int, [C.c_void_p, C.c_int, _c_double_p, _c_double_p, _c_double_p, _c_double_p]),
     'scfgp_fetch_factors': (C.c_int, [C.c_void_p, _c_double_p, _c_double_p]),
     'scfgp_exchange': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), _c_i64_p]),
+    'scfgp_stream_fence': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     'scfgp_opt_init': (C.c_int, [C.c_void_p, C.c_int, _c_double_p, C.c_int, C.c_double]),
     'scfgp_opt_state': (C.c_int, [C.c_void_p, C.c_int, C.c_int, _c_double_p]),
     'scfgp_train': (C.c_int, [C.c_void_p, C.c_int, _c_double_p, _c_double_p, _c_double_p]),

@@ -54,6 +54,9 @@ template <typename T> struct SweepKernels {
     static void convert(const double* src, T* dst, int K, int Kp, hipStream_t st);
 };
 
+// diagnostic builds only (-DSCFGP_TRACE): per-workgroup [start, end, xcc, kind] of the last Gram launch; -1 otherwise
+int64_t trace_read(void* host, int64_t max_bytes);
+
 // ---- reductions ------------------------------------------------------------
 // packed lower tiles = sum over splits of the per-split lower-tile slabs (tile t = ti(ti+1)/2+tj, row-major)
 void reduce_tri_tiles(const double* slabs, int nsplit, int nts, int tile, double* packed, hipStream_t st);

@@ -5,6 +5,32 @@
 
 #define SMEM_DECL extern __shared__ __attribute__((aligned(16))) char smem_raw[]
 
+// Diagnostic build (-DSCFGP_TRACE, library variant "_trace"): every workgroup of the Gram kernel records
+// [start, end] on the 100 MHz constant clock, its XCC id and its job kind, so the tail and the spread of job lengths
+// can be read off (tests/gpu_gram_trace.py).  No stamp reaches any output; the product build contains none of this.
+#ifdef SCFGP_TRACE
+constexpr int TRACE_CAP = 1 << 16;
+__device__ unsigned long long g_trace[TRACE_CAP][4];
+#define TRACE_BEGIN() const unsigned long long tr_t0 = __builtin_amdgcn_s_memrealtime()
+#define TRACE_END(kind)                                                                                     \
+    do {                                                                                                    \
+        __syncthreads();                                                                                    \
+        if (threadIdx.x == 0 && blockIdx.x < TRACE_CAP) {                                                   \
+            g_trace[blockIdx.x][0] = tr_t0; g_trace[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();      \
+            g_trace[blockIdx.x][2] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));           \
+            g_trace[blockIdx.x][3] = (unsigned long long)(kind);                                            \
+        }                                                                                                   \
+    } while (0)
+int64_t trace_read(void* host, int64_t max_bytes) {
+    const int64_t n = max_bytes < (int64_t)sizeof(g_trace) ? max_bytes : (int64_t)sizeof(g_trace);
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_trace), n) == hipSuccess ? n : -2;
+}
+#else
+#define TRACE_BEGIN()
+#define TRACE_END(kind)
+int64_t trace_read(void*, int64_t) { return -1; }
+#endif
+
 // --------------------------------------------------------------------------
 // tile configurations (tuning knobs)
 // --------------------------------------------------------------------------
@@ -269,6 +295,7 @@ void gram_kernel(
     static_assert(Cfg::THREADS == SCfg::THREADS && Cfg::THREADS == BCfg::THREADS && Cfg::BN == SCfg::BN && Cfg::BN == BCfg::BN &&
                   Cfg::BM == Cfg::BN, "one launch, three tile shapes");
     SMEM_DECL;
+    TRACE_BEGIN();
     constexpr int B = Cfg::BN;
     const int nall = nfull + nstrip, ntile_all = nall * (nall + 1) / 2;
     const int per_split = gram_jobs_per_split<BIG>(nfull, nstrip);
@@ -317,10 +344,11 @@ void gram_kernel(
     double* slab = slabs + ((int64_t)split * ntile_all + slab_t) * (B * B);
     double* slab2 = slabs + ((int64_t)split * ntile_all + slab_t2) * (B * B);
     double* sideout = sidepart + (int64_t)split * ld + acol;
-    if (kind == 1) { gram_body<SCfg, WEIGHT, true>(Phi, ld, w, side, r0, r1, chunk, acol, bcol, diag, sideout, slab, nullptr, smem_raw); return; }
+    if (kind == 1) { gram_body<SCfg, WEIGHT, true>(Phi, ld, w, side, r0, r1, chunk, acol, bcol, diag, sideout, slab, nullptr, smem_raw); TRACE_END(kind); return; }
     if constexpr (BIG)
-        if (kind == 2) { gram_body<BCfg, WEIGHT, false>(Phi, ld, w, side, r0, r1, chunk, acol, bcol, diag, sideout, slab, slab2, smem_raw); return; }
+        if (kind == 2) { gram_body<BCfg, WEIGHT, false>(Phi, ld, w, side, r0, r1, chunk, acol, bcol, diag, sideout, slab, slab2, smem_raw); TRACE_END(kind); return; }
     gram_body<Cfg, WEIGHT, false>(Phi, ld, w, side, r0, r1, chunk, acol, bcol, diag, sideout, slab, nullptr, smem_raw);
+    TRACE_END(kind + (diag ? 4 : 0));
 }
 
 template <class Cfg, typename S>

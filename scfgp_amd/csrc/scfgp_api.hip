@@ -3,6 +3,8 @@
 #include "../../include/scfgp_hip.h"
 #include "kernels.h"
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -24,6 +26,21 @@ static constexpr int64_t PRED_ROWS = 32768; // predict processes test rows in ch
 
 thread_local bool g_scfgp_capturing = false;
 
+// roctx ranges around every stage (visible in `rocprofv3 --marker-trace`): resolved at run time so the library has no
+// link-time dependency on the profiler SDK; without it the calls are no-ops
+struct Roctx {
+    int (*push)(const char*) = nullptr; int (*pop)() = nullptr;
+    Roctx() {
+        void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_LAZY | RTLD_LOCAL);
+        if (!h) h = dlopen("libroctx64.so", RTLD_LAZY | RTLD_LOCAL);
+        if (!h) return;
+        push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+        pop = (int (*)())dlsym(h, "roctxRangePop");
+        if (!push || !pop) { push = nullptr; pop = nullptr; }
+    }
+};
+static Roctx& roctx() { static Roctx r; return r; }
+
 struct ProfRec { std::string name; hipEvent_t e0, e1; };
 
 struct scfgp_ctx {
@@ -31,8 +48,9 @@ struct scfgp_ctx {
     int dtype = 0, device = 0;
     hipStream_t st = nullptr; bool own_stream = false;
     hipStream_t copy_st = nullptr; hipEvent_t ev_factor = nullptr;          // alpha/Li D2H beside pass 2/3 ...
+    hipEvent_t ev_fence = nullptr;                                          // scfgp_stream_fence
     double* h_pin = nullptr;                                                // ... through pinned staging (K*K + K doubles)
-    int64_t Ncap = 0, Nglobal = 0;
+    int64_t Ncap = 0, Nglobal = 0, Nglobal_full = 0;        // Nglobal_full: n_global given to scfgp_set_data
     bool have_params = false, have_data = false;
     int stage = 0, last_want_grad = 0;
     std::vector<double> h_params;
@@ -86,9 +104,11 @@ struct scfgp_ctx {
 };
 
 struct ProfScope {
-    scfgp_ctx* c; size_t idx = (size_t)-1;
+    scfgp_ctx* c; size_t idx = (size_t)-1; bool ranged = false;
     ProfScope(scfgp_ctx* c_, const char* name) : c(c_) {
-        if (!c->prof || g_scfgp_capturing) return;
+        if (g_scfgp_capturing) return;
+        if (roctx().push) { roctx().push(name); ranged = true; }
+        if (!c->prof) return;
         auto get = [&]() {
             if (c->pool_used == c->pool.size()) { hipEvent_t e; hipEventCreate(&e); c->pool.push_back(e); }
             return c->pool[c->pool_used++];
@@ -97,7 +117,10 @@ struct ProfScope {
         hipEventRecord(r.e0, c->st);
         c->recs.push_back(r); idx = c->recs.size() - 1;
     }
-    ~ProfScope() { if (idx != (size_t)-1) hipEventRecord(c->recs[idx].e1, c->st); }
+    ~ProfScope() {
+        if (idx != (size_t)-1) hipEventRecord(c->recs[idx].e1, c->st);
+        if (ranged) roctx().pop();
+    }
 };
 
 template <typename P> static int dmalloc(scfgp_ctx* c, P** p, size_t bytes) {
@@ -200,6 +223,7 @@ extern "C" int scfgp_create(scfgp_ctx** out, int D, int S, int M, int dtype, int
     else { HIPCHK(c, hipStreamCreate(&c->st)); c->own_stream = true; }
     HIPCHK(c, hipStreamCreateWithFlags(&c->copy_st, hipStreamNonBlocking));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_factor, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_fence, hipEventDisableTiming));
     const int64_t Kp = g.Kp, K2 = Kp * Kp;
     c->n_x1 = K2 + Kp + 8; c->n_x2 = K2 + Kp + 8; c->n_x3 = (int64_t)c->Dpp * g.Jp + 8;
     { const int64_t nts = Kp / g.tile; c->n_pk = nts * (nts + 1) / 2 * g.tile * g.tile; c->n_xp = c->n_pk + Kp + 8; }
@@ -258,6 +282,7 @@ extern "C" void scfgp_destroy(scfgp_ctx* c) {
     for (hipEvent_t e : c->pool) hipEventDestroy(e);
     if (c->copy_st) { hipStreamSynchronize(c->copy_st); hipStreamDestroy(c->copy_st); }
     if (c->ev_factor) hipEventDestroy(c->ev_factor);
+    if (c->ev_fence) hipEventDestroy(c->ev_fence);
     if (c->h_pin) hipHostFree(c->h_pin);
     if (c->own_stream && c->st) hipStreamDestroy(c->st);
     delete c;
@@ -304,7 +329,7 @@ extern "C" int scfgp_set_data(scfgp_ctx* c, const double* X, const double* y, in
         if (int rc = dmalloc(c, &c->d_yraw, sizeof(double) * N)) return rc;
         c->store_cap = N;
     }
-    c->Nstore = N;
+    c->Nstore = N; c->Nglobal_full = n_global > 0 ? n_global : N;
     HIPCHK(c, hipMemcpyAsync(c->d_Xraw, X, sizeof(double) * N * c->g.D, hipMemcpyHostToDevice, c->st));
     HIPCHK(c, hipMemcpyAsync(c->d_yraw, y, sizeof(double) * N, hipMemcpyHostToDevice, c->st));
     if (int rc = load_working_set(c, nullptr, N, n_global)) return rc;
@@ -406,8 +431,17 @@ static int ready(scfgp_ctx* c) {
     return SCFGP_OK;
 }
 
+// scfgp_eval_rows leaves a gathered minibatch as the working set; every entry point that evaluates "the resident
+// rows" (scfgp_eval with X == NULL, the staged path, scfgp_train) first brings all rows of the data set back,
+// with the n_global it was uploaded with (the reference refits on all N rows after minibatch training, SCFGP.py:265)
+static int restore_full_set(scfgp_ctx* c) {
+    if (!c->have_data || c->work_full) return SCFGP_OK;
+    return load_working_set(c, nullptr, c->Nstore, c->Nglobal_full);
+}
+
 extern "C" int scfgp_pass1(scfgp_ctx* c) {
     if (int rc = ready(c)) return rc;
+    if (int rc = restore_full_set(c)) return rc;
     if (c->prof) { c->recs.clear(); c->pool_used = 0; }
     if (int rc = DISPATCH(c, pass1, c)) return rc;
     c->stage = 1; return SCFGP_OK;
@@ -447,6 +481,21 @@ extern "C" int scfgp_exchange(scfgp_ctx* c, int stage, void** dev_ptr, int64_t* 
     }
     else if (stage == 3) { *dev_ptr = c->d_x3; *count = c->n_x3; }
     else return SCFGP_EARG;
+    return SCFGP_OK;
+}
+
+// Explicit ordering between the library's stream and the stream the host framework issues its collective on:
+//   direction 0: `peer` waits for everything queued on the library's stream (call before the all-reduce)
+//   direction 1: the library's stream waits for everything queued on `peer` (call after the all-reduce)
+// A no-op when both are the same stream.  peer == NULL names the legacy default stream.
+extern "C" int scfgp_stream_fence(scfgp_ctx* c, void* peer_stream, int direction) {
+    if (!c || (direction != 0 && direction != 1)) return SCFGP_EARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t peer = (hipStream_t)peer_stream;
+    if (peer == c->st) return SCFGP_OK;
+    hipStream_t from = direction == 0 ? c->st : peer, to = direction == 0 ? peer : c->st;
+    HIPCHK(c, hipEventRecord(c->ev_fence, from));
+    HIPCHK(c, hipStreamWaitEvent(to, c->ev_fence, 0));
     return SCFGP_OK;
 }
 
@@ -503,9 +552,15 @@ extern "C" int scfgp_finish(scfgp_ctx* c, int want_grad, double* cost, double* g
     return SCFGP_OK;
 }
 
-static int run_eval(scfgp_ctx* c, int want_grad, double* cost, double* grad, double* alpha, double* Li) {
+static int pass1_current(scfgp_ctx* c) {                  // pass 1 on the working set as it stands (full or gathered)
+    if (int rc = ready(c)) return rc;
+    if (c->prof) { c->recs.clear(); c->pool_used = 0; }
+    if (int rc = DISPATCH(c, pass1, c)) return rc;
+    c->stage = 1; return SCFGP_OK;
+}
+static int run_eval(scfgp_ctx* c, int want_grad, double* cost, double* grad, double* alpha, double* Li, bool subset = false) {
     int rc;
-    if ((rc = scfgp_pass1(c))) return rc;
+    if ((rc = subset ? pass1_current(c) : scfgp_pass1(c))) return rc;
     if ((rc = scfgp_factor(c))) return rc;
     if ((rc = scfgp_pass2(c, want_grad))) return rc;
     if (want_grad) {
@@ -522,11 +577,7 @@ extern "C" int scfgp_eval(scfgp_ctx* c, const double* X, const double* y, int64_
     if (!c) return SCFGP_EARG;
     int rc;
     if (X) { if ((rc = scfgp_set_data(c, X, y, N, N))) return rc; }
-    else if (c->have_data && !c->work_full) {           // a row subset was evaluated last: bring all rows back
-        if (hipSetDevice(c->device) != hipSuccess) return SCFGP_EHIP;
-        if ((rc = load_working_set(c, nullptr, c->Nstore, c->Nstore))) return rc;
-    }
-    return run_eval(c, want_grad, cost, grad, alpha, Li);
+    return run_eval(c, want_grad, cost, grad, alpha, Li);      // scfgp_pass1 brings all rows back after a row subset
 }
 
 extern "C" int scfgp_eval_rows(scfgp_ctx* c, const int64_t* idx, int64_t n, int want_grad,
@@ -544,7 +595,7 @@ extern "C" int scfgp_eval_rows(scfgp_ctx* c, const int64_t* idx, int64_t n, int 
     }
     HIPCHK(c, hipMemcpyAsync(c->d_idx, idx, sizeof(int64_t) * n, hipMemcpyHostToDevice, c->st));
     if (int rc = load_working_set(c, c->d_idx, n, n)) return rc;       // per-batch N, as SCFGP.py:126,128
-    return run_eval(c, want_grad, cost, grad, alpha, Li);
+    return run_eval(c, want_grad, cost, grad, alpha, Li, true);
 }
 
 // raw_mode: apply the registered X scaler while packing; post: y-scaler backward transform of the outputs on
@@ -709,6 +760,7 @@ static int enqueue_train_iter(scfgp_ctx* c) {
 extern "C" int scfgp_train(scfgp_ctx* c, int n_iters, double* cost_hist, double* alpha, double* Li) {
     if (int rc = ready(c)) return rc;
     if (c->opt_algo < 0 || n_iters < 1) { c->err = "train: call scfgp_opt_init first"; return SCFGP_EARG; }
+    if (int rc = restore_full_set(c)) return rc;
     const Geom& g = c->g;
     if (n_iters > c->hist_cap) {
         dfree(c->d_hist);
@@ -722,7 +774,10 @@ extern "C" int scfgp_train(scfgp_ctx* c, int n_iters, double* cost_hist, double*
     c->in_train = true;
     int rc = SCFGP_OK, done = 0;
     const bool graph_ok = c->use_graph && !c->prof;
-    if (graph_ok && !c->warm) { rc = enqueue_train_iter(c); done = 1; c->warm = true; }     // first touch of every kernel: eager
+    if (graph_ok && !c->warm) {                                  // first touch of every kernel: eager
+        rc = enqueue_train_iter(c); done = 1;
+        if (rc == SCFGP_OK) c->warm = true;
+    }
     if (rc == SCFGP_OK && graph_ok && done < n_iters) {
         if (!c->gexec || c->graph_N != g.N) {
             if (c->gexec) { hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
@@ -744,7 +799,10 @@ extern "C" int scfgp_train(scfgp_ctx* c, int n_iters, double* cost_hist, double*
             for (; done < n_iters && rc == SCFGP_OK; ++done)
                 if (hipGraphLaunch(c->gexec, c->st) != hipSuccess) { c->err = "hipGraphLaunch failed"; rc = SCFGP_EHIP; }
     }
-    for (; done < n_iters && rc == SCFGP_OK; ++done) rc = enqueue_train_iter(c);
+    for (; done < n_iters && rc == SCFGP_OK; ++done) {
+        if (c->prof) { c->recs.clear(); c->pool_used = 0; }      // timings describe the last eager iteration
+        rc = enqueue_train_iter(c);
+    }
     c->in_train = false;
     if (rc != SCFGP_OK) return rc;
     int h_flag[4] = {0, 0, 0, 0};
@@ -806,6 +864,7 @@ extern "C" int64_t scfgp_debug_read(scfgp_ctx* c, const char* name, void* host, 
     if (!c || !name || !host) return SCFGP_EARG;
     const Geom& g = c->g;
     const std::string s(name);
+    if (s == "trace") { if (hipStreamSynchronize(c->st) != hipSuccess) return SCFGP_EHIP; return trace_read(host, max_bytes); }
     const int64_t K2 = (int64_t)g.Kp * g.Kp;
     const size_t ts = c->tsize();
     const void* src = nullptr; int64_t bytes = 0;

@@ -138,6 +138,12 @@ class HipEngine(object):
         self._check(self.lib.scfgp_predict(self.ctx, dptr(Xs), T, dptr(alpha), dptr(Li), dptr(mu), dptr(sd)), 'predict')
         return mu, sd
 
+    @staticmethod
+    def scaler_key(scaler):
+        """Contents of a fitted Scaler (it is refitted IN PLACE by SCFGP.set_data, so identity says nothing)."""
+        d = scaler.data
+        return (scaler.algo,) + tuple((k, np.asarray(d[k], dtype=np.float64).tobytes()) for k in sorted(d) if np.size(d[k]))
+
     SCALER_MODES = {'min-max': 1, 'normal': 2, 'inv-normal': 3, 'auto-normal': 4, 'auto-inv-normal': 5}
 
     def set_x_scaler(self, scaler):
@@ -227,6 +233,12 @@ class HipEngine(object):
         self._early = None
         self._check(rc, 'finish')
         return cost.reshape(()), grad, alpha, Li
+
+    def stream_fence(self, peer_stream, direction):
+        """Order the library's stream against `peer_stream` (a raw hipStream_t handle, 0/None = legacy default
+        stream): direction 0 = peer waits for the library (before a collective), 1 = the library waits for peer."""
+        self._check(self.lib.scfgp_stream_fence(self.ctx, C.c_void_p(peer_stream) if peer_stream else None, int(direction)),
+                    'stream_fence')
 
     def exchange_ptr(self, stage):
         """(device pointer, number of float64) of exchange buffer `stage` (1..3)."""

@@ -35,14 +35,57 @@ class _GradSlot(object):
         self._g = g
 
 
-def _fingerprint(X, y):
-    """Identity of a data set for the residency check: object ids, buffer addresses, shapes and a strided sample
-    of 257 values of each array.  An in-place edit that misses every sampled element is not seen -- callers that
-    mutate a resident array call CompiledFuncs.invalidate() (the reference re-reads its arguments on every call)."""
-    flat = X.reshape(-1)
-    step = max(1, flat.size // 257)
-    return (id(X), id(y), X.shape, X.ctypes.data, y.ctypes.data,
-            float(flat[::step].sum()), float(y.reshape(-1)[::max(1, y.size // 257)].sum()))
+FULL_HASH_ELEMS = 1 << 24        # arrays up to this many elements are hashed completely on every call
+
+
+_pool = None
+
+
+def _hash_piece(mv):
+    try:
+        import xxhash
+        return xxhash.xxh3_64_intdigest(mv)
+    except ImportError:
+        import zlib
+        h = len(mv) // 2
+        return (zlib.crc32(mv[:h]) << 32) | zlib.crc32(mv[h:])
+
+
+def _hash64(buf):
+    """64-bit hashes of a contiguous buffer (xxh3 when the module is there, else crc32 of the two halves); buffers
+    above 4 MiB are hashed in 8 pieces on a small thread pool (both hash functions release the GIL)."""
+    global _pool
+    mv = memoryview(buf).cast('B')
+    if len(mv) <= (4 << 20):
+        return _hash_piece(mv)
+    if _pool is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _pool = ThreadPoolExecutor(max_workers=4)
+    n = len(mv); step = -(-n // 8)
+    return tuple(_pool.map(_hash_piece, [mv[i:i + step] for i in range(0, n, step)]))
+
+
+def _content_key(a):
+    """What identifies the CONTENTS of an array for the residency check.
+    Up to FULL_HASH_ELEMS elements (128 MiB of float64): a 64-bit hash of every byte -- any in-place edit is
+    seen, at the cost of one pass over the host copy (the reference re-reads its arguments on every call too,
+    SCFGP/SCFGP.py:237).  Above that: 4096 evenly spaced 512-byte blocks are hashed together with the array's
+    writeable flag; an edit between the blocks of a WRITEABLE array can be missed, so callers either freeze the
+    array (a.flags.writeable = False makes a missed edit impossible), pass a `version` token that they change
+    with the data, or call CompiledFuncs.invalidate()."""
+    flat = a.reshape(-1)
+    if flat.size <= FULL_HASH_ELEMS:
+        return ('full', _hash64(np.ascontiguousarray(flat)))
+    nblk, blk = 4096, 64
+    starts = np.linspace(0, flat.size - blk, nblk).astype(np.int64)
+    sample = np.concatenate([flat[s:s + blk] for s in starts])
+    return ('sampled', bool(a.flags.writeable), _hash64(sample))
+
+
+def _fingerprint(X, y, version=None):
+    """Identity of a data set for the residency check: shapes, buffer addresses, the caller's version token and
+    the content keys of both arrays (see _content_key)."""
+    return (X.shape, X.ctypes.data, y.ctypes.data, version, _content_key(X), _content_key(y))
 
 
 class CompiledFuncs(object):
@@ -59,6 +102,7 @@ class CompiledFuncs(object):
         if algo not in OPT.algos or algo.startswith('apply_'):
             raise ValueError("unknown update rule %r (choose from %s)" % (algo, OPT.algos[2:]))
         algo_params = {} if algo_params is None else algo_params
+        self.algo, self.algo_params, self.momentum, self.dtype = algo, dict(algo_params), momentum, dtype
         updates = getattr(OPT, algo)(self.params, self.grads, **algo_params)          # SCFGP.py:130
         self.updates = OPT.apply_nesterov_momentum(updates, momentum=momentum)        # SCFGP.py:131
         self._uploaded_version = None
@@ -84,8 +128,12 @@ class CompiledFuncs(object):
             self.engine.set_params(self.params.get_value(borrow=True))
             self._uploaded_version = self.params.version
 
+    def set_data_version(self, version):
+        """Caller-supplied token for very large arrays: change it whenever X or y were edited in place."""
+        self.data_version = version
+
     def _sync_data(self, X, y):
-        fp = _fingerprint(X, y)
+        fp = _fingerprint(X, y, getattr(self, 'data_version', None))
         if fp != self._resident:
             n_global = self.n_global
             if self.allreduce is not None and n_global is None:
@@ -94,6 +142,44 @@ class CompiledFuncs(object):
                 n_global = int(n[0])
             self.engine.set_data(X, y, n_global)
             self._resident = fp
+
+    def _sync_scalers(self, x_scaler, y_scaler):
+        """Register the scalers on the device when their CONTENTS changed: SCFGP.set_data refits the same Scaler
+        objects in place (SCFGP/SCFGP.py:155-156), so object identity cannot be the key."""
+        if x_scaler is not None:
+            key = self.engine.scaler_key(x_scaler)
+            if key != getattr(self, '_xscaler_key', None):
+                self.engine.set_x_scaler(x_scaler)
+                self._xscaler_key = key
+        if y_scaler is not None:
+            key = self.engine.scaler_key(y_scaler)
+            if key != getattr(self, '_yscaler_key', None):
+                self.engine.set_y_scaler(y_scaler)
+                self._yscaler_key = key
+
+    # -- optimiser state (checkpoints) ---------------------------------------------------------
+    def get_opt_state(self):
+        """Everything train_iter_func mutates besides the parameter vector, as a list of float64 arrays: the rule's
+        state variables in update-dictionary order (adam: m, v, t -- SCFGP/Optimizer.py:314-323) and the Nesterov
+        velocity (:92-93); in device_optimizer mode the device's [s1, s2, velocity, t]."""
+        if self.device_optimizer:
+            return [self.engine.opt_state(w).copy() for w in range(4)]
+        return [np.atleast_1d(var.get_value()) for var in self.updates if var is not self.params]
+
+    def set_opt_state(self, arrays):
+        arrays = [np.asarray(a, dtype=np.float64) for a in arrays]
+        if self.device_optimizer:
+            if len(arrays) != 4:
+                raise ValueError('device optimiser state has 4 arrays, got %d' % len(arrays))
+            for w, a in enumerate(arrays):
+                self.engine.opt_state(w, a)
+            return
+        slots = [var for var in self.updates if var is not self.params]
+        if len(slots) != len(arrays):
+            raise ValueError('update rule %r has %d state variables, checkpoint has %d' % (self.algo, len(slots), len(arrays)))
+        for var, a in zip(slots, arrays):
+            cur = var.get_value(borrow=True)
+            var.set_value(a.reshape(np.shape(cur)))
 
     def invalidate(self):
         """Forget the resident data set: the next call uploads its X, y again."""
@@ -150,20 +236,13 @@ class CompiledFuncs(object):
     def pred_raw(self, Xs_raw, x_scaler, alpha, Li):
         """pred_func on unscaled inputs: the X scaler's element-wise transform runs on the GPU."""
         self._sync_params()
-        if getattr(self, '_scaler_id', None) is not x_scaler:
-            self.engine.set_x_scaler(x_scaler)
-            self._scaler_id = x_scaler
+        self._sync_scalers(x_scaler, None)
         return self.engine.predict_raw(Xs_raw, alpha, Li)
 
     def pred_y(self, Xs_raw, x_scaler, y_scaler, alpha, Li, ys=None):
         """All of SCFGP.predict on the GPU: mu_y, std_y (T,1) and the metric dict (None without targets)."""
         self._sync_params()
-        if getattr(self, '_scaler_id', None) is not x_scaler:
-            self.engine.set_x_scaler(x_scaler)
-            self._scaler_id = x_scaler
-        if getattr(self, '_yscaler_id', None) is not y_scaler:
-            self.engine.set_y_scaler(y_scaler)
-            self._yscaler_id = y_scaler
+        self._sync_scalers(x_scaler, y_scaler)
         return self.engine.predict_y(Xs_raw, alpha, Li, ys)
 
     def value_and_grad(self, X, y):

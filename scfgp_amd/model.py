@@ -255,18 +255,34 @@ class SCFGP(object):
 
     # -- persistence -----------------------------------------------------------------------------------
     def save(self, path):
-        """Portable checkpoint (arrays only; never pickles code)."""
+        """Portable checkpoint (arrays only; never pickles code).  The reference pickles the compiled
+        train_iter_func itself (SCFGP/SCFGP.py:296-302), i.e. its Adam moments, step counter and Nesterov velocity
+        (SCFGP/Optimizer.py:314-323,92-93); here they are saved as arrays next to the rule's name and keyword
+        arguments, so load() + optimize(funcs=model.get_compiled_funcs()) continues the same trajectory."""
+        import json
         sc = {}
         for tag, s in (('X', self.X_scaler), ('y', self.y_scaler)):
             sc[tag + '_algo'] = s.algo
             for k, v in s.data.items():
                 sc['%s_scaler_%s' % (tag, k)] = np.asarray(v)
         ev = {'evals_' + k: np.asarray(v[1], dtype=np.float64) for k, v in self.evals.items()}
+        opt = {}
+        cf = getattr(self, '_compiled', None)
+        owner = getattr(getattr(self, 'train_iter_func', None), '__self__', None)
+        if isinstance(owner, CompiledFuncs):
+            cf = owner                                     # a reused triple owns the state that is being trained
+        if cf is not None:
+            opt = {'opt_algo': cf.algo, 'opt_kwargs': json.dumps(cf.algo_params, sort_keys=True),
+                   'opt_momentum': float(cf.momentum), 'opt_device': bool(cf.device_optimizer), 'dtype': str(cf.dtype)}
+            for i, a in enumerate(cf.get_opt_state()):
+                opt['opt_state_%d' % i] = a
         with open(path, 'wb') as f:
             np.savez(f, ID=self.ID, S=self.S, M=self.M, D=self.D, params=self.params.get_value(),
-                     alpha=self.alpha, Li=self.Li, **sc, **ev)
+                     alpha=self.alpha, Li=self.Li, **sc, **ev, **opt)
 
     def load(self, path):
+        import json
+        algo, kwargs, opt_state = 'adam', dict(_ADAM_DEFAULTS), None
         with np.load(path, allow_pickle=False) as z:
             self.ID = str(z['ID']); self.S = int(z['S']); self.M = int(z['M']); self.D = int(z['D'])
             self.params = Shared(z['params'])
@@ -282,8 +298,15 @@ class SCFGP(object):
             for k in self.evals:
                 if 'evals_' + k in z.files:
                     self.evals[k][1] = list(z['evals_' + k])
+            if 'opt_algo' in z.files:                       # checkpoints written before the optimiser was saved lack these
+                algo, kwargs = str(z['opt_algo']), json.loads(str(z['opt_kwargs']))
+                self.device_optimizer = bool(z['opt_device']); self.dtype = str(z['dtype'])
+                n = len([k for k in z.files if k.startswith('opt_state_')])
+                opt_state = [z['opt_state_%d' % i] for i in range(n)]
         self.NAME = "SCFGP (Sparsity=%d, Fourier Features=%d)" % (self.S, self.M)
-        self.build_hip_models('adam', dict(_ADAM_DEFAULTS))
+        self.build_hip_models(algo, kwargs)
+        if opt_state is not None:
+            self._compiled.set_opt_state(opt_state)
 
     def _print_current_evals(self):
         for metric in sorted(self.evals.keys()):

@@ -54,8 +54,30 @@ class ShardedEvaluator(object):
         self.allreduce = allreduce
 
     def _sum(self, stage):
-        if self.allreduce is not None:
-            self.allreduce(self.engine.exchange(stage))
+        """Sum exchange buffer `stage` over the ranks, in place.  The collective runs on torch's current stream,
+        the library on its own: both sides are fenced (include/scfgp_hip.h, scfgp_stream_fence), so the order
+        holds whatever stream the caller's torch code is on."""
+        if self.allreduce is None:
+            return
+        e = self.engine
+        peer = self._peer_stream()
+        fenced = peer is not False and hasattr(e, 'stream_fence')
+        if fenced:
+            e.stream_fence(peer, 0)
+        self.allreduce(e.exchange(stage))
+        if fenced:
+            e.stream_fence(peer, 1)
+
+    @staticmethod
+    def _peer_stream():
+        """Raw handle of torch's current CUDA stream; False when there is no GPU side (CPU fakes in the tests)."""
+        try:
+            import torch
+            if not torch.cuda.is_available():
+                return False
+            return torch.cuda.current_stream().cuda_stream
+        except ImportError:
+            return False
 
     def eval(self, want_grad=True):
         e = self.engine

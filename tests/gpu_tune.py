@@ -16,6 +16,7 @@ from scfgp_amd.engine import HipEngine                                # noqa: E4
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument('--config', default=None, help='C1..C5 / H of bench.py (sets rows, D, S, M, dtype)')
     ap.add_argument('--rows', type=int, default=1000000)
     ap.add_argument('--D', type=int, default=64)
     ap.add_argument('--S', type=int, default=32)
@@ -24,6 +25,9 @@ def main():
     ap.add_argument('--reps', type=int, default=3)
     ap.add_argument('--opts', nargs='*', default=[''])
     a = ap.parse_args()
+    if a.config:
+        import bench
+        a.rows, a.D, a.S, a.M, a.dtype = bench.CONFIGS[a.config][:5]
     N, D, S, M = a.rows, a.D, a.S, a.M
     K = 2 * (S + M)
     seed = 0x5CF600FF

@@ -128,3 +128,44 @@ def test_synth_is_counter_based():
     assert np.array_equal(synth.make_X(123, 100, 7, row0=400), X[400:500])   # any block, any rank
     z = synth.normal(5, 0, 200000)
     assert abs(z.mean()) < 0.01 and abs(z.std() - 1) < 0.01
+
+
+def test_residency_fingerprint_sees_every_element():
+    """Arrays up to 2^24 elements are hashed completely: any in-place edit changes the fingerprint; above that
+    the sample + writeable flag + version token are the key."""
+    from scfgp_amd import funcs
+    rng = np.random.default_rng(0)
+    X = rng.random((5000, 7)); y = rng.random((5000, 1))
+    f0 = funcs._fingerprint(X, y)
+    assert funcs._fingerprint(X, y) == f0
+    X[4321, 6] = np.nextafter(X[4321, 6], 2.0)
+    f1 = funcs._fingerprint(X, y)
+    assert f1 != f0
+    y[17, 0] += 1e-13
+    assert funcs._fingerprint(X, y) != f1
+    big = rng.random((3 << 20,))                               # > 4 MiB: the threaded path
+    k0 = funcs._content_key(big)
+    big[(3 << 20) - 5] += 1e-9
+    assert funcs._content_key(big) != k0
+    old = funcs.FULL_HASH_ELEMS
+    funcs.FULL_HASH_ELEMS = 1024
+    try:
+        s0 = funcs._content_key(X)
+        assert s0[0] == 'sampled' and s0[1] is True
+        X.flags.writeable = False
+        assert funcs._content_key(X)[1] is False
+        X.flags.writeable = True
+        assert funcs._fingerprint(X, y, version=1) != funcs._fingerprint(X, y, version=2)
+    finally:
+        funcs.FULL_HASH_ELEMS = old
+
+
+def test_scaler_key_follows_contents_not_identity():
+    from scfgp_amd.engine import HipEngine
+    rng = np.random.default_rng(1)
+    s = Scaler('auto-normal')
+    s.fit(rng.random((300, 2)))
+    k1 = HipEngine.scaler_key(s)
+    assert HipEngine.scaler_key(s) == k1
+    s.fit(rng.random((300, 2)) * 5 + 1)                        # same object, refitted in place
+    assert HipEngine.scaler_key(s) != k1
