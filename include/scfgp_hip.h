@@ -173,8 +173,14 @@ int scfgp_get_timings(scfgp_ctx* ctx, double* ms, const char** names, int n);
 /* copy an internal device buffer to the host for tests ("Phi","V","G","W","XZ","Li","B","Abar",
  * "p","q","vecs","Fall","Xt","scalars"); returns the number of bytes copied or <0 */
 int64_t scfgp_debug_read(scfgp_ctx* ctx, const char* name, void* host, int64_t max_bytes);
-/* tuning knobs: "gram_nsplit", "gram_chunk" (fp32 flush interval in rows), "xtz_nsplit", "use_graph" */
+/* tuning knobs: "gram_nsplit" (row-split units of the Gram products, 0 = default), "gram_taper" (1: the last unit of every
+ * XCD group is cut into 1/2, 1/4, 1/8, 1/8), "gram_chunk" (fp32 flush interval in rows), "xtz_nsplit", "use_graph" */
 int scfgp_set_option(scfgp_ctx* ctx, const char* name, int64_t value);
+
+/* host-only self-test of the row splits of the Gram products (how the N rows are cut into the splits whose partial
+ * sums the reduction adds; `nsplit` 0 = default, `taper` as the option): returns 0 when the splits tile [0, Np) in
+ * order on 256-row blocks.  Needs no GPU. */
+int scfgp_selftest_row_splits(int D, int S, int M, int64_t N, int dtype, int nsplit, int taper);
 
 #ifdef __cplusplus
 }

@@ -18,6 +18,39 @@ struct Geom {
     int64_t Np;  // round_up(N,256)
 };
 
+// Row splits of the Gram products.  A job is (row split, output tile); the launch runs the jobs split-major and the
+// XCD map hands each of the 8 XCD groups a contiguous run of splits, so the workgroups that are resident together
+// work on the same rows (their re-reads of Phi are served by the Infinity Cache / L2 instead of HBM) while faster CUs
+// simply take more jobs.  A launch ends when the last jobs of every group finish: with equal splits those are full-size
+// jobs (5.2 ms of a 38.6 ms launch, 3.7 ms of it with part of the chip idle: profiles/r02_tuning.md), so the LAST
+// unit of every group is cut into splits of 1/2, 1/4, 1/8, 1/8 of a unit (`taper`): the tail shrinks eightfold for
+// three more slabs per group.
+struct RowSplits {
+    int nsplit;          // all splits
+    int groups;          // 8 (one run of splits per XCD group) or 1
+    int units;           // equal-size units per group; taper: the last unit is 4 splits
+    int taper;
+    int64_t nrb;         // 256-row blocks: Np / 256
+    __host__ __device__ int per_group() const { return taper ? units + 3 : units; }
+    // rows [r0, r1) of split s (multiples of 256; may be empty)
+    __host__ __device__ void range(int s, int64_t& r0, int64_t& r1) const {
+        const int pg = per_group(), grp = s / pg, i = s % pg;
+        const int64_t g0 = nrb * grp / groups, g1 = nrb * (grp + 1) / groups, len = g1 - g0;
+        int64_t e0, e1;                                             // position in eighths of a unit
+        if (!taper) { e0 = 8 * (int64_t)i; e1 = e0 + 8; }
+        else {
+            const int k = i - (units - 1);                          // 0..3 inside the last unit
+            const int64_t base = 8 * (int64_t)(units - 1);
+            const int cut[5] = {0, 4, 6, 7, 8};
+            if (k < 0) { e0 = 8 * (int64_t)i; e1 = e0 + 8; }
+            else { e0 = base + cut[k]; e1 = base + cut[k + 1]; }
+        }
+        r0 = (g0 + len * e0 / (8 * (int64_t)units)) * 256;
+        r1 = (g0 + len * e1 / (8 * (int64_t)units)) * 256;
+    }
+};
+RowSplits gram_row_splits(int jobs_per_split, int64_t Np, bool f32, int nsplit_override, int taper);
+
 // operands of the phase projection: Fall (Dp x Jp); Lall (Dp x round_up(Sp,64)) = [l_F | e_D], Rall (Sp x Jp) =
 // [[I_S | r_F^T]; phase offsets], Tt (Np x Sp) scratch for T~
 struct Projection { const double* Fall; const double* Lall; const double* Rall; double* Tt; };
@@ -28,8 +61,8 @@ template <typename T> struct SweepKernels {
     static void featuremap(const Geom& g, const double* Xt, const Projection& pr, const Scal* sc, T* Phi, hipStream_t st);
     // lower tiles of  Phi^T diag(w) Phi  into per-split fp64 slabs (SCFGP.py:104; weighted: backward of :111-113)
     // and, from the diagonal tiles, sidepart[split][Kp] = partials of Phi^T side (side = y: SCFGP.py:108)
-    static void gram(const Geom& g, const T* Phi, const double* w, const double* side, int nsplit, int64_t chunk, double* slabs,
-                     double* sidepart, hipStream_t st);
+    static void gram(const Geom& g, const T* Phi, const double* w, const double* side, const RowSplits& rs, int64_t chunk,
+                     double* slabs, double* sidepart, hipStream_t st);
     static int gram_jobs(const Geom& g);        // workgroups per row split of gram() (sizes the row split)
     // V = Phi . Bm, vpart[jt][n] = sum_{j in tile} Phi[n][j] V[n][j]    (SCFGP.py:112); column tile jt also forms
     // mupart[jt][n] = its slice of mu = Phi . alpha (SCFGP.py:111 / :143) from the rows it stages

@@ -3,6 +3,8 @@
 #include "kernels.h"
 #include "tile_engine.h"
 
+#include <algorithm>
+
 #define SMEM_DECL extern __shared__ __attribute__((aligned(16))) char smem_raw[]
 
 // Diagnostic build (-DSCFGP_TRACE, library variant "_trace"): every workgroup of the Gram kernel records
@@ -17,7 +19,8 @@ __device__ unsigned long long g_trace[TRACE_CAP][4];
         __syncthreads();                                                                                    \
         if (threadIdx.x == 0 && blockIdx.x < TRACE_CAP) {                                                   \
             g_trace[blockIdx.x][0] = tr_t0; g_trace[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();      \
-            g_trace[blockIdx.x][2] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));           \
+            g_trace[blockIdx.x][2] = (unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) |    \
+                                     ((unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) << 8); \
             g_trace[blockIdx.x][3] = (unsigned long long)(kind);                                            \
         }                                                                                                   \
     } while (0)
@@ -72,6 +75,11 @@ template <typename T> struct GramStripCfg {
 // fp32 only: the tall Gram tile (64 x 64 wave tiles); fp64 would need 16 waves for the same tile
 template <typename T> struct GramBigCfg {
     typedef TileCfg<T, 256, 128, SCFGP_BK, Tune<T>::GRAM_WGM, Tune<T>::GRAM_WGN, Tune<T>::MS> type;
+};
+// fp32 only: four strip tiles side by side as one 64 x 512 tile (eight 64 x 64 wave tiles: the MFMA-per-barrier ratio of
+// the tall tile; the 64 x 128 strip tiles ran at half its rate and were 6 % of the launch)
+template <typename T> struct GramWideCfg {
+    typedef TileCfg<T, 64, 512, SCFGP_BK, 1, 8, Tune<T>::MS> type;
 };
 template <typename T, int TILE> struct ApplyCfg {
     typedef TileCfg<T, Tune<T>::APPLY_BM, TILE, SCFGP_BK, Tune<T>::APPLY_WGM, Tune<T>::apply_wgn(TILE), Tune<T>::MS,
@@ -226,11 +234,14 @@ __device__ __forceinline__ void slab_flush(const typename Cfg::MTr::acc_t (&acc)
                                            double* slab_hi = nullptr) {
     AccCoord<Cfg> co;
     if (Cfg::BM > 128 && co.wm0 >= 128) slab = slab_hi - 128 * Cfg::BN;          // a wave's rows lie in one half
+    // wide tiles (BN > 128): consecutive 128 x 128 slabs, one per 128 output columns; a wave's columns lie in one of them
+    constexpr int LDS_ = Cfg::BN > 128 ? 128 : Cfg::BN;
+    if (Cfg::BN > 128) slab += (co.wn0 / 128) * (128 * 128) - (co.wn0 / 128) * 128;
 #pragma unroll
     for (int tm = 0; tm < Cfg::TM; ++tm)
 #pragma unroll
         for (int r = 0; r < Cfg::MTr::NACC; ++r) {
-            double* d = slab + co.row(tm, r) * Cfg::BN;
+            double* d = slab + co.row(tm, r) * LDS_;
 #pragma unroll
             for (int tn = 0; tn < Cfg::TN; ++tn) {
                 const double v = (double)acc[tm][tn][r];
@@ -265,8 +276,9 @@ __device__ __forceinline__ void gram_body(
         if (diag) la.side_flush();
         first = false;
     }
-    if (STRIP) {                                               // lower half of the 128 x 128 slab: rows the strip does not have
-        for (int e = threadIdx.x; e < (Cfg::BN - Cfg::BM) * Cfg::BN; e += Cfg::THREADS) slab[Cfg::BM * Cfg::BN + e] = 0.0;
+    if (STRIP) {                                               // lower half of the 128 x 128 slab(s): rows the strip does not have
+        constexpr int NB = Cfg::BN / 128, REST = (128 - Cfg::BM) * 128;
+        for (int e = threadIdx.x; e < NB * REST; e += Cfg::THREADS) slab[(e / REST) * (128 * 128) + Cfg::BM * 128 + e % REST] = 0.0;
     }
     if (diag) la.side_reduce(reinterpret_cast<double*>(smem_raw), sideout);
 }
@@ -282,18 +294,18 @@ __device__ __forceinline__ void gram_body(
 // first and the short strip jobs last.
 template <bool BIG> __host__ __device__ inline int gram_jobs_per_split(int nfull, int nstrip) {
     if (!BIG) return nfull * (nfull + 1) / 2 + nstrip * (nfull + 1);
-    const int R = nfull / 2, odd = nfull & 1;
-    return R * R + R + odd * nfull + nstrip * (nfull + 1);
+    const int R = nfull / 2, odd = nfull & 1, nsb = nstrip * (nfull + 1);
+    return R * R + nsb / 4 + R + odd * nfull + nsb % 4;          // tall, wide (4 strip tiles each), small, single strips
 }
-template <class Cfg, class SCfg, class BCfg, bool WEIGHT, bool BIG>
+template <class Cfg, class SCfg, class BCfg, class WCfg, bool WEIGHT, bool BIG>
 __global__ __launch_bounds__(Cfg::THREADS)
 __attribute__((amdgpu_waves_per_eu(4, 4)))       // two 8-wave workgroups per CU: the compiler would take up to 256 VGPRs
 void gram_kernel(
     const typename Cfg::T* __restrict__ Phi, int64_t ld, const double* __restrict__ w, const double* __restrict__ side,
-    int64_t Np, int64_t rows_per_split, int64_t chunk, int nfull, int nstrip, int nsplit, double* __restrict__ sidepart,
-    double* __restrict__ slabs) {
-    static_assert(Cfg::THREADS == SCfg::THREADS && Cfg::THREADS == BCfg::THREADS && Cfg::BN == SCfg::BN && Cfg::BN == BCfg::BN &&
-                  Cfg::BM == Cfg::BN, "one launch, three tile shapes");
+    RowSplits rs, int64_t chunk, int nfull, int nstrip, double* __restrict__ sidepart, double* __restrict__ slabs) {
+    static_assert(Cfg::THREADS == SCfg::THREADS && Cfg::THREADS == BCfg::THREADS && Cfg::THREADS == WCfg::THREADS &&
+                  Cfg::BN == SCfg::BN && Cfg::BN == BCfg::BN && Cfg::BM == Cfg::BN && WCfg::BM == SCfg::BM && WCfg::BN == 4 * Cfg::BN,
+                  "one launch, four tile shapes");
     SMEM_DECL;
     TRACE_BEGIN();
     constexpr int B = Cfg::BN;
@@ -301,11 +313,11 @@ void gram_kernel(
     const int per_split = gram_jobs_per_split<BIG>(nfull, nstrip);
     const int j = (int)xcd_remap(blockIdx.x, gridDim.x);
     const int split = j / per_split;
-    int u = j % per_split, acol, bcol, slab_t, slab_t2 = 0, kind = 0;     // kind 0: 128-row tile, 1: strip, 2: 256-row tile
+    int u = j % per_split, acol, bcol, slab_t, slab_t2 = 0, kind = 0;     // kind 0: 128-row tile, 1: strip, 2: 256-row tile, 3: wide strip
     bool diag = false;
     const auto tri = [](int ti, int tj) { return ti * (ti + 1) / 2 + tj; };
     if (BIG) {
-        const int R = nfull / 2, nbig = R * R, nsmall = R + (nfull & 1) * nfull;
+        const int R = nfull / 2, nbig = R * R, nsmall = R + (nfull & 1) * nfull, nwide = nstrip * (nfull + 1) / 4;
         if (u < nbig) {                                        // tall tile (a, b), u = a^2 + b
             int a = (int)sqrtf((float)u);
             while ((a + 1) * (a + 1) <= u) ++a;
@@ -313,14 +325,18 @@ void gram_kernel(
             const int b = u - a * a;
             acol = 2 * a * B; bcol = b * B; slab_t = tri(2 * a, b); slab_t2 = tri(2 * a + 1, b); kind = 2;
             diag = side != nullptr && b == 2 * a;
-        } else if (u < nbig + R) {                             // diagonal block of the second row of a pair
-            const int i = 2 * (u - nbig) + 1;
+        } else if (u < nbig + nwide) {                         // wide strip tile: strip tiles 4q .. 4q+3
+            const int q = u - nbig;
+            acol = nfull * B; bcol = 4 * q * B; slab_t = tri(nfull, 4 * q); kind = 3;
+            diag = side != nullptr && nfull >= 4 * q && nfull < 4 * q + 4;
+        } else if (u < nbig + nwide + R) {                     // diagonal block of the second row of a pair
+            const int i = 2 * (u - nbig - nwide) + 1;
             acol = bcol = i * B; slab_t = tri(i, i);
-        } else if (u < nbig + nsmall) {                        // unpaired last block row
-            const int i = nfull - 1, b = u - nbig - R;
+        } else if (u < nbig + nwide + nsmall) {                // unpaired last block row
+            const int i = nfull - 1, b = u - nbig - nwide - R;
             acol = i * B; bcol = b * B; slab_t = tri(i, b); diag = side != nullptr && b == i;
-        } else {
-            const int tj = u - nbig - nsmall;
+        } else {                                               // the strip tiles that do not fill a wide one
+            const int tj = 4 * nwide + u - nbig - nwide - nsmall;
             acol = nfull * B; bcol = tj * B; slab_t = tri(nfull, tj); kind = 1; diag = side != nullptr && tj == nfull;
         }
     } else {
@@ -339,16 +355,18 @@ void gram_kernel(
             acol = nfull * B; bcol = tj * B; slab_t = tri(nfull, tj); kind = 1; diag = side != nullptr && tj == nfull;
         }
     }
-    const int64_t r0 = (int64_t)split * rows_per_split;
-    const int64_t r1 = r0 + rows_per_split < Np ? r0 + rows_per_split : Np;
+    int64_t r0, r1;
+    rs.range(split, r0, r1);
     double* slab = slabs + ((int64_t)split * ntile_all + slab_t) * (B * B);
     double* slab2 = slabs + ((int64_t)split * ntile_all + slab_t2) * (B * B);
     double* sideout = sidepart + (int64_t)split * ld + acol;
     if (kind == 1) { gram_body<SCfg, WEIGHT, true>(Phi, ld, w, side, r0, r1, chunk, acol, bcol, diag, sideout, slab, nullptr, smem_raw); TRACE_END(kind); return; }
-    if constexpr (BIG)
+    if constexpr (BIG) {
         if (kind == 2) { gram_body<BCfg, WEIGHT, false>(Phi, ld, w, side, r0, r1, chunk, acol, bcol, diag, sideout, slab, slab2, smem_raw); TRACE_END(kind); return; }
+        if (kind == 3) { gram_body<WCfg, WEIGHT, true>(Phi, ld, w, side, r0, r1, chunk, acol, bcol, diag, sideout, slab, nullptr, smem_raw); TRACE_END(kind); return; }
+    }
     gram_body<Cfg, WEIGHT, false>(Phi, ld, w, side, r0, r1, chunk, acol, bcol, diag, sideout, slab, nullptr, smem_raw);
-    TRACE_END(kind + (diag ? 4 : 0));
+    TRACE_END(kind);
 }
 
 template <class Cfg, typename S>
@@ -382,17 +400,37 @@ __global__ __launch_bounds__(Cfg::THREADS) void xtz_kernel(
 
 template <typename T>
 int SweepKernels<T>::gram_jobs(const Geom& g) { return gram_jobs_per_split<sizeof(T) == 4>(g.gfull, g.gstrip); }
+
+// Row splits: enough workgroups (>> 512 resident) that faster CUs can take more of them, but long jobs -- at least 5120
+// rows per unit (fp32) -- so that the slab traffic (nsplit x K^2/2 x 8 B written and re-read by the reduction) and the
+// per-job prologue stay small.  Measured (profiles/r01_tuning.md): the fp32 job list (tall tiles, 89 jobs per split at
+// K = 2112) is fastest at 48 units for N = 2.5e5..1e6 and at Np/5120 below that.  From 16 units on they are dealt to the
+// 8 XCD groups and the last unit of each group is tapered (kernels.h: RowSplits).
+RowSplits gram_row_splits(int jobs, int64_t Np, bool f32, int nsplit_override, int taper) {
+    int64_t s = ((f32 ? 4224 : 6144) + jobs - 1) / jobs;
+    const int64_t smax = std::max<int64_t>(Np / (f32 ? 5120 : 2048), 1);
+    if (s > smax) s = smax;
+    if (nsplit_override > 0) s = std::min<int64_t>(nsplit_override, Np / 256);
+    if (s < 1) s = 1;
+    RowSplits rs;
+    rs.nrb = Np / 256;
+    if (s >= 16) { rs.groups = 8; rs.units = (int)((s + 4) / 8); rs.taper = taper ? 1 : 0; }
+    else { rs.groups = 1; rs.units = (int)s; rs.taper = 0; }
+    rs.nsplit = rs.groups * rs.per_group();
+    return rs;
+}
+
 template <typename T>
-void SweepKernels<T>::gram(const Geom& g, const T* Phi, const double* w, const double* side, int nsplit, int64_t chunk, double* slabs,
-                           double* sidepart, hipStream_t st) {
+void SweepKernels<T>::gram(const Geom& g, const T* Phi, const double* w, const double* side, const RowSplits& rs, int64_t chunk,
+                           double* slabs, double* sidepart, hipStream_t st) {
     typedef typename GramCfg<T, 128>::type Cfg;
     typedef typename GramStripCfg<T>::type SCfg;
     typedef typename GramBigCfg<T>::type BCfg;
+    typedef typename GramWideCfg<T>::type WCfg;
     constexpr bool BIG = sizeof(T) == 4;
-    const int njobs = gram_jobs(g) * nsplit;
-    const int64_t rps = round_up((g.Np + nsplit - 1) / nsplit, 256);
-    if (chunk <= 0 || chunk > rps) chunk = rps;
-    chunk = round_up(chunk, Cfg::BK > BCfg::BK ? Cfg::BK : BCfg::BK);
+    const int njobs = gram_jobs(g) * rs.nsplit;
+    if (chunk <= 0 || chunk > g.Np) chunk = g.Np;
+    chunk = round_up(chunk, 256);                              // splits start and end on 256-row blocks
 #ifdef SCFGP_DIAG_PLAIN_W
     w = nullptr;                                               // timing diagnostic only: wrong numbers
 #endif
@@ -400,15 +438,17 @@ void SweepKernels<T>::gram(const Geom& g, const T* Phi, const double* w, const d
     side = nullptr;                                            // timing diagnostic only: wrong numbers
 #endif
     constexpr int L1 = Cfg::LDS_BYTES > SCfg::LDS_BYTES ? Cfg::LDS_BYTES : SCfg::LDS_BYTES;
-    constexpr int LDS = BIG && BCfg::LDS_BYTES > L1 ? BCfg::LDS_BYTES : L1;
-    allow_big_lds(gram_kernel<Cfg, SCfg, BCfg, true, BIG>, LDS);
-    allow_big_lds(gram_kernel<Cfg, SCfg, BCfg, false, BIG>, LDS);
+    constexpr int L2 = BIG && BCfg::LDS_BYTES > L1 ? BCfg::LDS_BYTES : L1;
+    constexpr int LDS = BIG && WCfg::LDS_BYTES > L2 ? WCfg::LDS_BYTES : L2;
+    static_assert(2 * LDS <= 160 * 1024, "two workgroups per CU");
+    allow_big_lds(gram_kernel<Cfg, SCfg, BCfg, WCfg, true, BIG>, LDS);
+    allow_big_lds(gram_kernel<Cfg, SCfg, BCfg, WCfg, false, BIG>, LDS);
     if (w)
-        hipLaunchKernelGGL((gram_kernel<Cfg, SCfg, BCfg, true, BIG>), dim3(njobs), dim3(Cfg::THREADS), LDS, st,
-                           Phi, (int64_t)g.Kp, w, side, g.Np, rps, chunk, g.gfull, g.gstrip, nsplit, sidepart, slabs);
+        hipLaunchKernelGGL((gram_kernel<Cfg, SCfg, BCfg, WCfg, true, BIG>), dim3(njobs), dim3(Cfg::THREADS), LDS, st,
+                           Phi, (int64_t)g.Kp, w, side, rs, chunk, g.gfull, g.gstrip, sidepart, slabs);
     else
-        hipLaunchKernelGGL((gram_kernel<Cfg, SCfg, BCfg, false, BIG>), dim3(njobs), dim3(Cfg::THREADS), LDS, st,
-                           Phi, (int64_t)g.Kp, w, side, g.Np, rps, chunk, g.gfull, g.gstrip, nsplit, sidepart, slabs);
+        hipLaunchKernelGGL((gram_kernel<Cfg, SCfg, BCfg, WCfg, false, BIG>), dim3(njobs), dim3(Cfg::THREADS), LDS, st,
+                           Phi, (int64_t)g.Kp, w, side, rs, chunk, g.gfull, g.gstrip, sidepart, slabs);
 }
 
 template <typename T>

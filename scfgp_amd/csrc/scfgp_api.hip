@@ -23,6 +23,7 @@
 
 static constexpr int XT = 128;              // tile of the X~^T Zbar product and padding unit of J (kernels_sweep.hip)
 static constexpr int64_t PRED_ROWS = 32768; // predict processes test rows in chunks of this size
+static void derive_geom(Geom& g, int D, int S, int M);
 
 thread_local bool g_scfgp_capturing = false;
 
@@ -84,7 +85,8 @@ struct scfgp_ctx {
     hipGraph_t graph = nullptr; hipGraphExec_t gexec = nullptr; int64_t graph_N = -1; bool in_train = false, warm = false;
     int use_graph = 1;
     // options
-    int gram_nsplit = 0, xtz_nsplit = 0; int64_t gram_chunk = 4096;
+    int gram_nsplit = 0, gram_taper = 1, xtz_nsplit = 0; int64_t gram_chunk = 4096;
+    RowSplits splits{};
     // profiling
     bool prof = false; std::vector<ProfRec> recs; std::vector<hipEvent_t> pool; size_t pool_used = 0;
     std::string err;
@@ -135,18 +137,6 @@ struct DevTmp {
     operator double*() const { return p; }
 };
 
-// row splits of the Gram products: enough workgroups (>> 512 resident) that the tail does not quantise, but long
-// jobs -- at least 5120 rows per split -- so that the slab traffic (nsplit x K^2/2 x 8 B written and re-read by the
-// reduction) and the per-job prologue stay small.  Measured (profiles/r01_tuning.md): the fp32 job list (tall tiles,
-// 89 jobs per split at K = 2112) is fastest at 48 splits for N = 2.5e5..1e6 and at Np/5120 below that.
-static int default_split(int jobs, int64_t Np, bool f32) {
-    int64_t s = ((f32 ? 4224 : 6144) + jobs - 1) / jobs;
-    const int64_t smax = std::max<int64_t>(Np / (f32 ? 5120 : 2048), 1);
-    if (s > smax) s = smax;
-    if (s < 1) s = 1;
-    return (int)s;
-}
-
 static int xtz_split(int ntiles, int64_t Np) {          // the X~^T Zbar grid has few tiles: ~1152 workgroups measured best
     int64_t s = (1152 + ntiles - 1) / ntiles;
     const int64_t smax = std::max<int64_t>(Np / 2048, 1);
@@ -171,7 +161,8 @@ static int ensure_rows(scfgp_ctx* c, int64_t N) {
     const int nts = g.Kp / g.tile, ntiles = nts * (nts + 1) / 2;
     const int ntx = ((g.Dp + XT - 1) / XT) * (g.Jp / XT);
     const int gjobs = c->dtype == SCFGP_F32 ? SweepKernels<float>::gram_jobs(g) : SweepKernels<double>::gram_jobs(g);
-    const int gs = c->gram_nsplit > 0 ? (int)std::min<int64_t>(c->gram_nsplit, Np / 256) : default_split(gjobs, Np, c->dtype == SCFGP_F32);
+    c->splits = gram_row_splits(gjobs, Np, c->dtype == SCFGP_F32, c->gram_nsplit, c->gram_taper);
+    const int gs = c->splits.nsplit;
     const int xs = c->xtz_nsplit > 0 ? (int)std::min<int64_t>(c->xtz_nsplit, Np / 256) : xtz_split(ntx, Np);
     // Gram slabs are followed by the per-split side-vector partials (gs x Kp)
     const size_t need = sizeof(double) * std::max<size_t>((size_t)gs * ntiles * g.tile * g.tile + (size_t)gs * g.Kp, (size_t)xs * ntx * XT * XT);
@@ -208,15 +199,8 @@ extern "C" int scfgp_create(scfgp_ctx** out, int D, int S, int M, int dtype, int
     *out = c;
     c->dtype = dtype; c->device = device;
     Geom& g = c->g;
-    g.D = D; g.S = S; g.M = M; g.J = S + M; g.K = 2 * g.J; g.P = 3 + D * S + M * S + S + M;
-    g.Dp = (int)round_up(D + 1, 16); g.Jp = (int)round_up(g.J, XT);
-    g.Sp = (int)round_up(S + 1, 16); g.lowrank = g.Sp < g.Dp;     // F = l_F r_F^T: project through the S columns when that is narrower
+    derive_geom(g, D, S, M);
     if (const char* e = getenv("SCFGP_LOWRANK")) g.lowrank = atoi(e) != 0;                       // tuning override
-    // Gram tile grid: 128-wide tiles cover K in 64-column blocks; an odd block count ends in a 64-high strip
-    g.tile = 128;
-    g.gfull = (int)(round_up(g.K, 64) / 128);
-    g.gstrip = (int)(round_up(g.K, 64) / 64 % 2);
-    g.Kp = (g.gfull + g.gstrip) * g.tile;
     c->Dpp = (int)round_up(g.Dp, XT);
     HIPCHK(c, hipSetDevice(device));
     if (stream) c->st = (hipStream_t)stream;
@@ -356,10 +340,10 @@ template <typename T> struct Impl {
     static void gram_to(scfgp_ctx* c, const T* Mx, const double* w, const double* side, double* out, const char* name) {
         const Geom& g = c->g;
         const int nts = g.Kp / g.tile, ntiles = nts * (nts + 1) / 2;
-        const int gs = c->gram_nsplit > 0 ? (int)std::min<int64_t>(c->gram_nsplit, g.Np / 256) : default_split(SK::gram_jobs(g), g.Np, sizeof(T) == 4);
+        const int gs = c->splits.nsplit;
         double* sidepart = c->d_slabs + (size_t)gs * ntiles * g.tile * g.tile;
         { ProfScope ps(c, name);
-          SK::gram(g, Mx, w, side, gs, c->dtype == SCFGP_F32 ? c->gram_chunk : 0, c->d_slabs, sidepart, c->st); }
+          SK::gram(g, Mx, w, side, c->splits, c->dtype == SCFGP_F32 ? c->gram_chunk : 0, c->d_slabs, sidepart, c->st); }
         { ProfScope ps(c, "reduce_tiles"); reduce_tri_tiles(c->d_slabs, gs, nts, g.tile, out, c->st);
           reduce_side(sidepart, gs, g.Kp, g.gfull * g.tile + g.gstrip * 64, out + c->n_pk, c->st); }
     }
@@ -848,10 +832,39 @@ extern "C" int scfgp_get_timings(scfgp_ctx* c, double* ms, const char** names, i
     return k;
 }
 
+// host-only: geometry as scfgp_create derives it, then the Gram plan's invariants (tests run this without a GPU)
+static void derive_geom(Geom& g, int D, int S, int M) {
+    g.D = D; g.S = S; g.M = M; g.J = S + M; g.K = 2 * g.J; g.P = 3 + D * S + M * S + S + M;
+    g.Dp = (int)round_up(D + 1, 16); g.Jp = (int)round_up(g.J, XT);
+    g.Sp = (int)round_up(S + 1, 16); g.lowrank = g.Sp < g.Dp;     // F = l_F r_F^T: project through the S columns when that is narrower
+    // Gram tile grid: 128-wide tiles cover K in 64-column blocks; an odd block count ends in a 64-high strip
+    g.tile = 128;
+    g.gfull = (int)(round_up(g.K, 64) / 128);
+    g.gstrip = (int)(round_up(g.K, 64) / 64 % 2);
+    g.Kp = (g.gfull + g.gstrip) * g.tile;
+}
+extern "C" int scfgp_selftest_row_splits(int D, int S, int M, int64_t N, int dtype, int nsplit, int taper) {
+    if (D < 1 || S < 1 || M < 1 || N < 1) return SCFGP_EARG;
+    Geom g{};
+    derive_geom(g, D, S, M);
+    g.N = N; g.Np = round_up(N, 256);
+    const int jobs = dtype == SCFGP_F32 ? SweepKernels<float>::gram_jobs(g) : SweepKernels<double>::gram_jobs(g);
+    const RowSplits rs = gram_row_splits(jobs, g.Np, dtype == SCFGP_F32, nsplit, taper);
+    if (rs.nsplit < 1 || rs.nsplit != rs.groups * rs.per_group()) return 1;
+    int64_t at = 0;
+    for (int s = 0; s < rs.nsplit; ++s) {                       // the splits tile [0, Np) in order, on 256-row blocks
+        int64_t r0, r1; rs.range(s, r0, r1);
+        if (r0 != at || r1 < r0 || r0 % 256 || r1 % 256) return 2;
+        at = r1;
+    }
+    return at == g.Np ? 0 : 3;
+}
+
 extern "C" int scfgp_set_option(scfgp_ctx* c, const char* name, int64_t value) {
     if (!c || !name) return SCFGP_EARG;
     const std::string s(name);
     if (s == "gram_nsplit") c->gram_nsplit = (int)value;
+    else if (s == "gram_taper") c->gram_taper = (int)value;
     else if (s == "gram_chunk") c->gram_chunk = value;
     else if (s == "xtz_nsplit") c->xtz_nsplit = (int)value;
     else if (s == "use_graph") c->use_graph = (int)value;

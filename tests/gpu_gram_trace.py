@@ -21,7 +21,7 @@ from scfgp_amd.engine import HipEngine                                # noqa: E4
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--config', default='H')
-    ap.add_argument('--opts', default='')
+    ap.add_argument('--opts', nargs='*', default=[''])
     a = ap.parse_args()
     N, D, S, M, dtype = bench.CONFIGS[a.config][:5]
     seed = 0x5CF600FF
@@ -30,37 +30,57 @@ def main():
     params = synth.make_params(seed + 0x0202, D, S, M, abc=(-1.0, 0.0, -1.0))
     eng = HipEngine(D, S, M, dtype=dtype)
     eng.set_params(params); eng.set_data(X, y)
-    for kv in [s for s in a.opts.split(',') if s]:
-        k, v = kv.split('=')
-        eng.set_option(k, int(v))
-    eng.eval(want_grad=True)
-    eng.set_profiling(True)
-    eng.pass1()                                    # the plain Gram launch is the last one traced
-    tm = dict(eng.timings())
-    tr = eng.debug_read('trace', (1 << 16, 4), dtype=np.uint64)
-    used = tr[:, 1] > 0
-    tr = tr[used].astype(np.int64)
-    t0 = tr[:, 0].min()
-    st, en = (tr[:, 0] - t0) / 100.0, (tr[:, 1] - t0) / 100.0       # microseconds (100 MHz clock)
-    xcc, kind = tr[:, 2], tr[:, 3]
-    print('gram hipEvent %.2f ms; %d workgroups; span %.2f ms' % (tm.get('gram', -1), len(tr), en.max() / 1e3))
-    names = {0: '128x128', 1: 'strip', 2: '256x128', 4: '128x128 diag', 5: 'strip diag', 6: '256x128 diag'}
-    for k in sorted(set(kind.tolist())):
-        d = (en - st)[kind == k]
-        print('  kind %-14s n=%5d  length us: min %.0f  median %.0f  max %.0f' % (names.get(int(k), k), len(d), d.min(), np.median(d), d.max()))
-    # busy slots over time
-    ev = np.concatenate([np.stack([st, np.ones_like(st)], 1), np.stack([en, -np.ones_like(en)], 1)])
-    ev = ev[np.argsort(ev[:, 0], kind='stable')]
-    busy = np.cumsum(ev[:, 1])
-    peak = busy.max()
-    t_full_end = ev[np.where(busy >= 0.95 * peak)[0][-1], 0]
-    area = np.sum(busy[:-1] * np.diff(ev[:, 0]))
-    print('  peak concurrent workgroups %d; last time >=95%% of them busy: %.2f ms (tail %.2f ms); mean occupancy of the slots %.3f'
-          % (peak, t_full_end / 1e3, (en.max() - t_full_end) / 1e3, area / (peak * en.max())))
-    for x in sorted(set(xcc.tolist())):
-        m = xcc == x
-        print('  xcc %d: %4d workgroups, first start %.0f us, last start %.2f ms, last end %.2f ms'
-              % (x, m.sum(), st[m].min(), st[m].max() / 1e3, en[m].max() / 1e3))
+    for spec in a.opts:
+        print('== options [%s]' % spec)
+        for kv in [s for s in spec.split(',') if s]:
+            k, v = kv.split('=')
+            eng.set_option(k, int(v))
+        eng.eval(want_grad=True)
+        eng.set_profiling(True)
+        eng.pass1()                                    # the plain Gram launch is the last one traced
+        tm = dict(eng.timings())
+        tr = eng.debug_read('trace', (1 << 16, 4), dtype=np.uint64)
+        tr = tr[tr[:, 1] > 0].astype(np.int64)
+        tr = tr[tr[:, 0] >= tr[:, 1].max() - int(100e6 * 1.5e-3 * max(tm.get('gram', 40.0), 1.0))]   # drop stale entries of wider launches
+        t0 = tr[:, 0].min()
+        st, en = (tr[:, 0] - t0) / 100.0, (tr[:, 1] - t0) / 100.0       # microseconds (100 MHz clock)
+        xcc, kind = tr[:, 2] & 0xF, tr[:, 3]
+        hwid = tr[:, 2] >> 8
+        cu = xcc * 256 + ((hwid >> 8) & 0xFF)                      # (xcc, se/sh/cu bits of HW_ID)
+        print('gram hipEvent %.2f ms; %d workgroups; span %.2f ms' % (tm.get('gram', -1), len(tr), en.max() / 1e3))
+        names = {0: '128x128', 1: 'strip', 2: '256x128', 3: 'wide 64x512'}
+        for k in sorted(set(kind.tolist())):
+            d = (en - st)[kind == k]
+            print('  kind %-14s n=%5d  length us: min %.0f  median %.0f  max %.0f' % (names.get(int(k), k), len(d), d.min(), np.median(d), d.max()))
+        # busy slots over time
+        ev = np.concatenate([np.stack([st, np.ones_like(st)], 1), np.stack([en, -np.ones_like(en)], 1)])
+        ev = ev[np.argsort(ev[:, 0], kind='stable')]
+        busy = np.cumsum(ev[:, 1])
+        peak = busy.max()
+        t_full_end = ev[np.where(busy >= 0.95 * peak)[0][-1], 0]
+        area = np.sum(busy[:-1] * np.diff(ev[:, 0]))
+        print('  peak concurrent workgroups %d; last time >=95%% of them busy: %.2f ms (tail %.2f ms); mean occupancy of the slots %.3f'
+              % (peak, t_full_end / 1e3, (en.max() - t_full_end) / 1e3, area / (peak * en.max())))
+        # per-CU: time with no workgroup at all on the CU
+        idle = []
+        for cid in sorted(set(cu.tolist())):
+            m = cu == cid
+            iv = sorted(zip(st[m].tolist(), en[m].tolist()))
+            covered, cur_s, cur_e = 0.0, iv[0][0], iv[0][1]
+            for s_, e_ in iv[1:]:
+                if s_ > cur_e:
+                    covered += cur_e - cur_s; cur_s, cur_e = s_, e_
+                else:
+                    cur_e = max(cur_e, e_)
+            covered += cur_e - cur_s
+            idle.append(en.max() - covered)
+        idle = np.array(idle)
+        print('  %d CUs seen; CU time with no workgroup resident: mean %.2f ms, max %.2f ms (= %.1f %% of the launch on average)'
+              % (len(idle), idle.mean() / 1e3, idle.max() / 1e3, 100 * idle.mean() / en.max()))
+        for x in sorted(set(xcc.tolist())):
+            m = xcc == x
+            print('  xcc %d: %4d workgroups, first start %.0f us, last start %.2f ms, last end %.2f ms'
+                  % (x, m.sum(), st[m].min(), st[m].max() / 1e3, en[m].max() / 1e3))
     eng.close()
 
 

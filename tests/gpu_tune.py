@@ -17,17 +17,17 @@ from scfgp_amd.engine import HipEngine                                # noqa: E4
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--config', default=None, help='C1..C5 / H of bench.py (sets rows, D, S, M, dtype)')
-    ap.add_argument('--rows', type=int, default=1000000)
-    ap.add_argument('--D', type=int, default=64)
-    ap.add_argument('--S', type=int, default=32)
-    ap.add_argument('--M', type=int, default=1024)
-    ap.add_argument('--dtype', default='f32')
+    ap.add_argument('--rows', type=int, default=None)
+    ap.add_argument('--D', type=int, default=None)
+    ap.add_argument('--S', type=int, default=None)
+    ap.add_argument('--M', type=int, default=None)
+    ap.add_argument('--dtype', default=None)
     ap.add_argument('--reps', type=int, default=3)
     ap.add_argument('--opts', nargs='*', default=[''])
     a = ap.parse_args()
-    if a.config:
-        import bench
-        a.rows, a.D, a.S, a.M, a.dtype = bench.CONFIGS[a.config][:5]
+    import bench
+    base = bench.CONFIGS[a.config or 'H'][:5]                  # explicit flags override the config's shape
+    a.rows, a.D, a.S, a.M, a.dtype = [v if v is not None else b for v, b in zip((a.rows, a.D, a.S, a.M, a.dtype), base)]
     N, D, S, M = a.rows, a.D, a.S, a.M
     K = 2 * (S + M)
     seed = 0x5CF600FF

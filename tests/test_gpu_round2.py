@@ -221,3 +221,31 @@ def test_bench_gpus_flag_starts_the_ranks_itself():
     o2 = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith('{')][-1])
     assert o1['n_gpus'] == 1 and o2['n_gpus'] == 2 and o2['config']['rows_per_gpu'] == 10000
     assert abs(o1['cost'] - o2['cost']) < 1e-11 * abs(o1['cost'])
+
+
+@pytest.mark.parametrize('dtype,tol', [('f64', 1e-10), ('f32', 2e-4)])
+def test_gram_row_splits_uniform_and_tapered_give_the_same_gram(dtype, tol):
+    """The Gram products under 1, 3, 16 (XCD groups) and 40 row-split units, tapered or not, agree with the oracle."""
+    from scfgp_amd.engine import HipEngine
+    name = 'kin8nm_like'
+    N, D, S, M, T, seed = CASES[name]
+    X, y, params, _ = case_inputs(name)
+    X = np.tile(X, (9, 1)); y = np.tile(y, (9, 1))               # 9000 rows: 36 row blocks
+    Phi = O.feature_map(X, params, D, S, M)
+    G0 = Phi.T @ Phi; g0 = Phi.T @ y.ravel()
+    K = 2 * (S + M)
+    c0, gr0, a0, L0 = O.value_and_grad(X, y, params, S, M)
+    for nsplit, taper in ((0, 1), (1, 0), (3, 1), (16, 1), (16, 0), (40, 1)):
+        eng = HipEngine(D, S, M, dtype=dtype); eng.set_params(params)
+        eng.set_option('gram_nsplit', nsplit); eng.set_option('gram_taper', taper)
+        eng.set_data(X, y)
+        eng.pass1()
+        Kp = eng.dims()['Kp']
+        x1 = eng.debug_read('G', (Kp * Kp + Kp,))
+        G = x1[:Kp * Kp].reshape(Kp, Kp)[:K, :K]; g = x1[Kp * Kp:Kp * Kp + K]
+        assert rel(G, G0) < tol and rel(g, g0) < tol, (nsplit, taper, rel(G, G0), rel(g, g0))
+        assert np.array_equal(G, G.T)
+        eng.factor(); eng.pass2(True); eng.adjoint(); eng.pass3()
+        c, gr, a, L = eng.finish(True)
+        assert rel(gr, gr0) < max(tol, 1e-8) * 50
+        eng.close()

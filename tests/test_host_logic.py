@@ -169,3 +169,17 @@ def test_scaler_key_follows_contents_not_identity():
     assert HipEngine.scaler_key(s) == k1
     s.fit(rng.random((300, 2)) * 5 + 1)                        # same object, refitted in place
     assert HipEngine.scaler_key(s) != k1
+
+
+@pytest.mark.parametrize('D,S,M', [(13, 8, 64), (32, 16, 256), (64, 32, 1024), (512, 64, 2048), (3, 2, 3), (8, 4, 60), (8, 2, 190)])
+def test_gram_row_splits_tile_the_rows(D, S, M):
+    """Row splits of the Gram products (scfgp_amd/csrc/kernels.h: RowSplits), uniform and tapered, checked by the
+    library's host-only self-test: the splits tile [0, Np) in order on 256-row blocks."""
+    from scfgp_amd import _lib
+    lib = _lib.load()
+    for N in (1, 257, 506, 3000, 100000, 125000, 1000000, 4000000):
+        for dtype in (0, 1):
+            for nsplit in (0, 1, 7, 16, 23, 48, 100, 1000):
+                for taper in (0, 1):
+                    assert lib.scfgp_selftest_row_splits(D, S, M, N, dtype, nsplit, taper) == 0, (N, dtype, nsplit, taper)
+    assert lib.scfgp_selftest_row_splits(0, 1, 1, 5, 0, 0, 0) == -1
