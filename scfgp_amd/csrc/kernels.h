@@ -140,7 +140,7 @@ void opt_update(int algo, const OptHyper& h, int P, double* theta, const double*
 // ---- K x K stage (fp64, all matrices Kp x Kp, leading dimension Kp) -----------
 struct KStage {
     int K, Kp;
-    double *A;      // in: G + lam I (full, symmetric)  -> out: L in the lower blocks
+    double *A;      // in: G + lam I (full, symmetric); working matrix of the factorisation (the factor L goes to T2)
     double *Li;     // L^{-1} (lower, zero above)
     double *B;      // Li^T Li
     double *T1, *T2;// scratch Kp x Kp

@@ -95,28 +95,142 @@ __global__ __launch_bounds__(KCfg::THREADS) void trinv_level_kernel(const double
 }
 
 // ---------------------------------------------------------------------------
-// 64 x 64 diagonal block: Cholesky and triangular inverse by one 4-wave workgroup.
+// 64 x 64 diagonal block: Cholesky and triangular inverse by one 4-wave workgroup, the matrix in LDS.
 //   Cholesky: left-to-right in four 16-column panels.  A panel (rows pb..63 x 16 columns) is factored by
 //   wave 0 alone with one matrix row per lane in registers: the pivot and the multipliers L[k][j] reach the
-//   other lanes by lane broadcasts, so the 16 sequential column steps need neither LDS nor barriers.  The
-//   rest of the matrix then gets one rank-16 update by all four waves: 2 barriers per panel.
+//   other lanes as v_readlane broadcasts (scalar registers; the ds_bpermute form of __shfl cost a 100-cycle LDS
+//   round trip per column on this 64-step critical path), so the 16 sequential column steps need neither LDS nor
+//   barriers.  The rest of the matrix then gets one rank-16 update as fp64 MFMA tiles (16 x 16 x 4, four k-steps).
 //   Inverse: the four 16 x 16 diagonal blocks by forward substitution in registers (one column per thread,
-//   chains of <= 120 FMAs), then two doubling levels X21 = -X22 (L21 X11) by all threads.
+//   chains of <= 120 FMAs), then two doubling levels X21 = -X22 (L21 X11), again as MFMA tiles.
 //   This kernel sits 34 times on the critical path of the K-stage at K = 2112.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void potrf_diag_kernel(double* A, double* Li, int64_t ld, int p, int* flag) {
+__device__ __forceinline__ double lane_bcast(double x, int lane) {           // lane must be wave-uniform
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane), hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
+    return __hiloint2double(hi, lo);
+}
+// one 16 x 16 tile  C = sum_k A[i][k] B[k][j], k < 4*NS, on one wave:  A[i][k] = pa[i*lda + k], B[k][j] = pb[k*ldbk + j*ldbj]
+template <int NS>
+__device__ __forceinline__ v4d mfma_tile(const double* pa, int lda, const double* pb, int ldbk, int ldbj, v4d acc, double sign) {
+    const int lane = threadIdx.x & 63, i = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sign * pa[i * lda + 4 * s + q], pb[(4 * s + q) * ldbk + i * ldbj], acc, 0, 0, 0);
+    return acc;
+}
+// Y (64 x 64, as 16 x 16 MFMA tiles: wave w owns tile row w, registers acc[b] = tile (w, b)) = X . W^T with W lower
+// triangular, both in LDS with pitch LD: Y[i][j] = sum_{k <= j} X[i][k] W[j][k]
+template <int LD>
+__device__ __forceinline__ void block_xwt(const double* sX, const double* sW, v4d (&acc)[4]) {
+    const int wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        acc[b] = v4d{0, 0, 0, 0};
+        const int lane = threadIdx.x & 63, i = lane & 15, q = lane >> 4;
+        for (int s = 0; s < 4 * (b + 1); ++s)                         // W[j][k] = 0 for k > j
+            acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(sX[(16 * wave + i) * LD + 4 * s + q], sW[(16 * b + i) * LD + 4 * s + q], acc[b], 0, 0, 0);
+    }
+}
+// tiles (w, b) of a 64 x 64 block between the MFMA register layout and memory with pitch `pitch`
+template <typename P>
+__device__ __forceinline__ void block_store(P* dst, int64_t pitch, const v4d (&acc)[4]) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, ci = lane & 15, cq = lane >> 4;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[(int64_t)(16 * wave + cq + 4 * r) * pitch + 16 * b + ci] = acc[b][r];
+}
+__device__ __forceinline__ void block_load(const double* src, int64_t pitch, v4d (&acc)[4]) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, ci = lane & 15, cq = lane >> 4;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[b][r] = src[(int64_t)(16 * wave + cq + 4 * r) * pitch + 16 * b + ci];
+}
+// acc (tiles (w, b)) -= P . Q^T, P and Q 64 x 64 in LDS
+template <int LD>
+__device__ __forceinline__ void block_sub_pqt(const double* sP, const double* sQ, v4d (&acc)[4]) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll 4
+        for (int s = 0; s < 16; ++s)
+            acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-sP[(16 * wave + i) * LD + 4 * s + q], sQ[(16 * b + i) * LD + 4 * s + q], acc[b], 0, 0, 0);
+}
+__device__ __forceinline__ void block_to_lds(const double* src, int64_t pitch, double* dst, int LD) {
+    for (int e = threadIdx.x; e < 64 * 64; e += 256) dst[(e / 64) * LD + e % 64] = src[(int64_t)(e / 64) * pitch + e % 64];
+}
+
+// One launch per 64-column step p of the blocked Cholesky (nb = Kp / 64 steps, ONE dependent launch each):
+//   workgroup 0      the diagonal block of step p.  It brings the block up to date itself -- D = A[p][p] - L_p L_p^T with
+//                    L_p = A[p][p-1] Inv(p-1)^T, the only part of step p-1's update it depends on -- then factors it,
+//                    D = L L^T, and inverts L:  Lm[p][p] = L, Li[p][p] = L^-1.
+//   workgroups 1..   the trailing update of step p-1, one 64 x 64 tile (i >= j >= p) each, with the panel solve folded
+//                    in: L_i = A[i][p-1] Inv(p-1)^T, L_j likewise, A[i][j] -= L_i L_j^T; the diagonal tiles also write
+//                    L_i to Lm[i][p-1].  The working matrix A keeps its unsolved panel columns (every tile re-derives
+//                    the L blocks it needs from them), the factor goes to the separate matrix Lm.
+// So the critical path of the factorisation is the chain of diagonal blocks alone -- one ~25 us workgroup per step --
+// with the O(K^3) update work of the previous step running beside it (the launch-per-operation version had three
+// dependent launches per step: diagonal block, panel solve, trailing update).
+__global__ __launch_bounds__(256) void chol_step_kernel(double* A, double* Lm, double* Li, int64_t ld, int p, int nb, int* flag) {
     constexpr int NB = 64, LD = NB + 1, PB = 16;
     __shared__ double sL[NB * LD];
     __shared__ double sI[NB * LD];
+    __shared__ double sW[NB * LD];
     __shared__ double sT[32 * 33];
     __shared__ double sD[NB];                                          // 1 / L[j][j]
-    double* a = A + (int64_t)p * NB * ld + p * NB;
-    double* li = Li + (int64_t)p * NB * ld + p * NB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int e = tid; e < NB * NB; e += 256) {
-        sL[(e / NB) * LD + e % NB] = a[(int64_t)(e / NB) * ld + e % NB];
-        sI[(e / NB) * LD + e % NB] = 0.0;
+    const int ci = lane & 15, cq = lane >> 4;                          // MFMA C/D map (fp64): column ci, rows cq + 4 r
+    v4d acc[4];
+    if (blockIdx.x > 0) {
+        // ---- trailing tile (i, j) of step q = p - 1
+        const int t = blockIdx.x - 1, q = p - 1;
+        int ti = (int)((sqrtf(8.0f * t + 1.0f) - 1.0f) * 0.5f);
+        while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+        while (ti * (ti + 1) / 2 > t) --ti;
+        const int i = p + ti, j = p + (t - ti * (ti + 1) / 2);
+        block_to_lds(Li + ((int64_t)q * ld + q) * NB, ld, sW, LD);
+        block_to_lds(A + ((int64_t)i * ld + q) * NB, ld, sL, LD);
+        if (i != j) block_to_lds(A + ((int64_t)j * ld + q) * NB, ld, sI, LD);
+        __syncthreads();
+        block_xwt<LD>(sL, sW, acc);                                    // L_i
+        v4d accj[4];
+        if (i != j) block_xwt<LD>(sI, sW, accj);                       // L_j
+        __syncthreads();
+        block_store(sL, LD, acc);
+        if (i != j) block_store(sI, LD, accj);
+        else block_store(Lm + ((int64_t)i * ld + q) * NB, ld, acc);    // the factor's block (i, q)
+        if (i == p && j == p) return;                                  // workgroup 0 updates and factors this block itself
+        __syncthreads();
+        double* c = A + ((int64_t)i * ld + j) * NB;
+        block_load(c, ld, acc);
+        block_sub_pqt<LD>(sL, i != j ? sI : sL, acc);
+        block_store(c, ld, acc);
+        return;
     }
+    // ---- diagonal block of step p
+    double* a = A + ((int64_t)p * ld + p) * NB;
+    if (p > 0) {
+        block_to_lds(A + ((int64_t)p * ld + (p - 1)) * NB, ld, sI, LD);
+        block_to_lds(Li + ((int64_t)(p - 1) * ld + (p - 1)) * NB, ld, sW, LD);
+        __syncthreads();
+        block_xwt<LD>(sI, sW, acc);                                    // L_p = A[p][p-1] Inv(p-1)^T
+        __syncthreads();
+        block_store(sI, LD, acc);
+        __syncthreads();
+        block_load(a, ld, acc);
+        block_sub_pqt<LD>(sI, sI, acc);                                // D = A[p][p] - L_p L_p^T
+        __syncthreads();
+        block_store(sL, LD, acc);
+        for (int e = tid; e < NB * NB; e += 256) sI[(e / NB) * LD + e % NB] = 0.0;
+    } else {
+        for (int e = tid; e < NB * NB; e += 256) {
+            sL[(e / NB) * LD + e % NB] = a[(int64_t)(e / NB) * ld + e % NB];
+            sI[(e / NB) * LD + e % NB] = 0.0;
+        }
+    }
+    double* lm = Lm + ((int64_t)p * ld + p) * NB;
+    double* li = Li + ((int64_t)p * ld + p) * NB;
     bool bad = false;
     for (int pb = 0; pb < NB; pb += PB) {
         const int pend = pb + PB;
@@ -128,7 +242,7 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* A, double* Li, 
             for (int c = 0; c < PB; ++c) v[c] = row < NB ? sL[row * LD + pb + c] : 0.0;
 #pragma unroll
             for (int j = 0; j < PB; ++j) {
-                const double d = __shfl(v[j], j);                      // pivot: row pb+j is lane j
+                const double d = lane_bcast(v[j], j);                  // pivot: row pb+j is lane j
                 bad |= !(d > 0.0);
                 // 1/sqrt(d): hardware estimate + two Newton steps (the library sqrt and divide are ~450 dependent
                 // cycles per column on this 64-step critical path)
@@ -138,23 +252,26 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* A, double* Li, 
                 if (lane == j) sD[pb + j] = inv;
                 v[j] = lane == j ? d * inv : v[j] * inv;               // entries above the diagonal are never used
 #pragma unroll
-                for (int k = j + 1; k < PB; ++k) v[k] -= v[j] * __shfl(v[j], k);    // L[pb+k][pb+j] lives in lane k
+                for (int k = j + 1; k < PB; ++k) v[k] = fma(-v[j], lane_bcast(v[j], k), v[k]);    // L[pb+k][pb+j] lives in lane k
             }
 #pragma unroll
             for (int c = 0; c < PB; ++c)
                 if (row < NB) sL[row * LD + pb + c] = v[c];
         }
         __syncthreads();
-        // rank-16 update of everything right of the panel: L[i][k] -= sum_c L[i][c] L[k][c], i >= k >= pend
-        const int rem = NB - pend;
-        for (int e = tid; e < rem * rem; e += 256) {
-            const int k = pend + e / rem, i = pend + e % rem;
-            if (i >= k) {
-                double s = 0;
+        // rank-16 update of everything right of the panel, 16 x 16 tiles (ti >= tj) dealt to the waves:
+        //   L[r0+i][c0+j] -= sum_c L[r0+i][pb+c] L[c0+j][pb+c]
+        const int nt = (NB - pend) / PB;
+        for (int t = wave; t < nt * (nt + 1) / 2; t += 4) {
+            int ti = 0;
+            while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+            const int tj = t - ti * (ti + 1) / 2, r0 = pend + PB * ti, c0 = pend + PB * tj;
+            v4d acc;
 #pragma unroll
-                for (int c = 0; c < PB; ++c) s += sL[i * LD + pb + c] * sL[k * LD + pb + c];
-                sL[i * LD + k] -= s;
-            }
+            for (int r = 0; r < 4; ++r) acc[r] = sL[(r0 + cq + 4 * r) * LD + c0 + ci];
+            acc = mfma_tile<4>(sL + r0 * LD + pb, LD, sL + c0 * LD + pb, 1, LD, acc, -1.0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sL[(r0 + cq + 4 * r) * LD + c0 + ci] = acc[r];
         }
     }
     if (bad && tid == 0) *flag = 1;                                    // not positive definite (or NaN)
@@ -173,27 +290,32 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* A, double* Li, 
         }
     }
     __syncthreads();
-    // ---- doubling levels h = 16, 32: for each pair of diagonal blocks T = L21 X11, X21 = -X22 T
+    // ---- doubling levels h = 16, 32: for each pair of diagonal blocks T = L21 X11, X21 = -X22 T (sI is zero above
+    //      its diagonal blocks' diagonals, so the triangular factors multiply as full tiles)
     for (int h = PB; h < NB; h *= 2) {
-        const int npair = NB / (2 * h), per = h * h;
-        for (int e = tid; e < npair * per; e += 256) {
-            const int q = e / per, r = (e % per) / h, c = e % h, o = q * 2 * h;
-            double s = 0;
-            for (int k = c; k < h; ++k) s += sL[(o + h + r) * LD + o + k] * sI[(o + k) * LD + o + c];      // X11 lower: k >= c
-            sT[q * 16 * 17 + r * (h + 1) + c] = s;
+        const int npair = NB / (2 * h), tpp = (h / PB) * (h / PB), LT = h + 1;       // tiles per pair
+        for (int t = wave; t < npair * tpp; t += 4) {
+            const int q = t / tpp, ti = (t % tpp) / (h / PB), tj = t % (h / PB), o = q * 2 * h;
+            v4d acc = {0, 0, 0, 0};
+            acc = h == PB ? mfma_tile<4>(sL + (o + h + PB * ti) * LD + o, LD, sI + o * LD + o + PB * tj, LD, 1, acc, 1.0)
+                          : mfma_tile<8>(sL + (o + h + PB * ti) * LD + o, LD, sI + o * LD + o + PB * tj, LD, 1, acc, 1.0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sT[q * 16 * 17 + (PB * ti + cq + 4 * r) * LT + PB * tj + ci] = acc[r];
         }
         __syncthreads();
-        for (int e = tid; e < npair * per; e += 256) {
-            const int q = e / per, r = (e % per) / h, c = e % h, o = q * 2 * h;
-            double s = 0;
-            for (int k = 0; k <= r; ++k) s += sI[(o + h + r) * LD + o + h + k] * sT[q * 16 * 17 + k * (h + 1) + c];  // X22 lower
-            sI[(o + h + r) * LD + o + c] = -s;
+        for (int t = wave; t < npair * tpp; t += 4) {
+            const int q = t / tpp, ti = (t % tpp) / (h / PB), tj = t % (h / PB), o = q * 2 * h;
+            v4d acc = {0, 0, 0, 0};
+            acc = h == PB ? mfma_tile<4>(sI + (o + h + PB * ti) * LD + o + h, LD, sT + q * 16 * 17 + PB * tj, LT, 1, acc, -1.0)
+                          : mfma_tile<8>(sI + (o + h + PB * ti) * LD + o + h, LD, sT + q * 16 * 17 + PB * tj, LT, 1, acc, -1.0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sI[(o + h + PB * ti + cq + 4 * r) * LD + o + PB * tj + ci] = acc[r];
         }
         __syncthreads();
     }
     for (int e = tid; e < NB * NB; e += 256) {
         const int i = e / NB, k = e % NB;
-        a[(int64_t)i * ld + k] = k <= i ? sL[i * LD + k] : 0.0;
+        lm[(int64_t)i * ld + k] = k <= i ? sL[i * LD + k] : 0.0;
         li[(int64_t)i * ld + k] = sI[i * LD + k];
     }
 }
@@ -268,19 +390,12 @@ __global__ __launch_bounds__(256) void adjoint_vec_kernel(const double* __restri
 // ---------------------------------------------------------------------------
 // host drivers
 // ---------------------------------------------------------------------------
-static void cholesky_inplace(const KStage& k, hipStream_t st) {
-    const int Kp = k.Kp, nb = Kp / 64;
-    const int64_t ld = Kp;
+// A (k.A, full symmetric) -> L in the lower blocks of k.T2, inverses of L's diagonal blocks in k.Li
+static void cholesky_blocked(const KStage& k, hipStream_t st) {
+    const int nb = k.Kp / 64;
     for (int p = 0; p < nb; ++p) {
-        hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, st, k.A, k.Li, ld, p, k.flag);
-        const int rem = Kp - (p + 1) * 64;
-        if (rem <= 0) break;
-        double* A21 = k.A + (int64_t)(p + 1) * 64 * ld + p * 64;
-        GemmArgs pa = {A21, k.Li + (int64_t)p * 64 * ld + p * 64, A21, ld, ld, ld, rem, 64, 64, 1.0, 0.0, 0, 0};
-        gemm64<true, true>(pa, st);                                   // L21 = A21 . Inv11^T
-        double* A22 = k.A + (int64_t)(p + 1) * 64 * ld + (p + 1) * 64;
-        GemmArgs tr = {A21, A21, A22, ld, ld, ld, rem, rem, 64, -1.0, 1.0, 1, 0};
-        gemm64<true, true>(tr, st);                                   // A22 -= L21 . L21^T (lower tiles)
+        const int n = nb - p, tiles = p > 0 ? n * (n + 1) / 2 : 0;     // trailing update of step p-1: blocks i >= j >= p
+        hipLaunchKernelGGL(chol_step_kernel, dim3(1 + tiles), dim3(256), 0, st, k.A, k.T2, k.Li, (int64_t)k.Kp, p, nb, k.flag);
     }
 }
 
@@ -289,8 +404,8 @@ static void trinv(const KStage& k, hipStream_t st) {
     for (int sz = 64; sz < Kp; sz *= 2) {
         const int npairs = (Kp - sz - 1) / (2 * sz) + 1;
         dim3 grid(sz / 64, sz / 64, npairs);
-        hipLaunchKernelGGL((trinv_level_kernel<0>), grid, dim3(KCfg::THREADS), KCfg::LDS_BYTES, st, k.A, k.Li, k.T1, (int64_t)Kp, Kp, sz);
-        hipLaunchKernelGGL((trinv_level_kernel<1>), grid, dim3(KCfg::THREADS), KCfg::LDS_BYTES, st, k.A, k.Li, k.T1, (int64_t)Kp, Kp, sz);
+        hipLaunchKernelGGL((trinv_level_kernel<0>), grid, dim3(KCfg::THREADS), KCfg::LDS_BYTES, st, k.T2, k.Li, k.T1, (int64_t)Kp, Kp, sz);
+        hipLaunchKernelGGL((trinv_level_kernel<1>), grid, dim3(KCfg::THREADS), KCfg::LDS_BYTES, st, k.T2, k.Li, k.T1, (int64_t)Kp, Kp, sz);
     }
 }
 
@@ -305,12 +420,12 @@ void kstage_factor(const KStage& k, const Scal* sc, hipStream_t st) {
     const int64_t ld = Kp;
     hipMemsetAsync(k.Li, 0, sizeof(double) * ld * Kp, st);
     hipLaunchKernelGGL(add_diag_kernel, dim3((Kp + 255) / 256), dim3(256), 0, st, k.A, ld, k.K, Kp, sc);
-    cholesky_inplace(k, st);
+    cholesky_blocked(k, st);
     trinv(k, st);
     kstage_gram_li(k, st);
     // alpha = Li^T (Li g) = B g  (SCFGP.py:108-110); B is symmetric, so one coalesced row-dot GEMV
     hipLaunchKernelGGL(gemv_rows_kernel, dim3((Kp + 3) / 4), dim3(256), 0, st, k.B, ld, k.g, k.alpha, Kp);
-    hipLaunchKernelGGL(factor_scalars_kernel, dim3(1), dim3(256), 0, st, k.A, ld, k.K, k.g, k.alpha, k.scalars);
+    hipLaunchKernelGGL(factor_scalars_kernel, dim3(1), dim3(256), 0, st, k.T2, ld, k.K, k.g, k.alpha, k.scalars);
 }
 
 // BWB = V^T diag(q) V and u = B h = V^T p arrive ready from the row sweep (V = Phi B is resident), so the adjoint
