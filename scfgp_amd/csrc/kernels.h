@@ -30,9 +30,10 @@ struct RowSplits {
     int groups;          // 8 (one run of splits per XCD group) or 1
     int units;           // equal-size units per group; taper: the last unit is 4 splits
     int taper;
-    int64_t nrb;         // 256-row blocks: Np / 256
+    int gran;            // row granule of the split boundaries: 256, or 64 for problems too small to fill the chip otherwise
+    int64_t nrb;         // granules: Np / gran
     __host__ __device__ int per_group() const { return taper ? units + 3 : units; }
-    // rows [r0, r1) of split s (multiples of 256; may be empty)
+    // rows [r0, r1) of split s (multiples of gran; may be empty)
     __host__ __device__ void range(int s, int64_t& r0, int64_t& r1) const {
         const int pg = per_group(), grp = s / pg, i = s % pg;
         const int64_t g0 = nrb * grp / groups, g1 = nrb * (grp + 1) / groups, len = g1 - g0;
@@ -45,8 +46,8 @@ struct RowSplits {
             if (k < 0) { e0 = 8 * (int64_t)i; e1 = e0 + 8; }
             else { e0 = base + cut[k]; e1 = base + cut[k + 1]; }
         }
-        r0 = (g0 + len * e0 / (8 * (int64_t)units)) * 256;
-        r1 = (g0 + len * e1 / (8 * (int64_t)units)) * 256;
+        r0 = (g0 + len * e0 / (8 * (int64_t)units)) * gran;
+        r1 = (g0 + len * e1 / (8 * (int64_t)units)) * gran;
     }
 };
 RowSplits gram_row_splits(int jobs_per_split, int64_t Np, bool f32, int nsplit_override, int taper);
@@ -58,11 +59,13 @@ struct Projection { const double* Fall; const double* Lall; const double* Rall; 
 template <typename T> struct SweepKernels {
     // Phi = s*[cos Z, sin Z], Z = X~ . Fall  or, F = l_F r_F^T being rank S (SCFGP.py:83), Z = (X~ . Lall) . Rall
     //                                                            (SCFGP.py:98-102 / :139-142)
-    static void featuremap(const Geom& g, const double* Xt, const Projection& pr, const Scal* sc, T* Phi, hipStream_t st);
+    //   Zout (experiment, else NULL): also the phases Z (Np x Jp; fp32: reduced to [-pi, pi]) for gram()'s Zsrc
+    static void featuremap(const Geom& g, const double* Xt, const Projection& pr, const Scal* sc, T* Phi, hipStream_t st, T* Zout = nullptr);
     // lower tiles of  Phi^T diag(w) Phi  into per-split fp64 slabs (SCFGP.py:104; weighted: backward of :111-113)
     // and, from the diagonal tiles, sidepart[split][Kp] = partials of Phi^T side (side = y: SCFGP.py:108)
+    //   Zsrc (experiment, unweighted product only): read the phases instead of Phi and form s cos / s sin in the loaders
     static void gram(const Geom& g, const T* Phi, const double* w, const double* side, const RowSplits& rs, int64_t chunk,
-                     double* slabs, double* sidepart, hipStream_t st);
+                     double* slabs, double* sidepart, hipStream_t st, const T* Zsrc = nullptr, double zscale = 0.0);
     static int gram_jobs(const Geom& g);        // workgroups per row split of gram() (sizes the row split)
     // V = Phi . Bm, vpart[jt][n] = sum_{j in tile} Phi[n][j] V[n][j]    (SCFGP.py:112); column tile jt also forms
     // mupart[jt][n] = its slice of mu = Phi . alpha (SCFGP.py:111 / :143) from the rows it stages

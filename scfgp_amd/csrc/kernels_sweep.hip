@@ -92,60 +92,12 @@ typedef TileCfg<double, 128, 64, 16, SCFGP_FMAP_WGM, 2, 16, true> FmapCfg;    //
 template <typename T> struct XtzCfg { typedef TileCfg<T, 128, 128, 16, 4, 2, Tune<T>::MS> type; };
 
 // --------------------------------------------------------------------------
-// sin/cos for |z| up to ~1e5 rad: two-term Cody-Waite reduction by pi/2 in fp64 (fdlibm's
-// medium-argument constants: exact n*pio2_1 for |n| < 2^20) and fdlibm's kernel polynomials on
-// [-pi/4, pi/4] (< 1 ulp).  Branch-free; the library sincos carries a Payne-Hanek path the
-// phases of this model never need (|FF| is tens to hundreds of radians).
-// --------------------------------------------------------------------------
-__device__ __forceinline__ void fast_sincos(double z, double& sn, double& cs) {
-    const double fn = rint(z * 6.36619772367581382433e-01);              // 2/pi
-    const double r = fma(-fn, 1.57079632673412561417e+00, z);            // pio2_1 (33 bits)
-    const double w = fn * 6.07710050650619224932e-11;                    // pio2_1t
-    const double x = r - w;
-    const double y = (r - x) - w;                                        // tail of x
-    const double z2 = x * x;
-    // __kernel_sin(x, y, 1)
-    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
-                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
-    const double v = z2 * x;
-    const double rs = S2 + z2 * (S3 + z2 * (S4 + z2 * (S5 + z2 * S6)));
-    const double s = x - ((z2 * (0.5 * y - v * rs) - y) - v * S1);
-    // __kernel_cos(x, y)
-    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
-                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
-    const double rc = z2 * (C1 + z2 * (C2 + z2 * (C3 + z2 * (C4 + z2 * (C5 + z2 * C6)))));
-    const double hz = 0.5 * z2;
-    const double wc = 1.0 - hz;
-    const double c = wc + (((1.0 - wc) - hz) + (z2 * rc - x * y));
-    const int q = (int)fn & 3;
-    const double ss = (q & 1) ? c : s, cc = (q & 1) ? s : c;
-    sn = (q & 2) ? -ss : ss;
-    cs = ((q + 1) & 2) ? -cc : cc;
-}
-
-// fp32 outputs: the same fp64 reduction (the phase itself needs it: |z| ~ 1e2 rad at 2^-24 would already be
-// 1e-5), then the reduced argument in fp32 with the cephes sinf / cosf kernel polynomials on [-pi/4, pi/4]
-// (~1 ulp of fp32, the precision Phi is stored in): a third of the VALU work of the fp64 kernels.
-__device__ __forceinline__ void fast_sincos(double z, float& sn, float& cs) {
-    const double fn = rint(z * 6.36619772367581382433e-01);
-    const double r = fma(-fn, 6.07710050650619224932e-11, fma(-fn, 1.57079632673412561417e+00, z));
-    const float x = (float)r, z2 = x * x;
-    const float s = fmaf(x * z2, fmaf(z2, fmaf(z2, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f), x);
-    const float c = fmaf(z2 * z2, fmaf(z2, fmaf(z2, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f),
-                         fmaf(-0.5f, z2, 1.0f));
-    const int q = (int)fn & 3;
-    const float ss = (q & 1) ? c : s, cc = (q & 1) ? s : c;
-    sn = (q & 2) ? -ss : ss;
-    cs = ((q + 1) & 2) ? -cc : cc;
-}
-
-// --------------------------------------------------------------------------
 // feature map:  Z = X~ . Fall  (fp64 MFMA, K-dim = Dp),  Phi = s [cos Z | sin Z]
 // --------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(FmapCfg::THREADS) void featuremap_kernel(
     const double* __restrict__ Xt, const double* __restrict__ Fall, const Scal* __restrict__ sc,
-    T* __restrict__ Phi, int Dp, int Jp, int Kp, int J, int64_t N, int njt) {
+    T* __restrict__ Phi, int Dp, int Jp, int Kp, int J, int64_t N, int njt, T* __restrict__ Zout) {
     typedef FmapCfg Cfg;
     SMEM_DECL;
     double* smem = reinterpret_cast<double*>(smem_raw);
@@ -173,6 +125,10 @@ __global__ __launch_bounds__(FmapCfg::THREADS) void featuremap_kernel(
                 // scale s = s_hi + s_lo in T: a rounded scale alone would bias every entry of Phi the same way
                 Phi[n * Kp + j] = n < N ? fma(cs, s_hi, cs * s_lo) : (T)0;
                 Phi[n * Kp + J + j] = n < N ? fma(sn, s_hi, sn * s_lo) : (T)0;
+                if (Zout) {                                                   // experiment: the phase itself, for ZSRC loaders
+                    const double z = acc[tm][tn][r];
+                    Zout[n * Jp + j] = sizeof(T) == 4 ? (T)fma(-rint(z * 1.5915494309189535e-01), 6.283185307179586e+00, z) : (T)z;
+                }
             }
         }
 }
@@ -203,7 +159,7 @@ __global__ __launch_bounds__(FmapCfg::THREADS) void project_kernel(
 }
 
 template <typename T>
-void SweepKernels<T>::featuremap(const Geom& g, const double* Xt, const Projection& pr, const Scal* sc, T* Phi, hipStream_t st) {
+void SweepKernels<T>::featuremap(const Geom& g, const double* Xt, const Projection& pr, const Scal* sc, T* Phi, hipStream_t st, T* Zout) {
     const int njt = g.Jp / FmapCfg::BN;
     const int64_t nrb = g.Np / FmapCfg::BM;
     allow_big_lds(featuremap_kernel<T>, FmapCfg::LDS_BYTES);
@@ -213,10 +169,10 @@ void SweepKernels<T>::featuremap(const Geom& g, const double* Xt, const Projecti
         hipLaunchKernelGGL(project_kernel, dim3((unsigned)(njs * nrb)), dim3(FmapCfg::THREADS), FmapCfg::LDS_BYTES, st,
                            Xt, pr.Lall, pr.Tt, g.Dp, g.Sp, Spp, njs);
         hipLaunchKernelGGL(featuremap_kernel<T>, dim3((unsigned)(njt * nrb)), dim3(FmapCfg::THREADS), FmapCfg::LDS_BYTES, st,
-                           pr.Tt, pr.Rall, sc, Phi, g.Sp, g.Jp, g.Kp, g.J, g.N, njt);
+                           pr.Tt, pr.Rall, sc, Phi, g.Sp, g.Jp, g.Kp, g.J, g.N, njt, Zout);
     } else {
         hipLaunchKernelGGL(featuremap_kernel<T>, dim3((unsigned)(njt * nrb)), dim3(FmapCfg::THREADS), FmapCfg::LDS_BYTES, st,
-                           Xt, pr.Fall, sc, Phi, g.Dp, g.Jp, g.Kp, g.J, g.N, njt);
+                           Xt, pr.Fall, sc, Phi, g.Dp, g.Jp, g.Kp, g.J, g.N, njt, Zout);
     }
 }
 
@@ -255,18 +211,20 @@ __device__ __forceinline__ void slab_flush(const typename Cfg::MTr::acc_t (&acc)
 // the slabs of tile row nfull.  Diagonal tiles also produce the side vector sum_n s_n Phi[n][col] (s = y: Phi^T y,
 // s = p: Phi^T p) for their columns from the rows they stream anyway: sidepart[split][col].
 // One launch covers everything; the job order is described at the decode in gram_kernel.
-template <class Cfg, bool WEIGHT, bool STRIP>
+// ZSRC (experiment): Phi points to the phase matrix Z (leading dimension ld = Jp) and the loaders form s cos / s sin
+template <class Cfg, bool WEIGHT, bool STRIP, bool ZSRC = false>
 __device__ __forceinline__ void gram_body(
     const typename Cfg::T* __restrict__ Phi, int64_t ld, const double* __restrict__ w, const double* __restrict__ side,
     int64_t r0, int64_t r1, int64_t chunk, int acol, int bcol, bool diag, double* __restrict__ sideout,
-    double* __restrict__ slab, double* __restrict__ slab_hi, char* smem_raw) {
+    double* __restrict__ slab, double* __restrict__ slab_hi, char* smem_raw, int zJ = 0, typename Cfg::T zs = 0) {
     typedef typename Cfg::T T;
     T* smem = reinterpret_cast<T*>(smem_raw);
     typename Cfg::MTr::acc_t acc[Cfg::TM][Cfg::TN];
     // consecutive chunks are consecutive k-tiles, so one pair of loaders walks the whole row range
-    NatLoader<T, T, Cfg::BM, Cfg::BK, Cfg::LDA, Cfg::THREADS, WEIGHT, false, true> la(
-        Phi + r0 * ld + acol, ld, threadIdx.x, WEIGHT ? w + r0 : nullptr, 0, diag ? side + r0 : nullptr);
-    NatLoader<T, T, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS, false, false> lb(Phi + r0 * ld + bcol, ld, threadIdx.x);
+    NatLoader<T, T, Cfg::BM, Cfg::BK, Cfg::LDA, Cfg::THREADS, WEIGHT, false, true, ZSRC> la(
+        Phi + r0 * ld + (ZSRC ? 0 : acol), ld, threadIdx.x, WEIGHT ? w + r0 : nullptr, 0, diag ? side + r0 : nullptr);
+    NatLoader<T, T, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS, false, false, false, ZSRC> lb(Phi + r0 * ld + (ZSRC ? 0 : bcol), ld, threadIdx.x);
+    if (ZSRC) { la.z_source(Phi + r0 * ld, ld, zJ, acol, zs); lb.z_source(Phi + r0 * ld, ld, zJ, bcol, zs); }
     bool first = true;
     for (int64_t c0 = r0; c0 < r1 || first; c0 += chunk) {
         const int64_t c1 = c0 + chunk < r1 ? c0 + chunk : r1;
@@ -297,12 +255,13 @@ template <bool BIG> __host__ __device__ inline int gram_jobs_per_split(int nfull
     const int R = nfull / 2, odd = nfull & 1, nsb = nstrip * (nfull + 1);
     return R * R + nsb / 4 + R + odd * nfull + nsb % 4;          // tall, wide (4 strip tiles each), small, single strips
 }
-template <class Cfg, class SCfg, class BCfg, class WCfg, bool WEIGHT, bool BIG>
+template <class Cfg, class SCfg, class BCfg, class WCfg, bool WEIGHT, bool BIG, bool ZSRC = false>
 __global__ __launch_bounds__(Cfg::THREADS)
 __attribute__((amdgpu_waves_per_eu(4, 4)))       // two 8-wave workgroups per CU: the compiler would take up to 256 VGPRs
 void gram_kernel(
     const typename Cfg::T* __restrict__ Phi, int64_t ld, const double* __restrict__ w, const double* __restrict__ side,
-    RowSplits rs, int64_t chunk, int nfull, int nstrip, double* __restrict__ sidepart, double* __restrict__ slabs) {
+    RowSplits rs, int64_t chunk, int nfull, int nstrip, double* __restrict__ sidepart, double* __restrict__ slabs,
+    int64_t zld, int zJ, double zscale) {                     // ZSRC: Phi is the phase matrix Z (leading dimension zld)
     static_assert(Cfg::THREADS == SCfg::THREADS && Cfg::THREADS == BCfg::THREADS && Cfg::THREADS == WCfg::THREADS &&
                   Cfg::BN == SCfg::BN && Cfg::BN == BCfg::BN && Cfg::BM == Cfg::BN && WCfg::BM == SCfg::BM && WCfg::BN == 4 * Cfg::BN,
                   "one launch, four tile shapes");
@@ -360,12 +319,15 @@ void gram_kernel(
     double* slab = slabs + ((int64_t)split * ntile_all + slab_t) * (B * B);
     double* slab2 = slabs + ((int64_t)split * ntile_all + slab_t2) * (B * B);
     double* sideout = sidepart + (int64_t)split * ld + acol;
-    if (kind == 1) { gram_body<SCfg, WEIGHT, true>(Phi, ld, w, side, r0, r1, chunk, acol, bcol, diag, sideout, slab, nullptr, smem_raw); TRACE_END(kind); return; }
+    typedef typename Cfg::T T;
+    const int64_t sld = ZSRC ? zld : ld;                       // leading dimension of the operand source
+    const T zs = (T)zscale;
+    if (kind == 1) { gram_body<SCfg, WEIGHT, true, ZSRC>(Phi, sld, w, side, r0, r1, chunk, acol, bcol, diag, sideout, slab, nullptr, smem_raw, zJ, zs); TRACE_END(kind); return; }
     if constexpr (BIG) {
-        if (kind == 2) { gram_body<BCfg, WEIGHT, false>(Phi, ld, w, side, r0, r1, chunk, acol, bcol, diag, sideout, slab, slab2, smem_raw); TRACE_END(kind); return; }
-        if (kind == 3) { gram_body<WCfg, WEIGHT, true>(Phi, ld, w, side, r0, r1, chunk, acol, bcol, diag, sideout, slab, nullptr, smem_raw); TRACE_END(kind); return; }
+        if (kind == 2) { gram_body<BCfg, WEIGHT, false, ZSRC>(Phi, sld, w, side, r0, r1, chunk, acol, bcol, diag, sideout, slab, slab2, smem_raw, zJ, zs); TRACE_END(kind); return; }
+        if (kind == 3) { gram_body<WCfg, WEIGHT, true, ZSRC>(Phi, sld, w, side, r0, r1, chunk, acol, bcol, diag, sideout, slab, nullptr, smem_raw, zJ, zs); TRACE_END(kind); return; }
     }
-    gram_body<Cfg, WEIGHT, false>(Phi, ld, w, side, r0, r1, chunk, acol, bcol, diag, sideout, slab, nullptr, smem_raw);
+    gram_body<Cfg, WEIGHT, false, ZSRC>(Phi, sld, w, side, r0, r1, chunk, acol, bcol, diag, sideout, slab, nullptr, smem_raw, zJ, zs);
     TRACE_END(kind);
 }
 
@@ -410,11 +372,17 @@ RowSplits gram_row_splits(int jobs, int64_t Np, bool f32, int nsplit_override, i
     int64_t s = ((f32 ? 4224 : 6144) + jobs - 1) / jobs;
     const int64_t smax = std::max<int64_t>(Np / (f32 ? 5120 : 2048), 1);
     if (s > smax) s = smax;
-    if (nsplit_override > 0) s = std::min<int64_t>(nsplit_override, Np / 256);
+    // small problems (the job list would leave most of the 512 workgroup slots empty): 64-row granules, as many
+    // splits as fill the slots -- each workgroup's k-loop is a chain of dependent fetches, so fewer rows per job
+    // is what shortens the launch (Boston shape, 512 rows: 80 -> 25 us)
+    int gran = 256;
+    if (jobs * s < 256 && Np / 64 > s) { gran = 64; s = std::min<int64_t>(Np / 64, (512 + jobs - 1) / jobs); }
+    if (nsplit_override > 0) s = std::min<int64_t>(nsplit_override, Np / gran);
     if (s < 1) s = 1;
     RowSplits rs;
-    rs.nrb = Np / 256;
-    if (s >= 16) { rs.groups = 8; rs.units = (int)((s + 4) / 8); rs.taper = taper ? 1 : 0; }
+    rs.gran = gran; rs.nrb = Np / gran;
+    // the taper pays once a group has at least 5 units; below that its extra slabs cost more in the reduction than the tail
+    if (s >= 16) { rs.groups = 8; rs.units = (int)((s + 4) / 8); rs.taper = taper && rs.units >= 5 ? 1 : 0; }
     else { rs.groups = 1; rs.units = (int)s; rs.taper = 0; }
     rs.nsplit = rs.groups * rs.per_group();
     return rs;
@@ -422,7 +390,7 @@ RowSplits gram_row_splits(int jobs, int64_t Np, bool f32, int nsplit_override, i
 
 template <typename T>
 void SweepKernels<T>::gram(const Geom& g, const T* Phi, const double* w, const double* side, const RowSplits& rs, int64_t chunk,
-                           double* slabs, double* sidepart, hipStream_t st) {
+                           double* slabs, double* sidepart, hipStream_t st, const T* Zsrc, double zscale) {
     typedef typename GramCfg<T, 128>::type Cfg;
     typedef typename GramStripCfg<T>::type SCfg;
     typedef typename GramBigCfg<T>::type BCfg;
@@ -430,7 +398,7 @@ void SweepKernels<T>::gram(const Geom& g, const T* Phi, const double* w, const d
     constexpr bool BIG = sizeof(T) == 4;
     const int njobs = gram_jobs(g) * rs.nsplit;
     if (chunk <= 0 || chunk > g.Np) chunk = g.Np;
-    chunk = round_up(chunk, 256);                              // splits start and end on 256-row blocks
+    chunk = round_up(chunk, 256);                              // splits start and end on 64- or 256-row granules
 #ifdef SCFGP_DIAG_PLAIN_W
     w = nullptr;                                               // timing diagnostic only: wrong numbers
 #endif
@@ -443,12 +411,16 @@ void SweepKernels<T>::gram(const Geom& g, const T* Phi, const double* w, const d
     static_assert(2 * LDS <= 160 * 1024, "two workgroups per CU");
     allow_big_lds(gram_kernel<Cfg, SCfg, BCfg, WCfg, true, BIG>, LDS);
     allow_big_lds(gram_kernel<Cfg, SCfg, BCfg, WCfg, false, BIG>, LDS);
-    if (w)
+    if (Zsrc && !w) {                                          // experiment: feature map fused into the operand loaders
+        allow_big_lds(gram_kernel<Cfg, SCfg, BCfg, WCfg, false, BIG, true>, LDS);
+        hipLaunchKernelGGL((gram_kernel<Cfg, SCfg, BCfg, WCfg, false, BIG, true>), dim3(njobs), dim3(Cfg::THREADS), LDS, st,
+                           Zsrc, (int64_t)g.Kp, w, side, rs, chunk, g.gfull, g.gstrip, sidepart, slabs, (int64_t)g.Jp, g.J, zscale);
+    } else if (w)
         hipLaunchKernelGGL((gram_kernel<Cfg, SCfg, BCfg, WCfg, true, BIG>), dim3(njobs), dim3(Cfg::THREADS), LDS, st,
-                           Phi, (int64_t)g.Kp, w, side, rs, chunk, g.gfull, g.gstrip, sidepart, slabs);
+                           Phi, (int64_t)g.Kp, w, side, rs, chunk, g.gfull, g.gstrip, sidepart, slabs, (int64_t)0, 0, 0.0);
     else
         hipLaunchKernelGGL((gram_kernel<Cfg, SCfg, BCfg, WCfg, false, BIG>), dim3(njobs), dim3(Cfg::THREADS), LDS, st,
-                           Phi, (int64_t)g.Kp, w, side, rs, chunk, g.gfull, g.gstrip, sidepart, slabs);
+                           Phi, (int64_t)g.Kp, w, side, rs, chunk, g.gfull, g.gstrip, sidepart, slabs, (int64_t)0, 0, 0.0);
 }
 
 template <typename T>
@@ -456,7 +428,7 @@ void SweepKernels<T>::xtz(const Geom& g, const double* Xt, const T* Phi, const T
                           hipStream_t st) {
     typedef typename XtzCfg<T>::type Cfg;
     const int ntm = (g.Dp + Cfg::BM - 1) / Cfg::BM, ntn = g.Jp / Cfg::BN;
-    const int64_t rps = round_up((g.Np + nsplit - 1) / nsplit, 256);
+    const int64_t rps = round_up((g.Np + nsplit - 1) / nsplit, 64);
     if (chunk <= 0 || chunk > rps) chunk = rps;
     chunk = round_up(chunk, Cfg::BK);
     allow_big_lds(xtz_kernel<Cfg, T>, Cfg::LDS_BYTES);

@@ -86,6 +86,7 @@ struct scfgp_ctx {
     int use_graph = 1;
     // options
     int gram_nsplit = 0, gram_taper = 1, xtz_nsplit = 0; int64_t gram_chunk = 4096;
+    int fuse_fmap = 0; void* d_Z = nullptr; int64_t z_cap = 0;         // experiment: Gram of pass 1 fed from the phases
     RowSplits splits{};
     // profiling
     bool prof = false; std::vector<ProfRec> recs; std::vector<hipEvent_t> pool; size_t pool_used = 0;
@@ -97,6 +98,7 @@ struct scfgp_ctx {
     double* ut() { return d_vecs + 3 * g.Kp; }
     double* alpha_pred() { return d_vecs + 4 * g.Kp; }
     size_t tsize() const { return dtype == SCFGP_F32 ? 4 : 8; }
+    double h_scale() const { return std::exp(h_params[1]) * std::sqrt(2.0 / g.M); }      // s = e^b sqrt(2/M) from the host copy
     KStage kstage() {
         KStage k; k.K = g.K; k.Kp = g.Kp; k.A = d_x1; k.Li = d_Li; k.B = d_B; k.T1 = d_T1; k.T2 = d_T2;
         k.g = d_x1 + (int64_t)g.Kp * g.Kp; k.beta = beta(); k.alpha = alpha(); k.h = d_x2 + (int64_t)g.Kp * g.Kp;
@@ -139,7 +141,8 @@ struct DevTmp {
 
 static int xtz_split(int ntiles, int64_t Np) {          // the X~^T Zbar grid has few tiles: ~1152 workgroups measured best
     int64_t s = (1152 + ntiles - 1) / ntiles;
-    const int64_t smax = std::max<int64_t>(Np / 2048, 1);
+    int64_t smax = std::max<int64_t>(Np / 2048, 1);
+    if (ntiles * smax < 256) smax = std::max<int64_t>(Np / 64, 1);      // small problems: short dependent k-loops instead of few long ones
     if (s > smax) s = smax;
     if (s < 1) s = 1;
     return (int)s;
@@ -163,7 +166,7 @@ static int ensure_rows(scfgp_ctx* c, int64_t N) {
     const int gjobs = c->dtype == SCFGP_F32 ? SweepKernels<float>::gram_jobs(g) : SweepKernels<double>::gram_jobs(g);
     c->splits = gram_row_splits(gjobs, Np, c->dtype == SCFGP_F32, c->gram_nsplit, c->gram_taper);
     const int gs = c->splits.nsplit;
-    const int xs = c->xtz_nsplit > 0 ? (int)std::min<int64_t>(c->xtz_nsplit, Np / 256) : xtz_split(ntx, Np);
+    const int xs = c->xtz_nsplit > 0 ? (int)std::min<int64_t>(c->xtz_nsplit, Np / 64) : xtz_split(ntx, Np);
     // Gram slabs are followed by the per-split side-vector partials (gs x Kp)
     const size_t need = sizeof(double) * std::max<size_t>((size_t)gs * ntiles * g.tile * g.tile + (size_t)gs * g.Kp, (size_t)xs * ntx * XT * XT);
     if (need > c->slabs_bytes) {
@@ -254,7 +257,7 @@ extern "C" void scfgp_destroy(scfgp_ctx* c) {
     hipSetDevice(c->device);
     if (c->st) hipStreamSynchronize(c->st);
     free_rows(c);
-    dfree(c->d_Xraw); dfree(c->d_yraw); dfree(c->d_idx); dfree(c->d_xscale); dfree(c->d_yscale);
+    dfree(c->d_Z); dfree(c->d_Xraw); dfree(c->d_yraw); dfree(c->d_idx); dfree(c->d_xscale); dfree(c->d_yscale);
     dfree(c->d_params); dfree(c->d_F); dfree(c->d_Fall); dfree(c->d_Lall); dfree(c->d_Rall); dfree(c->d_sc); dfree(c->p_Tt);
     dfree(c->d_xp1); dfree(c->d_xp2); dfree(c->d_x1); dfree(c->d_x2); dfree(c->d_x3); dfree(c->d_Li); dfree(c->d_B); dfree(c->d_T1); dfree(c->d_T2);
     dfree(c->d_Abar); dfree(c->d_BT); dfree(c->d_AbarT); dfree(c->d_vecs); dfree(c->d_scalars); dfree(c->d_yy);
@@ -337,21 +340,30 @@ template <typename T> struct Impl {
     static const T* AbarT(scfgp_ctx* c) { return (const T*)c->d_AbarT; }
 
     // out = [packed lower tiles of M^T diag(w) M | M^T side (Kp)],  M = Phi (pass 1) or V = Phi B (pass 2)
-    static void gram_to(scfgp_ctx* c, const T* Mx, const double* w, const double* side, double* out, const char* name) {
+    static void gram_to(scfgp_ctx* c, const T* Mx, const double* w, const double* side, double* out, const char* name,
+                        const T* Zsrc = nullptr) {
         const Geom& g = c->g;
         const int nts = g.Kp / g.tile, ntiles = nts * (nts + 1) / 2;
         const int gs = c->splits.nsplit;
         double* sidepart = c->d_slabs + (size_t)gs * ntiles * g.tile * g.tile;
         { ProfScope ps(c, name);
-          SK::gram(g, Mx, w, side, c->splits, c->dtype == SCFGP_F32 ? c->gram_chunk : 0, c->d_slabs, sidepart, c->st); }
+          SK::gram(g, Mx, w, side, c->splits, c->dtype == SCFGP_F32 ? c->gram_chunk : 0, c->d_slabs, sidepart, c->st, Zsrc,
+                   Zsrc ? c->h_scale() : 0.0); }
         { ProfScope ps(c, "reduce_tiles"); reduce_tri_tiles(c->d_slabs, gs, nts, g.tile, out, c->st);
           reduce_side(sidepart, gs, g.Kp, g.gfull * g.tile + g.gstrip * 64, out + c->n_pk, c->st); }
     }
     static int pass1(scfgp_ctx* c) {
         const Geom& g = c->g;
         if (!c->in_train) HIPCHK(c, hipMemsetAsync(c->d_flag, 0, sizeof(int) * 4, c->st));
-        { ProfScope ps(c, "featuremap"); SK::featuremap(g, c->d_Xt, Projection{c->d_Fall, c->d_Lall, c->d_Rall, c->d_Tt}, c->d_sc, (T*)c->d_Phi, c->st); }
-        gram_to(c, (const T*)c->d_Phi, nullptr, c->d_y, c->d_xp1, "gram");
+        const bool fuse = c->fuse_fmap && g.J % (16 / (int)sizeof(T)) == 0;
+        if (fuse && c->z_cap < g.Np) {
+            dfree(c->d_Z);
+            if (int rc = dmalloc(c, &c->d_Z, sizeof(T) * g.Np * g.Jp)) return rc;
+            c->z_cap = g.Np;
+        }
+        { ProfScope ps(c, "featuremap"); SK::featuremap(g, c->d_Xt, Projection{c->d_Fall, c->d_Lall, c->d_Rall, c->d_Tt}, c->d_sc, (T*)c->d_Phi, c->st,
+                                                        fuse ? (T*)c->d_Z : nullptr); }
+        gram_to(c, (const T*)c->d_Phi, nullptr, c->d_y, c->d_xp1, fuse ? "gram_fused" : "gram", fuse ? (const T*)c->d_Z : nullptr);
         HIPCHK(c, hipMemcpyAsync(c->d_xp1 + c->n_pk + g.Kp, c->d_yy, sizeof(double), hipMemcpyDeviceToDevice, c->st));
         HIPCHK(c, hipGetLastError());
         return SCFGP_OK;
@@ -390,7 +402,7 @@ template <typename T> struct Impl {
                                           c->d_bpart, c->st);
           reduce_scalars(c->d_bpart, nb, 1, c->d_x3 + (int64_t)c->Dpp * g.Jp, 0, c->st); }
         const int ntm = c->Dpp / XT, ntn = g.Jp / XT;
-        const int xs = c->xtz_nsplit > 0 ? (int)std::min<int64_t>(c->xtz_nsplit, g.Np / 256) : xtz_split(ntm * ntn, g.Np);
+        const int xs = c->xtz_nsplit > 0 ? (int)std::min<int64_t>(c->xtz_nsplit, g.Np / 64) : xtz_split(ntm * ntn, g.Np);
         { ProfScope ps(c, "xtz");
           SK::xtz(g, c->d_Xt, (const T*)c->d_Phi, (const T*)c->d_V, xs, c->dtype == SCFGP_F32 ? c->gram_chunk : 0, c->d_slabs, c->st);
           reduce_full_tiles(c->d_slabs, xs, ntm, ntn, c->d_x3, g.Jp, c->st); }
@@ -854,7 +866,7 @@ extern "C" int scfgp_selftest_row_splits(int D, int S, int M, int64_t N, int dty
     int64_t at = 0;
     for (int s = 0; s < rs.nsplit; ++s) {                       // the splits tile [0, Np) in order, on 256-row blocks
         int64_t r0, r1; rs.range(s, r0, r1);
-        if (r0 != at || r1 < r0 || r0 % 256 || r1 % 256) return 2;
+        if (r0 != at || r1 < r0 || r0 % rs.gran || r1 % rs.gran || (rs.gran != 64 && rs.gran != 256)) return 2;
         at = r1;
     }
     return at == g.Np ? 0 : 3;
@@ -865,6 +877,7 @@ extern "C" int scfgp_set_option(scfgp_ctx* c, const char* name, int64_t value) {
     const std::string s(name);
     if (s == "gram_nsplit") c->gram_nsplit = (int)value;
     else if (s == "gram_taper") c->gram_taper = (int)value;
+    else if (s == "fuse_fmap") c->fuse_fmap = (int)value;
     else if (s == "gram_chunk") c->gram_chunk = value;
     else if (s == "xtz_nsplit") c->xtz_nsplit = (int)value;
     else if (s == "use_graph") c->use_graph = (int)value;

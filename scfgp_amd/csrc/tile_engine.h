@@ -15,6 +15,7 @@
 // the bound of every kernel built on this engine.
 #pragma once
 #include "common.h"
+#include "sincos.h"
 
 #ifndef SCFGP_DRY_LOOP
 #define SCFGP_DRY_LOOP 0
@@ -80,7 +81,10 @@ template <> struct Vec16<float> { typedef v4f type; static constexpr int N = 4; 
 //   side[x] = sum_k s[k] * S[k][x] (Phi^T y, Phi^T p on the Gram's diagonal tiles): in the compute type
 //   per thread between side_flush() calls (one row in BK: a chain 1/BK as long as the MFMA's), fp64 across.
 // ---------------------------------------------------------------------------
-template <typename S, typename T, int BX, int BK, int LD, int THREADS, bool WEIGHT, bool GUARD, bool SIDE = false>
+//   ZSRC (experiment: feature map fused into the consumer's loader): the source is the phase matrix Z (N x ldz, reduced
+//   to [-pi, pi] in fp32 mode) and the staged value of tile column c is s cos Z[k][c] (c < J), s sin Z[k][c - J]
+//   (J <= c < 2J) or 0; z_source() re-points the loader.  Needs J % VS == 0.
+template <typename S, typename T, int BX, int BK, int LD, int THREADS, bool WEIGHT, bool GUARD, bool SIDE = false, bool ZSRC = false>
 struct NatLoader {
     typedef typename Vec16<S>::type vec_t;
     static constexpr int VS = Vec16<S>::N;
@@ -95,6 +99,17 @@ struct NatLoader {
     static constexpr bool SAMEX = THREADS % VPR == 0;
     static constexpr int NS = SAMEX ? 1 : NV;
     const double* sptr[NV]; double sr[NV]; T sacc[NS][VS]; double stot[NS][VS]; bool side_on = false;
+    int zmode[NV]; T zscale;                                  // ZSRC: 0 cos, 1 sin, 2 zero column
+    __device__ __forceinline__ void z_source(const S* zrow0, int64_t ldz, int J, int col0, T scale) {
+        zscale = scale; step = (int64_t)BK * ldz;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int v = tid + i * THREADS;
+            const int k = v / VPR, c = col0 + (v % VPR) * VS;
+            zmode[i] = c < J ? 0 : (c < 2 * J ? 1 : 2);
+            ptr[i] = zrow0 + (int64_t)k * ldz + (c < J ? c : (c < 2 * J ? c - J : 0));
+        }
+    }
     __device__ __forceinline__ NatLoader(const S* b, int64_t l, int t, const double* w_ = nullptr, int xl = 0,
                                          const double* s_ = nullptr)
         : step((int64_t)BK * l), xlim(xl), tid(t) {
@@ -141,17 +156,26 @@ struct NatLoader {
             constexpr int TV = 16 / (int)sizeof(T) < VS ? 16 / (int)sizeof(T) : VS;   // elements per LDS store
             typedef T tv_t __attribute__((ext_vector_type(TV)));
             const T wt = WEIGHT ? (T)wr[SET][i] : (T)1;
+            T val[VS];
+#pragma unroll
+            for (int e = 0; e < VS; ++e) {
+                if constexpr (ZSRC) {
+                    T sn, cs;
+                    phase_sincos((T)r[SET][i][e], sn, cs);
+                    val[e] = zmode[i] == 2 ? (T)0 : zscale * (zmode[i] == 1 ? sn : cs);
+                } else val[e] = (T)r[SET][i][e];
+            }
 #pragma unroll
             for (int e0 = 0; e0 < VS; e0 += TV) {
                 tv_t o;
 #pragma unroll
-                for (int e = 0; e < TV; ++e) o[e] = WEIGHT ? (T)r[SET][i][e0 + e] * wt : (T)r[SET][i][e0 + e];
+                for (int e = 0; e < TV; ++e) o[e] = WEIGHT ? val[e0 + e] * wt : val[e0 + e];
                 *reinterpret_cast<tv_t*>(d + e0) = o;
             }
             if (SIDE && side_on) {
                 const T sv = (T)sr[i];
 #pragma unroll
-                for (int e = 0; e < VS; ++e) sacc[SAMEX ? 0 : i][e] += sv * (T)r[SET][i][e];
+                for (int e = 0; e < VS; ++e) sacc[SAMEX ? 0 : i][e] += sv * val[e];
             }
         }
     }

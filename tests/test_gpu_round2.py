@@ -249,3 +249,27 @@ def test_gram_row_splits_uniform_and_tapered_give_the_same_gram(dtype, tol):
         c, gr, a, L = eng.finish(True)
         assert rel(gr, gr0) < max(tol, 1e-8) * 50
         eng.close()
+
+
+@pytest.mark.parametrize('dtype,tol', [('f64', 1e-10), ('f32', 5e-4)])
+def test_fused_feature_map_gram_experiment_matches(dtype, tol):
+    """Option fuse_fmap (profiles/r02_tuning.md): the Gram of pass 1 evaluates cos / sin of the stored phases inside
+    its operand loaders instead of reading Phi; same G and Phi^T y as the oracle."""
+    from scfgp_amd.engine import HipEngine
+    name = 'c2_small_n'                                        # S + M = 272: a multiple of the loaders' vector width
+    N, D, S, M, T, seed = CASES[name]
+    X, y, params, _ = case_inputs(name)
+    Phi = O.feature_map(X, params, D, S, M)
+    G0 = Phi.T @ Phi; g0 = Phi.T @ y.ravel()
+    K = 2 * (S + M)
+    eng = HipEngine(D, S, M, dtype=dtype); eng.set_params(params)
+    eng.set_option('fuse_fmap', 1)
+    eng.set_data(X, y)
+    eng.set_profiling(True)
+    eng.pass1()
+    assert 'gram_fused' in dict(eng.timings())
+    Kp = eng.dims()['Kp']
+    x1 = eng.debug_read('G', (Kp * Kp + Kp,))
+    G = x1[:Kp * Kp].reshape(Kp, Kp)[:K, :K]; g = x1[Kp * Kp:Kp * Kp + K]
+    assert rel(G, G0) < tol and rel(g, g0) < tol, (rel(G, G0), rel(g, g0))
+    eng.close()
