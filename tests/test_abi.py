@@ -36,3 +36,17 @@ def test_bad_arguments_rejected_without_gpu():
     assert lib.scfgp_create(ctypes.byref(ctx), 0, 1, 1, 0, 0, None) == -1      # D < 1
     assert lib.scfgp_create(None, 4, 2, 3, 0, 0, None) == -1
     assert lib.scfgp_last_error(None) == b'null context'
+
+
+def test_host_side_is_clean_under_asan_ubsan():
+    """tools/asan_host.sh: the library's host code built with -fsanitize=address,undefined (device code untouched) and
+    every GPU-less entry point driven through it; any report makes the run exit non-zero."""
+    import shutil
+    import subprocess
+    if not os.path.exists('/opt/rocm/bin/hipcc') or shutil.which('make') is None:
+        import pytest
+        pytest.skip('no hipcc in this environment')
+    r = subprocess.run(['bash', os.path.join(ROOT, 'tools', 'asan_host.sh')], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       universal_newlines=True, timeout=900)
+    assert r.returncode == 0 and 'ok' in r.stdout.splitlines()[-1], r.stdout[-2000:]
+    assert 'ERROR: AddressSanitizer' not in r.stdout and 'runtime error' not in r.stdout
