@@ -32,7 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 SEED = 0x5CF600FF
-PEAK_TFLOPS = {'f32': 157.3, 'f64': 78.6}     # dense MFMA peaks, MI355X_MICROARCH.md / datasheet
+PEAK_TFLOPS = {'f32': 157.3, 'f64': 78.6, 'bf16x3': 157.3}     # dense MFMA peaks, MI355X_MICROARCH.md / datasheet (bf16x3: priced as fp32)
 HBM_PEAK_GBS = 8000.0
 
 # BASELINE.json `configs` (C1..C5) and the headline metric (H): N, D, S (rank), M, compute dtype
@@ -151,45 +151,69 @@ def rel(a, b):
     return float(np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(np.asarray(b)), 1e-300))
 
 
-def f64_leg_and_parity(X, y, params, D, S, M, local, f32_out, f32_eng, steps=5, warmup=2):
-    """The reference's arithmetic is float64: run the fp64 engine on the SAME resident rows, time it, and report
-    how far the fp32-mode outputs are from it at this size (relative, norm-wise; gradient per block)."""
-    from scfgp_amd import synth
-    from scfgp_amd.engine import HipEngine
+def _timed_leg(eng, steps, warmup):
+    """median wall time per evaluation, median stage times and the outputs of the last evaluation"""
     from scfgp_amd.sharded import ShardedEvaluator
-    N = X.shape[0]; J = S + M; K = 2 * J
-    eng = HipEngine(D, S, M, dtype='f64', device=local)
-    eng.set_params(params); eng.set_data(X, y, n_global=N)
     ev = ShardedEvaluator(eng, None)
     for _ in range(warmup):
         ev.eval(True)
     eng.set_profiling(True)
-    per_kernel, times = {}, []
+    per_kernel, times, out = {}, [], None
     for _ in range(steps):
         t0 = time.perf_counter()
-        c64, g64, a64, L64 = ev.eval(True)
+        out = ev.eval(True)
         times.append(time.perf_counter() - t0)
         for name, ms in eng.timings():
             per_kernel.setdefault(name, []).append(ms)
-    ms = float(np.median(times)) * 1e3
-    ap_ms = float(np.median(per_kernel.get('apply_v', [0]) + per_kernel.get('apply_phibar', [0])))
+    eng.set_profiling(False)
+    return float(np.median(times)) * 1e3, {k: float(np.median(v)) for k, v in per_kernel.items()}, out
+
+
+def _parity(out, ref, eng, eng_ref, D, S, M, what):
+    from scfgp_amd import synth
+    c, g, a, L = out
+    c64, g64, a64, L64 = ref
+    o = 3 + D * S
+    Xs = synth.make_X(SEED + 0x0909, 4096, D)
+    mu64, sd64 = eng_ref.predict(Xs, a64, L64)
+    mu, sd = eng.predict(Xs, a, L)
+    return {"what": what, "cost": abs(float(c) - float(c64)) / abs(float(c64)),
+            "grad_abc": rel(g[:3], g64[:3]), "grad_lF": rel(g[3:o], g64[3:o]), "grad_rF": rel(g[o:o + M * S], g64[o:o + M * S]),
+            "alpha": rel(a, a64), "Li": rel(L, L64), "mu": rel(mu, mu64), "std": rel(sd, sd64)}
+
+
+def f64_leg_and_parity(X, y, params, D, S, M, local, f32_out, f32_eng, steps=5, warmup=2):
+    """The reference's arithmetic is float64: run the fp64 engine on the SAME resident rows, time it, and report how far
+    the fp32-mode outputs are from it at this size (relative, norm-wise; gradient per block).  Then the experimental
+    split-precision mode (dtype "bf16x3", include/scfgp_hip.h) on the same rows: its own rate and its own parity block --
+    a separately labelled figure, never the fp32 or fp64 line."""
+    from scfgp_amd.engine import HipEngine
+    N = X.shape[0]; J = S + M; K = 2 * J
+    e64 = HipEngine(D, S, M, dtype='f64', device=local)
+    e64.set_params(params); e64.set_data(X, y, n_global=N)
+    ms, stages, ref = _timed_leg(e64, steps, warmup)
+    ap_ms = float(np.median([stages.get('apply_v', 0), stages.get('apply_phibar', 0)]))
     ach = 2.0 * N * K * K / (ap_ms * 1e-3) / 1e12 if ap_ms > 0 else 0.0
     sec = {"evals_per_s": 1e3 / ms, "ms_per_step": ms, "steps": steps, "statistic": "median",
            "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS['f64'], "unit": "TFLOP/s",
                         "frac": ach / PEAK_TFLOPS['f64'], "kernel": "apply_kernel (fp64 MFMA 16x16x4)", "avg_launch_ms": ap_ms},
-           "stages_ms": {k: float(np.median(v)) for k, v in per_kernel.items()}, "cost": float(c64)}
-    c32, g32, a32, L32 = f32_out
-    o = 3 + D * S
-    Xs = synth.make_X(SEED + 0x0909, 4096, D)
-    mu64, sd64 = eng.predict(Xs, a64, L64)
-    mu32, sd32 = f32_eng.predict(Xs, a32, L32)
-    parity = {"what": "fp32 mode vs fp64 mode of this library on the same %d rows (fp64 mode equals the oracle to 1e-12 wherever "
-                      "the oracle is run: tests/test_gpu_parity.py); relative, norm-wise" % N,
-              "cost": abs(float(c32) - float(c64)) / abs(float(c64)),
-              "grad_abc": rel(g32[:3], g64[:3]), "grad_lF": rel(g32[3:o], g64[3:o]), "grad_rF": rel(g32[o:o + M * S], g64[o:o + M * S]),
-              "alpha": rel(a32, a64), "Li": rel(L32, L64), "mu": rel(mu32, mu64), "std": rel(sd32, sd64)}
-    eng.close()
-    return sec, parity
+           "stages_ms": stages, "cost": float(ref[0])}
+    base = "mode of this library on the same %d rows (fp64 mode equals the oracle to 1e-12 wherever the oracle is run: " \
+           "tests/test_gpu_parity.py); relative, norm-wise" % N
+    parity = _parity(f32_out, ref, f32_eng, e64, D, S, M, "fp32 mode vs fp64 " + base)
+    eb = HipEngine(D, S, M, dtype='bf16x3', device=local)
+    eb.set_params(params); eb.set_data(X, y, n_global=N)
+    msb, stb, outb = _timed_leg(eb, steps, warmup)
+    apb = float(np.median([stb.get('apply_v', 0), stb.get('apply_phibar', 0)]))
+    bf3 = {"dtype": "bf16x3", "evals_per_s": 1e3 / msb, "ms_per_step": msb, "steps": steps, "statistic": "median",
+           "what": "EXPERIMENTAL: fp32 mode with the two N x K x K apply products on split-precision MFMA (each fp32 operand = three "
+                   "bf16 pieces, six bf16 MFMAs per product, fp32 accumulate); everything else as fp32 mode",
+           "apply_product_ms": apb, "apply_fp32_equivalent_TFLOPs": 2.0 * N * K * K / (apb * 1e-3) / 1e12 if apb > 0 else 0.0,
+           "stages_ms": stb, "cost": float(outb[0]),
+           "parity_at_size": _parity(outb, ref, eb, e64, D, S, M, "bf16x3 mode vs fp64 " + base)}
+    eb.close()
+    e64.close()
+    return sec, parity, bf3
 
 
 def main(a):
@@ -284,7 +308,7 @@ def main(a):
         # the two other figures the north star asks for: the feature map against the HBM roof (it writes Phi once:
         # rows x K x element size, SURVEY 8(d) kernel K3) and the Gram build against the MFMA peak (executed flops:
         # lower triangle in 64-column blocks, so about 1.06 x N K^2 rather than the algorithmic 2 N K^2)
-        esz = 4 if a.dtype == 'f32' else 8
+        esz = 8 if a.dtype == 'f64' else 4
         fm_ms, gr_ms, xz_ms = med('featuremap'), med('gram'), med('xtz')
         b64 = -(-K // 64); nf = b64 // 2
         gram_exec = 2.0 * (hi - lo) * ((nf * (nf + 1) // 2) * 128 * 128 + (b64 % 2) * (nf + 1) * 64 * 128)
@@ -303,8 +327,8 @@ def main(a):
         for v in out["secondary"].values():
             v["frac"] = v["achieved"] / v["peak"]
         if world == 1 and a.config == 'H' and a.dtype == 'f32' and not a.custom and not a.no_secondary:
-            out["secondary"]["f64"], out["parity_at_size"] = f64_leg_and_parity(X, y, params, D, S, M, local,
-                                                                                   (cost, grad, alpha, Li), eng)
+            out["secondary"]["f64"], out["parity_at_size"], out["secondary"]["bf16x3"] = f64_leg_and_parity(
+                X, y, params, D, S, M, local, (cost, grad, alpha, Li), eng)
         if not a.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(X, y, params, S, M, N, a.cpu_rows)
         print(json.dumps(out))

@@ -44,6 +44,11 @@ typedef struct scfgp_ctx scfgp_ctx;
 #define SCFGP_F64 0             /* fp64 MFMA everywhere (reference numerics)             */
 #define SCFGP_F32 1             /* N-sized products in exact-fp32 MFMA, fp64 projection,
                                    fp64 cross-chunk accumulation and fp64 K x K stage    */
+#define SCFGP_BF16X3 2          /* EXPERIMENTAL: as SCFGP_F32 (fp32 storage, everything else unchanged) but the N x K x K
+                                   products split every fp32 operand exactly into three bf16 pieces while staging it and
+                                   run six bf16 MFMAs per product term (fp32 accumulate): fp32-grade results at 2.67x the
+                                   MFMA rate.  Neither the reference's nor BASELINE.json's arithmetic: reported only as
+                                   its own dtype "bf16x3", never in place of the f32 / f64 figures                     */
 
 /* ---- life cycle --------------------------------------------------------------------
  * Replaces SCFGP.build_theano_models (SCFGP/SCFGP.py:92-148): "compile" becomes "create a

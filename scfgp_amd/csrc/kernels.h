@@ -69,12 +69,14 @@ template <typename T> struct SweepKernels {
     static int gram_jobs(const Geom& g);        // workgroups per row split of gram() (sizes the row split)
     // V = Phi . Bm, vpart[jt][n] = sum_{j in tile} Phi[n][j] V[n][j]    (SCFGP.py:112); column tile jt also forms
     // mupart[jt][n] = its slice of mu = Phi . alpha (SCFGP.py:111 / :143) from the rows it stages
+    //   bf3 (fp32 only): split-precision MFMA tiles (tile_bf16x3.h), compute mode SCFGP_BF16X3; Bm / Abar then point to
+    //   the matrix pre-split by bf3_presplit()
     static void apply_v(const Geom& g, const T* Phi, const T* Bm, T* V, double* vpart, const double* alpha, double* mupart,
-                        hipStream_t st);
+                        hipStream_t st, bool bf3 = false);
     // Phibar = 2 Phi.Abar + 2 q V + p alpha^T + y ut^T  (in place over V); bpart[block] = partial of
     // bbar = sum Phibar o Phi.  Returns the number of blocks (= partials written).
     static int apply_phibar(const Geom& g, const T* Phi, const T* Abar, T* V, const double* p, const double* q,
-                            const double* y, const double* alpha, const double* ut, double* bpart, hipStream_t st);
+                            const double* y, const double* alpha, const double* ut, double* bpart, hipStream_t st, bool bf3 = false);
     static int apply_blocks(const Geom& g);
     // per-row moments and adjoint scalars; block partials of (T2, kbar)  (SCFGP.py:111-113,121-124)
     static void rowstats(const Geom& g, const double* mupart, const double* vpart, const double* y,
@@ -92,6 +94,9 @@ template <typename T> struct SweepKernels {
 
 // diagnostic builds only (-DSCFGP_TRACE): per-workgroup [start, end, xcc, kind] of the last Gram launch; -1 otherwise
 int64_t trace_read(void* host, int64_t max_bytes);
+
+// fp32 Kp x Kp sweep operand -> bf16 plane layout of the split-precision apply product (Kp*Kp*6 bytes)
+void bf3_presplit(const float* M, void* out, int Kp, hipStream_t st);
 
 // ---- reductions ------------------------------------------------------------
 // packed lower tiles = sum over splits of the per-split lower-tile slabs (tile t = ti(ti+1)/2+tj, row-major)

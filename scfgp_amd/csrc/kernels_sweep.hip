@@ -2,6 +2,7 @@
 // Built on tile_engine.h; templated on the compute type T (double | float).
 #include "kernels.h"
 #include "tile_engine.h"
+#include "tile_bf16x3.h"
 
 #include <algorithm>
 
@@ -85,6 +86,10 @@ template <typename T, int TILE> struct ApplyCfg {
     typedef TileCfg<T, Tune<T>::APPLY_BM, TILE, SCFGP_BK, Tune<T>::APPLY_WGM, Tune<T>::apply_wgn(TILE), Tune<T>::MS,
                     SCFGP_BK == 16 && Tune<T>::MS == 16> type;                 // swizzled Phi image (TrLoader)
 };
+// split-precision variant of the apply tile (tile_bf16x3.h): 8 waves of 64 x 64 (BN = 128) or 64 x 32 (BN = 64)
+template <int TILE> struct ApplyBf3Cfg { typedef Bf3Cfg<256, TILE, 4, 2> type; };
+template <class Cfg> struct IsBf3 { static constexpr bool value = false; };
+template <int BM, int BN, int WGM, int WGN> struct IsBf3<Bf3Cfg<BM, BN, WGM, WGN>> { static constexpr bool value = true; };
 #ifndef SCFGP_FMAP_WGM
 #define SCFGP_FMAP_WGM 4     // 8 waves: one wave's fp64 sincos overlaps another's projection MFMAs
 #endif
@@ -441,32 +446,16 @@ void SweepKernels<T>::xtz(const Geom& g, const double* Xt, const T* Phi, const T
 //   EPI 0: V = C,  vpart[jt][n] = sum_j Phi[n][j] C[n][j]
 //   EPI 1: Phibar = 2 C + 2 q_n V[n][j] + p_n alpha_j + y_n ut_j   (in place over V)
 // --------------------------------------------------------------------------
+// epilogues of the apply product: V and the row dots (EPI 0) or Phibar and bbar (EPI 1) from the accumulators
 template <class Cfg, int EPI>
-__global__ __launch_bounds__(Cfg::THREADS) void apply_kernel(
-    const typename Cfg::T* __restrict__ Phi, const typename Cfg::T* __restrict__ Bm, typename Cfg::T* V,
+__device__ __forceinline__ void apply_epilogue(
+    const typename Cfg::MTr::acc_t (&acc)[Cfg::TM][Cfg::TN], const typename Cfg::T* __restrict__ Phi, typename Cfg::T* V,
     double* __restrict__ vpart, const double* __restrict__ p, const double* __restrict__ q, const double* __restrict__ y,
-    const double* __restrict__ alpha, const double* __restrict__ ut, int K, int Kp, int64_t Np, int njt,
-    double* __restrict__ bpart, int col0, int jt0, double* __restrict__ mu, int ntot) {
-    // this launch covers columns [col0, col0 + njt*BN); jt0 = index of its first tile in vpart
+    const double* __restrict__ alpha, const double* __restrict__ ut, int K, int Kp, int64_t Np, int64_t rb, int cbase, int jtg,
+    double* __restrict__ bpart, char* smem_raw) {
     typedef typename Cfg::T T;
-    SMEM_DECL;
-    T* smem = reinterpret_cast<T*>(smem_raw);
-    const unsigned wid = xcd_remap(blockIdx.x, gridDim.x);
-    const int jt = wid % njt;
-    const int64_t rb = wid / njt;
-    const int cbase = col0 + jt * Cfg::BN;
-    // EPI 0: column tile t of ntot also forms the slice kt % ntot == t of mu = Phi.alpha for its rows
-    const bool want_mu = EPI == 0 && mu != nullptr;
-    TrLoader<T, T, Cfg::BM, Cfg::BK, Cfg::LDA, Cfg::THREADS, EPI == 0, Cfg::SWZA> la(Phi + rb * Cfg::BM * Kp, Kp, threadIdx.x,
-                                                                        want_mu ? alpha : nullptr, jt0 + jt, ntot);
-    NatLoader<T, T, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS, false, false> lb(Bm + cbase, Kp, threadIdx.x);
-    typename Cfg::MTr::acc_t acc[Cfg::TM][Cfg::TN];
-    acc_zero<Cfg>(acc);
-    // rows >= K of the operand matrix are zero padding, so the contraction stops at K rounded up to the k-tile
-    tile_mainloop<Cfg>(la, lb, (K + Cfg::BK - 1) / Cfg::BK, acc, smem);
     AccCoord<Cfg> co;
     if (EPI == 0) {
-        if (want_mu) la.dot_reduce(mu + (int64_t)(jt0 + jt) * Np + rb * Cfg::BM);
         double* red = reinterpret_cast<double*>(smem_raw);          // [WGN][BM]; main loop ended with a barrier
         const int wn = (threadIdx.x >> 6) % Cfg::WGN;
 #pragma unroll
@@ -491,7 +480,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void apply_kernel(
             double s = 0;
 #pragma unroll
             for (int k = 0; k < Cfg::WGN; ++k) s += red[k * Cfg::BM + threadIdx.x];
-            vpart[(int64_t)(jt0 + jt) * Np + rb * Cfg::BM + threadIdx.x] = s;
+            vpart[(int64_t)jtg * Np + rb * Cfg::BM + threadIdx.x] = s;
         }
     } else {
         double bb = 0;                                                  // bbar = sum Phibar o Phi  (d cost / d b)
@@ -520,6 +509,48 @@ __global__ __launch_bounds__(Cfg::THREADS) void apply_kernel(
             for (int k = 0; k < Cfg::THREADS / 64; ++k) s += red[k];
             bpart[blockIdx.x] = s;
         }
+    }
+}
+#ifndef SCFGP_BF3_WAVES
+#define SCFGP_BF3_WAVES 2        // waves per SIMD the split-precision apply kernel is compiled for (2: one workgroup per CU)
+#endif
+template <class Cfg, int EPI>
+__global__ __launch_bounds__(Cfg::THREADS)
+__attribute__((amdgpu_waves_per_eu(IsBf3<Cfg>::value ? SCFGP_BF3_WAVES : 1, IsBf3<Cfg>::value ? SCFGP_BF3_WAVES : 8)))
+void apply_kernel(
+    const typename Cfg::T* __restrict__ Phi, const typename Cfg::T* __restrict__ Bm, typename Cfg::T* V,
+    double* __restrict__ vpart, const double* __restrict__ p, const double* __restrict__ q, const double* __restrict__ y,
+    const double* __restrict__ alpha, const double* __restrict__ ut, int K, int Kp, int64_t Np, int njt,
+    double* __restrict__ bpart, int col0, int jt0, double* __restrict__ mu, int ntot) {
+    // this launch covers columns [col0, col0 + njt*BN); jt0 = index of its first tile in vpart
+    typedef typename Cfg::T T;
+    SMEM_DECL;
+    T* smem = reinterpret_cast<T*>(smem_raw);
+    const unsigned wid = xcd_remap(blockIdx.x, gridDim.x);
+    const int jt = wid % njt;
+    const int64_t rb = wid / njt;
+    const int cbase = col0 + jt * Cfg::BN;
+    // EPI 0: column tile t of ntot also forms the slice kt % ntot == t of mu = Phi.alpha for its rows
+    const bool want_mu = EPI == 0 && mu != nullptr;
+    // rows >= K of the operand matrix are zero padding, so the contraction stops at K rounded up to the k-tile
+    const int nkt = (K + Cfg::BK - 1) / Cfg::BK;
+    if constexpr (IsBf3<Cfg>::value) {                         // split-precision tiles; Bm: the matrix pre-split by bf3_presplit()
+        typename Cfg::MTr::acc_t acc[Cfg::TM][Cfg::TN];
+        acc_zero<Cfg>(acc);
+        Bf3TrLoader<Cfg::BM, Cfg::THREADS, EPI == 0> la(Phi + rb * Cfg::BM * Kp, Kp, threadIdx.x, want_mu ? alpha : nullptr, jt0 + jt, ntot);
+        Bf3CopyLoader<Cfg::BN, Cfg::THREADS> lb(Bm, Kp, cbase, threadIdx.x);
+        bf3_mainloop<Cfg>(la, lb, nkt, acc, smem_raw);
+        if (EPI == 0 && want_mu) la.dot_reduce(mu + (int64_t)(jt0 + jt) * Np + rb * Cfg::BM);
+        apply_epilogue<Cfg, EPI>(acc, Phi, V, vpart, p, q, y, alpha, ut, K, Kp, Np, rb, cbase, jt0 + jt, bpart, smem_raw);
+    } else {
+        typename Cfg::MTr::acc_t acc[Cfg::TM][Cfg::TN];
+        acc_zero<Cfg>(acc);
+        TrLoader<T, T, Cfg::BM, Cfg::BK, Cfg::LDA, Cfg::THREADS, EPI == 0, Cfg::SWZA> la(Phi + rb * Cfg::BM * Kp, Kp, threadIdx.x,
+                                                                            want_mu ? alpha : nullptr, jt0 + jt, ntot);
+        NatLoader<T, T, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS, false, false> lb(Bm + cbase, Kp, threadIdx.x);
+        tile_mainloop<Cfg>(la, lb, nkt, acc, smem);
+        if (EPI == 0 && want_mu) la.dot_reduce(mu + (int64_t)(jt0 + jt) * Np + rb * Cfg::BM);
+        apply_epilogue<Cfg, EPI>(acc, Phi, V, vpart, p, q, y, alpha, ut, K, Kp, Np, rb, cbase, jt0 + jt, bpart, smem_raw);
     }
 }
 
@@ -556,26 +587,39 @@ static int apply_launch_cfg(const Geom& g, int njt, int col0, int jt0, int boff,
 }
 template <typename T, int EPI>
 static int apply_launch(const Geom& g, const T* Phi, const T* Bm, T* V, double* vpart, const double* p, const double* q,
-                        const double* y, const double* alpha, const double* ut, double* bpart, double* mu, hipStream_t st) {
+                        const double* y, const double* alpha, const double* ut, double* bpart, double* mu, hipStream_t st, bool bf3 = false) {
     const ApplyPlan<T> pl(g.K);
     int nb = 0;
+    if constexpr (sizeof(T) == 4) {
+        if (bf3) {                                             // split-precision tiles (same column plan: 128-wide, then 64)
+            static_assert(Tune<T>::APPLY_BN == 128, "bf16x3 apply tiles are 128 and 64 wide");
+            nb += apply_launch_cfg<typename ApplyBf3Cfg<128>::type, EPI, T>(g, pl.count[0], pl.col0[0], pl.jt0[0], nb, Phi, Bm, V, vpart, p, q, y, alpha, ut, bpart, mu, st);
+            nb += apply_launch_cfg<typename ApplyBf3Cfg<64>::type, EPI, T>(g, pl.count[2], pl.col0[2], pl.jt0[2], nb, Phi, Bm, V, vpart, p, q, y, alpha, ut, bpart, mu, st);
+            return nb;
+        }
+    }
     nb += apply_launch_cfg<typename ApplyCfg<T, Tune<T>::APPLY_BN>::type, EPI, T>(g, pl.count[0], pl.col0[0], pl.jt0[0], nb, Phi, Bm, V, vpart, p, q, y, alpha, ut, bpart, mu, st);
     nb += apply_launch_cfg<typename ApplyCfg<T, 128>::type, EPI, T>(g, pl.count[1], pl.col0[1], pl.jt0[1], nb, Phi, Bm, V, vpart, p, q, y, alpha, ut, bpart, mu, st);
     nb += apply_launch_cfg<typename ApplyCfg<T, 64>::type, EPI, T>(g, pl.count[2], pl.col0[2], pl.jt0[2], nb, Phi, Bm, V, vpart, p, q, y, alpha, ut, bpart, mu, st);
     return nb;
 }
+// fp32 K x K operand -> the plane layout Bf3CopyLoader reads (tile_bf16x3.h); out: Kp * Kp * 6 bytes
+void bf3_presplit(const float* M, void* out, int Kp, hipStream_t st) {
+    hipLaunchKernelGGL(bf3_presplit_kernel, dim3(2048), dim3(256), 0, st, M, reinterpret_cast<__bf16*>(out), Kp);
+}
+
 template <typename T>
 void SweepKernels<T>::apply_v(const Geom& g, const T* Phi, const T* Bm, T* V, double* vpart, const double* alpha, double* mu,
-                              hipStream_t st) {
+                              hipStream_t st, bool bf3) {
 #ifdef SCFGP_DIAG_NOMU
     mu = nullptr;                                              // timing diagnostic only: wrong numbers
 #endif
-    apply_launch<T, 0>(g, Phi, Bm, V, vpart, nullptr, nullptr, nullptr, alpha, nullptr, nullptr, mu, st);
+    apply_launch<T, 0>(g, Phi, Bm, V, vpart, nullptr, nullptr, nullptr, alpha, nullptr, nullptr, mu, st, bf3);
 }
 template <typename T>
 int SweepKernels<T>::apply_phibar(const Geom& g, const T* Phi, const T* Abar, T* V, const double* p, const double* q,
-                                  const double* y, const double* alpha, const double* ut, double* bpart, hipStream_t st) {
-    return apply_launch<T, 1>(g, Phi, Abar, V, nullptr, p, q, y, alpha, ut, bpart, nullptr, st);
+                                  const double* y, const double* alpha, const double* ut, double* bpart, hipStream_t st, bool bf3) {
+    return apply_launch<T, 1>(g, Phi, Abar, V, nullptr, p, q, y, alpha, ut, bpart, nullptr, st, bf3);
 }
 // number of column tiles of the apply kernel (vpart leading count)
 template <typename T> static int apply_njt(const Geom& g) { return ApplyPlan<T>(g.K).total; }

@@ -70,7 +70,7 @@ struct scfgp_ctx {
     double *d_xp1 = nullptr, *d_xp2 = nullptr; int64_t n_xp = 0, n_pk = 0;
     double *d_x1 = nullptr, *d_x2 = nullptr, *d_x3 = nullptr; int64_t n_x1 = 0, n_x2 = 0, n_x3 = 0; int Dpp = 0;
     double *d_Li = nullptr, *d_B = nullptr, *d_T1 = nullptr, *d_T2 = nullptr, *d_Abar = nullptr;
-    void *d_BT = nullptr, *d_AbarT = nullptr;
+    void *d_BT = nullptr, *d_AbarT = nullptr, *d_M3 = nullptr;     // d_M3: B / Abar split into bf16 planes (SCFGP_BF16X3)
     double *d_vecs = nullptr;            // beta, alpha, u, ut, alpha_pred (Kp each)
     double *d_scalars = nullptr, *d_yy = nullptr; int* d_flag = nullptr;
     double *d_slabs = nullptr; size_t slabs_bytes = 0;
@@ -97,6 +97,7 @@ struct scfgp_ctx {
     double* u() { return d_vecs + 2 * g.Kp; }
     double* ut() { return d_vecs + 3 * g.Kp; }
     double* alpha_pred() { return d_vecs + 4 * g.Kp; }
+    bool bf3 = false;                                                       // SCFGP_BF16X3: dtype is SCFGP_F32 plus split-precision products
     size_t tsize() const { return dtype == SCFGP_F32 ? 4 : 8; }
     double h_scale() const { return std::exp(h_params[1]) * std::sqrt(2.0 / g.M); }      // s = e^b sqrt(2/M) from the host copy
     KStage kstage() {
@@ -197,10 +198,11 @@ static int ensure_rows(scfgp_ctx* c, int64_t N) {
 }
 
 extern "C" int scfgp_create(scfgp_ctx** out, int D, int S, int M, int dtype, int device, void* stream) {
-    if (!out || D < 1 || S < 1 || M < 1 || (dtype != SCFGP_F64 && dtype != SCFGP_F32)) return SCFGP_EARG;
+    if (!out || D < 1 || S < 1 || M < 1 || (dtype != SCFGP_F64 && dtype != SCFGP_F32 && dtype != SCFGP_BF16X3)) return SCFGP_EARG;
     scfgp_ctx* c = new scfgp_ctx();
     *out = c;
-    c->dtype = dtype; c->device = device;
+    c->bf3 = dtype == SCFGP_BF16X3;
+    c->dtype = c->bf3 ? SCFGP_F32 : dtype; c->device = device;
     Geom& g = c->g;
     derive_geom(g, D, S, M);
     if (const char* e = getenv("SCFGP_LOWRANK")) g.lowrank = atoi(e) != 0;                       // tuning override
@@ -235,6 +237,7 @@ extern "C" int scfgp_create(scfgp_ctx** out, int D, int S, int M, int dtype, int
     if ((rc = dmalloc(c, &c->d_Abar, sizeof(double) * K2))) return rc;
     if ((rc = dmalloc(c, &c->d_BT, c->tsize() * K2))) return rc;        // sweep operands: typed, padding zeroed
     if ((rc = dmalloc(c, &c->d_AbarT, c->tsize() * K2))) return rc;
+    if (c->bf3 && (rc = dmalloc(c, &c->d_M3, 6 * K2))) return rc;
     if ((rc = dmalloc(c, &c->d_vecs, sizeof(double) * 5 * Kp))) return rc;
     if ((rc = dmalloc(c, &c->d_scalars, sizeof(double) * 32))) return rc;
     if ((rc = dmalloc(c, &c->d_yy, sizeof(double) * 8))) return rc;
@@ -260,7 +263,7 @@ extern "C" void scfgp_destroy(scfgp_ctx* c) {
     dfree(c->d_Z); dfree(c->d_Xraw); dfree(c->d_yraw); dfree(c->d_idx); dfree(c->d_xscale); dfree(c->d_yscale);
     dfree(c->d_params); dfree(c->d_F); dfree(c->d_Fall); dfree(c->d_Lall); dfree(c->d_Rall); dfree(c->d_sc); dfree(c->p_Tt);
     dfree(c->d_xp1); dfree(c->d_xp2); dfree(c->d_x1); dfree(c->d_x2); dfree(c->d_x3); dfree(c->d_Li); dfree(c->d_B); dfree(c->d_T1); dfree(c->d_T2);
-    dfree(c->d_Abar); dfree(c->d_BT); dfree(c->d_AbarT); dfree(c->d_vecs); dfree(c->d_scalars); dfree(c->d_yy);
+    dfree(c->d_Abar); dfree(c->d_BT); dfree(c->d_AbarT); dfree(c->d_M3); dfree(c->d_vecs); dfree(c->d_scalars); dfree(c->d_yy);
     dfree(c->d_flag); dfree(c->d_partial); dfree(c->d_work); dfree(c->d_grad);
     dfree(c->p_Xt); dfree(c->p_vpart); dfree(c->p_mupart); dfree(c->p_mu); dfree(c->p_sd); dfree(c->p_Phi); dfree(c->p_V);
     if (c->gexec) hipGraphExecDestroy(c->gexec);
@@ -336,8 +339,15 @@ static void unpack_exchange(scfgp_ctx* c, const double* xp, double* x) {
 
 template <typename T> struct Impl {
     typedef SweepKernels<T> SK;
-    static const T* BT(scfgp_ctx* c) { return (const T*)c->d_BT; }
-    static const T* AbarT(scfgp_ctx* c) { return (const T*)c->d_AbarT; }
+    // sweep operand of the apply products: the typed matrix, or in SCFGP_BF16X3 mode its bf16-plane split (made here)
+    static const T* operand(scfgp_ctx* c, const void* typed) {
+        if constexpr (sizeof(T) == 4) {
+            if (c->bf3) { bf3_presplit((const float*)typed, c->d_M3, c->g.Kp, c->st); return (const T*)c->d_M3; }
+        }
+        return (const T*)typed;
+    }
+    static const T* BT(scfgp_ctx* c) { return operand(c, c->d_BT); }
+    static const T* AbarT(scfgp_ctx* c) { return operand(c, c->d_AbarT); }
 
     // out = [packed lower tiles of M^T diag(w) M | M^T side (Kp)],  M = Phi (pass 1) or V = Phi B (pass 2)
     static void gram_to(scfgp_ctx* c, const T* Mx, const double* w, const double* side, double* out, const char* name,
@@ -377,7 +387,7 @@ template <typename T> struct Impl {
     }
     static int pass2(scfgp_ctx* c, int want_grad) {
         const Geom& g = c->g;
-        { ProfScope ps(c, "apply_v"); SK::apply_v(g, (const T*)c->d_Phi, BT(c), (T*)c->d_V, c->d_vpart, c->alpha(), c->d_mu, c->st); }
+        { ProfScope ps(c, "apply_v"); SK::apply_v(g, (const T*)c->d_Phi, BT(c), (T*)c->d_V, c->d_vpart, c->alpha(), c->d_mu, c->st, c->bf3); }
         const int nb = (int)std::min<int64_t>(g.Np / 4, 2048);
         { ProfScope ps(c, "rowstats");
           SK::rowstats(g, c->d_mu, c->d_vpart, c->d_y, c->d_sc, c->d_p, c->d_q, c->d_partial, nb, c->st);
@@ -399,7 +409,7 @@ template <typename T> struct Impl {
         const Geom& g = c->g;
         { ProfScope ps(c, "apply_phibar");
           const int nb = SK::apply_phibar(g, (const T*)c->d_Phi, AbarT(c), (T*)c->d_V, c->d_p, c->d_q, c->d_y, c->alpha(), c->ut(),
-                                          c->d_bpart, c->st);
+                                          c->d_bpart, c->st, c->bf3);
           reduce_scalars(c->d_bpart, nb, 1, c->d_x3 + (int64_t)c->Dpp * g.Jp, 0, c->st); }
         const int ntm = c->Dpp / XT, ntn = g.Jp / XT;
         const int xs = c->xtz_nsplit > 0 ? (int)std::min<int64_t>(c->xtz_nsplit, g.Np / 64) : xtz_split(ntm * ntn, g.Np);
@@ -411,7 +421,7 @@ template <typename T> struct Impl {
     }
     static int predict_chunk(scfgp_ctx* c, const Geom& g, const T* Bt) {
         SK::featuremap(g, c->p_Xt, Projection{c->d_Fall, c->d_Lall, c->d_Rall, c->p_Tt}, c->d_sc, (T*)c->p_Phi, c->st);
-        SK::apply_v(g, (const T*)c->p_Phi, Bt, (T*)c->p_V, c->p_vpart, c->alpha_pred(), c->p_mupart, c->st);
+        SK::apply_v(g, (const T*)c->p_Phi, Bt, (T*)c->p_V, c->p_vpart, c->alpha_pred(), c->p_mupart, c->st, c->bf3);     // Bt: split already
         SK::rowpredict(g, c->p_mupart, c->p_vpart, c->d_sc, c->p_mu, c->p_sd, c->st);
         HIPCHK(c, hipGetLastError());
         return SCFGP_OK;
@@ -630,6 +640,7 @@ static int predict_impl(scfgp_ctx* c, const double* Xs, int64_t T, const double*
     const void* Bt = c->d_AbarT;                                  // AbarT is scratch outside adjoint..pass3
     if (c->dtype == SCFGP_F32) SweepKernels<float>::convert(c->d_T2, (float*)c->d_AbarT, g0.K, g0.Kp, c->st);
     else SweepKernels<double>::convert(c->d_T2, (double*)c->d_AbarT, g0.K, g0.Kp, c->st);
+    if (c->bf3) { bf3_presplit((const float*)c->d_AbarT, c->d_M3, g0.Kp, c->st); Bt = c->d_M3; }
     HIPCHK(c, hipStreamSynchronize(c->st));                     // raw is reused below
     const int nchunks = (int)((T + PRED_ROWS - 1) / PRED_ROWS);
     if (post && ys) {

@@ -76,13 +76,14 @@ def test_oracle_kats_fp64(name):
     assert float(c3) != float(cost)
 
 
+@pytest.mark.parametrize('mode', ['f32', 'bf16x3'])           # bf16x3: the split-precision products keep fp32-mode bounds
 @pytest.mark.parametrize('name', ['artifact_shape', 'c1_boston_shape', 'c2_small_n'])
-def test_oracle_kats_fp32_mode(name):
+def test_oracle_kats_fp32_mode(name, mode):
     from scfgp_amd.engine import HipEngine
     z = np.load(os.path.join(GOLD, 'oracle_kats.npz'))
     N, D, S, M, T, seed = CASES[name]
     X, y, params, Xs = case_inputs(name)
-    eng = HipEngine(D, S, M, dtype='f32'); eng.set_params(params); eng.set_data(X, y)
+    eng = HipEngine(D, S, M, dtype=mode); eng.set_params(params); eng.set_data(X, y)
     cost, grad, alpha, Li = eng.eval(want_grad=True)
     c0 = float(z[name + '/cost'])
     assert abs(float(cost) - c0) < 1e-5 * max(1.0, abs(c0))
@@ -146,7 +147,7 @@ def test_minibatches_of_different_sizes():
 @pytest.mark.parametrize('N,D,S,M', [(1, 1, 2, 2), (3, 2, 2, 3), (255, 3, 2, 5), (513, 70, 5, 60),
                                      (300, 200, 3, 9), (1000, 5, 64, 3), (2000, 7, 31, 33),
                                      (700, 4, 8, 120), (900, 6, 10, 150)])      # K = 256: no Gram strip; K = 320: strip
-@pytest.mark.parametrize('dtype', ['f64', 'f32'])
+@pytest.mark.parametrize('dtype', ['f64', 'f32', 'bf16x3'])
 def test_ragged_and_degenerate_shapes(N, D, S, M, dtype):
     """Sizes that are not multiples of any tile: padding rows/columns must never leak."""
     from scfgp_amd.engine import HipEngine

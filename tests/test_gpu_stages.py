@@ -17,7 +17,7 @@ def rel(a, b):
 
 
 @pytest.mark.parametrize('name', ['tiny_257x5', 'kin8nm_like', 'c1_boston_shape'])
-@pytest.mark.parametrize('dtype,tol', [('f64', 1e-9), ('f32', 2e-4)])
+@pytest.mark.parametrize('dtype,tol', [('f64', 1e-9), ('f32', 2e-4), ('bf16x3', 2e-4)])
 def test_stages_match_oracle(name, dtype, tol):
     from scfgp_amd.engine import HipEngine
     N, D, S, M, T, seed = CASES[name]
@@ -27,7 +27,7 @@ def test_stages_match_oracle(name, dtype, tol):
     eng = HipEngine(D, S, M, dtype=dtype)
     eng.set_params(params); eng.set_data(X, y)
     d = eng.dims(); Kp, Jp, Dp, Np = d['Kp'], d['Jp'], d['Dp'], d['Np']
-    tdt = np.float32 if dtype == 'f32' else np.float64
+    tdt = np.float64 if dtype == 'f64' else np.float32
     Dpp = -(-Dp // 128) * 128
 
     # unpack
