@@ -5,14 +5,15 @@ TEST INFRASTRUCTURE ONLY.  Nothing under scfgp_amd/ may import this module; it
 is the checker for tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
 leg, never the thing measured or shipped.
 
-Parity status: PINNED.  `forward()` reproduces the Theano-computed Li / alpha /
-COST stored in the reference's own artifact
-experiments/boston_housing/boston_scfgp.pkl (see tests/golden/make_artifact_kat.py
-and tests/test_oracle_golden.py).  The gradient is not stored anywhere in the
-reference; it is pinned by three-way agreement between `value_and_grad()` (the
-hand-derived 3-sweep algorithm the HIP kernels implement), torch float64
-autograd of the literal reference graph (oracle/autograd_ref.py) and central
-finite differences.
+Parity status: PINNED for the forward path, self-consistent for the rest.  `forward()` reproduces the
+Theano-computed Li / alpha / COST stored in the reference's own artifact
+experiments/boston_housing/boston_scfgp.pkl (see tests/golden/make_artifact_kat.py and
+tests/test_oracle_golden.py): that pins layout, feature map, Gram, Cholesky, Li, alpha, the
+Gauss-Hermite term, penalty and cost.  The gradient, the predictive sigma and the update rules are
+stored nowhere in the reference, so NO reference vector pins them: they rest on three restatements
+of this repository agreeing with each other -- `value_and_grad()` (the hand-derived 3-sweep algorithm
+the HIP kernels implement), torch float64 autograd of the literal reference graph
+(oracle/autograd_ref.py) and central finite differences.
 
 Every function cites the reference lines it restates (paths relative to the
 reference checkout, file SCFGP/SCFGP.py unless stated otherwise).

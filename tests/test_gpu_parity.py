@@ -273,6 +273,60 @@ def test_headline_size_fp32_properties():
         assert measured[nm] < bound, (nm, measured[nm], bound)
 
 
+@pytest.mark.parametrize('cfg', ['C3', 'C4', 'C5'])
+def test_baseline_configs_at_full_size(cfg):
+    """BASELINE.json configs 3-5 at their FULL sizes (N = 1e6 / 4e6 / 1e6 rows, fp32 mode; C4's Phi has 8.7e9 elements,
+    past 2^32).  The oracle cannot run there, so: size-independent properties, plus sampled entries of the Gram, of
+    Phi^T y and sampled rows of the per-row adjoint scalars against float64 numpy on the same inputs."""
+    import bench
+    from scfgp_amd.engine import HipEngine
+    N, D, S, M, dtype = bench.CONFIGS[cfg][:5]
+    J = S + M; K = 2 * J
+    seed = 0x5CF60030 + int(cfg[1])
+    X, params = _synthetic(N, D, S, M, seed)
+    eng = HipEngine(D, S, M, dtype=dtype)
+    y = _teacher_targets(eng, X, D, S, M, seed)
+    eng.set_params(params); eng.set_data(X, y)
+    cost, grad, alpha, Li = eng.eval(want_grad=True)
+    assert np.isfinite(cost) and np.all(np.isfinite(grad)) and np.all(np.triu(Li, 1) == 0)
+    assert np.abs(grad[-J:]).max() < 1e-3 * np.abs(grad).max()              # phases carry no gradient
+    c2, g2, a2, _ = eng.eval(want_grad=True)                                  # deterministic
+    assert float(c2) == float(cost) and np.array_equal(g2, grad) and np.array_equal(a2, alpha)
+    p2 = params.copy(); p2[-J:] += np.linspace(0.0, 3.0, J)                   # phase-shift invariance of the cost
+    eng.set_params(p2)
+    c3 = eng.eval(want_grad=False)[0]
+    assert abs(float(c3) - float(cost)) < 1e-5 * max(1.0, abs(float(cost)))
+    eng.set_params(params)
+    # sampled Gram entries / Phi^T y over ALL rows: the phases of a few columns in float64 numpy
+    a_, b_, c_, l_F, r_F, F, l_FC, FC = O.unpack_params(params, D, S, M)
+    cols = np.array([0, 1, S, J // 2, J - 1])                                 # indices into the J phases
+    W = np.concatenate([l_F, F], 1)[:, cols]; off = np.concatenate([l_FC, FC], 1)[:, cols]
+    Zc = X @ W + off                                                          # (N, 5)
+    s = np.exp(b_) * np.sqrt(2.0 / M)
+    Pc, Ps = s * np.cos(Zc), s * np.sin(Zc)                                   # Phi columns cols and J + cols
+    eng.pass1()
+    Kp = eng.dims()['Kp']
+    x1 = eng.debug_read('G', (Kp * Kp + Kp,))
+    G = x1[:Kp * Kp].reshape(Kp, Kp); g = x1[Kp * Kp:Kp * Kp + K]
+    idx = np.concatenate([cols, J + cols])
+    Pall = np.concatenate([Pc, Ps], 1)
+    assert rel(G[np.ix_(idx, idx)], Pall.T @ Pall) < 2e-6
+    assert rel(g[idx], Pall.T @ y.ravel()) < 2e-5
+    assert np.allclose(np.diag(G)[:J] + np.diag(G)[J:K], N * s * s, rtol=2e-6)      # cos^2 + sin^2
+    A = G[:K, :K] + (np.exp(2 * a_) + 1e-6) * np.eye(K)
+    assert rel(A @ alpha.ravel(), g) < 1e-6                                   # alpha solves the normal equations
+    # sampled rows of p_n = 2 (mu_n - y_n) / d_n, incl. the very last rows (row offsets past 2^32 elements at C4)
+    eng.factor(); eng.pass2(True)
+    rows = np.unique(np.concatenate([np.arange(3), np.random.default_rng(1).integers(0, N, 20), np.arange(N - 3, N)]))
+    pn = eng.debug_read('p', (eng.dims()['Np'],))[rows]
+    B = eng.debug_read('B', (Kp, Kp))[:K, :K]
+    Phi_r = O.feature_map(X[rows], params, D, S, M)
+    mu = Phi_r @ alpha.ravel(); v = np.einsum('nk,kl,nl->n', Phi_r, B, Phi_r)
+    d = np.log1p(np.exp(c_)) * (v + 1.0)
+    assert rel(pn, 2.0 * (mu - y.ravel()[rows]) / d) < 1e-3, rel(pn, 2.0 * (mu - y.ravel()[rows]) / d)
+    eng.close()
+
+
 # ---------------------------------------------------------------------------------------------
 def test_two_shards_on_one_gpu_equal_single():
     """Row sharding through the staged C ABI: two contexts, each with half of the rows, their
