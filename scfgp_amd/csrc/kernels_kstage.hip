@@ -14,8 +14,9 @@ struct GemmArgs {
     int64_t lda, ldb, ldc;
     int M, N, K;
     double alpha, beta;
-    int tri;        // 1: skip tiles strictly above the diagonal
-    int kskip;      // 1: operands are Li^T-shaped, contraction starts at max(m0,n0)
+    int tri;        // 1: skip tiles strictly above the diagonal; 2: also store every tile's transpose (C symmetric)
+    int kskip;      // contraction range by the operands' triangular shape: 0 all of K; 1 both Li^T-shaped: from max(m0, n0);
+                    // 2 B lower triangular (B[k][n] = 0 for k < n): from n0; 3 A lower triangular (A[m][k] = 0 for k > m): up to m0 + 64
 };
 
 // C[m][n] = alpha * sum_k Aop[k][m] Bop[k][n] + beta * C[m][n]
@@ -25,8 +26,9 @@ __device__ __forceinline__ void gemm64_body(const GemmArgs& a, int tm, int tn, d
     typedef KCfg Cfg;
     if (tm * Cfg::BM >= a.M || tn * Cfg::BN >= a.N) return;
     if (a.tri && tn > tm) return;
-    const int k0 = a.kskip ? (tm > tn ? tm : tn) * Cfg::BM : 0;
-    const int nkt = (a.K - k0) / Cfg::BK;
+    const int k0 = a.kskip == 1 ? (tm > tn ? tm : tn) * Cfg::BM : (a.kskip == 2 ? tn * Cfg::BN : 0);
+    const int k1 = a.kskip == 3 && (tm + 1) * Cfg::BM < a.K ? (tm + 1) * Cfg::BM : a.K;
+    const int nkt = (k1 - k0) / Cfg::BK;
     v4d acc[Cfg::TM][Cfg::TN];
     acc_zero<Cfg>(acc);
     if (TRA) {
@@ -58,6 +60,7 @@ __device__ __forceinline__ void gemm64_body(const GemmArgs& a, int tm, int tn, d
             for (int t2 = 0; t2 < Cfg::TN; ++t2) {
                 const double v = a.alpha * acc[t1][t2][r];
                 c[co.col(t2)] = a.beta == 0.0 ? v : v + a.beta * c[co.col(t2)];
+                if (a.tri == 2 && tm != tn) a.C[(int64_t)(tn * Cfg::BN + co.col(t2)) * a.ldc + tm * Cfg::BM + co.row(t1, r)] = v;
             }
         }
 }
@@ -83,13 +86,13 @@ __global__ __launch_bounds__(KCfg::THREADS) void trinv_level_kernel(const double
     const int o1 = 2 * blockIdx.z * sz, o2 = o1 + sz;
     const int n2 = Kp - o2 < sz ? Kp - o2 : sz;
     GemmArgs a;
-    a.lda = a.ldb = a.ldc = ld; a.tri = 0; a.kskip = 0; a.beta = 0.0;
-    if (STEP == 0) {
+    a.lda = a.ldb = a.ldc = ld; a.tri = 0; a.beta = 0.0;
+    if (STEP == 0) {                                           // Inv11 is lower triangular: k >= n
         a.A = L + (int64_t)o2 * ld + o1; a.B = Li + (int64_t)o1 * ld + o1; a.C = Tmp + (int64_t)o2 * ld + o1;
-        a.M = n2; a.N = sz; a.K = sz; a.alpha = 1.0;
-    } else {
+        a.M = n2; a.N = sz; a.K = sz; a.alpha = 1.0; a.kskip = 2;
+    } else {                                                   // Inv22 is lower triangular: k <= m
         a.A = Li + (int64_t)o2 * ld + o2; a.B = Tmp + (int64_t)o2 * ld + o1; a.C = Li + (int64_t)o2 * ld + o1;
-        a.M = n2; a.N = sz; a.K = n2; a.alpha = -1.0;
+        a.M = n2; a.N = sz; a.K = n2; a.alpha = -1.0; a.kskip = 3;
     }
     gemm64_body<true, false>(a, blockIdx.y, blockIdx.x, reinterpret_cast<double*>(smem_raw));
 }
@@ -174,9 +177,8 @@ __device__ __forceinline__ void block_to_lds(const double* src, int64_t pitch, d
 // dependent launches per step: diagonal block, panel solve, trailing update).
 __global__ __launch_bounds__(256) void chol_step_kernel(double* A, double* Lm, double* Li, int64_t ld, int p, int nb, int* flag) {
     constexpr int NB = 64, LD = NB + 1, PB = 16;
-    __shared__ double sL[NB * LD];
+    __shared__ double sL[NB * LD];                                     // 2 x 33 KB + 9 KB: two workgroups per CU
     __shared__ double sI[NB * LD];
-    __shared__ double sW[NB * LD];
     __shared__ double sT[32 * 33];
     __shared__ double sD[NB];                                          // 1 / L[j][j]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -189,15 +191,19 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* A, double* Lm, d
         while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
         while (ti * (ti + 1) / 2 > t) --ti;
         const int i = p + ti, j = p + (t - ti * (ti + 1) / 2);
-        block_to_lds(Li + ((int64_t)q * ld + q) * NB, ld, sW, LD);
-        block_to_lds(A + ((int64_t)i * ld + q) * NB, ld, sL, LD);
-        if (i != j) block_to_lds(A + ((int64_t)j * ld + q) * NB, ld, sI, LD);
+        block_to_lds(Li + ((int64_t)q * ld + q) * NB, ld, sL, LD);     // W = Inv(q)
+        block_to_lds(A + ((int64_t)i * ld + q) * NB, ld, sI, LD);
         __syncthreads();
-        block_xwt<LD>(sL, sW, acc);                                    // L_i
+        block_xwt<LD>(sI, sL, acc);                                    // L_i (registers)
         v4d accj[4];
-        if (i != j) block_xwt<LD>(sI, sW, accj);                       // L_j
+        if (i != j) {
+            __syncthreads();
+            block_to_lds(A + ((int64_t)j * ld + q) * NB, ld, sI, LD);
+            __syncthreads();
+            block_xwt<LD>(sI, sL, accj);                               // L_j
+        }
         __syncthreads();
-        block_store(sL, LD, acc);
+        block_store(sL, LD, acc);                                      // W is done with: L_i takes its place, L_j stays in sI's
         if (i != j) block_store(sI, LD, accj);
         else block_store(Lm + ((int64_t)i * ld + q) * NB, ld, acc);    // the factor's block (i, q)
         if (i == p && j == p) return;                                  // workgroup 0 updates and factors this block itself
@@ -212,9 +218,9 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* A, double* Lm, d
     double* a = A + ((int64_t)p * ld + p) * NB;
     if (p > 0) {
         block_to_lds(A + ((int64_t)p * ld + (p - 1)) * NB, ld, sI, LD);
-        block_to_lds(Li + ((int64_t)(p - 1) * ld + (p - 1)) * NB, ld, sW, LD);
+        block_to_lds(Li + ((int64_t)(p - 1) * ld + (p - 1)) * NB, ld, sL, LD);
         __syncthreads();
-        block_xwt<LD>(sI, sW, acc);                                    // L_p = A[p][p-1] Inv(p-1)^T
+        block_xwt<LD>(sI, sL, acc);                                    // L_p = A[p][p-1] Inv(p-1)^T
         __syncthreads();
         block_store(sI, LD, acc);
         __syncthreads();
@@ -411,8 +417,8 @@ static void trinv(const KStage& k, hipStream_t st) {
 
 void kstage_gram_li(const KStage& k, hipStream_t st) {
     const int64_t ld = k.Kp;
-    GemmArgs a = {k.Li, k.Li, k.B, ld, ld, ld, k.Kp, k.Kp, k.Kp, 1.0, 0.0, 0, 1};
-    gemm64<false, false>(a, st);                                      // B = Li^T Li
+    GemmArgs a = {k.Li, k.Li, k.B, ld, ld, ld, k.Kp, k.Kp, k.Kp, 1.0, 0.0, 2, 1};
+    gemm64<false, false>(a, st);                                      // B = Li^T Li: lower tiles, mirrored on the store
 }
 
 void kstage_factor(const KStage& k, const Scal* sc, hipStream_t st) {
