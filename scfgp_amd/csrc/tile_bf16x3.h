@@ -8,9 +8,10 @@
 // rounding.  bf16 MFMA runs at 16x the fp32-input MFMA rate, so six of them are 2.67x faster than one exact-fp32 MFMA;
 // operands stay fp32 in HBM (no extra bytes), the split costs ~6 VALU instructions per staged element.
 //
-// LDS image of an operand tile: three planes [x][16 k] of bf16, 32 bytes per row x, the two 16-byte halves of a row
-// XOR-swizzled with bit 3 of x so that the 16-lane groups of a ds_read_b128 fragment read hit 64 distinct banks.
-// A lane's MFMA fragment (row x = lane & 31, k = 8 (lane >> 5) .. +7) is ONE ds_read_b128 per plane.
+// LDS image of an operand tile (32 k deep = two MFMA steps per barrier): three planes [x][32 k] of bf16, 64 bytes per
+// row x, the four 16-byte chunks of a row XOR-swizzled with bits 2..3 of x so that the 16-lane groups of a
+// ds_read_b128 fragment read hit 64 distinct banks.  A lane's MFMA fragment of step s (row x = lane & 31,
+// k = 16 s + 8 (lane >> 5) .. +7) is ONE ds_read_b128 per plane.
 #pragma once
 #include "tile_engine.h"
 
@@ -21,20 +22,22 @@ template <int BM_, int BN_, int WGM_, int WGN_>
 struct Bf3Cfg {
     typedef float T;
     typedef MT<float, 32> MTr;                                  // accumulator tile and C/D map of the 32x32 shapes
-    static constexpr int BM = BM_, BN = BN_, BK = 16, WGM = WGM_, WGN = WGN_, MS = 32;
+    static constexpr int BM = BM_, BN = BN_, BK = 32, WGM = WGM_, WGN = WGN_, MS = 32;
     static constexpr bool SWZA = false;
     static constexpr int THREADS = 64 * WGM * WGN;
     static constexpr int WM = BM / WGM, WN = BN / WGN;
     static constexpr int TM = WM / MS, TN = WN / MS;
-    static constexpr int PITCH = 32;                            // bytes per row of a plane
+    static constexpr int PITCH = 64;                            // bytes per row of a plane
     static constexpr int PA = BM * PITCH, PB = BN * PITCH;      // bytes per plane
     static constexpr int BUF = 3 * (PA + PB);                   // one k-tile: A planes h, m, l then B planes h, m, l
     static constexpr int LDS_BYTES = 2 * BUF;
     static_assert(BM % (MS * WGM) == 0 && BN % (MS * WGN) == 0, "tile shape");
 };
 
-// byte offset of the 8-byte piece holding k = 4 kq .. 4 kq + 3 of row x inside a plane
-__device__ __forceinline__ int bf3_piece(int x, int kq) { return x * 32 + (((kq >> 1) ^ ((x >> 3) & 1)) << 4) + ((kq & 1) << 3); }
+// byte offset of the 8-byte piece holding k = 4 kq .. 4 kq + 3 (kq < 8) of row x inside a plane
+__device__ __forceinline__ int bf3_piece(int x, int kq) { return x * 64 + (((kq >> 1) ^ ((x >> 2) & 3)) << 4) + ((kq & 1) << 3); }
+// byte offset of the 16-byte chunk c (k = 8 c .. 8 c + 7) of row x
+__device__ __forceinline__ int bf3_chunk(int x, int c) { return x * 64 + ((c ^ ((x >> 2) & 3)) << 4); }
 
 // exact three-way split of 4 fp32 values into bf16 pieces
 __device__ __forceinline__ void bf3_split4(const float (&x)[4], bf16x4& h, bf16x4& m, bf16x4& l) {
@@ -55,7 +58,7 @@ __device__ __forceinline__ void bf3_split4(const float (&x)[4], bf16x4& h, bf16x
 // ---------------------------------------------------------------------------
 template <int BX, int THREADS, bool DOT>
 struct Bf3TrLoader {
-    static constexpr int VPR = 4;                             // vectors per row of a 16-deep k-tile
+    static constexpr int VPR = 8;                             // vectors per row of a 32-deep k-tile
     static constexpr int NV = (BX * VPR + THREADS - 1) / THREADS;
     const float* ptr[NV]; int tid;
     v4f r[2][NV];                                             // two k-tiles in flight (prefetch distance 2)
@@ -81,7 +84,7 @@ struct Bf3TrLoader {
             v4f val = {0, 0, 0, 0};
             if (ok) val = *reinterpret_cast<const v4f*>(ptr[i]);
             r[SET][i] = val;
-            ptr[i] += 16;
+            ptr[i] += 32;
         }
         if (DOT && dot_on) {
             dot_now[SET] = dphase == dpart;
@@ -89,7 +92,7 @@ struct Bf3TrLoader {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) dv[SET][e] = dptr[e];
             }
-            dptr += 16;
+            dptr += 32;
             dphase = dphase + 1 == dnparts ? 0 : dphase + 1;
         }
     }
@@ -107,7 +110,7 @@ struct Bf3TrLoader {
             *reinterpret_cast<bf16x4*>(d) = h;
             *reinterpret_cast<bf16x4*>(d + plane_bytes) = m;
             *reinterpret_cast<bf16x4*>(d + 2 * plane_bytes) = l;
-            if (DOT && dot_on && dot_now[SET]) {
+            if (DOT && dot_on && dot_now[SET]) {                // fp64 work in this loop is expensive: only in the tile's own k-tiles
 #pragma unroll
                 for (int e = 0; e < 4; ++e) dacc[i] = fma((double)r[SET][i][e], dv[SET][e], dacc[i]);
             }
@@ -117,7 +120,7 @@ struct Bf3TrLoader {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             double s = dacc[i];
-            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2);
+            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
             const int v = tid + i * THREADS;
             if (((BX * VPR) % THREADS == 0 || v < BX * VPR) && v % VPR == 0) out[v / VPR] = s;
         }
@@ -125,117 +128,23 @@ struct Bf3TrLoader {
 };
 
 // ---------------------------------------------------------------------------
-// Bf3NatLoader: source S[k][x] (fp32, row-major, x contiguous).  A work item is 4 k rows x one 16-byte vector of 4
-// columns: four coalesced loads, a 4 x 4 transpose in registers, one 8-byte piece per column and plane.
-//   WEIGHT: row k is scaled by w[k] before the split.   SIDE: side[x] = sum_k s[k] S[k][x] (unweighted values) as in
-//   NatLoader: fp32 partial chains between side_flush() calls, fp64 across.
-// ---------------------------------------------------------------------------
-template <int BX, int THREADS, bool WEIGHT, bool SIDE = false>
-struct Bf3NatLoader {
-    static constexpr int XV = BX / 4;                         // vectors per k row
-    static constexpr int ITEMS = XV * 4;                      // (vector, k quarter) pairs per k-tile
-    static constexpr int NI = (ITEMS + THREADS - 1) / THREADS;
-    const float* ptr[NI]; const double* wptr[NI]; const double* sptr[NI]; int64_t ld; int tid;
-    v4f r[2][NI][4]; double wr[2][NI][4]; double sr[2][NI][4];
-    float sacc[NI][4]; double stot[NI][4]; bool side_on = false;
-    __device__ __forceinline__ Bf3NatLoader(const float* b, int64_t l, int t, const double* w_ = nullptr, const double* s_ = nullptr)
-        : ld(l), tid(t) {
-        side_on = SIDE && s_ != nullptr;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int it = tid + i * THREADS;
-            const int xv = it % XV, kq = it / XV;
-            ptr[i] = b + (int64_t)(4 * kq) * l + xv * 4;
-            wptr[i] = WEIGHT ? w_ + 4 * kq : nullptr;
-            sptr[i] = side_on ? s_ + 4 * kq : nullptr;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { sacc[i][e] = 0; stot[i][e] = 0; }
-        }
-    }
-    template <int SET>
-    __device__ __forceinline__ void load() {
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int it = tid + i * THREADS;
-            const bool ok = ITEMS % THREADS == 0 || it < ITEMS;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                v4f val = {0, 0, 0, 0};
-                if (ok) val = *reinterpret_cast<const v4f*>(ptr[i] + j * ld);
-                r[SET][i][j] = val;
-                if (WEIGHT) wr[SET][i][j] = ok ? wptr[i][j] : 0.0;
-                if (SIDE && side_on) sr[SET][i][j] = ok ? sptr[i][j] : 0.0;
-            }
-            ptr[i] += 16 * ld;
-            if (WEIGHT) wptr[i] += 16;
-            if (SIDE && side_on) sptr[i] += 16;
-        }
-    }
-    template <int SET>
-    __device__ __forceinline__ void store(char* planes, int plane_bytes) {
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int it = tid + i * THREADS;
-            if (ITEMS % THREADS != 0 && it >= ITEMS) continue;
-            const int xv = it % XV, kq = it / XV;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float xs[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) xs[j] = WEIGHT ? r[SET][i][j][e] * (float)wr[SET][i][j] : r[SET][i][j][e];
-                bf16x4 h, m, l;
-                bf3_split4(xs, h, m, l);
-                char* d = planes + bf3_piece(xv * 4 + e, kq);
-                *reinterpret_cast<bf16x4*>(d) = h;
-                *reinterpret_cast<bf16x4*>(d + plane_bytes) = m;
-                *reinterpret_cast<bf16x4*>(d + 2 * plane_bytes) = l;
-                if (SIDE && side_on) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) sacc[i][e] += (float)sr[SET][i][j] * r[SET][i][j][e];
-                }
-            }
-        }
-    }
-    __device__ __forceinline__ void side_flush() {
-#pragma unroll
-        for (int i = 0; i < NI; ++i)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { stot[i][e] += (double)sacc[i][e]; sacc[i][e] = 0; }
-    }
-    // out[x] = side[x], x < BX: the four k-quarter partials of a column meet in lds (4 * BX doubles).  All threads call.
-    __device__ __forceinline__ void side_reduce(double* lds, double* __restrict__ out) const {
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int it = tid + i * THREADS;
-            if (ITEMS % THREADS != 0 && it >= ITEMS) continue;
-            const int xv = it % XV, kq = it / XV;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) lds[kq * BX + xv * 4 + e] = stot[i][e];
-        }
-        __syncthreads();
-        for (int x = tid; x < BX; x += THREADS) out[x] = (lds[x] + lds[BX + x]) + (lds[2 * BX + x] + lds[3 * BX + x]);
-        __syncthreads();
-    }
-};
-
-// ---------------------------------------------------------------------------
 // Bf3CopyLoader: an operand that was split ONCE in global memory (bf3_presplit: the K x K matrices B and Abar, which
 // every workgroup of the apply product re-reads) arrives as ready-made plane rows and is copied, 16 bytes per lane,
 // straight into the image: no conversion work in the loop.
-//   global layout: [k-tile][plane][column j < ld][16 k] bf16 = 32 bytes per (k-tile, plane, j), halves swizzled with
-//   bit 3 of j (tile origins are multiples of 16 columns, so it is the image's swizzle).
+//   global layout: [k-tile][plane][column j < ld][32 k] bf16 = 64 bytes per (k-tile, plane, j), chunks swizzled with
+//   bits 2..3 of j (tile origins are multiples of 16 columns, so it is the image's swizzle).
 // ---------------------------------------------------------------------------
 template <int BX, int THREADS>
 struct Bf3CopyLoader {
-    static constexpr int VPP = BX * 2;                        // 16-byte vectors per plane
+    static constexpr int VPP = BX * 4;                        // 16-byte vectors per plane
     static constexpr int NV = (3 * VPP + THREADS - 1) / THREADS;
     const char* ptr[NV]; int64_t step; int tid;
     v4f r[2][NV];
-    __device__ __forceinline__ Bf3CopyLoader(const void* split, int64_t ldj, int col0, int t) : step(3 * ldj * 32), tid(t) {
+    __device__ __forceinline__ Bf3CopyLoader(const void* split, int64_t ldj, int col0, int t) : step(3 * ldj * 64), tid(t) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int v = tid + i * THREADS, pl = v / VPP, off = v % VPP;
-            ptr[i] = reinterpret_cast<const char*>(split) + ((int64_t)pl * ldj + col0) * 32 + off * 16;
+            ptr[i] = reinterpret_cast<const char*>(split) + ((int64_t)pl * ldj + col0) * 64 + off * 16;
         }
     }
     template <int SET>
@@ -257,7 +166,7 @@ struct Bf3CopyLoader {
         }
     }
 };
-// out (layout above, Kp/16 k-tiles x 3 planes x Kp columns) from the fp32 matrix M (Kp x Kp, element (k, j) = M[k*Kp + j])
+// out (layout above, Kp/32 k-tiles x 3 planes x Kp columns) from the fp32 matrix M (Kp x Kp, element (k, j) = M[k*Kp + j])
 __global__ void bf3_presplit_kernel(const float* __restrict__ M, __bf16* __restrict__ out, int Kp) {
     const int64_t n = (int64_t)Kp * Kp;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -265,47 +174,50 @@ __global__ void bf3_presplit_kernel(const float* __restrict__ M, __bf16* __restr
         const float x = M[i];
         const __bf16 h = (__bf16)x; const float r1 = x - (float)h;
         const __bf16 m = (__bf16)r1; const float r2 = r1 - (float)m;
-        const int kt = k >> 4, kk = k & 15;
-        const int64_t row = ((int64_t)kt * 3 * Kp + j) * 16 + ((((kk >> 3) ^ ((j >> 3) & 1)) << 3) | (kk & 7));
-        out[row] = h; out[row + (int64_t)Kp * 16] = m; out[row + (int64_t)2 * Kp * 16] = (__bf16)r2;
+        const int kt = k >> 5, kk = k & 31;
+        const int64_t row = ((int64_t)kt * 3 * Kp + j) * 32 + ((((kk >> 3) ^ ((j >> 2) & 3)) << 3) | (kk & 7));
+        out[row] = h; out[row + (int64_t)Kp * 32] = m; out[row + (int64_t)2 * Kp * 32] = (__bf16)r2;
     }
 }
 
-// MFMAs of one k-tile (16 deep = one 32x32x16 step) out of LDS buffer `buf`
+// MFMAs of one k-tile (32 deep = two 32x32x16 steps) out of LDS buffer `buf`
 template <class Cfg>
 __device__ __forceinline__ void bf3_compute(const char* buf, typename Cfg::MTr::acc_t (&acc)[Cfg::TM][Cfg::TN]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm0 = (wave / Cfg::WGN) * Cfg::WM, wn0 = (wave % Cfg::WGN) * Cfg::WN;
     const int r = lane & 31, hk = lane >> 5;
-    bf16x8 b[Cfg::TN][3], a[Cfg::TM][3];
 #pragma unroll
-    for (int tn = 0; tn < Cfg::TN; ++tn) {
-        const int x = wn0 + tn * 32 + r;
-        const char* p = buf + 3 * Cfg::PA + x * 32 + ((hk ^ ((x >> 3) & 1)) << 4);
+    for (int st = 0; st < 2; ++st) {
+        bf16x8 b[Cfg::TN][3], a[Cfg::TM][3];
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) b[tn][pl] = *reinterpret_cast<const bf16x8*>(p + pl * Cfg::PB);
+        for (int tn = 0; tn < Cfg::TN; ++tn) {
+            const char* p = buf + 3 * Cfg::PA + bf3_chunk(wn0 + tn * 32 + r, 2 * st + hk);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) b[tn][pl] = *reinterpret_cast<const bf16x8*>(p + pl * Cfg::PB);
+        }
+#pragma unroll
+        for (int tm = 0; tm < Cfg::TM; ++tm) {
+            const char* p = buf + bf3_chunk(wm0 + tm * 32 + r, 2 * st + hk);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) a[tm][pl] = *reinterpret_cast<const bf16x8*>(p + pl * Cfg::PA);
+        }
+        // six terms per accumulator tile, smallest first; consecutive MFMAs go to different accumulators
+        constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};      // (plane of A, plane of B): l.h h.l m.m m.h h.m h.h
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int tm = 0; tm < Cfg::TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < Cfg::TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][TA[t]], b[tn][TB[t]], acc[tm][tn], 0, 0, 0);
     }
-#pragma unroll
-    for (int tm = 0; tm < Cfg::TM; ++tm) {
-        const int x = wm0 + tm * 32 + r;
-        const char* p = buf + x * 32 + ((hk ^ ((x >> 3) & 1)) << 4);
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) a[tm][pl] = *reinterpret_cast<const bf16x8*>(p + pl * Cfg::PA);
-    }
-    // six terms per accumulator tile, smallest first; consecutive MFMAs go to different accumulators
-    constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};      // (plane of A, plane of B): l.h h.l m.m m.h h.m h.h
-#pragma unroll
-    for (int t = 0; t < 6; ++t)
-#pragma unroll
-        for (int tm = 0; tm < Cfg::TM; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < Cfg::TN; ++tn)
-                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][TA[t]], b[tn][TB[t]], acc[tm][tn], 0, 0, 0);
 }
 
 // main loop: nkt k-tiles into acc; smem = Cfg::LDS_BYTES.  LDS double buffered, one barrier per k-tile; the global
 // fetches run TWO k-tiles ahead in two register sets: iteration kt issues the fetch of tile kt+2, multiplies tile kt
-// out of LDS and splits / stores tile kt+1 (fetched a whole iteration ago).
+// out of LDS and splits / stores tile kt+1 (fetched a whole iteration ago).  Measured and not kept
+// (profiles/r02_tuning.md): the split's VALU work forced between the MFMAs with sched_group_barrier (+35 % time), a
+// branch-free form of the fp64 row dots (+30 %), a peeled steady-state iteration without the two conditions (+7 %).
 template <class Cfg, int SET, class LA, class LB>
 __device__ __forceinline__ void bf3_step(LA& la, LB& lb, int kt, int nkt, typename Cfg::MTr::acc_t (&acc)[Cfg::TM][Cfg::TN], char* smem) {
     // SET = kt & 1: registers of tile kt+1 are set SET^1, tile kt+2 goes into set SET (tile kt's set, stored last iteration)

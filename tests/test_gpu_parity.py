@@ -328,9 +328,10 @@ def test_baseline_configs_at_full_size(cfg):
 
 
 # ---------------------------------------------------------------------------------------------
-def test_two_shards_on_one_gpu_equal_single():
-    """Row sharding through the staged C ABI: two contexts, each with half of the rows, their
-    exchange buffers summed as torch tensors aliasing the library's device memory."""
+@pytest.mark.parametrize('R', [2, 4, 8])
+def test_row_shards_on_one_gpu_equal_single(R):
+    """Row sharding through the staged C ABI: R contexts (the rank counts of BASELINE config 4), each with its block
+    of the rows, their exchange buffers summed as torch tensors aliasing the library's device memory."""
     import torch
     from scfgp_amd.engine import HipEngine
     from scfgp_amd.sharded import shard_rows
@@ -341,15 +342,17 @@ def test_two_shards_on_one_gpu_equal_single():
     c0, g0, a0, L0 = single.eval(want_grad=True)
     stream = torch.cuda.current_stream().cuda_stream
     engs = []
-    for r in range(2):
-        lo, hi = shard_rows(N, r, 2)
+    for r in range(R):
+        lo, hi = shard_rows(N, r, R)
         e = HipEngine(D, S, M, stream=stream)
         e.set_params(params); e.set_data(np.ascontiguousarray(X[lo:hi]), np.ascontiguousarray(y[lo:hi]), n_global=N)
         engs.append(e)
 
     def allsum(stage):
         bufs = [e.exchange(stage) for e in engs]
-        tot = bufs[0] + bufs[1]
+        tot = bufs[0].clone()
+        for b in bufs[1:]:
+            tot += b
         for b in bufs:
             b.copy_(tot)
 
