@@ -220,6 +220,11 @@ def main(a):
     import torch
     from scfgp_amd.engine import HipEngine
     from scfgp_amd.sharded import ShardedEvaluator, shard_rows, torch_allreduce
+    # stdout carries exactly ONE line, rank 0's JSON: anything libraries print to fd 1 meanwhile (RCCL's version banner
+    # at communicator creation, for one) goes to stderr
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get('RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0)) % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
@@ -331,7 +336,10 @@ def main(a):
                 X, y, params, D, S, M, local, (cost, grad, alpha, Li), eng)
         if not a.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(X, y, params, S, M, N, a.cpu_rows)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
