@@ -564,10 +564,13 @@ template <typename T> struct ApplyPlan {
     explicit ApplyPlan(int K) {
         const int w[NW] = {Tune<T>::APPLY_BN, 128, 64};
         int col = 0, jt = 0;
+        // K <= 256: a handful of workgroups whatever the tiling, so ONE launch of 64-wide tiles (a launch costs more
+        // than the half-empty tile there: Boston shape, K = 144, 80 -> 45 us per product)
+        const bool small = K <= 256;
         for (int i = 0; i < NW; ++i) {
             width[i] = w[i];
             const bool last = i == NW - 1, dup = i > 0 && w[i] >= w[i - 1];
-            count[i] = dup ? 0 : (last ? (K - col + w[i] - 1) / w[i] : (K - col) / w[i]);
+            count[i] = dup || (small && !last) ? 0 : (last ? (K - col + w[i] - 1) / w[i] : (K - col) / w[i]);
             col0[i] = col; jt0[i] = jt;
             col += count[i] * w[i]; jt += count[i];
         }
