@@ -273,3 +273,31 @@ def test_fused_feature_map_gram_experiment_matches(dtype, tol):
     G = x1[:Kp * Kp].reshape(Kp, Kp)[:K, :K]; g = x1[Kp * Kp:Kp * Kp + K]
     assert rel(G, G0) < tol and rel(g, g0) < tol, (rel(G, G0), rel(g, g0))
     eng.close()
+
+
+def _random_shapes(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        out.append((int(rng.integers(1, 3000)), int(rng.integers(1, 90)), int(rng.integers(1, 40)), int(rng.integers(1, 300))))
+    return out
+
+
+@pytest.mark.parametrize('dtype,ctol,gtol', [('f64', 1e-10, 1e-8), ('f32', 2e-5, 3e-3), ('bf16x3', 2e-5, 3e-3)])
+def test_random_shapes_against_oracle(dtype, ctol, gtol):
+    """24 seeded random (N, D, S, M): every tile-edge combination of the Gram job list (tall / wide / square / strip tiles,
+    64- and 256-row granules), the apply column plans (128 + 64, 64 only) and the Cholesky step counts against the
+    oracle's cost and gradient; fp64 tight, the fp32-storage modes at their usual bounds."""
+    from scfgp_amd.engine import HipEngine
+    for N, D, S, M in _random_shapes(24, 20261004):
+        rng = np.random.default_rng(N * 131 + D * 17 + S * 3 + M)
+        X = rng.random((N, D)); y = rng.standard_normal((N, 1))
+        params = O.init_params(D, S, M, rng)
+        params[0] = -0.4; params[1] = 0.1; params[2] = -0.6; params[3:3 + D * S] *= 0.6
+        eng = HipEngine(D, S, M, dtype=dtype); eng.set_params(params); eng.set_data(X, y)
+        cost, grad, alpha, Li = eng.eval(want_grad=True)
+        c0, g0, a0, L0 = O.value_and_grad(X, y, params, S, M)
+        assert abs(float(cost) - c0) < ctol * max(1.0, abs(c0)), (N, D, S, M, float(cost), c0)
+        assert rel(grad, g0) < gtol, (N, D, S, M, rel(grad, g0))
+        assert np.all(np.triu(Li, 1) == 0)
+        eng.close()
