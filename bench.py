@@ -331,6 +331,17 @@ def main(a):
         }
         for v in out["secondary"].values():
             v["frac"] = v["achieved"] / v["peak"]
+        if world == 1 and not a.no_secondary:
+            # the same evaluation when the caller hands over HOST arrays every call (what the reference's Theano functions
+            # receive, SCFGP/SCFGP.py:237): upload of X, y over PCIe from pageable memory + packing + evaluation.  Never `value`.
+            ts = []
+            for _ in range(3):
+                t1 = time.perf_counter()
+                eng.eval(X, y, want_grad=True)
+                ts.append(time.perf_counter() - t1)
+            out["secondary"]["pcie_inclusive"] = {"evals_per_s": 1.0 / float(np.median(ts)), "ms_per_step": float(np.median(ts)) * 1e3,
+                                                  "host_bytes_per_call": int(X.nbytes + y.nbytes),
+                                                  "note": "scfgp_eval with host X, y on every call (median of 3); resident-data rate is `value`"}
         if world == 1 and a.config == 'H' and a.dtype == 'f32' and not a.custom and not a.no_secondary:
             out["secondary"]["f64"], out["parity_at_size"], out["secondary"]["bf16x3"] = f64_leg_and_parity(
                 X, y, params, D, S, M, local, (cost, grad, alpha, Li), eng)
