@@ -73,6 +73,10 @@ template <typename T> struct SweepKernels {
     //   the matrix pre-split by bf3_presplit()
     static void apply_v(const Geom& g, const T* Phi, const T* Bm, T* V, double* vpart, const double* alpha, double* mupart,
                         hipStream_t st, bool bf3 = false);
+    // predict: vpart[jt][n] = slices of v_n = || Li phi_n ||^2 (the reference's rowsum((Phi Li^T)^2), SCFGP.py:144) from the
+    // triangular product Phi . LiT, LiT[k][j] = Li[j][k] (convert_transposed); mupart as apply_v.  Half the flops of apply_v.
+    static void apply_predict(const Geom& g, const T* Phi, const T* LiT, double* vpart, const double* alpha, double* mupart,
+                              hipStream_t st, bool bf3 = false);
     // Phibar = 2 Phi.Abar + 2 q V + p alpha^T + y ut^T  (in place over V); bpart[block] = partial of
     // bbar = sum Phibar o Phi.  Returns the number of blocks (= partials written).
     static int apply_phibar(const Geom& g, const T* Phi, const T* Abar, T* V, const double* p, const double* q,
@@ -90,6 +94,7 @@ template <typename T> struct SweepKernels {
                     hipStream_t st);
     // fp64 Kp x Kp matrix -> sweep operand (type T, rows/cols >= K zeroed)
     static void convert(const double* src, T* dst, int K, int Kp, hipStream_t st);
+    static void convert_transposed(const double* src, T* dst, int K, int Kp, hipStream_t st);      // dst = src^T on the K x K block
 };
 
 // diagnostic builds only (-DSCFGP_TRACE): per-workgroup [start, end, xcc, kind] of the last Gram launch; -1 otherwise

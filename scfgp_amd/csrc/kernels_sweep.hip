@@ -445,6 +445,9 @@ void SweepKernels<T>::xtz(const Geom& g, const double* Xt, const T* Phi, const T
 // NT products (contraction over feature columns):  C = Phi . Bm  with Bm symmetric
 //   EPI 0: V = C,  vpart[jt][n] = sum_j Phi[n][j] C[n][j]
 //   EPI 1: Phibar = 2 C + 2 q_n V[n][j] + p_n alpha_j + y_n ut_j   (in place over V)
+//   EPI 2 (predict): Bm = Li^T, so C = Phi Li^T is the reference's own product (SCFGP/SCFGP.py:144) and
+//          vpart[jt][n] = sum_j C[n][j]^2; nothing is stored, and since Li^T[k][j] = 0 for k > j the contraction of column
+//          tile jt stops at its last column: half the flops of the symmetric product
 // --------------------------------------------------------------------------
 // epilogues of the apply product: V and the row dots (EPI 0) or Phibar and bbar (EPI 1) from the accumulators
 template <class Cfg, int EPI>
@@ -455,7 +458,7 @@ __device__ __forceinline__ void apply_epilogue(
     double* __restrict__ bpart, char* smem_raw) {
     typedef typename Cfg::T T;
     AccCoord<Cfg> co;
-    if (EPI == 0) {
+    if (EPI == 0 || EPI == 2) {
         double* red = reinterpret_cast<double*>(smem_raw);          // [WGN][BM]; main loop ended with a barrier
         const int wn = (threadIdx.x >> 6) % Cfg::WGN;
 #pragma unroll
@@ -468,6 +471,7 @@ __device__ __forceinline__ void apply_epilogue(
 #pragma unroll
                 for (int tn = 0; tn < Cfg::TN; ++tn) {
                     const T c = acc[tm][tn][r];
+                    if (EPI == 2) { part += (double)c * (double)c; continue; }
                     V[off + co.col(tn)] = c;
                     if (cbase + co.col(tn) < K) part += (double)Phi[off + co.col(tn)] * (double)c;
                 }
@@ -531,25 +535,31 @@ void apply_kernel(
     const int64_t rb = wid / njt;
     const int cbase = col0 + jt * Cfg::BN;
     // EPI 0: column tile t of ntot also forms the slice kt % ntot == t of mu = Phi.alpha for its rows
-    const bool want_mu = EPI == 0 && mu != nullptr;
-    // rows >= K of the operand matrix are zero padding, so the contraction stops at K rounded up to the k-tile
-    const int nkt = (K + Cfg::BK - 1) / Cfg::BK;
+    const bool want_mu = (EPI == 0 || EPI == 2) && mu != nullptr;
+    // rows >= K of the operand matrix are zero padding, so the contraction stops at K rounded up to the k-tile;
+    // EPI 2: the operand is lower-triangular-transposed, column tile jt needs k < cbase + BN only, and forms the slice
+    // k in [cbase, cbase + BN) of mu (the k-tiles no earlier column tile visits)
+    const int nkt_all = (K + Cfg::BK - 1) / Cfg::BK;
+    const int nkt_tri = (cbase + Cfg::BN + Cfg::BK - 1) / Cfg::BK;
+    const int nkt = EPI == 2 && nkt_tri < nkt_all ? nkt_tri : nkt_all;
     if constexpr (IsBf3<Cfg>::value) {                         // split-precision tiles; Bm: the matrix pre-split by bf3_presplit()
         typename Cfg::MTr::acc_t acc[Cfg::TM][Cfg::TN];
         acc_zero<Cfg>(acc);
-        Bf3TrLoader<Cfg::BM, Cfg::THREADS, EPI == 0> la(Phi + rb * Cfg::BM * Kp, Kp, threadIdx.x, want_mu ? alpha : nullptr, jt0 + jt, ntot);
+        Bf3TrLoader<Cfg::BM, Cfg::THREADS, EPI != 1> la(Phi + rb * Cfg::BM * Kp, Kp, threadIdx.x, want_mu ? alpha : nullptr, jt0 + jt, ntot);
+        if (EPI == 2) la.dot_range(cbase / Cfg::BK, nkt);
         Bf3CopyLoader<Cfg::BN, Cfg::THREADS> lb(Bm, Kp, cbase, threadIdx.x);
         bf3_mainloop<Cfg>(la, lb, nkt, acc, smem_raw);
-        if (EPI == 0 && want_mu) la.dot_reduce(mu + (int64_t)(jt0 + jt) * Np + rb * Cfg::BM);
+        if (EPI != 1 && want_mu) la.dot_reduce(mu + (int64_t)(jt0 + jt) * Np + rb * Cfg::BM);
         apply_epilogue<Cfg, EPI>(acc, Phi, V, vpart, p, q, y, alpha, ut, K, Kp, Np, rb, cbase, jt0 + jt, bpart, smem_raw);
     } else {
         typename Cfg::MTr::acc_t acc[Cfg::TM][Cfg::TN];
         acc_zero<Cfg>(acc);
-        TrLoader<T, T, Cfg::BM, Cfg::BK, Cfg::LDA, Cfg::THREADS, EPI == 0, Cfg::SWZA> la(Phi + rb * Cfg::BM * Kp, Kp, threadIdx.x,
+        TrLoader<T, T, Cfg::BM, Cfg::BK, Cfg::LDA, Cfg::THREADS, EPI != 1, Cfg::SWZA> la(Phi + rb * Cfg::BM * Kp, Kp, threadIdx.x,
                                                                             want_mu ? alpha : nullptr, jt0 + jt, ntot);
+        if (EPI == 2) la.dot_range(cbase / Cfg::BK, nkt);
         NatLoader<T, T, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS, false, false> lb(Bm + cbase, Kp, threadIdx.x);
         tile_mainloop<Cfg>(la, lb, nkt, acc, smem);
-        if (EPI == 0 && want_mu) la.dot_reduce(mu + (int64_t)(jt0 + jt) * Np + rb * Cfg::BM);
+        if (EPI != 1 && want_mu) la.dot_reduce(mu + (int64_t)(jt0 + jt) * Np + rb * Cfg::BM);
         apply_epilogue<Cfg, EPI>(acc, Phi, V, vpart, p, q, y, alpha, ut, K, Kp, Np, rb, cbase, jt0 + jt, bpart, smem_raw);
     }
 }
@@ -618,6 +628,11 @@ void SweepKernels<T>::apply_v(const Geom& g, const T* Phi, const T* Bm, T* V, do
     mu = nullptr;                                              // timing diagnostic only: wrong numbers
 #endif
     apply_launch<T, 0>(g, Phi, Bm, V, vpart, nullptr, nullptr, nullptr, alpha, nullptr, nullptr, mu, st, bf3);
+}
+template <typename T>
+void SweepKernels<T>::apply_predict(const Geom& g, const T* Phi, const T* LiT, double* vpart, const double* alpha, double* mu,
+                                    hipStream_t st, bool bf3) {
+    apply_launch<T, 2>(g, Phi, LiT, (T*)nullptr, vpart, nullptr, nullptr, nullptr, alpha, nullptr, nullptr, mu, st, bf3);
 }
 template <typename T>
 int SweepKernels<T>::apply_phibar(const Geom& g, const T* Phi, const T* Abar, T* V, const double* p, const double* q,
@@ -702,6 +717,19 @@ __global__ void convert_kernel(const double* __restrict__ src, T* __restrict__ d
         const int r = (int)(i / Kp), c = (int)(i % Kp);
         dst[i] = (r < K && c < K) ? (T)src[i] : (T)0;
     }
+}
+// dst[k][j] = src[j][k] on the K x K block, zero elsewhere (Li -> the sweep operand Li^T of the predict product)
+template <typename T>
+__global__ void convert_t_kernel(const double* __restrict__ src, T* __restrict__ dst, int K, int Kp) {
+    const int64_t n = (int64_t)Kp * Kp;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i / Kp), j = (int)(i % Kp);
+        dst[i] = (k < K && j < K) ? (T)src[(int64_t)j * Kp + k] : (T)0;
+    }
+}
+template <typename T>
+void SweepKernels<T>::convert_transposed(const double* src, T* dst, int K, int Kp, hipStream_t st) {
+    hipLaunchKernelGGL(convert_t_kernel<T>, dim3(2048), dim3(256), 0, st, src, dst, K, Kp);
 }
 template <typename T>
 void SweepKernels<T>::convert(const double* src, T* dst, int K, int Kp, hipStream_t st) {

@@ -79,7 +79,7 @@ struct scfgp_ctx {
     int xs_mode = 0; double* d_xscale = nullptr;                 // X scaler for scfgp_predict_raw (5*D doubles)
     int ys_mode = 0; double* d_yscale = nullptr;                 // y scaler for scfgp_predict_y (5 doubles)
     // predict chunk buffers
-    double *p_Xt = nullptr, *p_vpart = nullptr, *p_mupart = nullptr, *p_mu = nullptr, *p_sd = nullptr; void *p_Phi = nullptr, *p_V = nullptr;
+    double *p_Xt = nullptr, *p_vpart = nullptr, *p_mupart = nullptr; void *p_Phi = nullptr;
     // on-device optimiser + captured training iteration
     int opt_algo = -1; OptHyper opt_h{}; double *d_opt = nullptr, *d_tctr = nullptr, *d_hist = nullptr; int hist_cap = 0;
     hipGraph_t graph = nullptr; hipGraphExec_t gexec = nullptr; int64_t graph_N = -1; bool in_train = false, warm = false;
@@ -265,7 +265,7 @@ extern "C" void scfgp_destroy(scfgp_ctx* c) {
     dfree(c->d_xp1); dfree(c->d_xp2); dfree(c->d_x1); dfree(c->d_x2); dfree(c->d_x3); dfree(c->d_Li); dfree(c->d_B); dfree(c->d_T1); dfree(c->d_T2);
     dfree(c->d_Abar); dfree(c->d_BT); dfree(c->d_AbarT); dfree(c->d_M3); dfree(c->d_vecs); dfree(c->d_scalars); dfree(c->d_yy);
     dfree(c->d_flag); dfree(c->d_partial); dfree(c->d_work); dfree(c->d_grad);
-    dfree(c->p_Xt); dfree(c->p_vpart); dfree(c->p_mupart); dfree(c->p_mu); dfree(c->p_sd); dfree(c->p_Phi); dfree(c->p_V);
+    dfree(c->p_Xt); dfree(c->p_vpart); dfree(c->p_mupart); dfree(c->p_Phi);
     if (c->gexec) hipGraphExecDestroy(c->gexec);
     if (c->graph) hipGraphDestroy(c->graph);
     dfree(c->d_opt); dfree(c->d_tctr); dfree(c->d_hist);
@@ -419,10 +419,10 @@ template <typename T> struct Impl {
         HIPCHK(c, hipGetLastError());
         return SCFGP_OK;
     }
-    static int predict_chunk(scfgp_ctx* c, const Geom& g, const T* Bt) {
+    static int predict_chunk(scfgp_ctx* c, const Geom& g, const T* Bt, double* mu, double* sd) {
         SK::featuremap(g, c->p_Xt, Projection{c->d_Fall, c->d_Lall, c->d_Rall, c->p_Tt}, c->d_sc, (T*)c->p_Phi, c->st);
-        SK::apply_v(g, (const T*)c->p_Phi, Bt, (T*)c->p_V, c->p_vpart, c->alpha_pred(), c->p_mupart, c->st, c->bf3);     // Bt: split already
-        SK::rowpredict(g, c->p_mupart, c->p_vpart, c->d_sc, c->p_mu, c->p_sd, c->st);
+        SK::apply_predict(g, (const T*)c->p_Phi, Bt, c->p_vpart, c->alpha_pred(), c->p_mupart, c->st, c->bf3);   // Bt = Li^T (split already in bf16x3 mode)
+        SK::rowpredict(g, c->p_mupart, c->p_vpart, c->d_sc, mu, sd, c->st);
         HIPCHK(c, hipGetLastError());
         return SCFGP_OK;
     }
@@ -621,25 +621,23 @@ static int predict_impl(scfgp_ctx* c, const double* Xs, int64_t T, const double*
         if (g0.lowrank && (rc = dmalloc(c, &c->p_Tt, sizeof(double) * PRED_ROWS * g0.Sp))) return rc;
         if ((rc = dmalloc(c, &c->p_vpart, sizeof(double) * PRED_ROWS * (Kp / 64)))) return rc;
         if ((rc = dmalloc(c, &c->p_mupart, sizeof(double) * PRED_ROWS * (Kp / 64)))) return rc;
-        if ((rc = dmalloc(c, &c->p_mu, sizeof(double) * PRED_ROWS))) return rc;
-        if ((rc = dmalloc(c, &c->p_sd, sizeof(double) * PRED_ROWS))) return rc;
         if ((rc = dmalloc(c, &c->p_Phi, ts * PRED_ROWS * Kp))) return rc;
-        if ((rc = dmalloc(c, &c->p_V, ts * PRED_ROWS * Kp))) return rc;
         HIPCHK(c, hipMemsetAsync(c->p_Phi, 0, ts * PRED_ROWS * Kp, c->st));
-        HIPCHK(c, hipMemsetAsync(c->p_V, 0, ts * PRED_ROWS * Kp, c->st));
     }
-    // Li (K x K host) -> T1 (Kp x Kp, identity padding); B = Li^T Li -> T2; typed copy -> AbarT scratch
-    DevTmp raw, d_ys, d_part;                                     // Li / chunk of Xs | targets, mean, metrics | chunk partials
-    if ((rc = dmalloc(c, &raw.p, sizeof(double) * std::max<int64_t>((int64_t)g0.K * g0.K, PRED_ROWS * g0.D)))) return rc;
+    // Li (K x K host) -> T1 (Kp x Kp, identity padding); typed transposed copy -> AbarT scratch
+    DevTmp raw, d_out, d_ys, d_part;                              // Li / two chunks of Xs | mu, sd of all T rows | targets, mean, metrics | chunk partials
+    const int64_t rawstride = PRED_ROWS * g0.D;
+    if ((rc = dmalloc(c, &raw.p, sizeof(double) * std::max<int64_t>((int64_t)g0.K * g0.K, 2 * rawstride)))) return rc;
+    if ((rc = dmalloc(c, &d_out.p, sizeof(double) * 2 * T))) return rc;
+    double* d_mu = d_out; double* d_sd = d_out + T;
     HIPCHK(c, hipMemcpyAsync(raw, Li, sizeof(double) * g0.K * g0.K, hipMemcpyHostToDevice, c->st));
     pad_square(raw, g0.K, g0.Kp, c->d_T1, c->st);
     HIPCHK(c, hipMemsetAsync(c->alpha_pred(), 0, sizeof(double) * Kp, c->st));
     HIPCHK(c, hipMemcpyAsync(c->alpha_pred(), alpha, sizeof(double) * g0.K, hipMemcpyHostToDevice, c->st));
-    KStage k = c->kstage(); k.Li = c->d_T1; k.B = c->d_T2;
-    kstage_gram_li(k, c->st);
+    // the sweep operand is Li^T itself: sigma* needs rowsum((Phi* Li^T)^2) (SCFGP/SCFGP.py:144), a triangular product
     const void* Bt = c->d_AbarT;                                  // AbarT is scratch outside adjoint..pass3
-    if (c->dtype == SCFGP_F32) SweepKernels<float>::convert(c->d_T2, (float*)c->d_AbarT, g0.K, g0.Kp, c->st);
-    else SweepKernels<double>::convert(c->d_T2, (double*)c->d_AbarT, g0.K, g0.Kp, c->st);
+    if (c->dtype == SCFGP_F32) SweepKernels<float>::convert_transposed(c->d_T1, (float*)c->d_AbarT, g0.K, g0.Kp, c->st);
+    else SweepKernels<double>::convert_transposed(c->d_T1, (double*)c->d_AbarT, g0.K, g0.Kp, c->st);
     if (c->bf3) { bf3_presplit((const float*)c->d_AbarT, c->d_M3, g0.Kp, c->st); Bt = c->d_M3; }
     HIPCHK(c, hipStreamSynchronize(c->st));                     // raw is reused below
     const int nchunks = (int)((T + PRED_ROWS - 1) / PRED_ROWS);
@@ -649,20 +647,44 @@ static int predict_impl(scfgp_ctx* c, const double* Xs, int64_t T, const double*
         HIPCHK(c, hipMemcpyAsync(d_ys, ys, sizeof(double) * T, hipMemcpyHostToDevice, c->st));
         ypost_mean(d_ys, T, d_ys + T, c->st);
     }
-    for (int64_t t0 = 0; t0 < T; t0 += PRED_ROWS) {
+    // chunk i+1 is uploaded (pageable host memory: the call blocks the host while it stages) on the copy stream while the
+    // kernels of chunk i run; raw holds two chunks, ev_up / ev_free order its two halves between the streams
+    struct Events {
+        hipEvent_t up[2] = {nullptr, nullptr}, fre[2] = {nullptr, nullptr};
+        ~Events() { for (int i = 0; i < 2; ++i) { if (up[i]) (void)hipEventDestroy(up[i]); if (fre[i]) (void)hipEventDestroy(fre[i]); } }
+    } ev;
+    for (int i = 0; i < 2; ++i) {
+        HIPCHK(c, hipEventCreateWithFlags(&ev.up[i], hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&ev.fre[i], hipEventDisableTiming));
+    }
+    auto upload = [&](int64_t i) -> int {
+        const int64_t t0 = i * PRED_ROWS, n = std::min<int64_t>(PRED_ROWS, T - t0);
+        const int h = (int)(i & 1);
+        if (i >= 2) HIPCHK(c, hipStreamWaitEvent(c->copy_st, ev.fre[h], 0));
+        HIPCHK(c, hipMemcpyAsync(raw + h * rawstride, Xs + t0 * g0.D, sizeof(double) * n * g0.D, hipMemcpyHostToDevice, c->copy_st));
+        HIPCHK(c, hipEventRecord(ev.up[h], c->copy_st));
+        return SCFGP_OK;
+    };
+    if ((rc = upload(0))) return rc;
+    for (int64_t i = 0; i < nchunks; ++i) {
+        const int64_t t0 = i * PRED_ROWS;
+        const int h = (int)(i & 1);
         Geom g = g0;
         g.N = std::min<int64_t>(PRED_ROWS, T - t0); g.Np = round_up(g.N, 256);
-        HIPCHK(c, hipMemcpyAsync(raw, Xs + t0 * g.D, sizeof(double) * g.N * g.D, hipMemcpyHostToDevice, c->st));
-        pack_data(g, raw, nullptr, nullptr, c->p_Xt, nullptr, c->st, raw_mode ? c->xs_mode : 0, c->d_xscale);
-        rc = c->dtype == SCFGP_F32 ? Impl<float>::predict_chunk(c, g, (const float*)Bt) : Impl<double>::predict_chunk(c, g, (const double*)Bt);
+        HIPCHK(c, hipStreamWaitEvent(c->st, ev.up[h], 0));
+        pack_data(g, raw + h * rawstride, nullptr, nullptr, c->p_Xt, nullptr, c->st, raw_mode ? c->xs_mode : 0, c->d_xscale);
+        HIPCHK(c, hipEventRecord(ev.fre[h], c->st));
+        rc = c->dtype == SCFGP_F32 ? Impl<float>::predict_chunk(c, g, (const float*)Bt, d_mu + t0, d_sd + t0)
+                                   : Impl<double>::predict_chunk(c, g, (const double*)Bt, d_mu + t0, d_sd + t0);
         if (rc) return rc;
         if (post)
-            ypost_chunk(c->p_mu, c->p_sd, d_ys.p ? d_ys + t0 : nullptr, g.N, c->ys_mode, c->d_yscale, d_ys.p ? d_ys + T : nullptr,
-                        d_part.p ? d_part + 4 * YPOST_BLOCKS * (t0 / PRED_ROWS) : nullptr, c->st);
-        HIPCHK(c, hipMemcpyAsync(mu + t0, c->p_mu, sizeof(double) * g.N, hipMemcpyDeviceToHost, c->st));
-        HIPCHK(c, hipMemcpyAsync(sd + t0, c->p_sd, sizeof(double) * g.N, hipMemcpyDeviceToHost, c->st));
-        HIPCHK(c, hipStreamSynchronize(c->st));
+            ypost_chunk(d_mu + t0, d_sd + t0, d_ys.p ? d_ys + t0 : nullptr, g.N, c->ys_mode, c->d_yscale, d_ys.p ? d_ys + T : nullptr,
+                        d_part.p ? d_part + 4 * YPOST_BLOCKS * i : nullptr, c->st);
+        if (i + 1 < nchunks && (rc = upload(i + 1))) return rc;
     }
+    HIPCHK(c, hipMemcpyAsync(mu, d_mu, sizeof(double) * T, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipMemcpyAsync(sd, d_sd, sizeof(double) * T, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
     if (post && ys) {
         ypost_metrics(d_part, YPOST_BLOCKS * nchunks, T, d_ys + T + 1, c->st);
         HIPCHK(c, hipMemcpyAsync(metrics, d_ys + T + 1, sizeof(double) * 6, hipMemcpyDeviceToHost, c->st));

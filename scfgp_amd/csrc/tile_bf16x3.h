@@ -64,6 +64,8 @@ struct Bf3TrLoader {
     v4f r[2][NV];                                             // two k-tiles in flight (prefetch distance 2)
     const double* dptr = nullptr; double dv[2][4]; double dacc[NV]; bool dot_on = false, dot_now[2] = {false, false};
     int dpart = 0, dnparts = 1, dphase = 0;
+    int dlo = 0, dhi = -1, dkt = 0;                             // range mode (dot_range): k-tiles [dlo, dhi) instead of the modulo rule
+    __device__ __forceinline__ void dot_range(int lo, int hi) { dlo = lo; dhi = hi; }
     __device__ __forceinline__ Bf3TrLoader(const float* b, int64_t l, int t, const double* d_ = nullptr, int part = 0, int nparts = 1)
         : tid(t), dpart(part), dnparts(nparts) {
         dot_on = DOT && d_ != nullptr;
@@ -87,7 +89,8 @@ struct Bf3TrLoader {
             ptr[i] += 32;
         }
         if (DOT && dot_on) {
-            dot_now[SET] = dphase == dpart;
+            dot_now[SET] = dhi >= 0 ? (dkt >= dlo && dkt < dhi) : dphase == dpart;
+            ++dkt;
             if (dot_now[SET]) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) dv[SET][e] = dptr[e];

@@ -232,6 +232,8 @@ struct TrLoader {
     vec_t r[1][NV];
     const double* dptr = nullptr; double dv[VS]; double dacc[NV]; bool dot_on = false, dot_now = false;
     int dpart = 0, dnparts = 1, dphase = 0;                     // dphase: (index of the k-tile being loaded) % dnparts
+    int dlo = 0, dhi = -1, dkt = 0;                             // range mode (dot_range): k-tiles [dlo, dhi) instead of the modulo rule
+    __device__ __forceinline__ void dot_range(int lo, int hi) { dlo = lo; dhi = hi; }
     __device__ __forceinline__ TrLoader(const S* b, int64_t l, int t, const double* d_ = nullptr, int part = 0, int nparts = 1)
         : tid(t), dpart(part), dnparts(nparts) {
         dot_on = DOT && d_ != nullptr;
@@ -257,7 +259,8 @@ struct TrLoader {
             ptr[i] += BK;
         }
         if (DOT && dot_on) {
-            dot_now = dphase == dpart;
+            dot_now = dhi >= 0 ? (dkt >= dlo && dkt < dhi) : dphase == dpart;
+            ++dkt;
             if (dot_now) {
 #pragma unroll
                 for (int e = 0; e < VS; ++e) dv[e] = dptr[e];
