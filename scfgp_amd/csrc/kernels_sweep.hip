@@ -93,49 +93,172 @@ template <int BM, int BN, int WGM, int WGN> struct IsBf3<Bf3Cfg<BM, BN, WGM, WGN
 #ifndef SCFGP_FMAP_WGM
 #define SCFGP_FMAP_WGM 4     // 8 waves: one wave's fp64 sincos overlaps another's projection MFMAs
 #endif
+#ifndef SCFGP_FMAP_MIN_WGS
+#define SCFGP_FMAP_MIN_WGS 6144   // workgroups below which a row block's column tiles are spread over several workgroups
+#endif
+#ifndef SCFGP_FMAP_REG
+#define SCFGP_FMAP_REG 1          // register-resident feature-map kernel for contractions 16 or 32 deep
+#endif
+#ifndef SCFGP_FMAP_REG_MIN_WGS
+#define SCFGP_FMAP_REG_MIN_WGS 16384
+#endif
 typedef TileCfg<double, 128, 64, 16, SCFGP_FMAP_WGM, 2, 16, true> FmapCfg;    // swizzled X~ image (TrLoader)
 template <typename T> struct XtzCfg { typedef TileCfg<T, 128, 128, 16, 4, 2, Tune<T>::MS> type; };
 
 // --------------------------------------------------------------------------
 // feature map:  Z = X~ . Fall  (fp64 MFMA, K-dim = Dp),  Phi = s [cos Z | sin Z]
 // --------------------------------------------------------------------------
-template <typename T>
+// One workgroup: 128 rows x the column tiles [jt0, jt0 + njt_wg) of Z, as one stream of k-tiles (the contraction is
+// only Dp or Sp deep: 2..4 k-tiles for the headline shape, so tile-per-workgroup launches were all prologue).
+template <typename T, bool ZOUT>
 __global__ __launch_bounds__(FmapCfg::THREADS) void featuremap_kernel(
     const double* __restrict__ Xt, const double* __restrict__ Fall, const Scal* __restrict__ sc,
-    T* __restrict__ Phi, int Dp, int Jp, int Kp, int J, int64_t N, int njt, T* __restrict__ Zout) {
+    T* __restrict__ Phi, int Dp, int Jp, int Kp, int J, int64_t N, int njt, int ncs, T* __restrict__ Zout) {
     typedef FmapCfg Cfg;
     SMEM_DECL;
     double* smem = reinterpret_cast<double*>(smem_raw);
-    const int jt = blockIdx.x % njt;
-    const int64_t rb = blockIdx.x / njt;
+    const int cs = blockIdx.x % ncs;                            // column range of this workgroup
+    const int64_t rb = blockIdx.x / ncs;
+    const int per = (njt + ncs - 1) / ncs, jt0 = cs * per, nseg = (jt0 + per <= njt ? per : njt - jt0);
+    if (nseg <= 0) return;
+    const int nkt = Dp / Cfg::BK;
     TrLoader<double, double, Cfg::BM, Cfg::BK, Cfg::LDA, Cfg::THREADS, false, Cfg::SWZA> la(Xt + rb * Cfg::BM * Dp, Dp, threadIdx.x);
-    NatLoader<double, double, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS, false, false> lb(Fall + jt * Cfg::BN, Jp, threadIdx.x);
+    NatLoader<double, double, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS, false, false> lb(Fall + jt0 * Cfg::BN, Jp, threadIdx.x);
     typename Cfg::MTr::acc_t acc[Cfg::TM][Cfg::TN];
     acc_zero<Cfg>(acc);
-    tile_mainloop<Cfg>(la, lb, Dp / Cfg::BK, acc, smem);
     const double s = sc->s;
     const T s_hi = (T)s, s_lo = (T)(s - (double)s_hi);
     AccCoord<Cfg> co;
+    // the next segment starts at k = 0 again, one column tile to the right
+    tile_mainloop_segments<Cfg>(la, lb, nkt, nseg, -(int64_t)Dp, (int64_t)Cfg::BN - (int64_t)Dp * Jp, acc, smem,
+        [&](int seg, typename Cfg::MTr::acc_t (&a)[Cfg::TM][Cfg::TN]) {
+            // all sin / cos values of the tile first (independent chains the scheduler can interleave), then the stores
+            T vs[Cfg::TM][Cfg::TN][Cfg::MTr::NACC], vc[Cfg::TM][Cfg::TN][Cfg::MTr::NACC];
 #pragma unroll
-    for (int tm = 0; tm < Cfg::TM; ++tm)
+            for (int tm = 0; tm < Cfg::TM; ++tm)
 #pragma unroll
-        for (int tn = 0; tn < Cfg::TN; ++tn) {
-            const int j = jt * Cfg::BN + co.col(tn);
-            if (j >= J) continue;
+                for (int tn = 0; tn < Cfg::TN; ++tn)
 #pragma unroll
-            for (int r = 0; r < Cfg::MTr::NACC; ++r) {
-                const int64_t n = rb * Cfg::BM + co.row(tm, r);
-                T sn, cs;                                          // fp64 or fp32 kernels by output type
-                fast_sincos(acc[tm][tn][r], sn, cs);
-                // scale s = s_hi + s_lo in T: a rounded scale alone would bias every entry of Phi the same way
-                Phi[n * Kp + j] = n < N ? fma(cs, s_hi, cs * s_lo) : (T)0;
-                Phi[n * Kp + J + j] = n < N ? fma(sn, s_hi, sn * s_lo) : (T)0;
-                if (Zout) {                                                   // experiment: the phase itself, for ZSRC loaders
-                    const double z = acc[tm][tn][r];
-                    Zout[n * Jp + j] = sizeof(T) == 4 ? (T)fma(-rint(z * 1.5915494309189535e-01), 6.283185307179586e+00, z) : (T)z;
+                    for (int r = 0; r < Cfg::MTr::NACC; ++r) {
+                        T sn, cs_;                                         // fp64 or fp32 kernels by output type
+#ifdef SCFGP_DIAG_FMAP_NOSINCOS                                 // timing diagnostics only (wrong numbers)
+                        sn = (T)a[tm][tn][r]; cs_ = sn + (T)1;
+#else
+                        fast_sincos(a[tm][tn][r], sn, cs_);
+#endif
+                        // scale s = s_hi + s_lo in T: a rounded scale alone would bias every entry of Phi the same way
+                        vc[tm][tn][r] = fma(cs_, s_hi, cs_ * s_lo);
+                        vs[tm][tn][r] = fma(sn, s_hi, sn * s_lo);
+                    }
+#pragma unroll
+            for (int tm = 0; tm < Cfg::TM; ++tm)
+#pragma unroll
+                for (int r = 0; r < Cfg::MTr::NACC; ++r) {
+                    const int64_t n = rb * Cfg::BM + co.row(tm, r);
+                    T* __restrict__ prow = Phi + n * Kp;
+#pragma unroll
+                    for (int tn = 0; tn < Cfg::TN; ++tn) {
+                        const int j = (jt0 + seg) * Cfg::BN + co.col(tn);
+#ifdef SCFGP_DIAG_FMAP_NOSTORE
+                        asm volatile("" :: "v"(vs[tm][tn][r]), "v"(vc[tm][tn][r]));
+                        if (n == -1) Phi[j] = vs[tm][tn][r] + vc[tm][tn][r];
+#else
+                        if (j < J) {
+                            prow[j] = n < N ? vc[tm][tn][r] : (T)0;
+                            prow[J + j] = n < N ? vs[tm][tn][r] : (T)0;
+                        }
+#endif
+                        if constexpr (ZOUT) {                                         // experiment: the phase itself, for ZSRC loaders
+                            const double z = a[tm][tn][r];
+                            if (j < J) Zout[n * Jp + j] = sizeof(T) == 4 ? (T)fma(-rint(z * 1.5915494309189535e-01), 6.283185307179586e+00, z) : (T)z;
+                        }
+                    }
+                }
+        });
+}
+
+// Shallow contractions (4 NK <= 36 live rows: the rank-S projection or a small D; rows beyond are zero padding and are
+// not multiplied): no LDS and no barriers.  A wave keeps the
+// fp64 MFMA fragments of its 32 rows in registers for its whole life and streams the 32-column tiles of Z through
+// them; the fragments of Fall come straight from L2 (the matrix is a few hundred KB), fetched for the next tile while
+// the current one goes through sin / cos.  Waves are independent, so one wave's MFMAs run under another's VALU work.
+// MFMA column (tn, i) is Z column 2 i + tn of the tile: a lane ends up with two adjacent columns and stores them as
+// one vector, 16 lanes cover a full 128-byte line of a Phi row.
+template <typename T, int NK>
+__global__ __launch_bounds__(256) void featuremap_reg_kernel(
+    const double* __restrict__ A, int lda, const double* __restrict__ Fall, const Scal* __restrict__ sc,
+    T* __restrict__ Phi, int Jp, int Kp, int J, int64_t N, int nct, int ncs) {
+    typedef MT<double, 16> M;
+    typedef T tv2 __attribute__((ext_vector_type(2)));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, i = lane & 15;
+    const int cs = blockIdx.x % ncs;
+    const int64_t rb = blockIdx.x / ncs;
+    const int per = (nct + ncs - 1) / ncs, ct0 = cs * per, nseg = ct0 + per <= nct ? per : nct - ct0;
+    if (nseg <= 0) return;
+    const int64_t row0 = rb * 128 + wave * 32;
+    double a[2][NK];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) a[tm][ks] = A[(row0 + tm * 16 + i) * lda + ks * 4 + q];
+    const double* bp = Fall + (int64_t)q * Jp + ct0 * 32 + 2 * i;
+    v2d b[NK];
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) b[ks] = *reinterpret_cast<const v2d*>(bp + (int64_t)ks * 4 * Jp);
+    const double s = sc->s;
+    const T s_hi = (T)s, s_lo = (T)(s - (double)s_hi);
+    const bool vec = (J & 1) == 0;                              // the sine half starts at column J
+    for (int seg = 0; seg < nseg; ++seg) {
+        v4d acc[2][2];
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) acc[tm][tn] = v4d{0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks)
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn) M::mfma(acc[tm][tn], a[tm][ks], b[ks][tn]);
+        bp += 32;
+        if (seg + 1 < nseg) {
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks) b[ks] = *reinterpret_cast<const v2d*>(bp + (int64_t)ks * 4 * Jp);
+        }
+        const int c = (ct0 + seg) * 32 + 2 * i;
+        T vs[2][4][2], vc[2][4][2];
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn) {
+                    T sn, cs_;
+                    fast_sincos(acc[tm][tn][r], sn, cs_);
+                    // scale s = s_hi + s_lo in T: a rounded scale alone would bias every entry of Phi the same way
+                    vc[tm][r][tn] = fma(cs_, s_hi, cs_ * s_lo);
+                    vs[tm][r][tn] = fma(sn, s_hi, sn * s_lo);
+                }
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t n = row0 + tm * 16 + M::crow(lane, r);
+                T* __restrict__ prow = Phi + n * Kp;
+                const bool live = n < N;                       // padding rows of Phi are zero
+                const T c0 = live ? vc[tm][r][0] : (T)0, c1 = live ? vc[tm][r][1] : (T)0;
+                const T s0 = live ? vs[tm][r][0] : (T)0, s1 = live ? vs[tm][r][1] : (T)0;
+                if (vec) {
+                    if (c < J) {
+                        *reinterpret_cast<tv2*>(prow + c) = tv2{c0, c1};
+                        *reinterpret_cast<tv2*>(prow + J + c) = tv2{s0, s1};
+                    }
+                } else {
+                    if (c < J) { prow[c] = c0; prow[J + c] = s0; }
+                    if (c + 1 < J) { prow[c + 1] = c1; prow[J + c + 1] = s1; }
                 }
             }
-        }
+    }
 }
 
 // T~ = X~ . Lall (fp64 MFMA), the first factor of the rank-S projection
@@ -167,18 +290,37 @@ template <typename T>
 void SweepKernels<T>::featuremap(const Geom& g, const double* Xt, const Projection& pr, const Scal* sc, T* Phi, hipStream_t st, T* Zout) {
     const int njt = g.Jp / FmapCfg::BN;
     const int64_t nrb = g.Np / FmapCfg::BM;
-    allow_big_lds(featuremap_kernel<T>, FmapCfg::LDS_BYTES);
+    // column ranges per row block: one for large N (>= 3 workgroups per CU and several rounds of them), more for small N
+    int ncs = (int)std::min<int64_t>(njt, std::max<int64_t>(1, (SCFGP_FMAP_MIN_WGS + nrb - 1) / nrb));
+    const auto launch = [&](auto kernel, const double* A, const double* Bm, int Kd) {
+        allow_big_lds(kernel, FmapCfg::LDS_BYTES);
+        hipLaunchKernelGGL(kernel, dim3((unsigned)(ncs * nrb)), dim3(FmapCfg::THREADS), FmapCfg::LDS_BYTES, st,
+                           A, Bm, sc, Phi, Kd, g.Jp, g.Kp, g.J, g.N, njt, ncs, Zout);
+    };
+    const double *A = Xt, *Bm = pr.Fall; int Kd = g.Dp;
     if (g.lowrank) {
         const int Spp = (int)round_up(g.Sp, FmapCfg::BN), njs = Spp / FmapCfg::BN;
         allow_big_lds(project_kernel, FmapCfg::LDS_BYTES);
         hipLaunchKernelGGL(project_kernel, dim3((unsigned)(njs * nrb)), dim3(FmapCfg::THREADS), FmapCfg::LDS_BYTES, st,
                            Xt, pr.Lall, pr.Tt, g.Dp, g.Sp, Spp, njs);
-        hipLaunchKernelGGL(featuremap_kernel<T>, dim3((unsigned)(njt * nrb)), dim3(FmapCfg::THREADS), FmapCfg::LDS_BYTES, st,
-                           pr.Tt, pr.Rall, sc, Phi, g.Sp, g.Jp, g.Kp, g.J, g.N, njt, Zout);
-    } else {
-        hipLaunchKernelGGL(featuremap_kernel<T>, dim3((unsigned)(njt * nrb)), dim3(FmapCfg::THREADS), FmapCfg::LDS_BYTES, st,
-                           Xt, pr.Fall, sc, Phi, g.Dp, g.Jp, g.Kp, g.J, g.N, njt, Zout);
+        A = pr.Tt; Bm = pr.Rall; Kd = g.Sp;
     }
+    if (Zout) { launch(featuremap_kernel<T, true>, A, Bm, Kd); return; }
+    const int live = (g.lowrank ? g.S : g.D) + 1, nk = (live + 3) / 4;     // rows of the contraction that are not padding
+    if (SCFGP_FMAP_REG && nk <= 9) {
+        const int nct = g.Jp / 32;
+        const int rcs = (int)std::min<int64_t>(nct, std::max<int64_t>(1, (SCFGP_FMAP_REG_MIN_WGS + nrb - 1) / nrb));
+        const auto reg = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, dim3((unsigned)(rcs * nrb)), dim3(256), 0, st, A, Kd, Bm, sc, Phi, g.Jp, g.Kp, g.J, g.N, nct, rcs);
+        };
+        // the next instantiated depth that still lies inside the padded leading dimension
+        if (nk <= 3 && Kd >= 12) { reg(featuremap_reg_kernel<T, 3>); return; }
+        if (nk <= 4 && Kd >= 16) { reg(featuremap_reg_kernel<T, 4>); return; }
+        if (nk <= 5 && Kd >= 20) { reg(featuremap_reg_kernel<T, 5>); return; }
+        if (nk <= 8 && Kd >= 32) { reg(featuremap_reg_kernel<T, 8>); return; }
+        if (Kd >= 36) { reg(featuremap_reg_kernel<T, 9>); return; }
+    }
+    launch(featuremap_kernel<T, false>, A, Bm, Kd);
 }
 
 // --------------------------------------------------------------------------

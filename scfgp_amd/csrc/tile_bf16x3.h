@@ -108,7 +108,12 @@ struct Bf3TrLoader {
             const int x = v / VPR, kq = v % VPR;
             const float xs[4] = {r[SET][i][0], r[SET][i][1], r[SET][i][2], r[SET][i][3]};
             bf16x4 h, m, l;
+#ifdef SCFGP_DIAG_BF3_NOSPLIT                                   // timing diagnostic only (wrong numbers): no split arithmetic
+            { const float2 lo = {xs[0], xs[1]}, hi = {xs[2], xs[3]};
+              h = __builtin_bit_cast(bf16x4, lo); m = __builtin_bit_cast(bf16x4, hi); l = h; }
+#else
             bf3_split4(xs, h, m, l);
+#endif
             char* d = planes + bf3_piece(x, kq);
             *reinterpret_cast<bf16x4*>(d) = h;
             *reinterpret_cast<bf16x4*>(d + plane_bytes) = m;

@@ -128,6 +128,10 @@ struct NatLoader {
 #pragma unroll
             for (int e = 0; e < VS; ++e) { sacc[i][e] = 0; stot[i][e] = 0; }
     }
+    __device__ __forceinline__ void advance(int64_t delta) {   // move the source window (segmented main loop)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) ptr[i] += delta;
+    }
     template <int SET = 0>
     __device__ __forceinline__ void load(int) {
 #pragma unroll
@@ -244,6 +248,10 @@ struct TrLoader {
             ptr[i] = b + (int64_t)(v / VPR) * l + (v % VPR) * VS;
             dacc[i] = 0;
         }
+    }
+    __device__ __forceinline__ void advance(int64_t delta) {   // move the source window (segmented main loop)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) ptr[i] += delta;
     }
     template <int SET = 0>
     __device__ __forceinline__ void load(int) {
@@ -423,6 +431,37 @@ __device__ __forceinline__ void acc_zero(typename Cfg::MTr::acc_t (&acc)[Cfg::TM
         for (int tn = 0; tn < Cfg::TN; ++tn)
 #pragma unroll
             for (int r = 0; r < Cfg::MTr::NACC; ++r) acc[tm][tn][r] = 0;
+}
+
+// Segmented main loop: nseg products of nkt k-tiles each run as ONE stream of k-tiles, so the operand fetch of a
+// segment's first k-tile is in flight while the previous segment is multiplied and flushed (short contractions would
+// otherwise be all prologue).  Before the first k-tile of segment s > 0 is fetched the loaders move by (dA, dB)
+// elements; flush(s, acc) consumes the finished accumulators (registers and global memory only: the LDS buffers
+// already belong to the next segment) and the accumulators restart from zero.
+template <class Cfg, class LA, class LB, class F>
+__device__ __forceinline__ void tile_mainloop_segments(LA& la, LB& lb, int nkt, int nseg, int64_t dA, int64_t dB,
+                                                       typename Cfg::MTr::acc_t (&acc)[Cfg::TM][Cfg::TN],
+                                                       typename Cfg::T* smem, F&& flush) {
+    typedef typename Cfg::T T;
+    T* sA = smem;
+    T* sB = smem + 2 * Cfg::SA;
+    la.template load<0>(0); lb.template load<0>(0);
+    la.template store<0>(sA); lb.template store<0>(sB);
+    __syncthreads();
+    const int total = nkt * nseg;
+    int kin = 0, seg = 0;                                       // k-tile inside the segment, segment
+    for (int t = 0; t < total; ++t) {
+        const int cur = t & 1;
+        const bool stage = t + 1 < total, last = kin + 1 == nkt;
+        if (stage) {
+            if (last) { la.advance(dA); lb.advance(dB); }
+            la.template load<0>(t + 1); lb.template load<0>(t + 1);
+        }
+        tile_compute<Cfg>(sA + cur * Cfg::SA, sB + cur * Cfg::SB, acc);
+        if (last) { flush(seg, acc); acc_zero<Cfg>(acc); ++seg; kin = 0; } else ++kin;
+        if (stage) { la.template store<0>(sA + (cur ^ 1) * Cfg::SA); lb.template store<0>(sB + (cur ^ 1) * Cfg::SB); }
+        __syncthreads();
+    }
 }
 
 // coordinates of accumulator element (tm,tn,r) inside the workgroup tile
