@@ -56,7 +56,14 @@ RowSplits gram_row_splits(int jobs_per_split, int64_t Np, bool f32, int nsplit_o
 // [[I_S | r_F^T]; phase offsets], Tt (Np x Sp) scratch for T~
 struct Projection { const double* Fall; const double* Lall; const double* Rall; double* Tt; };
 
-template <typename T> struct SweepKernels {
+// bf16-plane copies of the operands of one apply product (SCFGP_BF16X3 mode)
+struct Bf3Planes {
+    const void* rows = nullptr;       // Phi:  bf3_split_rows
+    const void* matrix16 = nullptr;   // B^T / Abar^T: bf3_presplit16
+};
+
+template <typename T>
+struct SweepKernels {
     // Phi = s*[cos Z, sin Z], Z = X~ . Fall  or, F = l_F r_F^T being rank S (SCFGP.py:83), Z = (X~ . Lall) . Rall
     //                                                            (SCFGP.py:98-102 / :139-142)
     //   Zout (experiment, else NULL): also the phases Z (Np x Jp; fp32: reduced to [-pi, pi]) for gram()'s Zsrc
@@ -71,8 +78,9 @@ template <typename T> struct SweepKernels {
     // mupart[jt][n] = its slice of mu = Phi . alpha (SCFGP.py:111 / :143) from the rows it stages
     //   bf3 (fp32 only): split-precision MFMA tiles (tile_bf16x3.h), compute mode SCFGP_BF16X3; Bm / Abar then point to
     //   the matrix pre-split by bf3_presplit()
+    //   planes (bf3 only): row planes of Phi and 16-deep matrix planes of Bm for the DMA-fed 256-wide tiles (tile_bf16x3_dma.h)
     static void apply_v(const Geom& g, const T* Phi, const T* Bm, T* V, double* vpart, const double* alpha, double* mupart,
-                        hipStream_t st, bool bf3 = false);
+                        hipStream_t st, bool bf3 = false, const Bf3Planes* planes = nullptr);
     // predict: vpart[jt][n] = slices of v_n = || Li phi_n ||^2 (the reference's rowsum((Phi Li^T)^2), SCFGP.py:144) from the
     // triangular product Phi . LiT, LiT[k][j] = Li[j][k] (convert_transposed); mupart as apply_v.  Half the flops of apply_v.
     static void apply_predict(const Geom& g, const T* Phi, const T* LiT, double* vpart, const double* alpha, double* mupart,
@@ -80,7 +88,8 @@ template <typename T> struct SweepKernels {
     // Phibar = 2 Phi.Abar + 2 q V + p alpha^T + y ut^T  (in place over V); bpart[block] = partial of
     // bbar = sum Phibar o Phi.  Returns the number of blocks (= partials written).
     static int apply_phibar(const Geom& g, const T* Phi, const T* Abar, T* V, const double* p, const double* q,
-                            const double* y, const double* alpha, const double* ut, double* bpart, hipStream_t st, bool bf3 = false);
+                            const double* y, const double* alpha, const double* ut, double* bpart, hipStream_t st, bool bf3 = false,
+                            const Bf3Planes* planes = nullptr);
     static int apply_blocks(const Geom& g);
     // per-row moments and adjoint scalars; block partials of (T2, kbar)  (SCFGP.py:111-113,121-124)
     static void rowstats(const Geom& g, const double* mupart, const double* vpart, const double* y,
@@ -102,6 +111,10 @@ int64_t trace_read(void* host, int64_t max_bytes);
 
 // fp32 Kp x Kp sweep operand -> bf16 plane layout of the split-precision apply product (Kp*Kp*6 bytes)
 void bf3_presplit(const float* M, void* out, int Kp, hipStream_t st);
+// the same matrix as 16-deep planes [k16][plane][Kp][16] (Kp*Kp*6 bytes), and a row-major fp32 matrix S (Np x Kp, leading
+// dimension ld) as row planes [k16][plane][Np][16] (Np*Kp*6 bytes): the operands of the DMA-fed tiles
+void bf3_presplit16(const float* M, void* out, int Kp, hipStream_t st);
+void bf3_split_rows(const float* S, int64_t ld, void* out, int64_t Np, int Kp, hipStream_t st);
 
 // ---- reductions ------------------------------------------------------------
 // packed lower tiles = sum over splits of the per-split lower-tile slabs (tile t = ti(ti+1)/2+tj, row-major)

@@ -3,6 +3,7 @@
 #include "kernels.h"
 #include "tile_engine.h"
 #include "tile_bf16x3.h"
+#include "tile_bf16x3_dma.h"
 
 #include <algorithm>
 
@@ -592,41 +593,59 @@ void SweepKernels<T>::xtz(const Geom& g, const double* Xt, const T* Phi, const T
 //          tile jt stops at its last column: half the flops of the symmetric product
 // --------------------------------------------------------------------------
 // epilogues of the apply product: V and the row dots (EPI 0) or Phibar and bbar (EPI 1) from the accumulators
-template <class Cfg, int EPI>
+//   MU (EPI 0 only): also mupart[jtg][n] = sum_{j in tile} Phi[n][j] alpha[j] from the Phi values the row dot reads anyway
+//   (the DMA-fed kernel has no operand values in registers for the loader-side dot)
+template <class Cfg, int EPI, bool MU = false>
 __device__ __forceinline__ void apply_epilogue(
     const typename Cfg::MTr::acc_t (&acc)[Cfg::TM][Cfg::TN], const typename Cfg::T* __restrict__ Phi, typename Cfg::T* V,
     double* __restrict__ vpart, const double* __restrict__ p, const double* __restrict__ q, const double* __restrict__ y,
     const double* __restrict__ alpha, const double* __restrict__ ut, int K, int Kp, int64_t Np, int64_t rb, int cbase, int jtg,
-    double* __restrict__ bpart, char* smem_raw) {
+    double* __restrict__ bpart, char* smem_raw, double* __restrict__ mupart = nullptr) {
     typedef typename Cfg::T T;
     AccCoord<Cfg> co;
     if (EPI == 0 || EPI == 2) {
-        double* red = reinterpret_cast<double*>(smem_raw);          // [WGN][BM]; main loop ended with a barrier
+        double* red = reinterpret_cast<double*>(smem_raw);          // [WGN][BM] (MU: twice); main loop ended with a barrier
+        double* red2 = red + Cfg::WGN * Cfg::BM;
         const int wn = (threadIdx.x >> 6) % Cfg::WGN;
+        double al[Cfg::TN];
+        if (MU) {
+#pragma unroll
+            for (int tn = 0; tn < Cfg::TN; ++tn) al[tn] = cbase + co.col(tn) < K ? alpha[cbase + co.col(tn)] : 0.0;
+        }
 #pragma unroll
         for (int tm = 0; tm < Cfg::TM; ++tm)
 #pragma unroll
             for (int r = 0; r < Cfg::MTr::NACC; ++r) {
                 const int row = co.row(tm, r);
                 const int64_t off = (rb * Cfg::BM + row) * Kp + cbase;
-                double part = 0;
+                double part = 0, mup = 0;
 #pragma unroll
                 for (int tn = 0; tn < Cfg::TN; ++tn) {
                     const T c = acc[tm][tn][r];
                     if (EPI == 2) { part += (double)c * (double)c; continue; }
                     V[off + co.col(tn)] = c;
-                    if (cbase + co.col(tn) < K) part += (double)Phi[off + co.col(tn)] * (double)c;
+                    if (cbase + co.col(tn) < K) {
+                        const double ph = (double)Phi[off + co.col(tn)];
+                        part += ph * (double)c;
+                        if (MU) mup += ph * al[tn];
+                    }
                 }
 #pragma unroll
                 for (int m = 1; m < Cfg::MS; m <<= 1) part += __shfl_xor(part, m);      // lanes of one MFMA row group
                 if ((co.lane % Cfg::MS) == 0) red[wn * Cfg::BM + row] = part;
+                if (MU) {
+#pragma unroll
+                    for (int m = 1; m < Cfg::MS; m <<= 1) mup += __shfl_xor(mup, m);
+                    if ((co.lane % Cfg::MS) == 0) red2[wn * Cfg::BM + row] = mup;
+                }
             }
         __syncthreads();
         if (threadIdx.x < Cfg::BM) {
-            double s = 0;
+            double s = 0, s2 = 0;
 #pragma unroll
-            for (int k = 0; k < Cfg::WGN; ++k) s += red[k * Cfg::BM + threadIdx.x];
+            for (int k = 0; k < Cfg::WGN; ++k) { s += red[k * Cfg::BM + threadIdx.x]; if (MU) s2 += red2[k * Cfg::BM + threadIdx.x]; }
             vpart[(int64_t)jtg * Np + rb * Cfg::BM + threadIdx.x] = s;
+            if (MU && mupart) mupart[(int64_t)jtg * Np + rb * Cfg::BM + threadIdx.x] = s2;
         }
     } else {
         double bb = 0;                                                  // bbar = sum Phibar o Phi  (d cost / d b)
@@ -689,6 +708,10 @@ void apply_kernel(
         acc_zero<Cfg>(acc);
         Bf3TrLoader<Cfg::BM, Cfg::THREADS, EPI != 1> la(Phi + rb * Cfg::BM * Kp, Kp, threadIdx.x, want_mu ? alpha : nullptr, jt0 + jt, ntot);
         if (EPI == 2) la.dot_range(cbase / Cfg::BK, nkt);
+        else if (ntot == 0) {                                   // beside DMA-fed tiles: mu slices are the tiles' own column bands
+            const int hi = (cbase + Cfg::BN) / Cfg::BK;
+            la.dot_range(cbase / Cfg::BK, hi < nkt ? hi : nkt);
+        }
         Bf3CopyLoader<Cfg::BN, Cfg::THREADS> lb(Bm, Kp, cbase, threadIdx.x);
         bf3_mainloop<Cfg>(la, lb, nkt, acc, smem_raw);
         if (EPI != 1 && want_mu) la.dot_reduce(mu + (int64_t)(jt0 + jt) * Np + rb * Cfg::BM);
@@ -703,6 +726,30 @@ void apply_kernel(
         tile_mainloop<Cfg>(la, lb, nkt, acc, smem);
         if (EPI != 1 && want_mu) la.dot_reduce(mu + (int64_t)(jt0 + jt) * Np + rb * Cfg::BM);
         apply_epilogue<Cfg, EPI>(acc, Phi, V, vpart, p, q, y, alpha, ut, K, Kp, Np, rb, cbase, jt0 + jt, bpart, smem_raw);
+    }
+}
+
+// DMA-fed split-precision product (tile_bf16x3_dma.h): column tiles [0, 256 njt) of C = Phi . Bm from the row planes of Phi
+// and the matrix planes of Bm; epilogues as above, a tile reports through slot 2 jt of vpart / mupart (slot 2 jt + 1: zero)
+template <int EPI>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void apply_bf3dma_kernel(const char* __restrict__ Apl, const char* __restrict__ Bpl, const float* __restrict__ Phi, float* V,
+                         double* __restrict__ vpart, const double* __restrict__ p, const double* __restrict__ q,
+                         const double* __restrict__ y, const double* __restrict__ alpha, const double* __restrict__ ut,
+                         int K, int Kp, int64_t Np, int njt, double* __restrict__ bpart, double* __restrict__ mu) {
+    typedef Bf3DCfg Cfg;
+    SMEM_DECL;
+    const unsigned wid = xcd_remap(blockIdx.x, gridDim.x);
+    const int jt = wid % njt;
+    const int64_t rb = wid / njt;
+    const int cbase = jt * Bf3D::BN;
+    typename Cfg::MTr::acc_t acc[Cfg::TM][Cfg::TN];
+    acc_zero<Cfg>(acc);
+    bf3dma_mainloop(Apl + rb * Bf3D::BM * 32, Np * 32, Bpl + (int64_t)cbase * 32, (int64_t)Kp * 32, (K + 15) / 16, acc, smem_raw);
+    apply_epilogue<Cfg, EPI, EPI == 0>(acc, Phi, V, vpart, p, q, y, alpha, ut, K, Kp, Np, rb, cbase, 2 * jt, bpart, smem_raw, mu);
+    if (EPI == 0 && threadIdx.x < Bf3D::BM) {
+        vpart[(int64_t)(2 * jt + 1) * Np + rb * Bf3D::BM + threadIdx.x] = 0.0;
+        if (mu) mu[(int64_t)(2 * jt + 1) * Np + rb * Bf3D::BM + threadIdx.x] = 0.0;
     }
 }
 
@@ -740,14 +787,41 @@ static int apply_launch_cfg(const Geom& g, int njt, int col0, int jt0, int boff,
                        Phi, Bm, V, vpart, p, q, y, alpha, ut, g.K, g.Kp, g.Np, njt, bpart ? bpart + boff : nullptr, col0, jt0, mu, ApplyPlan<T>(g.K).total);
     return (int)(njt * nrb);
 }
+// bf3: Bm is the matrix pre-split for Bf3CopyLoader; with planes (row planes of Phi + the 16-deep matrix planes of Bm) the
+// 256-wide column tiles go through the DMA-fed kernel and only the remainder through the loader-split tiles
 template <typename T, int EPI>
 static int apply_launch(const Geom& g, const T* Phi, const T* Bm, T* V, double* vpart, const double* p, const double* q,
-                        const double* y, const double* alpha, const double* ut, double* bpart, double* mu, hipStream_t st, bool bf3 = false) {
+                        const double* y, const double* alpha, const double* ut, double* bpart, double* mu, hipStream_t st, bool bf3 = false,
+                        const Bf3Planes* planes = nullptr) {
     const ApplyPlan<T> pl(g.K);
     int nb = 0;
     if constexpr (sizeof(T) == 4) {
         if (bf3) {                                             // split-precision tiles (same column plan: 128-wide, then 64)
             static_assert(Tune<T>::APPLY_BN == 128, "bf16x3 apply tiles are 128 and 64 wide");
+            const int n256 = planes && planes->rows && planes->matrix16 && EPI != 2 && g.K > 256 ? g.K / 256 : 0;
+            if (n256 > 0) {
+                const int64_t nrb = g.Np / Bf3D::BM;
+                allow_big_lds(apply_bf3dma_kernel<EPI>, Bf3D::LDS_BYTES);
+                hipLaunchKernelGGL((apply_bf3dma_kernel<EPI>), dim3((unsigned)(n256 * nrb)), dim3(512), Bf3D::LDS_BYTES, st,
+                                   (const char*)planes->rows, (const char*)planes->matrix16, Phi, V, vpart, p, q, y, alpha, ut,
+                                   g.K, g.Kp, g.Np, n256, bpart, mu);
+                nb += (int)(n256 * nrb);
+                // remainder: at most one 128-wide tile, then 64-wide ones; slots continue after the 2 n256 of the wide tiles
+                const int c0 = 256 * n256, n128 = (g.K - c0) / 128, c1 = c0 + 128 * n128, n64 = (g.K - c1 + 63) / 64;
+                const auto rest = [&](auto cfg, int njt, int col0, int jt0) {
+                    typedef typename decltype(cfg)::type Cfg;
+                    if (njt <= 0) return;
+                    const int64_t nr = g.Np / Cfg::BM;
+                    allow_big_lds(apply_kernel<Cfg, EPI>, Cfg::LDS_BYTES);
+                    hipLaunchKernelGGL((apply_kernel<Cfg, EPI>), dim3((unsigned)(njt * nr)), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st,
+                                       Phi, Bm, V, vpart, p, q, y, alpha, ut, g.K, g.Kp, g.Np, njt, bpart ? bpart + nb : nullptr, col0, jt0, mu,
+                                       0);                      // ntot = 0: mu slices are column bands
+                    nb += (int)(njt * nr);
+                };
+                rest(ApplyBf3Cfg<128>{}, n128, c0, 2 * n256);
+                rest(ApplyBf3Cfg<64>{}, n64, c1, 2 * n256 + n128);
+                return nb;
+            }
             nb += apply_launch_cfg<typename ApplyBf3Cfg<128>::type, EPI, T>(g, pl.count[0], pl.col0[0], pl.jt0[0], nb, Phi, Bm, V, vpart, p, q, y, alpha, ut, bpart, mu, st);
             nb += apply_launch_cfg<typename ApplyBf3Cfg<64>::type, EPI, T>(g, pl.count[2], pl.col0[2], pl.jt0[2], nb, Phi, Bm, V, vpart, p, q, y, alpha, ut, bpart, mu, st);
             return nb;
@@ -762,14 +836,21 @@ static int apply_launch(const Geom& g, const T* Phi, const T* Bm, T* V, double* 
 void bf3_presplit(const float* M, void* out, int Kp, hipStream_t st) {
     hipLaunchKernelGGL(bf3_presplit_kernel, dim3(2048), dim3(256), 0, st, M, reinterpret_cast<__bf16*>(out), Kp);
 }
+void bf3_presplit16(const float* M, void* out, int Kp, hipStream_t st) {
+    hipLaunchKernelGGL(bf3_presplit16_kernel, dim3(2048), dim3(256), 0, st, M, reinterpret_cast<__bf16*>(out), Kp);
+}
+void bf3_split_rows(const float* S, int64_t ld, void* out, int64_t Np, int Kp, hipStream_t st) {
+    hipLaunchKernelGGL(bf3_split_rows_kernel, dim3((unsigned)((Kp / 128) * (Np / 64))), dim3(256), 0, st, S, ld,
+                       reinterpret_cast<__bf16*>(out), Np, Kp);
+}
 
 template <typename T>
 void SweepKernels<T>::apply_v(const Geom& g, const T* Phi, const T* Bm, T* V, double* vpart, const double* alpha, double* mu,
-                              hipStream_t st, bool bf3) {
+                              hipStream_t st, bool bf3, const Bf3Planes* planes) {
 #ifdef SCFGP_DIAG_NOMU
     mu = nullptr;                                              // timing diagnostic only: wrong numbers
 #endif
-    apply_launch<T, 0>(g, Phi, Bm, V, vpart, nullptr, nullptr, nullptr, alpha, nullptr, nullptr, mu, st, bf3);
+    apply_launch<T, 0>(g, Phi, Bm, V, vpart, nullptr, nullptr, nullptr, alpha, nullptr, nullptr, mu, st, bf3, planes);
 }
 template <typename T>
 void SweepKernels<T>::apply_predict(const Geom& g, const T* Phi, const T* LiT, double* vpart, const double* alpha, double* mu,
@@ -778,8 +859,9 @@ void SweepKernels<T>::apply_predict(const Geom& g, const T* Phi, const T* LiT, d
 }
 template <typename T>
 int SweepKernels<T>::apply_phibar(const Geom& g, const T* Phi, const T* Abar, T* V, const double* p, const double* q,
-                                  const double* y, const double* alpha, const double* ut, double* bpart, hipStream_t st, bool bf3) {
-    return apply_launch<T, 1>(g, Phi, Abar, V, nullptr, p, q, y, alpha, ut, bpart, nullptr, st, bf3);
+                                  const double* y, const double* alpha, const double* ut, double* bpart, hipStream_t st, bool bf3,
+                                  const Bf3Planes* planes) {
+    return apply_launch<T, 1>(g, Phi, Abar, V, nullptr, p, q, y, alpha, ut, bpart, nullptr, st, bf3, planes);
 }
 // number of column tiles of the apply kernel (vpart leading count)
 template <typename T> static int apply_njt(const Geom& g) { return ApplyPlan<T>(g.K).total; }

@@ -71,6 +71,7 @@ struct scfgp_ctx {
     double *d_x1 = nullptr, *d_x2 = nullptr, *d_x3 = nullptr; int64_t n_x1 = 0, n_x2 = 0, n_x3 = 0; int Dpp = 0;
     double *d_Li = nullptr, *d_B = nullptr, *d_T1 = nullptr, *d_T2 = nullptr, *d_Abar = nullptr;
     void *d_BT = nullptr, *d_AbarT = nullptr, *d_M3 = nullptr;     // d_M3: B / Abar split into bf16 planes (SCFGP_BF16X3)
+    void *d_M16 = nullptr, *d_P3 = nullptr; int64_t p3_cap = 0; int bf3_dma = 0;   // 16-deep planes of B / Abar; row planes of Phi (DMA-fed tiles)
     double *d_vecs = nullptr;            // beta, alpha, u, ut, alpha_pred (Kp each)
     double *d_scalars = nullptr, *d_yy = nullptr; int* d_flag = nullptr;
     double *d_slabs = nullptr; size_t slabs_bytes = 0;
@@ -94,6 +95,11 @@ struct scfgp_ctx {
 
     double* beta() { return d_vecs; }
     double* alpha() { return d_vecs + g.Kp; }
+    Bf3Planes planes() const {                                  // valid after pass 1 of the current working set
+        Bf3Planes pl;
+        if (bf3 && bf3_dma && g.K > 256 && d_P3 && p3_cap >= g.Np) { pl.rows = d_P3; pl.matrix16 = d_M16; }
+        return pl;
+    }
     double* u() { return d_vecs + 2 * g.Kp; }
     double* ut() { return d_vecs + 3 * g.Kp; }
     double* alpha_pred() { return d_vecs + 4 * g.Kp; }
@@ -238,6 +244,7 @@ extern "C" int scfgp_create(scfgp_ctx** out, int D, int S, int M, int dtype, int
     if ((rc = dmalloc(c, &c->d_BT, c->tsize() * K2))) return rc;        // sweep operands: typed, padding zeroed
     if ((rc = dmalloc(c, &c->d_AbarT, c->tsize() * K2))) return rc;
     if (c->bf3 && (rc = dmalloc(c, &c->d_M3, 6 * K2))) return rc;
+    if (c->bf3 && (rc = dmalloc(c, &c->d_M16, 6 * K2))) return rc;
     if ((rc = dmalloc(c, &c->d_vecs, sizeof(double) * 5 * Kp))) return rc;
     if ((rc = dmalloc(c, &c->d_scalars, sizeof(double) * 32))) return rc;
     if ((rc = dmalloc(c, &c->d_yy, sizeof(double) * 8))) return rc;
@@ -263,7 +270,7 @@ extern "C" void scfgp_destroy(scfgp_ctx* c) {
     dfree(c->d_Z); dfree(c->d_Xraw); dfree(c->d_yraw); dfree(c->d_idx); dfree(c->d_xscale); dfree(c->d_yscale);
     dfree(c->d_params); dfree(c->d_F); dfree(c->d_Fall); dfree(c->d_Lall); dfree(c->d_Rall); dfree(c->d_sc); dfree(c->p_Tt);
     dfree(c->d_xp1); dfree(c->d_xp2); dfree(c->d_x1); dfree(c->d_x2); dfree(c->d_x3); dfree(c->d_Li); dfree(c->d_B); dfree(c->d_T1); dfree(c->d_T2);
-    dfree(c->d_Abar); dfree(c->d_BT); dfree(c->d_AbarT); dfree(c->d_M3); dfree(c->d_vecs); dfree(c->d_scalars); dfree(c->d_yy);
+    dfree(c->d_Abar); dfree(c->d_BT); dfree(c->d_AbarT); dfree(c->d_M3); dfree(c->d_M16); dfree(c->d_P3); dfree(c->d_vecs); dfree(c->d_scalars); dfree(c->d_yy);
     dfree(c->d_flag); dfree(c->d_partial); dfree(c->d_work); dfree(c->d_grad);
     dfree(c->p_Xt); dfree(c->p_vpart); dfree(c->p_mupart); dfree(c->p_Phi);
     if (c->gexec) hipGraphExecDestroy(c->gexec);
@@ -342,7 +349,11 @@ template <typename T> struct Impl {
     // sweep operand of the apply products: the typed matrix, or in SCFGP_BF16X3 mode its bf16-plane split (made here)
     static const T* operand(scfgp_ctx* c, const void* typed) {
         if constexpr (sizeof(T) == 4) {
-            if (c->bf3) { bf3_presplit((const float*)typed, c->d_M3, c->g.Kp, c->st); return (const T*)c->d_M3; }
+            if (c->bf3) {
+                bf3_presplit((const float*)typed, c->d_M3, c->g.Kp, c->st);
+                if (c->planes().rows) bf3_presplit16((const float*)typed, c->d_M16, c->g.Kp, c->st);
+                return (const T*)c->d_M3;
+            }
         }
         return (const T*)typed;
     }
@@ -373,6 +384,17 @@ template <typename T> struct Impl {
         }
         { ProfScope ps(c, "featuremap"); SK::featuremap(g, c->d_Xt, Projection{c->d_Fall, c->d_Lall, c->d_Rall, c->d_Tt}, c->d_sc, (T*)c->d_Phi, c->st,
                                                         fuse ? (T*)c->d_Z : nullptr); }
+        if constexpr (sizeof(T) == 4) {
+            if (c->bf3 && c->bf3_dma && g.K > 256) {           // row planes of Phi for the DMA-fed apply tiles
+                if (c->p3_cap < g.Np) {
+                    dfree(c->d_P3); c->p3_cap = 0;
+                    if (int rc = dmalloc(c, &c->d_P3, (size_t)6 * g.Np * g.Kp)) return rc;
+                    c->p3_cap = g.Np;
+                }
+                ProfScope ps(c, "split_rows");
+                bf3_split_rows((const float*)c->d_Phi, g.Kp, c->d_P3, g.Np, g.Kp, c->st);
+            }
+        }
         gram_to(c, (const T*)c->d_Phi, nullptr, c->d_y, c->d_xp1, fuse ? "gram_fused" : "gram", fuse ? (const T*)c->d_Z : nullptr);
         HIPCHK(c, hipMemcpyAsync(c->d_xp1 + c->n_pk + g.Kp, c->d_yy, sizeof(double), hipMemcpyDeviceToDevice, c->st));
         HIPCHK(c, hipGetLastError());
@@ -387,7 +409,8 @@ template <typename T> struct Impl {
     }
     static int pass2(scfgp_ctx* c, int want_grad) {
         const Geom& g = c->g;
-        { ProfScope ps(c, "apply_v"); SK::apply_v(g, (const T*)c->d_Phi, BT(c), (T*)c->d_V, c->d_vpart, c->alpha(), c->d_mu, c->st, c->bf3); }
+        { ProfScope ps(c, "apply_v"); const Bf3Planes pl = c->planes();
+          SK::apply_v(g, (const T*)c->d_Phi, BT(c), (T*)c->d_V, c->d_vpart, c->alpha(), c->d_mu, c->st, c->bf3, &pl); }
         const int nb = (int)std::min<int64_t>(g.Np / 4, 2048);
         { ProfScope ps(c, "rowstats");
           SK::rowstats(g, c->d_mu, c->d_vpart, c->d_y, c->d_sc, c->d_p, c->d_q, c->d_partial, nb, c->st);
@@ -407,9 +430,9 @@ template <typename T> struct Impl {
     }
     static int pass3(scfgp_ctx* c) {
         const Geom& g = c->g;
-        { ProfScope ps(c, "apply_phibar");
+        { ProfScope ps(c, "apply_phibar"); const Bf3Planes pl = c->planes();
           const int nb = SK::apply_phibar(g, (const T*)c->d_Phi, AbarT(c), (T*)c->d_V, c->d_p, c->d_q, c->d_y, c->alpha(), c->ut(),
-                                          c->d_bpart, c->st, c->bf3);
+                                          c->d_bpart, c->st, c->bf3, &pl);
           reduce_scalars(c->d_bpart, nb, 1, c->d_x3 + (int64_t)c->Dpp * g.Jp, 0, c->st); }
         const int ntm = c->Dpp / XT, ntn = g.Jp / XT;
         const int xs = c->xtz_nsplit > 0 ? (int)std::min<int64_t>(c->xtz_nsplit, g.Np / 64) : xtz_split(ntm * ntn, g.Np);
@@ -911,6 +934,7 @@ extern "C" int scfgp_set_option(scfgp_ctx* c, const char* name, int64_t value) {
     if (s == "gram_nsplit") c->gram_nsplit = (int)value;
     else if (s == "gram_taper") c->gram_taper = (int)value;
     else if (s == "fuse_fmap") c->fuse_fmap = (int)value;
+    else if (s == "bf3_dma") c->bf3_dma = (int)value;
     else if (s == "gram_chunk") c->gram_chunk = value;
     else if (s == "xtz_nsplit") c->xtz_nsplit = (int)value;
     else if (s == "use_graph") c->use_graph = (int)value;

@@ -275,6 +275,34 @@ def test_fused_feature_map_gram_experiment_matches(dtype, tol):
     eng.close()
 
 
+@pytest.mark.parametrize('K_case', [(700, 24, 20, 300), (1500, 40, 16, 560), (3000, 12, 8, 184)])
+def test_bf16x3_dma_fed_tiles_match_loader_split_tiles(K_case):
+    """Option bf3_dma (tile_bf16x3_dma.h, experiment): the 256-wide column tiles of the two apply products run from
+    pre-split bf16 planes through LDS-DMA, the remainder through the loader-split tiles; cost, gradient, alpha and the
+    per-row moments equal the default bf16x3 path (the six-term order differs, so fp32 rounding only) and the oracle
+    at the mode's usual bounds.  K = 640 (two wide tiles + one 128), 1152 (four + one 128), 384 (one + one 128)."""
+    from scfgp_amd.engine import HipEngine
+    from scfgp_amd import synth
+    N, D, S, M = K_case
+    seed = 0x5CF63000 + N
+    X = synth.make_X(seed, N, D)
+    y = synth.normal(seed + 9, 0, N).reshape(-1, 1)
+    params = synth.make_params(seed + 0x0202, D, S, M, abc=(-1.0, 0.0, -1.0))
+    c0, g0, a0, _ = O.value_and_grad(X, y, params, S, M)
+    out = {}
+    for dma in (0, 1):
+        eng = HipEngine(D, S, M, dtype='bf16x3'); eng.set_params(params); eng.set_option('bf3_dma', dma); eng.set_data(X, y)
+        eng.set_profiling(True)
+        cost, grad, alpha, Li = eng.eval(want_grad=True)
+        assert ('split_rows' in dict(eng.timings())) == bool(dma)
+        out[dma] = (float(cost), grad.copy(), alpha.copy(), eng.debug_read('p', (N,)).copy(), eng.debug_read('q', (N,)).copy())
+        eng.close()
+    assert abs(out[1][0] - out[0][0]) < 1e-7 * abs(out[0][0])
+    for k in (1, 2, 3, 4):
+        assert rel(out[1][k], out[0][k]) < 2e-5, (k, rel(out[1][k], out[0][k]))
+    assert abs(out[1][0] - c0) < 2e-5 * abs(c0) and rel(out[1][1], g0) < 3e-3 and rel(out[1][2], a0) < 1e-3
+
+
 def _random_shapes(n, seed):
     rng = np.random.default_rng(seed)
     out = []
