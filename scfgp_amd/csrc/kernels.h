@@ -108,6 +108,7 @@ struct SweepKernels {
 
 // diagnostic builds only (-DSCFGP_TRACE): per-workgroup [start, end, xcc, kind] of the last Gram launch; -1 otherwise
 int64_t trace_read(void* host, int64_t max_bytes);
+int64_t chol_trace_read(void* host, int64_t max_bytes);     // per Cholesky step: 12 phase stamps of workgroup 0
 
 // fp32 Kp x Kp sweep operand -> bf16 plane layout of the split-precision apply product (Kp*Kp*6 bytes)
 void bf3_presplit(const float* M, void* out, int Kp, hipStream_t st);

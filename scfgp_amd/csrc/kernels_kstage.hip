@@ -123,15 +123,19 @@ __device__ __forceinline__ v4d mfma_tile(const double* pa, int lda, const double
 }
 // Y (64 x 64, as 16 x 16 MFMA tiles: wave w owns tile row w, registers acc[b] = tile (w, b)) = X . W^T with W lower
 // triangular, both in LDS with pitch LD: Y[i][j] = sum_{k <= j} X[i][k] W[j][k]
+// (k-steps outermost: the X fragment is read once per step and the four column tiles are independent MFMA chains, so
+// the LDS latency of a step hides under the other tiles' MFMAs; tile-by-tile it was exposed 64 times)
 template <int LD>
 __device__ __forceinline__ void block_xwt(const double* sX, const double* sW, v4d (&acc)[4]) {
-    const int wave = threadIdx.x >> 6;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, q = lane >> 4;
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        acc[b] = v4d{0, 0, 0, 0};
-        const int lane = threadIdx.x & 63, i = lane & 15, q = lane >> 4;
-        for (int s = 0; s < 4 * (b + 1); ++s)                         // W[j][k] = 0 for k > j
-            acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(sX[(16 * wave + i) * LD + 4 * s + q], sW[(16 * b + i) * LD + 4 * s + q], acc[b], 0, 0, 0);
+    for (int b = 0; b < 4; ++b) acc[b] = v4d{0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const double x = sX[(16 * wave + i) * LD + 4 * s + q];
+#pragma unroll
+        for (int b = s / 4; b < 4; ++b)                               // W[j][k] = 0 for k > j: tile b needs k < 16 (b + 1)
+            acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(x, sW[(16 * b + i) * LD + 4 * s + q], acc[b], 0, 0, 0);
     }
 }
 // tiles (w, b) of a 64 x 64 block between the MFMA register layout and memory with pitch `pitch`
@@ -155,14 +159,29 @@ template <int LD>
 __device__ __forceinline__ void block_sub_pqt(const double* sP, const double* sQ, v4d (&acc)[4]) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, q = lane >> 4;
 #pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll 4
-        for (int s = 0; s < 16; ++s)
-            acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-sP[(16 * wave + i) * LD + 4 * s + q], sQ[(16 * b + i) * LD + 4 * s + q], acc[b], 0, 0, 0);
+    for (int s = 0; s < 16; ++s) {
+        const double x = -sP[(16 * wave + i) * LD + 4 * s + q];
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+            acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(x, sQ[(16 * b + i) * LD + 4 * s + q], acc[b], 0, 0, 0);
+    }
 }
 __device__ __forceinline__ void block_to_lds(const double* src, int64_t pitch, double* dst, int LD) {
     for (int e = threadIdx.x; e < 64 * 64; e += 256) dst[(e / 64) * LD + e % 64] = src[(int64_t)(e / 64) * pitch + e % 64];
 }
+
+// Diagnostic build (-DSCFGP_TRACE): workgroup 0 of every Cholesky step stamps its phases (s_memrealtime, 100 MHz)
+#ifdef SCFGP_TRACE
+__device__ unsigned long long g_ctrace[64][16];
+#define CSTAMP(k) do { if (threadIdx.x == 0 && p < 64) g_ctrace[p][k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+int64_t chol_trace_read(void* host, int64_t max_bytes) {
+    const int64_t n = max_bytes < (int64_t)sizeof(g_ctrace) ? max_bytes : (int64_t)sizeof(g_ctrace);
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ctrace), n) == hipSuccess ? n : -2;
+}
+#else
+#define CSTAMP(k)
+int64_t chol_trace_read(void*, int64_t) { return -1; }
+#endif
 
 // One launch per 64-column step p of the blocked Cholesky (nb = Kp / 64 steps, ONE dependent launch each):
 //   workgroup 0      the diagonal block of step p.  It brings the block up to date itself -- D = A[p][p] - L_p L_p^T with
@@ -215,18 +234,41 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* A, double* Lm, d
         return;
     }
     // ---- diagonal block of step p
+    CSTAMP(0);
     double* a = A + ((int64_t)p * ld + p) * NB;
     if (p > 0) {
-        block_to_lds(A + ((int64_t)p * ld + (p - 1)) * NB, ld, sI, LD);
-        block_to_lds(Li + ((int64_t)(p - 1) * ld + (p - 1)) * NB, ld, sL, LD);
+        // all three blocks are fetched at once (the launch starts cold: every dependent fetch is ~2.5 us on this chain):
+        // A[p][p-1] and Inv(p-1) as 16-byte vectors on their way to LDS, A[p][p] straight into the accumulator layout
+        const double* gx = A + ((int64_t)p * ld + (p - 1)) * NB;
+        const double* gw = Li + ((int64_t)(p - 1) * ld + (p - 1)) * NB;
+        v2d rx[8], rw[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = (tid + i * 256) * 2;
+            rx[i] = *reinterpret_cast<const v2d*>(gx + (int64_t)(e / NB) * ld + e % NB);
+            rw[i] = *reinterpret_cast<const v2d*>(gw + (int64_t)(e / NB) * ld + e % NB);
+        }
+        v4d accd[4];
+        block_load(a, ld, accd);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = (tid + i * 256) * 2, o = (e / NB) * LD + e % NB;
+            sI[o] = rx[i][0]; sI[o + 1] = rx[i][1];
+            sL[o] = rw[i][0]; sL[o + 1] = rw[i][1];
+        }
         __syncthreads();
+        CSTAMP(12);
         block_xwt<LD>(sI, sL, acc);                                    // L_p = A[p][p-1] Inv(p-1)^T
         __syncthreads();
         block_store(sI, LD, acc);
         __syncthreads();
-        block_load(a, ld, acc);
+        CSTAMP(13);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[b] = accd[b];
+        CSTAMP(14);
         block_sub_pqt<LD>(sI, sI, acc);                                // D = A[p][p] - L_p L_p^T
         __syncthreads();
+        CSTAMP(15);
         block_store(sL, LD, acc);
         for (int e = tid; e < NB * NB; e += 256) sI[(e / NB) * LD + e % NB] = 0.0;
     } else {
@@ -238,6 +280,7 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* A, double* Lm, d
     double* lm = Lm + ((int64_t)p * ld + p) * NB;
     double* li = Li + ((int64_t)p * ld + p) * NB;
     bool bad = false;
+    CSTAMP(1);
     for (int pb = 0; pb < NB; pb += PB) {
         const int pend = pb + PB;
         __syncthreads();
@@ -265,6 +308,7 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* A, double* Lm, d
                 if (row < NB) sL[row * LD + pb + c] = v[c];
         }
         __syncthreads();
+        CSTAMP(2 + pb / PB * 2);
         // rank-16 update of everything right of the panel, 16 x 16 tiles (ti >= tj) dealt to the waves:
         //   L[r0+i][c0+j] -= sum_c L[r0+i][pb+c] L[c0+j][pb+c]
         const int nt = (NB - pend) / PB;
@@ -279,6 +323,7 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* A, double* Lm, d
 #pragma unroll
             for (int r = 0; r < 4; ++r) sL[(r0 + cq + 4 * r) * LD + c0 + ci] = acc[r];
         }
+        CSTAMP(3 + pb / PB * 2);
     }
     if (bad && tid == 0) *flag = 1;                                    // not positive definite (or NaN)
     __syncthreads();
@@ -296,6 +341,7 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* A, double* Lm, d
         }
     }
     __syncthreads();
+    CSTAMP(10);
     // ---- doubling levels h = 16, 32: for each pair of diagonal blocks T = L21 X11, X21 = -X22 T (sI is zero above
     //      its diagonal blocks' diagonals, so the triangular factors multiply as full tiles)
     for (int h = PB; h < NB; h *= 2) {
@@ -324,6 +370,7 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* A, double* Lm, d
         lm[(int64_t)i * ld + k] = k <= i ? sL[i * LD + k] : 0.0;
         li[(int64_t)i * ld + k] = sI[i * LD + k];
     }
+    CSTAMP(11);
 }
 
 // ---------------------------------------------------------------------------

@@ -947,6 +947,7 @@ extern "C" int64_t scfgp_debug_read(scfgp_ctx* c, const char* name, void* host, 
     if (!c || !name || !host) return SCFGP_EARG;
     const Geom& g = c->g;
     const std::string s(name);
+    if (s == "chol_trace") { if (hipStreamSynchronize(c->st) != hipSuccess) return SCFGP_EHIP; return chol_trace_read(host, max_bytes); }
     if (s == "trace") { if (hipStreamSynchronize(c->st) != hipSuccess) return SCFGP_EHIP; return trace_read(host, max_bytes); }
     const int64_t K2 = (int64_t)g.Kp * g.Kp;
     const size_t ts = c->tsize();
