@@ -6,7 +6,10 @@
 #include "kernels.h"
 #include "tile_engine.h"
 
-typedef TileCfg<double, 64, 64, 16, 2, 2> KCfg;
+#ifndef SCFGP_KSTAGE_BK
+#define SCFGP_KSTAGE_BK 16   // measured (profiles/r02_tuning.md): 32 and 64 are slower for the inverse's doubling levels
+#endif
+typedef TileCfg<double, 64, 64, SCFGP_KSTAGE_BK, 2, 2> KCfg;
 #define SMEM_DECL extern __shared__ __attribute__((aligned(16))) char smem_raw[]
 
 struct GemmArgs {
@@ -74,6 +77,7 @@ __global__ __launch_bounds__(KCfg::THREADS) void gemm64_kernel(GemmArgs a) {
 template <bool TRA, bool TRB>
 static void gemm64(const GemmArgs& a, hipStream_t st) {
     if (a.M <= 0 || a.N <= 0) return;
+    allow_big_lds(gemm64_kernel<TRA, TRB>, KCfg::LDS_BYTES);
     hipLaunchKernelGGL((gemm64_kernel<TRA, TRB>), dim3(a.N / KCfg::BN, a.M / KCfg::BM), dim3(KCfg::THREADS), KCfg::LDS_BYTES, st, a);
 }
 
@@ -460,6 +464,8 @@ static void trinv(const KStage& k, hipStream_t st) {
     for (int sz = 64; sz < Kp; sz *= 2) {
         const int npairs = (Kp - sz - 1) / (2 * sz) + 1;
         dim3 grid(sz / 64, sz / 64, npairs);
+        allow_big_lds(trinv_level_kernel<0>, KCfg::LDS_BYTES);
+        allow_big_lds(trinv_level_kernel<1>, KCfg::LDS_BYTES);
         hipLaunchKernelGGL((trinv_level_kernel<0>), grid, dim3(KCfg::THREADS), KCfg::LDS_BYTES, st, k.T2, k.Li, k.T1, (int64_t)Kp, Kp, sz);
         hipLaunchKernelGGL((trinv_level_kernel<1>), grid, dim3(KCfg::THREADS), KCfg::LDS_BYTES, st, k.T2, k.Li, k.T1, (int64_t)Kp, Kp, sz);
     }
