@@ -214,14 +214,39 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* A, double* Lm, d
         while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
         while (ti * (ti + 1) / 2 > t) --ti;
         const int i = p + ti, j = p + (t - ti * (ti + 1) / 2);
-        block_to_lds(Li + ((int64_t)q * ld + q) * NB, ld, sL, LD);     // W = Inv(q)
-        block_to_lds(A + ((int64_t)i * ld + q) * NB, ld, sI, LD);
+        // every block this tile needs is requested before anything is waited for (the launch starts cold)
+        const double* gw = Li + ((int64_t)q * ld + q) * NB;            // W = Inv(q)
+        const double* gi = A + ((int64_t)i * ld + q) * NB;
+        const double* gj = A + ((int64_t)j * ld + q) * NB;
+        double* c = A + ((int64_t)i * ld + j) * NB;
+        const bool own = i == p && j == p;                             // workgroup 0 updates and factors this block itself
+        v2d rw[8], ri[8], rj[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = (tid + u * 256) * 2;
+            const int64_t o = (int64_t)(e / NB) * ld + e % NB;
+            rw[u] = *reinterpret_cast<const v2d*>(gw + o);
+            ri[u] = *reinterpret_cast<const v2d*>(gi + o);
+            if (i != j) rj[u] = *reinterpret_cast<const v2d*>(gj + o);
+        }
+        v4d accc[4];
+        if (!own) block_load(c, ld, accc);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = (tid + u * 256) * 2, o = (e / NB) * LD + e % NB;
+            sL[o] = rw[u][0]; sL[o + 1] = rw[u][1];
+            sI[o] = ri[u][0]; sI[o + 1] = ri[u][1];
+        }
         __syncthreads();
         block_xwt<LD>(sI, sL, acc);                                    // L_i (registers)
         v4d accj[4];
         if (i != j) {
             __syncthreads();
-            block_to_lds(A + ((int64_t)j * ld + q) * NB, ld, sI, LD);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = (tid + u * 256) * 2, o = (e / NB) * LD + e % NB;
+                sI[o] = rj[u][0]; sI[o + 1] = rj[u][1];
+            }
             __syncthreads();
             block_xwt<LD>(sI, sL, accj);                               // L_j
         }
@@ -229,12 +254,10 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* A, double* Lm, d
         block_store(sL, LD, acc);                                      // W is done with: L_i takes its place, L_j stays in sI's
         if (i != j) block_store(sI, LD, accj);
         else block_store(Lm + ((int64_t)i * ld + q) * NB, ld, acc);    // the factor's block (i, q)
-        if (i == p && j == p) return;                                  // workgroup 0 updates and factors this block itself
+        if (own) return;
         __syncthreads();
-        double* c = A + ((int64_t)i * ld + j) * NB;
-        block_load(c, ld, acc);
-        block_sub_pqt<LD>(sL, i != j ? sI : sL, acc);
-        block_store(c, ld, acc);
+        block_sub_pqt<LD>(sL, i != j ? sI : sL, accc);
+        block_store(c, ld, accc);
         return;
     }
     // ---- diagonal block of step p
