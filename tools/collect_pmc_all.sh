@@ -1,4 +1,6 @@
 #!/bin/bash
+# PMC passes (profiles/collect_pmc.sh) for the three workloads profiles/r02_pmc_traffic.json holds; summarise each with
+# python profiles/pmc_summarize.py gpurun_out/pmc_<key> <key> profiles/r02_pmc_traffic.json
 set -e
 cd $GRAFT_REPO_ROOT
 timeout -k 10 400 bash profiles/collect_pmc.sh H_f32 --config H
