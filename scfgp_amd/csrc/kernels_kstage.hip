@@ -9,7 +9,11 @@
 #ifndef SCFGP_KSTAGE_BK
 #define SCFGP_KSTAGE_BK 16   // measured (profiles/r02_tuning.md): 32 and 64 are slower for the inverse's doubling levels
 #endif
-typedef TileCfg<double, 64, 64, SCFGP_KSTAGE_BK, 2, 2> KCfg;
+#ifndef SCFGP_KSTAGE_WGM
+#define SCFGP_KSTAGE_WGM 2
+#define SCFGP_KSTAGE_WGN 2
+#endif
+typedef TileCfg<double, 64, 64, SCFGP_KSTAGE_BK, SCFGP_KSTAGE_WGM, SCFGP_KSTAGE_WGN> KCfg;
 #define SMEM_DECL extern __shared__ __attribute__((aligned(16))) char smem_raw[]
 
 struct GemmArgs {
@@ -35,22 +39,22 @@ __device__ __forceinline__ void gemm64_body(const GemmArgs& a, int tm, int tn, d
     v4d acc[Cfg::TM][Cfg::TN];
     acc_zero<Cfg>(acc);
     if (TRA) {
-        TrLoader<double, double, Cfg::BM, Cfg::BK, Cfg::LDA, Cfg::THREADS> la(a.A + (int64_t)tm * Cfg::BM * a.lda + k0, a.lda, threadIdx.x);
+        TrLoader<double, double, Cfg::BM, Cfg::BK, Cfg::LDA, Cfg::THREADS, false, false, 3> la(a.A + (int64_t)tm * Cfg::BM * a.lda + k0, a.lda, threadIdx.x);
         if (TRB) {
-            TrLoader<double, double, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS> lb(a.B + (int64_t)tn * Cfg::BN * a.ldb + k0, a.ldb, threadIdx.x);
-            tile_mainloop<Cfg>(la, lb, nkt, acc, smem);
+            TrLoader<double, double, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS, false, false, 3> lb(a.B + (int64_t)tn * Cfg::BN * a.ldb + k0, a.ldb, threadIdx.x);
+            tile_mainloop_deep3<Cfg>(la, lb, nkt, acc, smem);
         } else {
-            NatLoader<double, double, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS, false, false> lb(a.B + (int64_t)k0 * a.ldb + tn * Cfg::BN, a.ldb, threadIdx.x);
-            tile_mainloop<Cfg>(la, lb, nkt, acc, smem);
+            NatLoader<double, double, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS, false, false, false, false, 3> lb(a.B + (int64_t)k0 * a.ldb + tn * Cfg::BN, a.ldb, threadIdx.x);
+            tile_mainloop_deep3<Cfg>(la, lb, nkt, acc, smem);
         }
     } else {
-        NatLoader<double, double, Cfg::BM, Cfg::BK, Cfg::LDA, Cfg::THREADS, false, false> la(a.A + (int64_t)k0 * a.lda + tm * Cfg::BM, a.lda, threadIdx.x);
+        NatLoader<double, double, Cfg::BM, Cfg::BK, Cfg::LDA, Cfg::THREADS, false, false, false, false, 3> la(a.A + (int64_t)k0 * a.lda + tm * Cfg::BM, a.lda, threadIdx.x);
         if (TRB) {
-            TrLoader<double, double, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS> lb(a.B + (int64_t)tn * Cfg::BN * a.ldb + k0, a.ldb, threadIdx.x);
-            tile_mainloop<Cfg>(la, lb, nkt, acc, smem);
+            TrLoader<double, double, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS, false, false, 3> lb(a.B + (int64_t)tn * Cfg::BN * a.ldb + k0, a.ldb, threadIdx.x);
+            tile_mainloop_deep3<Cfg>(la, lb, nkt, acc, smem);
         } else {
-            NatLoader<double, double, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS, false, false> lb(a.B + (int64_t)k0 * a.ldb + tn * Cfg::BN, a.ldb, threadIdx.x);
-            tile_mainloop<Cfg>(la, lb, nkt, acc, smem);
+            NatLoader<double, double, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS, false, false, false, false, 3> lb(a.B + (int64_t)k0 * a.ldb + tn * Cfg::BN, a.ldb, threadIdx.x);
+            tile_mainloop_deep3<Cfg>(la, lb, nkt, acc, smem);
         }
     }
     AccCoord<Cfg> co;

@@ -84,7 +84,8 @@ template <> struct Vec16<float> { typedef v4f type; static constexpr int N = 4; 
 //   ZSRC (experiment: feature map fused into the consumer's loader): the source is the phase matrix Z (N x ldz, reduced
 //   to [-pi, pi] in fp32 mode) and the staged value of tile column c is s cos Z[k][c] (c < J), s sin Z[k][c - J]
 //   (J <= c < 2J) or 0; z_source() re-points the loader.  Needs J % VS == 0.
-template <typename S, typename T, int BX, int BK, int LD, int THREADS, bool WEIGHT, bool GUARD, bool SIDE = false, bool ZSRC = false>
+//   NSETS: register sets for fetches more than one k-tile ahead (tile_mainloop_deep3); load<SET> / store<SET> name the set
+template <typename S, typename T, int BX, int BK, int LD, int THREADS, bool WEIGHT, bool GUARD, bool SIDE = false, bool ZSRC = false, int NSETS = 1>
 struct NatLoader {
     typedef typename Vec16<S>::type vec_t;
     static constexpr int VS = Vec16<S>::N;
@@ -93,7 +94,7 @@ struct NatLoader {
     // Loads are issued for consecutive k-tiles (0, 1, 2, ...): each vector keeps a running pointer
     // that advances by BK rows per call, so the loop carries no 64-bit multiplies.
     const S* ptr[NV]; const double* wptr[NV]; int64_t step; int xlim;     // xlim: first invalid x (GUARD)
-    vec_t r[1][NV]; double wr[1][NV];                         // weights stay raw until store(): converting in
+    vec_t r[NSETS][NV]; double wr[NSETS][NV];                 // weights stay raw until store(): converting in
     int tid;                                                  // load() would wait on the fetch before the MFMAs
     // side accumulators: when THREADS is a multiple of VPR every vector of a thread has the same columns -> one set
     static constexpr bool SAMEX = THREADS % VPR == 0;
@@ -225,7 +226,7 @@ struct NatLoader {
 //   a 4-way (fp32) or 8-way (fp64) bank conflict; with it the lanes of a store group spread over all banks.
 //   Fragment reads XOR the same constant (tile_compute): within a 16-lane group it only permutes the group's 16
 //   columns, so reads stay conflict-free.
-template <typename S, typename T, int BX, int BK, int LD, int THREADS, bool DOT = false, bool SWZ = false>
+template <typename S, typename T, int BX, int BK, int LD, int THREADS, bool DOT = false, bool SWZ = false, int NSETS = 1>
 struct TrLoader {
     typedef typename Vec16<S>::type vec_t;
     static constexpr int VS = Vec16<S>::N;
@@ -233,7 +234,7 @@ struct TrLoader {
     static constexpr int NV = (BX * VPR + THREADS - 1) / THREADS;
     static_assert(!DOT || (THREADS % VPR == 0 && (VPR & (VPR - 1)) == 0 && VPR <= 64), "DOT: a row's vectors sit in adjacent lanes");
     const S* ptr[NV]; int tid;
-    vec_t r[1][NV];
+    vec_t r[NSETS][NV];
     const double* dptr = nullptr; double dv[VS]; double dacc[NV]; bool dot_on = false, dot_now = false;
     int dpart = 0, dnparts = 1, dphase = 0;                     // dphase: (index of the k-tile being loaded) % dnparts
     int dlo = 0, dhi = -1, dkt = 0;                             // range mode (dot_range): k-tiles [dlo, dhi) instead of the modulo rule
@@ -420,6 +421,37 @@ __device__ __forceinline__ void tile_mainloop(LA& la, LB& lb, int nkt,
 #if SCFGP_DRY_LOOP != 1 && SCFGP_DRY_LOOP != 3
         __syncthreads();
 #endif
+    }
+}
+
+// Main loop for products that run ONE workgroup per CU (the K x K stage): the operand fetch of k-tile t+3 is issued while
+// tile t is multiplied (three register sets in the loaders, NSETS = 3), so three fetch latencies overlap instead of one;
+// LDS stays double buffered, one barrier per k-tile.
+template <class Cfg, int S, class LA, class LB>
+__device__ __forceinline__ void tile_deep3_step(LA& la, LB& lb, int t, int nkt, typename Cfg::MTr::acc_t (&acc)[Cfg::TM][Cfg::TN],
+                                                typename Cfg::T* sA, typename Cfg::T* sB) {
+    const int cur = t & 1;
+    tile_compute<Cfg>(sA + cur * Cfg::SA, sB + cur * Cfg::SB, acc);
+    if (t + 1 < nkt) { la.template store<(S + 1) % 3>(sA + (cur ^ 1) * Cfg::SA); lb.template store<(S + 1) % 3>(sB + (cur ^ 1) * Cfg::SB); }
+    if (t + 3 < nkt) { la.template load<S>(t + 3); lb.template load<S>(t + 3); }     // set S: tile t's, stored an iteration ago
+    __syncthreads();
+}
+template <class Cfg, class LA, class LB>
+__device__ __forceinline__ void tile_mainloop_deep3(LA& la, LB& lb, int nkt, typename Cfg::MTr::acc_t (&acc)[Cfg::TM][Cfg::TN],
+                                                    typename Cfg::T* smem) {
+    typedef typename Cfg::T T;
+    T* sA = smem;
+    T* sB = smem + 2 * Cfg::SA;
+    if (nkt <= 0) return;
+    la.template load<0>(0); lb.template load<0>(0);
+    if (nkt > 1) { la.template load<1>(1); lb.template load<1>(1); }
+    if (nkt > 2) { la.template load<2>(2); lb.template load<2>(2); }
+    la.template store<0>(sA); lb.template store<0>(sB);
+    __syncthreads();
+    for (int t = 0; t < nkt; t += 3) {
+        tile_deep3_step<Cfg, 0>(la, lb, t, nkt, acc, sA, sB);
+        if (t + 1 < nkt) tile_deep3_step<Cfg, 1>(la, lb, t + 1, nkt, acc, sA, sB);
+        if (t + 2 < nkt) tile_deep3_step<Cfg, 2>(la, lb, t + 2, nkt, acc, sA, sB);
     }
 }
 
