@@ -105,6 +105,10 @@ template <int BM, int BN, int WGM, int WGN> struct IsBf3<Bf3Cfg<BM, BN, WGM, WGN
 #endif
 typedef TileCfg<double, 128, 64, 16, SCFGP_FMAP_WGM, 2, 16, true> FmapCfg;    // swizzled X~ image (TrLoader)
 template <typename T> struct XtzCfg { typedef TileCfg<T, 128, 128, 16, 4, 2, Tune<T>::MS> type; };
+// row tiles of X~^T Zbar that hold at most 96 / 64 live rows of X~^T (D + 1 = 65 at the headline shape): same 128-wide
+// slabs, fewer MFMA rows
+template <typename T> struct Xtz96Cfg { typedef TileCfg<T, 96, 128, 16, 2, 4, Tune<T>::MS> type; };
+template <typename T> struct Xtz64Cfg { typedef TileCfg<T, 64, 128, 16, 2, 4, Tune<T>::MS> type; };
 
 // --------------------------------------------------------------------------
 // feature map:  Z = X~ . Fall  (fp64 MFMA, K-dim = Dp),  Phi = s [cos Z | sin Z]
@@ -479,19 +483,22 @@ void gram_kernel(
     TRACE_END(kind);
 }
 
+// Row tile ti0 + (t / ntn) of the output (tiles are 128 rows apart whatever Cfg::BM is: a narrower Cfg multiplies only the
+// first BM rows of its tile and zeroes the rest of the 128 x 128 slab)
 template <class Cfg, typename S>
 __global__ __launch_bounds__(Cfg::THREADS) void xtz_kernel(
     const double* __restrict__ Xt, int Dp, const S* __restrict__ Phi, const S* __restrict__ Pb, int64_t ld, int J, int64_t Np,
-    int64_t rows_per_split, int64_t chunk, int ntn, int ntile, double* __restrict__ slabs) {
+    int64_t rows_per_split, int64_t chunk, int ntn, int ntile, int ntile_all, int ti0, double* __restrict__ slabs) {
     typedef typename Cfg::T T;
+    static_assert(Cfg::BN == 128 && Cfg::BM <= 128, "slabs are 128 x 128");
     SMEM_DECL;
     T* smem = reinterpret_cast<T*>(smem_raw);
     const unsigned wid = xcd_remap(blockIdx.x, gridDim.x);
     const int t = (int)(wid % ntile), split = (int)(wid / ntile);
-    const int ti = t / ntn, tj = t % ntn;
+    const int ti = ti0 + t / ntn, tj = t % ntn;
     const int64_t r0 = (int64_t)split * rows_per_split;
     const int64_t r1 = r0 + rows_per_split < Np ? r0 + rows_per_split : Np;
-    double* slab = slabs + ((int64_t)split * ntile + t) * (Cfg::BM * Cfg::BN);
+    double* slab = slabs + ((int64_t)split * ntile_all + ti * ntn + tj) * (128 * 128);
     typename Cfg::MTr::acc_t acc[Cfg::TM][Cfg::TN];
     bool first = true;
     for (int64_t c0 = r0; c0 < r1 || first; c0 += chunk) {
@@ -499,13 +506,15 @@ __global__ __launch_bounds__(Cfg::THREADS) void xtz_kernel(
         acc_zero<Cfg>(acc);
         if (c0 < r1) {
             NatLoader<double, T, Cfg::BM, Cfg::BK, Cfg::LDA, Cfg::THREADS, false, true> la(
-                Xt + c0 * Dp + (int64_t)ti * Cfg::BM, Dp, threadIdx.x, nullptr, Dp - ti * Cfg::BM);
+                Xt + c0 * Dp + (int64_t)ti * 128, Dp, threadIdx.x, nullptr, Dp - ti * 128);
             ZbarLoader<S, T, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS> lb(Phi + c0 * ld, Pb + c0 * ld, ld, J, tj * Cfg::BN, threadIdx.x);
             tile_mainloop<Cfg>(la, lb, (int)((c1 - c0) / Cfg::BK), acc, smem);
         }
         slab_flush<Cfg>(acc, slab, first);
         first = false;
     }
+    if (Cfg::BM < 128)
+        for (int e = threadIdx.x; e < (128 - Cfg::BM) * 128; e += Cfg::THREADS) slab[Cfg::BM * 128 + e] = 0.0;
 }
 
 template <typename T>
@@ -574,14 +583,25 @@ void SweepKernels<T>::gram(const Geom& g, const T* Phi, const double* w, const d
 template <typename T>
 void SweepKernels<T>::xtz(const Geom& g, const double* Xt, const T* Phi, const T* Phibar, int nsplit, int64_t chunk, double* slabs,
                           hipStream_t st) {
-    typedef typename XtzCfg<T>::type Cfg;
-    const int ntm = (g.Dp + Cfg::BM - 1) / Cfg::BM, ntn = g.Jp / Cfg::BN;
+    const int ntm = (g.Dp + 127) / 128, ntn = g.Jp / 128;
     const int64_t rps = round_up((g.Np + nsplit - 1) / nsplit, 64);
     if (chunk <= 0 || chunk > rps) chunk = rps;
-    chunk = round_up(chunk, Cfg::BK);
-    allow_big_lds(xtz_kernel<Cfg, T>, Cfg::LDS_BYTES);
-    hipLaunchKernelGGL((xtz_kernel<Cfg, T>), dim3(ntm * ntn * nsplit), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st,
-                       Xt, g.Dp, Phi, Phibar, (int64_t)g.Kp, g.J, g.Np, rps, chunk, ntn, ntm * ntn, slabs);
+    chunk = round_up(chunk, 16);
+    const auto launch = [&](auto cfg, int ti0, int nti) {
+        typedef typename decltype(cfg)::type Cfg;
+        if (nti <= 0) return;
+        allow_big_lds(xtz_kernel<Cfg, T>, Cfg::LDS_BYTES);
+        hipLaunchKernelGGL((xtz_kernel<Cfg, T>), dim3(nti * ntn * nsplit), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st,
+                           Xt, g.Dp, Phi, Phibar, (int64_t)g.Kp, g.J, g.Np, rps, chunk, ntn, nti * ntn, ntm * ntn, ti0, slabs);
+    };
+    // the last row tile holds Dp - 128 (ntm - 1) live rows: a 64- or 96-row tile when that is enough
+    const int last = g.Dp - 128 * (ntm - 1);
+    const int nfull = last > 96 ? ntm : ntm - 1;
+    launch(XtzCfg<T>{}, 0, nfull);
+    if (nfull < ntm) {
+        if (last <= 64) launch(Xtz64Cfg<T>{}, nfull, 1);
+        else launch(Xtz96Cfg<T>{}, nfull, 1);
+    }
 }
 
 // --------------------------------------------------------------------------
