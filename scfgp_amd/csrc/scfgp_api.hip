@@ -86,7 +86,7 @@ struct scfgp_ctx {
     hipGraph_t graph = nullptr; hipGraphExec_t gexec = nullptr; int64_t graph_N = -1; bool in_train = false, warm = false;
     int use_graph = 1;
     // options
-    int gram_nsplit = 0, gram_taper = 1, xtz_nsplit = 0; int64_t gram_chunk = 4096;
+    int gram_nsplit = 0, gram_taper = 1, xtz_nsplit = 0; int64_t gram_chunk = 16384;
     int fuse_fmap = 0; void* d_Z = nullptr; int64_t z_cap = 0;         // experiment: Gram of pass 1 fed from the phases
     RowSplits splits{};
     // profiling
