@@ -28,26 +28,26 @@ struct Geom {
 struct RowSplits {
     int nsplit;          // all splits
     int groups;          // 8 (one run of splits per XCD group) or 1
-    int units;           // equal-size units per group; taper: the last unit is 4 splits
-    int taper;
+    int units;           // equal-size units per group; taper: the last unit is cut into taper + 1 splits
+    int taper;           // 0, or t: the last unit of every group is cut into 1/2, 1/4, .., 1/2^t, 1/2^t
     int gran;            // row granule of the split boundaries: 256, or 64 for problems too small to fill the chip otherwise
     int64_t nrb;         // granules: Np / gran
-    __host__ __device__ int per_group() const { return taper ? units + 3 : units; }
+    __host__ __device__ int per_group() const { return units + taper; }
     // rows [r0, r1) of split s (multiples of gran; may be empty)
     __host__ __device__ void range(int s, int64_t& r0, int64_t& r1) const {
         const int pg = per_group(), grp = s / pg, i = s % pg;
         const int64_t g0 = nrb * grp / groups, g1 = nrb * (grp + 1) / groups, len = g1 - g0;
-        int64_t e0, e1;                                             // position in eighths of a unit
-        if (!taper) { e0 = 8 * (int64_t)i; e1 = e0 + 8; }
+        const int64_t den = (int64_t)1 << taper;                    // position in 2^-taper of a unit
+        const int k = i - (units - 1);                              // 0..taper inside the last unit
+        int64_t e0, e1;
+        if (taper == 0 || k < 0) { e0 = den * i; e1 = e0 + den; }
         else {
-            const int k = i - (units - 1);                          // 0..3 inside the last unit
-            const int64_t base = 8 * (int64_t)(units - 1);
-            const int cut[5] = {0, 4, 6, 7, 8};
-            if (k < 0) { e0 = 8 * (int64_t)i; e1 = e0 + 8; }
-            else { e0 = base + cut[k]; e1 = base + cut[k + 1]; }
+            const int64_t base = den * (units - 1);
+            e0 = base + den - (den >> k);                           // 0, 1/2, 3/4, ...
+            e1 = k == taper ? base + den : base + den - (den >> (k + 1));
         }
-        r0 = (g0 + len * e0 / (8 * (int64_t)units)) * gran;
-        r1 = (g0 + len * e1 / (8 * (int64_t)units)) * gran;
+        r0 = (g0 + len * e0 / (den * units)) * gran;
+        r1 = (g0 + len * e1 / (den * units)) * gran;
     }
 };
 RowSplits gram_row_splits(int jobs_per_split, int64_t Np, bool f32, int nsplit_override, int taper);

@@ -539,7 +539,8 @@ RowSplits gram_row_splits(int jobs, int64_t Np, bool f32, int nsplit_override, i
     RowSplits rs;
     rs.gran = gran; rs.nrb = Np / gran;
     // the taper pays once a group has at least 5 units; below that its extra slabs cost more in the reduction than the tail
-    if (s >= 16) { rs.groups = 8; rs.units = (int)((s + 4) / 8); rs.taper = taper && rs.units >= 5 ? 1 : 0; }
+    // option value 1 (default): 1/2, 1/4, 1/8, 1/8; values t >= 2: t + 2 halvings
+    if (s >= 16) { rs.groups = 8; rs.units = (int)((s + 4) / 8); rs.taper = taper && rs.units >= 5 ? (taper == 1 ? 3 : taper + 2) : 0; }
     else { rs.groups = 1; rs.units = (int)s; rs.taper = 0; }
     rs.nsplit = rs.groups * rs.per_group();
     return rs;

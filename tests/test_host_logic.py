@@ -180,6 +180,6 @@ def test_gram_row_splits_tile_the_rows(D, S, M):
     for N in (1, 257, 506, 3000, 100000, 125000, 1000000, 4000000):
         for dtype in (0, 1):
             for nsplit in (0, 1, 7, 16, 23, 48, 100, 1000):
-                for taper in (0, 1):
+                for taper in (0, 1, 2, 3):
                     assert lib.scfgp_selftest_row_splits(D, S, M, N, dtype, nsplit, taper) == 0, (N, dtype, nsplit, taper)
     assert lib.scfgp_selftest_row_splits(0, 1, 1, 5, 0, 0, 0) == -1
