@@ -94,3 +94,38 @@ def test_stages_match_oracle(name, dtype, tol):
     assert rel(grad, g_o) < ctol
     assert rel(alpha, al_o) < ctol and rel(Li_h, Li_o) < ctol
     eng.close()
+
+
+# (D, S, M) -> live rows of the phase contraction (S + 1 through the rank-S form when that is narrower, else D + 1) -> kernel
+FMAP_SHAPES = [
+    (8, 20, 40, '9 live rows: register kernel, 3 k-steps'),
+    (13, 40, 27, '14: register kernel, 4 k-steps; odd J (scalar stores of the sine half)'),
+    (40, 17, 130, '18 (rank-S form): register kernel, 5 k-steps; odd J'),
+    (60, 30, 70, '31 (rank-S form): register kernel, 8 k-steps'),
+    (64, 32, 96, '33 (rank-S form): register kernel, 9 k-steps (the headline depth)'),
+    (90, 60, 33, '61 (rank-S form): LDS kernel, segmented k-tile stream; odd J'),
+    (70, 80, 50, '71 live rows of X~ itself: LDS kernel, five k-tiles'),
+]
+
+
+@pytest.mark.parametrize('D,S,M,what', FMAP_SHAPES)
+@pytest.mark.parametrize('dtype,tol', [('f64', 1e-12), ('f32', 1e-6)])
+def test_feature_map_kernel_variants(D, S, M, what, dtype, tol):
+    """Every dispatch of the feature map (register kernel at each instantiated depth, LDS kernel, rank-S and direct
+    projection, even and odd J, N not a multiple of the 128-row block) against the oracle's Phi; padding stays zero."""
+    from scfgp_amd.engine import HipEngine
+    from scfgp_amd import synth
+    N = 1000 + D                                               # never a multiple of 128
+    seed = 0x5CF64000 + 131 * D + S
+    X = synth.make_X(seed, N, D)
+    y = synth.normal(seed + 9, 0, N).reshape(-1, 1)
+    params = synth.make_params(seed + 0x0202, D, S, M, abc=(-1.0, 0.0, -1.0))
+    J = S + M; K = 2 * J
+    eng = HipEngine(D, S, M, dtype=dtype); eng.set_params(params); eng.set_data(X, y)
+    eng.pass1()
+    d = eng.dims(); Kp, Np = d['Kp'], d['Np']
+    Phi = eng.debug_read('Phi', (Np, Kp), np.float64 if dtype == 'f64' else np.float32).astype(np.float64)
+    Phi0 = O.feature_map(X, params, D, S, M)
+    assert rel(Phi[:N, :K], Phi0) < tol, (what, rel(Phi[:N, :K], Phi0))
+    assert np.all(Phi[N:] == 0) and np.all(Phi[:, K:] == 0)
+    eng.close()
