@@ -303,6 +303,31 @@ def test_bf16x3_dma_fed_tiles_match_loader_split_tiles(K_case):
     assert abs(out[1][0] - c0) < 2e-5 * abs(c0) and rel(out[1][1], g0) < 3e-3 and rel(out[1][2], a0) < 1e-3
 
 
+@pytest.mark.parametrize('dtype,tol', [('f64', 1e-10), ('f32', 3e-6), ('bf16x3', 3e-6)])
+@pytest.mark.parametrize('D,S,M,T', [(12, 9, 291, 5000), (30, 20, 44, 777), (20, 16, 1040, 40000)])
+def test_predict_triangular_product_against_the_oracle(D, S, M, T, dtype, tol):
+    """scfgp_predict forms sigma* from the triangular product Phi* Li^T (contraction of a column tile cut at its last
+    column) and mu* from the tiles' own column bands: K = 600 (four 128-wide tiles, then 64-wide ones), 128 (one launch of
+    64-wide tiles) and 2112 (the headline plan; two upload chunks) against the oracle on the same alpha / Li, T never a
+    multiple of the row block."""
+    from scfgp_amd.engine import HipEngine
+    from scfgp_amd import synth
+    seed = 0x5CF65000 + M
+    K = 2 * (S + M)
+    Xs = synth.make_X(seed, T, D)
+    params = synth.make_params(seed + 0x0202, D, S, M, abc=(-1.0, 0.0, -1.0))
+    rng = np.random.default_rng(seed)
+    alpha = rng.standard_normal(K) / np.sqrt(K)
+    Li = np.tril(rng.standard_normal((K, K))) / np.sqrt(K)
+    eng = HipEngine(D, S, M, dtype=dtype); eng.set_params(params)
+    mu, sd = eng.predict(Xs, alpha, Li)
+    sel = np.r_[0:300, T // 2:T // 2 + 300, T - 300:T] if T > 2000 else np.arange(T)
+    mu0, sd0 = O.predict(Xs[sel], alpha, Li, params, S, M)
+    assert mu.shape == (T, 1) and sd.shape == (T,)
+    assert rel(mu[sel], mu0) < tol and rel(sd[sel], sd0) < tol, (rel(mu[sel], mu0), rel(sd[sel], sd0))
+    eng.close()
+
+
 def _random_shapes(n, seed):
     rng = np.random.default_rng(seed)
     out = []
