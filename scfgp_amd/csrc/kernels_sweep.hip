@@ -146,11 +146,7 @@ __global__ __launch_bounds__(FmapCfg::THREADS) void featuremap_kernel(
 #pragma unroll
                     for (int r = 0; r < Cfg::MTr::NACC; ++r) {
                         T sn, cs_;                                         // fp64 or fp32 kernels by output type
-#ifdef SCFGP_DIAG_FMAP_NOSINCOS                                 // timing diagnostics only (wrong numbers)
-                        sn = (T)a[tm][tn][r]; cs_ = sn + (T)1;
-#else
                         fast_sincos(a[tm][tn][r], sn, cs_);
-#endif
                         // scale s = s_hi + s_lo in T: a rounded scale alone would bias every entry of Phi the same way
                         vc[tm][tn][r] = fma(cs_, s_hi, cs_ * s_lo);
                         vs[tm][tn][r] = fma(sn, s_hi, sn * s_lo);
@@ -164,15 +160,10 @@ __global__ __launch_bounds__(FmapCfg::THREADS) void featuremap_kernel(
 #pragma unroll
                     for (int tn = 0; tn < Cfg::TN; ++tn) {
                         const int j = (jt0 + seg) * Cfg::BN + co.col(tn);
-#ifdef SCFGP_DIAG_FMAP_NOSTORE
-                        asm volatile("" :: "v"(vs[tm][tn][r]), "v"(vc[tm][tn][r]));
-                        if (n == -1) Phi[j] = vs[tm][tn][r] + vc[tm][tn][r];
-#else
                         if (j < J) {
                             prow[j] = n < N ? vc[tm][tn][r] : (T)0;
                             prow[J + j] = n < N ? vs[tm][tn][r] : (T)0;
                         }
-#endif
                         if constexpr (ZOUT) {                                         // experiment: the phase itself, for ZSRC loaders
                             const double z = a[tm][tn][r];
                             if (j < J) Zout[n * Jp + j] = sizeof(T) == 4 ? (T)fma(-rint(z * 1.5915494309189535e-01), 6.283185307179586e+00, z) : (T)z;
