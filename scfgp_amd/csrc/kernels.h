@@ -128,8 +128,8 @@ void reduce_full_tiles(const double* slabs, int nsplit, int ntm, int ntn, double
 void reduce_side(const double* sidepart, int nsplit, int Kp, int ncov, double* vec, hipStream_t st);
 // out[i] = sum_s partial[s][i], i < n
 void reduce_rows(const double* partial, int nsplit, int64_t n, double* out, hipStream_t st);
-// scalars[slot0 + k] = sum_b partial[b*width + k], k < width
-void reduce_scalars(const double* partial, int nblocks, int width, double* scalars, int slot0, hipStream_t st);
+// scalars[slot0 + k] = sum_b partial[b*width + k], k < width (the partials are scratch: a large single-scalar sum is staged in place)
+void reduce_scalars(double* partial, int nblocks, int width, double* scalars, int slot0, hipStream_t st);
 // scalars[slot] = sum y^2
 void sum_squares(const double* y, int64_t n, double* scalars, int slot, double* scratch, hipStream_t st);
 

@@ -1034,7 +1034,8 @@ __global__ __launch_bounds__(256) void reduce_full_kernel(const double* __restri
     }
 }
 void reduce_full_tiles(const double* slabs, int nsplit, int ntm, int ntn, double* out, int64_t ldo, hipStream_t st) {
-    hipLaunchKernelGGL(reduce_full_kernel, dim3(ntm * ntn, 16), dim3(256), 0, st, slabs, nsplit, ntm * ntn, ntn, out, ldo);
+    // few tiles, many splits: 64 workgroups per tile keep the 150 MB of slabs streaming (16: 210 us at the headline shape)
+    hipLaunchKernelGGL(reduce_full_kernel, dim3(ntm * ntn, 64), dim3(256), 0, st, slabs, nsplit, ntm * ntn, ntn, out, ldo);
 }
 
 __global__ void reduce_rows_kernel(const double* __restrict__ partial, int nsplit, int64_t n, double* __restrict__ out) {
@@ -1065,7 +1066,40 @@ __global__ __launch_bounds__(256) void reduce_scalars_kernel(const double* __res
         __syncthreads();
     }
 }
-void reduce_scalars(const double* partial, int nblocks, int width, double* scalars, int slot0, hipStream_t st) {
+// many partials of one scalar (one per workgroup of the apply product: 6.6e4 at the headline shape, 108 us for the single
+// workgroup above): 128 workgroups first sum a contiguous chunk each, in a fixed order, into the chunk's first slot
+__global__ __launch_bounds__(256) void reduce_chunks_kernel(double* __restrict__ partial, int n, int chunk) {
+    __shared__ double red[256];
+    const int64_t b0 = (int64_t)blockIdx.x * chunk;
+    const int len = b0 + chunk <= n ? chunk : (int)(n - b0);
+    double s = 0;
+    for (int b = threadIdx.x; b < len; b += 256) s += partial[b0 + b];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int m = 128; m >= 1; m >>= 1) {
+        if (threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && len > 0) partial[b0] = red[0];
+}
+__global__ __launch_bounds__(128) void reduce_strided_kernel(const double* __restrict__ partial, int nchunks, int chunk,
+                                                             double* __restrict__ scalars, int slot0) {
+    __shared__ double red[128];
+    red[threadIdx.x] = (int)threadIdx.x < nchunks ? partial[(int64_t)threadIdx.x * chunk] : 0.0;
+    __syncthreads();
+    for (int m = 64; m >= 1; m >>= 1) {
+        if ((int)threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) scalars[slot0] = red[0];
+}
+void reduce_scalars(double* partial, int nblocks, int width, double* scalars, int slot0, hipStream_t st) {
+    if (width == 1 && nblocks > 8192) {                        // the partials are scratch: the first stage works in place
+        const int chunk = (nblocks + 127) / 128, nchunks = (nblocks + chunk - 1) / chunk;
+        hipLaunchKernelGGL(reduce_chunks_kernel, dim3(nchunks), dim3(256), 0, st, partial, nblocks, chunk);
+        hipLaunchKernelGGL(reduce_strided_kernel, dim3(1), dim3(128), 0, st, partial, nchunks, chunk, scalars, slot0);
+        return;
+    }
     hipLaunchKernelGGL(reduce_scalars_kernel, dim3(1), dim3(256), 0, st, partial, nblocks, width, scalars, slot0);
 }
 
