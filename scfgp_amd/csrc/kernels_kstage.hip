@@ -312,10 +312,23 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* A, double* Lm, d
     double* li = Li + ((int64_t)p * ld + p) * NB;
     bool bad = false;
     CSTAMP(1);
+    // rank-16 update of one 16 x 16 tile with the panel at column pp:  L[r0+i][c0+j] -= sum_c L[r0+i][pp+c] L[c0+j][pp+c]
+    const auto tile_update = [&](int r0, int c0, int pp) {
+        v4d acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = sL[(r0 + cq + 4 * r) * LD + c0 + ci];
+        acc = mfma_tile<4>(sL + r0 * LD + pp, LD, sL + c0 * LD + pp, 1, LD, acc, -1.0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sL[(r0 + cq + 4 * r) * LD + c0 + ci] = acc[r];
+    };
+    // Look-ahead: the update with panel pb-16 is split.  Wave 0 applies it to the NEXT panel's columns only and factors
+    // them at once; waves 1..3 apply it to the columns right of that meanwhile.  One barrier per panel.
     for (int pb = 0; pb < NB; pb += PB) {
-        const int pend = pb + PB;
         __syncthreads();
+        const int nt = (NB - pb) / PB;                                 // 16-row tiles from row pb down
         if (wave == 0) {
+            if (pb > 0)
+                for (int ti = 0; ti < nt; ++ti) tile_update(pb + PB * ti, pb, pb - PB);
             const int row = pb + lane;                                 // lanes past the last row idle along
             double v[PB];
 #pragma unroll
@@ -337,24 +350,15 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* A, double* Lm, d
 #pragma unroll
             for (int c = 0; c < PB; ++c)
                 if (row < NB) sL[row * LD + pb + c] = v[c];
+            CSTAMP(2 + pb / PB * 2);
+            CSTAMP(3 + pb / PB * 2);
+        } else if (pb > 0) {
+            // tiles (ti >= tj >= 1) of the region that starts at row / column pb
+            int t = 0;
+            for (int tj = 1; tj < nt; ++tj)
+                for (int ti = tj; ti < nt; ++ti, ++t)
+                    if (t % 3 == wave - 1) tile_update(pb + PB * ti, pb + PB * tj, pb - PB);
         }
-        __syncthreads();
-        CSTAMP(2 + pb / PB * 2);
-        // rank-16 update of everything right of the panel, 16 x 16 tiles (ti >= tj) dealt to the waves:
-        //   L[r0+i][c0+j] -= sum_c L[r0+i][pb+c] L[c0+j][pb+c]
-        const int nt = (NB - pend) / PB;
-        for (int t = wave; t < nt * (nt + 1) / 2; t += 4) {
-            int ti = 0;
-            while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-            const int tj = t - ti * (ti + 1) / 2, r0 = pend + PB * ti, c0 = pend + PB * tj;
-            v4d acc;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r] = sL[(r0 + cq + 4 * r) * LD + c0 + ci];
-            acc = mfma_tile<4>(sL + r0 * LD + pb, LD, sL + c0 * LD + pb, 1, LD, acc, -1.0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sL[(r0 + cq + 4 * r) * LD + c0 + ci] = acc[r];
-        }
-        CSTAMP(3 + pb / PB * 2);
     }
     if (bad && tid == 0) *flag = 1;                                    // not positive definite (or NaN)
     __syncthreads();
