@@ -58,10 +58,16 @@ int64_t trace_read(void*, int64_t) { return -1; }
 #ifndef SCFGP_APPLY_BN_F32
 #define SCFGP_APPLY_BN_F32 128
 #endif
+#ifndef SCFGP_APPLY_BM_F32          // experiment knobs of the fp32 apply tile (profiles/r02_tuning.md)
+#define SCFGP_APPLY_BM_F32 256
+#define SCFGP_APPLY_WGM_F32 4
+#define SCFGP_APPLY_WGN_F32 2
+#define SCFGP_APPLY_WAVES_F32 8       // upper bound of waves per SIMD the kernel is compiled for
+#endif
 template <typename T> struct Tune;
 template <> struct Tune<float>  {
-    static constexpr int MS = SCFGP_F32_MS, GRAM_WGM = 4, GRAM_WGN = 2, GRAM_BK = SCFGP_GRAM_BK_F32, APPLY_BM = 256, APPLY_BN = SCFGP_APPLY_BN_F32, APPLY_WGM = 4;
-    static constexpr int apply_wgn(int bn) { return bn >= 256 ? 4 : 2; }
+    static constexpr int MS = SCFGP_F32_MS, GRAM_WGM = 4, GRAM_WGN = 2, GRAM_BK = SCFGP_GRAM_BK_F32, APPLY_BM = SCFGP_APPLY_BM_F32, APPLY_BN = SCFGP_APPLY_BN_F32, APPLY_WGM = SCFGP_APPLY_WGM_F32;
+    static constexpr int apply_wgn(int bn) { return bn >= 256 ? 4 : (bn >= 128 ? SCFGP_APPLY_WGN_F32 : 2); }
 };
 template <> struct Tune<double> {
     static constexpr int MS = 16, GRAM_WGM = 4, GRAM_WGN = 2, GRAM_BK = SCFGP_BK, APPLY_BM = 256, APPLY_BN = 128, APPLY_WGM = 4;
@@ -693,7 +699,8 @@ __device__ __forceinline__ void apply_epilogue(
 #endif
 template <class Cfg, int EPI>
 __global__ __launch_bounds__(Cfg::THREADS)
-__attribute__((amdgpu_waves_per_eu(IsBf3<Cfg>::value ? SCFGP_BF3_WAVES : 1, IsBf3<Cfg>::value ? SCFGP_BF3_WAVES : 8)))
+__attribute__((amdgpu_waves_per_eu(IsBf3<Cfg>::value ? SCFGP_BF3_WAVES : (sizeof(typename Cfg::T) == 4 && SCFGP_APPLY_WAVES_F32 != 8 ? SCFGP_APPLY_WAVES_F32 : 1),
+                                   IsBf3<Cfg>::value ? SCFGP_BF3_WAVES : (sizeof(typename Cfg::T) == 4 ? SCFGP_APPLY_WAVES_F32 : 8))))
 void apply_kernel(
     const typename Cfg::T* __restrict__ Phi, const typename Cfg::T* __restrict__ Bm, typename Cfg::T* V,
     double* __restrict__ vpart, const double* __restrict__ p, const double* __restrict__ q, const double* __restrict__ y,
