@@ -113,7 +113,7 @@ typedef TileCfg<double, 128, 64, 16, SCFGP_FMAP_WGM, 2, 16, true> FmapCfg;    //
 template <typename T> struct XtzCfg { typedef TileCfg<T, 128, 128, 16, 4, 2, Tune<T>::MS> type; };
 // row tiles of X~^T Zbar that hold at most 96 / 64 live rows of X~^T (D + 1 = 65 at the headline shape): same 128-wide
 // slabs, fewer MFMA rows
-template <typename T> struct Xtz96Cfg { typedef TileCfg<T, 96, 128, 16, 2, 4, Tune<T>::MS> type; };
+template <typename T> struct Xtz96Cfg { typedef TileCfg<T, 96, 128, 16, 2, 4, 16> type; };     // 48-row wave tiles: 16 x 16 MFMA shape only
 template <typename T> struct Xtz64Cfg { typedef TileCfg<T, 64, 128, 16, 2, 4, Tune<T>::MS> type; };
 
 // --------------------------------------------------------------------------
@@ -383,7 +383,7 @@ __device__ __forceinline__ void gram_body(
         if (diag) la.side_flush();
         first = false;
     }
-    if (STRIP) {                                               // lower half of the 128 x 128 slab(s): rows the strip does not have
+    if constexpr (STRIP) {                                     // lower half of the 128 x 128 slab(s): rows the strip does not have
         constexpr int NB = Cfg::BN / 128, REST = (128 - Cfg::BM) * 128;
         for (int e = threadIdx.x; e < NB * REST; e += Cfg::THREADS) slab[(e / REST) * (128 * 128) + Cfg::BM * 128 + e % REST] = 0.0;
     }
