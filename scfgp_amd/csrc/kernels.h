@@ -60,6 +60,7 @@ struct Projection { const double* Fall; const double* Lall; const double* Rall; 
 struct Bf3Planes {
     const void* rows = nullptr;       // Phi:  bf3_split_rows
     const void* matrix16 = nullptr;   // B^T / Abar^T: bf3_presplit16
+    bool dma = false;                 // fp32 mode: 128-wide apply tiles by LDS-DMA (option apply_dma); needs no planes
 };
 
 template <typename T>

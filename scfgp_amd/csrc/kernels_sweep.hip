@@ -741,11 +741,93 @@ void apply_kernel(
         TrLoader<T, T, Cfg::BM, Cfg::BK, Cfg::LDA, Cfg::THREADS, EPI != 1, Cfg::SWZA> la(Phi + rb * Cfg::BM * Kp, Kp, threadIdx.x,
                                                                             want_mu ? alpha : nullptr, jt0 + jt, ntot);
         if (EPI == 2) la.dot_range(cbase / Cfg::BK, nkt);
+        else if (ntot == 0) {                                   // beside DMA-fed tiles: mu slices are the tiles' own column bands
+            const int hi = (cbase + Cfg::BN) / Cfg::BK;
+            la.dot_range(cbase / Cfg::BK, hi < nkt ? hi : nkt);
+        }
         NatLoader<T, T, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS, false, false> lb(Bm + cbase, Kp, threadIdx.x);
         tile_mainloop<Cfg>(la, lb, nkt, acc, smem);
         if (EPI != 1 && want_mu) la.dot_reduce(mu + (int64_t)(jt0 + jt) * Np + rb * Cfg::BM);
         apply_epilogue<Cfg, EPI>(acc, Phi, V, vpart, p, q, y, alpha, ut, K, Kp, Np, rb, cbase, jt0 + jt, bpart, smem_raw);
     }
+}
+
+// fp32 apply product with LDS-DMA staging (option apply_dma): both operands go global -> LDS by global_load_lds_dwordx4
+// into a ring of three 24 KB stages (16 k of the 256 x 128 tile), counted vmcnt, one raw barrier per stage: no staging
+// registers, no ds_write, and the fetch of stage s+2 is in flight while stage s is multiplied.  Bm must be SYMMETRIC
+// (B and Abar are): row j of it supplies the k-contiguous column j.
+//   LDS image of an operand: row x at x * 64 B = its 16 k as four 16-byte chunks, chunk c stored at position
+//   c ^ ((x >> 2) & 3) (source-side swizzle, the DMA writes linearly): the 16 lanes of an MFMA row group read 64 banks.
+//   Lane group q of the 16x16x4 shape takes chunk q -- k = 4q .. 4q+3 -- and feeds component e to k-step e: both
+//   operands use the same permutation of the 16 k, so the sum is unchanged and a fragment is ONE ds_read_b128 per stage.
+struct ApplyDma {
+    static constexpr int BM = 256, BN = 128, STAGE = (BM + BN) * 64, STAGES = 3, LDS_BYTES = STAGES * STAGE, DMA_PER_WAVE = STAGE / 1024 / 8;
+};
+template <int EPI>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void apply_dma_kernel(const float* __restrict__ Phi, const float* __restrict__ Bm, float* V,
+                      double* __restrict__ vpart, const double* __restrict__ p, const double* __restrict__ q,
+                      const double* __restrict__ y, const double* __restrict__ alpha, const double* __restrict__ ut,
+                      int K, int Kp, int64_t Np, int njt, double* __restrict__ bpart, double* __restrict__ mu) {
+    typedef typename ApplyCfg<float, 128>::type Cfg;
+    static_assert(Cfg::BM == ApplyDma::BM && Cfg::BN == ApplyDma::BN && Cfg::THREADS == 512 && Cfg::MS == 16, "tile of the epilogue");
+    SMEM_DECL;
+    char* smem = smem_raw;
+    const unsigned wid = xcd_remap(blockIdx.x, gridDim.x);
+    const int jt = wid % njt;
+    const int64_t rb = wid / njt;
+    const int cbase = jt * ApplyDma::BN;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // DMA instruction t = 3 wave + u of a stage: rows 16 t .. 16 t + 15 of the stacked (A: 256, then B: 128) operand rows;
+    // lane l carries row + l / 4, position l % 4 <- chunk (l % 4) ^ ((row >> 2) & 3)
+    const char* src[ApplyDma::DMA_PER_WAVE]; int dst[ApplyDma::DMA_PER_WAVE];
+#pragma unroll
+    for (int u = 0; u < ApplyDma::DMA_PER_WAVE; ++u) {
+        const int t = wave * ApplyDma::DMA_PER_WAVE + u, x = 16 * t + (lane >> 2), c = (lane & 3) ^ ((x >> 2) & 3);
+        const float* rowp = x < ApplyDma::BM ? Phi + (rb * ApplyDma::BM + x) * Kp : Bm + (int64_t)(cbase + x - ApplyDma::BM) * Kp;
+        src[u] = reinterpret_cast<const char*>(rowp) + c * 16;
+        dst[u] = t * 1024;
+    }
+    const auto issue = [&](int slot) {
+#pragma unroll
+        for (int u = 0; u < ApplyDma::DMA_PER_WAVE; ++u) {
+            __builtin_amdgcn_global_load_lds((gbl_void*)src[u], (lds_void*)(smem + slot * ApplyDma::STAGE + dst[u]), 16, 0, 0);
+            src[u] += 64;                                       // 16 k further
+        }
+    };
+    const int i = lane & 15, qg = lane >> 4;
+    const int wm0 = (wave / Cfg::WGN) * Cfg::WM, wn0 = (wave % Cfg::WGN) * Cfg::WN;
+    const int sw = (qg ^ ((i >> 2) & 3)) << 4;
+    const int aoff = (wm0 + i) * 64 + sw, boff = ApplyDma::BM * 64 + (wn0 + i) * 64 + sw;
+    typename Cfg::MTr::acc_t acc[Cfg::TM][Cfg::TN];
+    acc_zero<Cfg>(acc);
+    const int nst = (K + 15) / 16;
+    issue(0);
+    if (nst > 1) issue(1);
+    int slot = 0, fill = 2;
+    for (int s = 0; s < nst; ++s) {
+        if (s + 1 < nst) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");      // this wave's share of stage s has landed
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                          // everybody's has; nobody reads the slot of stage s-1 any more
+        asm volatile("" ::: "memory");
+        if (s + 2 < nst) issue(fill);
+        const char* base = smem + slot * ApplyDma::STAGE;
+        v4f a[Cfg::TM], b[Cfg::TN];
+#pragma unroll
+        for (int tm = 0; tm < Cfg::TM; ++tm) a[tm] = *reinterpret_cast<const v4f*>(base + aoff + tm * 1024);
+#pragma unroll
+        for (int tn = 0; tn < Cfg::TN; ++tn) b[tn] = *reinterpret_cast<const v4f*>(base + boff + tn * 1024);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int tm = 0; tm < Cfg::TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < Cfg::TN; ++tn) Cfg::MTr::mfma(acc[tm][tn], a[tm][e], b[tn][e]);
+        slot = slot == 2 ? 0 : slot + 1;
+        fill = fill == 2 ? 0 : fill + 1;
+    }
+    __syncthreads();
+    apply_epilogue<Cfg, EPI, EPI == 0>(acc, Phi, V, vpart, p, q, y, alpha, ut, K, Kp, Np, rb, cbase, jt, bpart, smem_raw, mu);
 }
 
 // DMA-fed split-precision product (tile_bf16x3_dma.h): column tiles [0, 256 njt) of C = Phi . Bm from the row planes of Phi
@@ -843,6 +925,27 @@ static int apply_launch(const Geom& g, const T* Phi, const T* Bm, T* V, double* 
             }
             nb += apply_launch_cfg<typename ApplyBf3Cfg<128>::type, EPI, T>(g, pl.count[0], pl.col0[0], pl.jt0[0], nb, Phi, Bm, V, vpart, p, q, y, alpha, ut, bpart, mu, st);
             nb += apply_launch_cfg<typename ApplyBf3Cfg<64>::type, EPI, T>(g, pl.count[2], pl.col0[2], pl.jt0[2], nb, Phi, Bm, V, vpart, p, q, y, alpha, ut, bpart, mu, st);
+            return nb;
+        }
+    }
+    if constexpr (sizeof(T) == 4 && EPI != 2) {
+        if (planes && planes->dma && pl.count[0] > 0 && Tune<T>::APPLY_BN == 128 && Tune<T>::APPLY_BM == 256) {
+            // the 128-wide tiles by LDS-DMA (Bm symmetric); the 64-wide remainder by the loader-staged kernel, whose mu slices
+            // then are column bands as well (ntot = 0)
+            const int64_t nrb = g.Np / ApplyDma::BM;
+            allow_big_lds(apply_dma_kernel<EPI>, ApplyDma::LDS_BYTES);
+            hipLaunchKernelGGL((apply_dma_kernel<EPI>), dim3((unsigned)(pl.count[0] * nrb)), dim3(512), ApplyDma::LDS_BYTES, st,
+                               Phi, Bm, V, vpart, p, q, y, alpha, ut, g.K, g.Kp, g.Np, pl.count[0], bpart, mu);
+            nb += (int)(pl.count[0] * nrb);
+            typedef typename ApplyCfg<T, 64>::type RCfg;
+            if (pl.count[2] > 0) {
+                const int64_t nr = g.Np / RCfg::BM;
+                allow_big_lds(apply_kernel<RCfg, EPI>, RCfg::LDS_BYTES);
+                hipLaunchKernelGGL((apply_kernel<RCfg, EPI>), dim3((unsigned)(pl.count[2] * nr)), dim3(RCfg::THREADS), RCfg::LDS_BYTES, st,
+                                   Phi, Bm, V, vpart, p, q, y, alpha, ut, g.K, g.Kp, g.Np, pl.count[2], bpart ? bpart + nb : nullptr,
+                                   pl.col0[2], pl.jt0[2], mu, 0);
+                nb += (int)(pl.count[2] * nr);
+            }
             return nb;
         }
     }

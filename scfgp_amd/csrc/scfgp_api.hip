@@ -71,7 +71,7 @@ struct scfgp_ctx {
     double *d_x1 = nullptr, *d_x2 = nullptr, *d_x3 = nullptr; int64_t n_x1 = 0, n_x2 = 0, n_x3 = 0; int Dpp = 0;
     double *d_Li = nullptr, *d_B = nullptr, *d_T1 = nullptr, *d_T2 = nullptr, *d_Abar = nullptr;
     void *d_BT = nullptr, *d_AbarT = nullptr, *d_M3 = nullptr;     // d_M3: B / Abar split into bf16 planes (SCFGP_BF16X3)
-    void *d_M16 = nullptr, *d_P3 = nullptr; int64_t p3_cap = 0; int bf3_dma = 0;   // 16-deep planes of B / Abar; row planes of Phi (DMA-fed tiles)
+    void *d_M16 = nullptr, *d_P3 = nullptr; int64_t p3_cap = 0; int bf3_dma = 0, apply_dma = 0;   // 16-deep planes of B / Abar; row planes of Phi (DMA-fed tiles)
     double *d_vecs = nullptr;            // beta, alpha, u, ut, alpha_pred (Kp each)
     double *d_scalars = nullptr, *d_yy = nullptr; int* d_flag = nullptr;
     double *d_slabs = nullptr; size_t slabs_bytes = 0;
@@ -98,6 +98,7 @@ struct scfgp_ctx {
     Bf3Planes planes() const {                                  // valid after pass 1 of the current working set
         Bf3Planes pl;
         if (bf3 && bf3_dma && g.K > 256 && d_P3 && p3_cap >= g.Np) { pl.rows = d_P3; pl.matrix16 = d_M16; }
+        pl.dma = !bf3 && dtype == SCFGP_F32 && apply_dma != 0;
         return pl;
     }
     double* u() { return d_vecs + 2 * g.Kp; }
@@ -935,6 +936,7 @@ extern "C" int scfgp_set_option(scfgp_ctx* c, const char* name, int64_t value) {
     else if (s == "gram_taper") c->gram_taper = (int)value;
     else if (s == "fuse_fmap") c->fuse_fmap = (int)value;
     else if (s == "bf3_dma") c->bf3_dma = (int)value;
+    else if (s == "apply_dma") c->apply_dma = (int)value;
     else if (s == "gram_chunk") c->gram_chunk = value;
     else if (s == "xtz_nsplit") c->xtz_nsplit = (int)value;
     else if (s == "use_graph") c->use_graph = (int)value;

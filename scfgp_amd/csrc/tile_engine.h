@@ -129,6 +129,10 @@ struct NatLoader {
 #pragma unroll
             for (int e = 0; e < VS; ++e) { sacc[i][e] = 0; stot[i][e] = 0; }
     }
+    __device__ __forceinline__ void keep() const {               // diagnostic builds: the fetched registers stay live
+#pragma unroll
+        for (int i = 0; i < NV; ++i) asm volatile("" :: "v"(r[0][i]));
+    }
     __device__ __forceinline__ void advance(int64_t delta) {   // move the source window (segmented main loop)
 #pragma unroll
         for (int i = 0; i < NV; ++i) ptr[i] += delta;
@@ -250,6 +254,10 @@ struct TrLoader {
             dacc[i] = 0;
         }
     }
+    __device__ __forceinline__ void keep() const {               // diagnostic builds: the fetched registers stay live
+#pragma unroll
+        for (int i = 0; i < NV; ++i) asm volatile("" :: "v"(r[0][i]));
+    }
     __device__ __forceinline__ void advance(int64_t delta) {   // move the source window (segmented main loop)
 #pragma unroll
         for (int i = 0; i < NV; ++i) ptr[i] += delta;
@@ -344,6 +352,10 @@ struct ZbarLoader {
         }
         ++kt;
     }
+    __device__ __forceinline__ void keep() const {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) asm volatile("" :: "v"(raw[i][0]), "v"(raw[i][1]), "v"(raw[i][2]), "v"(raw[i][3]));
+    }
     template <int SET = 0>
     __device__ __forceinline__ void store(T* s) const {
 #pragma unroll
@@ -415,9 +427,18 @@ __device__ __forceinline__ void tile_mainloop(LA& la, LB& lb, int nkt,
 #else                                                //   3: staging kept, no barrier
         const bool stage = kt + 1 < nkt;
 #endif
+#if SCFGP_DRY_LOOP == 4                              //   4: LDS stores kept (of the first tile's registers), no fetches
+        tile_compute<Cfg>(sA + cur * Cfg::SA, sB + cur * Cfg::SB, acc);
+        if (stage) { la.template store<0>(sA + (cur ^ 1) * Cfg::SA); lb.template store<0>(sB + (cur ^ 1) * Cfg::SB); }
+#elif SCFGP_DRY_LOOP == 5                            //   5: fetches kept (and waited for), no LDS stores
+        if (stage) { la.template load<0>(kt + 1); lb.template load<0>(kt + 1); }
+        tile_compute<Cfg>(sA + cur * Cfg::SA, sB + cur * Cfg::SB, acc);
+        if (stage) { la.keep(); lb.keep(); }
+#else
         if (stage) { la.template load<0>(kt + 1); lb.template load<0>(kt + 1); }
         tile_compute<Cfg>(sA + cur * Cfg::SA, sB + cur * Cfg::SB, acc);
         if (stage) { la.template store<0>(sA + (cur ^ 1) * Cfg::SA); lb.template store<0>(sB + (cur ^ 1) * Cfg::SB); }
+#endif
 #if SCFGP_DRY_LOOP != 1 && SCFGP_DRY_LOOP != 3
         __syncthreads();
 #endif

@@ -328,6 +328,31 @@ def test_predict_triangular_product_against_the_oracle(D, S, M, T, dtype, tol):
     eng.close()
 
 
+@pytest.mark.parametrize('N,D,S,M', [(1500, 40, 16, 560), (3000, 12, 8, 184), (700, 24, 20, 300)])
+def test_fp32_apply_tiles_fed_by_lds_dma_match(N, D, S, M):
+    """Option apply_dma (fp32 mode, experiment): the 128-wide tiles of the two apply products take both operands through
+    LDS-DMA into a three-stage ring (no register staging), the 64-wide remainder and the mu slices as column bands;
+    cost, gradient, alpha and the per-row adjoint scalars equal the default path (same products, the 16 k of a stage
+    summed in a permuted order) and the oracle at the mode's usual bounds.  K = 1152 (9 tiles), 384 (3), 640 (5)."""
+    from scfgp_amd.engine import HipEngine
+    from scfgp_amd import synth
+    seed = 0x5CF66000 + N
+    X = synth.make_X(seed, N, D)
+    y = synth.normal(seed + 9, 0, N).reshape(-1, 1)
+    params = synth.make_params(seed + 0x0202, D, S, M, abc=(-1.0, 0.0, -1.0))
+    c0, g0, a0, _ = O.value_and_grad(X, y, params, S, M)
+    out = {}
+    for dma in (0, 1):
+        eng = HipEngine(D, S, M, dtype='f32'); eng.set_params(params); eng.set_option('apply_dma', dma); eng.set_data(X, y)
+        cost, grad, alpha, Li = eng.eval(want_grad=True)
+        out[dma] = (float(cost), grad.copy(), alpha.copy(), eng.debug_read('p', (N,)).copy(), eng.debug_read('q', (N,)).copy())
+        eng.close()
+    assert abs(out[1][0] - out[0][0]) < 1e-7 * abs(out[0][0])
+    for k in (1, 2, 3, 4):
+        assert rel(out[1][k], out[0][k]) < 2e-5, (k, rel(out[1][k], out[0][k]))
+    assert abs(out[1][0] - c0) < 2e-5 * abs(c0) and rel(out[1][1], g0) < 3e-3 and rel(out[1][2], a0) < 1e-3
+
+
 def _random_shapes(n, seed):
     rng = np.random.default_rng(seed)
     out = []
