@@ -180,8 +180,8 @@ int scfgp_get_timings(scfgp_ctx* ctx, double* ms, const char** names, int n);
 int64_t scfgp_debug_read(scfgp_ctx* ctx, const char* name, void* host, int64_t max_bytes);
 /* tuning knobs: "gram_nsplit" (row-split units of the Gram products, 0 = default), "gram_taper" (1: the last unit of every
  * XCD group is cut into 1/2, 1/4, 1/8, 1/8; t >= 2: into t + 3 pieces down to 1/2^(t+2)), "gram_chunk" (fp32 flush interval in rows), "xtz_nsplit", "use_graph", "fuse_fmap" (experiment, profiles/r02_tuning.md: the
- * Gram of pass 1 reads the phases and evaluates cos / sin inside its operand loaders instead of reading Phi), "apply_dma" (experiment, fp32 mode: the 128-wide tiles of the apply products staged by LDS-DMA
- * instead of through registers; measured equal), "bf3_dma"
+ * Gram of pass 1 reads the phases and evaluates cos / sin inside its operand loaders instead of reading Phi), "apply_dma" (experiment, fp32 mode: the full tiles of the apply products staged by LDS-DMA
+ * instead of through registers, 1 = 128 wide, 2 = 256 wide; measured equal), "bf3_dma"
  * (experiment, SCFGP_BF16X3 only: 256-wide apply tiles fed by LDS-DMA from pre-split planes of Phi, 6 bytes per element more) */
 int scfgp_set_option(scfgp_ctx* ctx, const char* name, int64_t value);
 

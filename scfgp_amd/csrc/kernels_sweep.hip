@@ -760,45 +760,50 @@ void apply_kernel(
 //   c ^ ((x >> 2) & 3) (source-side swizzle, the DMA writes linearly): the 16 lanes of an MFMA row group read 64 banks.
 //   Lane group q of the 16x16x4 shape takes chunk q -- k = 4q .. 4q+3 -- and feeds component e to k-step e: both
 //   operands use the same permutation of the 16 k, so the sum is unchanged and a fragment is ONE ds_read_b128 per stage.
+template <int BN_>
 struct ApplyDma {
-    static constexpr int BM = 256, BN = 128, STAGE = (BM + BN) * 64, STAGES = 3, LDS_BYTES = STAGES * STAGE, DMA_PER_WAVE = STAGE / 1024 / 8;
+    static constexpr int BM = 256, BN = BN_, WAVES = 4 * (BN / 64), STAGE = (BM + BN) * 64, STAGES = 3, LDS_BYTES = STAGES * STAGE,
+                         DMA_PER_WAVE = STAGE / 1024 / WAVES;
+    typedef TileCfg<float, BM, BN, 16, 4, BN / 64, 16, true> Cfg;         // wave grid / accumulator map of the epilogue: 64 x 64 wave tiles
+    static_assert(STAGE / 1024 % WAVES == 0, "whole DMA instructions per wave");
 };
-template <int EPI>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4)))
+// BN = 128: 8 waves, two workgroups per CU, 48 operand bytes per MFMA; BN = 256: 16 waves, one workgroup per CU, 32 bytes per MFMA
+template <int EPI, int BN>
+__global__ __launch_bounds__(64 * ApplyDma<BN>::WAVES) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void apply_dma_kernel(const float* __restrict__ Phi, const float* __restrict__ Bm, float* V,
                       double* __restrict__ vpart, const double* __restrict__ p, const double* __restrict__ q,
                       const double* __restrict__ y, const double* __restrict__ alpha, const double* __restrict__ ut,
-                      int K, int Kp, int64_t Np, int njt, double* __restrict__ bpart, double* __restrict__ mu) {
-    typedef typename ApplyCfg<float, 128>::type Cfg;
-    static_assert(Cfg::BM == ApplyDma::BM && Cfg::BN == ApplyDma::BN && Cfg::THREADS == 512 && Cfg::MS == 16, "tile of the epilogue");
+                      int K, int Kp, int64_t Np, int njt, double* __restrict__ bpart, double* __restrict__ mu, int col0, int slot0) {
+    typedef ApplyDma<BN> D;
+    typedef typename D::Cfg Cfg;
     SMEM_DECL;
     char* smem = smem_raw;
     const unsigned wid = xcd_remap(blockIdx.x, gridDim.x);
     const int jt = wid % njt;
     const int64_t rb = wid / njt;
-    const int cbase = jt * ApplyDma::BN;
+    const int cbase = col0 + jt * D::BN;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // DMA instruction t = 3 wave + u of a stage: rows 16 t .. 16 t + 15 of the stacked (A: 256, then B: 128) operand rows;
-    // lane l carries row + l / 4, position l % 4 <- chunk (l % 4) ^ ((row >> 2) & 3)
-    const char* src[ApplyDma::DMA_PER_WAVE]; int dst[ApplyDma::DMA_PER_WAVE];
+    // DMA instruction t = DMA_PER_WAVE wave + u of a stage: rows 16 t .. 16 t + 15 of the stacked (A: 256, then B: BN) operand
+    // rows; lane l carries row + l / 4, position l % 4 <- chunk (l % 4) ^ ((row >> 2) & 3)
+    const char* src[D::DMA_PER_WAVE]; int dst[D::DMA_PER_WAVE];
 #pragma unroll
-    for (int u = 0; u < ApplyDma::DMA_PER_WAVE; ++u) {
-        const int t = wave * ApplyDma::DMA_PER_WAVE + u, x = 16 * t + (lane >> 2), c = (lane & 3) ^ ((x >> 2) & 3);
-        const float* rowp = x < ApplyDma::BM ? Phi + (rb * ApplyDma::BM + x) * Kp : Bm + (int64_t)(cbase + x - ApplyDma::BM) * Kp;
+    for (int u = 0; u < D::DMA_PER_WAVE; ++u) {
+        const int t = wave * D::DMA_PER_WAVE + u, x = 16 * t + (lane >> 2), c = (lane & 3) ^ ((x >> 2) & 3);
+        const float* rowp = x < D::BM ? Phi + (rb * D::BM + x) * Kp : Bm + (int64_t)(cbase + x - D::BM) * Kp;
         src[u] = reinterpret_cast<const char*>(rowp) + c * 16;
         dst[u] = t * 1024;
     }
     const auto issue = [&](int slot) {
 #pragma unroll
-        for (int u = 0; u < ApplyDma::DMA_PER_WAVE; ++u) {
-            __builtin_amdgcn_global_load_lds((gbl_void*)src[u], (lds_void*)(smem + slot * ApplyDma::STAGE + dst[u]), 16, 0, 0);
+        for (int u = 0; u < D::DMA_PER_WAVE; ++u) {
+            __builtin_amdgcn_global_load_lds((gbl_void*)src[u], (lds_void*)(smem + slot * D::STAGE + dst[u]), 16, 0, 0);
             src[u] += 64;                                       // 16 k further
         }
     };
     const int i = lane & 15, qg = lane >> 4;
     const int wm0 = (wave / Cfg::WGN) * Cfg::WM, wn0 = (wave % Cfg::WGN) * Cfg::WN;
     const int sw = (qg ^ ((i >> 2) & 3)) << 4;
-    const int aoff = (wm0 + i) * 64 + sw, boff = ApplyDma::BM * 64 + (wn0 + i) * 64 + sw;
+    const int aoff = (wm0 + i) * 64 + sw, boff = D::BM * 64 + (wn0 + i) * 64 + sw;
     typename Cfg::MTr::acc_t acc[Cfg::TM][Cfg::TN];
     acc_zero<Cfg>(acc);
     const int nst = (K + 15) / 16;
@@ -806,12 +811,13 @@ void apply_dma_kernel(const float* __restrict__ Phi, const float* __restrict__ B
     if (nst > 1) issue(1);
     int slot = 0, fill = 2;
     for (int s = 0; s < nst; ++s) {
-        if (s + 1 < nst) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");      // this wave's share of stage s has landed
+        // this wave's share of stage s has landed when only the DMAs of stage s+1 are outstanding
+        if (s + 1 < nst) { if (D::DMA_PER_WAVE == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                          // everybody's has; nobody reads the slot of stage s-1 any more
         asm volatile("" ::: "memory");
         if (s + 2 < nst) issue(fill);
-        const char* base = smem + slot * ApplyDma::STAGE;
+        const char* base = smem + slot * D::STAGE;
         v4f a[Cfg::TM], b[Cfg::TN];
 #pragma unroll
         for (int tm = 0; tm < Cfg::TM; ++tm) a[tm] = *reinterpret_cast<const v4f*>(base + aoff + tm * 1024);
@@ -827,7 +833,13 @@ void apply_dma_kernel(const float* __restrict__ Phi, const float* __restrict__ B
         fill = fill == 2 ? 0 : fill + 1;
     }
     __syncthreads();
-    apply_epilogue<Cfg, EPI, EPI == 0>(acc, Phi, V, vpart, p, q, y, alpha, ut, K, Kp, Np, rb, cbase, jt, bpart, smem_raw, mu);
+    constexpr int SLOTS = BN / 128;                            // vpart / mupart slots are 128 columns wide
+    const int vslot = slot0 + SLOTS * jt;
+    apply_epilogue<Cfg, EPI, EPI == 0>(acc, Phi, V, vpart, p, q, y, alpha, ut, K, Kp, Np, rb, cbase, vslot, bpart, smem_raw, mu);
+    if (SLOTS == 2 && EPI == 0 && threadIdx.x < D::BM) {
+        vpart[(int64_t)(vslot + 1) * Np + rb * D::BM + threadIdx.x] = 0.0;
+        if (mu) mu[(int64_t)(vslot + 1) * Np + rb * D::BM + threadIdx.x] = 0.0;
+    }
 }
 
 // DMA-fed split-precision product (tile_bf16x3_dma.h): column tiles [0, 256 njt) of C = Phi . Bm from the row planes of Phi
@@ -888,6 +900,18 @@ static int apply_launch_cfg(const Geom& g, int njt, int col0, int jt0, int boff,
                        Phi, Bm, V, vpart, p, q, y, alpha, ut, g.K, g.Kp, g.Np, njt, bpart ? bpart + boff : nullptr, col0, jt0, mu, ApplyPlan<T>(g.K).total);
     return (int)(njt * nrb);
 }
+template <int EPI, int BN>
+static int apply_dma_launch(const Geom& g, int njt, int col0, int slot0, int boff, const float* Phi, const float* Bm, float* V, double* vpart,
+                            const double* p, const double* q, const double* y, const double* alpha, const double* ut,
+                            double* bpart, double* mu, hipStream_t st) {
+    if (njt <= 0) return 0;
+    typedef ApplyDma<BN> D;
+    const int64_t nrb = g.Np / D::BM;
+    allow_big_lds(apply_dma_kernel<EPI, BN>, D::LDS_BYTES);
+    hipLaunchKernelGGL((apply_dma_kernel<EPI, BN>), dim3((unsigned)(njt * nrb)), dim3(64 * D::WAVES), D::LDS_BYTES, st,
+                       Phi, Bm, V, vpart, p, q, y, alpha, ut, g.K, g.Kp, g.Np, njt, bpart ? bpart + boff : nullptr, mu, col0, slot0);
+    return (int)(njt * nrb);
+}
 // bf3: Bm is the matrix pre-split for Bf3CopyLoader; with planes (row planes of Phi + the 16-deep matrix planes of Bm) the
 // 256-wide column tiles go through the DMA-fed kernel and only the remainder through the loader-split tiles
 template <typename T, int EPI>
@@ -930,13 +954,11 @@ static int apply_launch(const Geom& g, const T* Phi, const T* Bm, T* V, double* 
     }
     if constexpr (sizeof(T) == 4 && EPI != 2) {
         if (planes && planes->dma && pl.count[0] > 0 && Tune<T>::APPLY_BN == 128 && Tune<T>::APPLY_BM == 256) {
-            // the 128-wide tiles by LDS-DMA (Bm symmetric); the 64-wide remainder by the loader-staged kernel, whose mu slices
-            // then are column bands as well (ntot = 0)
-            const int64_t nrb = g.Np / ApplyDma::BM;
-            allow_big_lds(apply_dma_kernel<EPI>, ApplyDma::LDS_BYTES);
-            hipLaunchKernelGGL((apply_dma_kernel<EPI>), dim3((unsigned)(pl.count[0] * nrb)), dim3(512), ApplyDma::LDS_BYTES, st,
-                               Phi, Bm, V, vpart, p, q, y, alpha, ut, g.K, g.Kp, g.Np, pl.count[0], bpart, mu);
-            nb += (int)(pl.count[0] * nrb);
+            // the full tiles by LDS-DMA (Bm symmetric): option value 1 = 128 wide, 2 = 256 wide with a 128-wide one for an odd
+            // count; the 64-wide remainder by the loader-staged kernel, whose mu slices then are column bands too (ntot = 0)
+            const int n256 = planes->dma >= 2 ? pl.count[0] / 2 : 0, n128 = pl.count[0] - 2 * n256;
+            nb += apply_dma_launch<EPI, 256>(g, n256, 0, 0, nb, Phi, Bm, V, vpart, p, q, y, alpha, ut, bpart, mu, st);
+            nb += apply_dma_launch<EPI, 128>(g, n128, 256 * n256, 2 * n256, nb, Phi, Bm, V, vpart, p, q, y, alpha, ut, bpart, mu, st);
             typedef typename ApplyCfg<T, 64>::type RCfg;
             if (pl.count[2] > 0) {
                 const int64_t nr = g.Np / RCfg::BM;

@@ -98,7 +98,7 @@ struct scfgp_ctx {
     Bf3Planes planes() const {                                  // valid after pass 1 of the current working set
         Bf3Planes pl;
         if (bf3 && bf3_dma && g.K > 256 && d_P3 && p3_cap >= g.Np) { pl.rows = d_P3; pl.matrix16 = d_M16; }
-        pl.dma = !bf3 && dtype == SCFGP_F32 && apply_dma != 0;
+        pl.dma = !bf3 && dtype == SCFGP_F32 ? apply_dma : 0;
         return pl;
     }
     double* u() { return d_vecs + 2 * g.Kp; }
