@@ -342,7 +342,9 @@ def main(a):
             out["secondary"]["pcie_inclusive"] = {"evals_per_s": 1.0 / float(np.median(ts)), "ms_per_step": float(np.median(ts)) * 1e3,
                                                   "host_bytes_per_call": int(X.nbytes + y.nbytes),
                                                   "note": "scfgp_eval with host X, y on every call (median of 3); resident-data rate is `value`"}
-        if world == 1 and a.config == 'H' and a.dtype == 'f32' and not a.custom and not a.no_secondary:
+        # the fp64 leg and the fp32-vs-fp64 parity block: at the headline shape and at the two other 1e6-row fp32 configs (C3's
+        # D = 8 makes A ill-conditioned: that is where fp32 products cost the most accuracy, and the line says so)
+        if world == 1 and a.config in ('H', 'C3', 'C5') and a.dtype == 'f32' and not a.custom and not a.no_secondary:
             out["secondary"]["f64"], out["parity_at_size"], out["secondary"]["bf16x3"] = f64_leg_and_parity(
                 X, y, params, D, S, M, local, (cost, grad, alpha, Li), eng)
         if not a.no_cpu and world == 1:

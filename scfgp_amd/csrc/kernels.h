@@ -60,7 +60,7 @@ struct Projection { const double* Fall; const double* Lall; const double* Rall; 
 struct Bf3Planes {
     const void* rows = nullptr;       // Phi:  bf3_split_rows
     const void* matrix16 = nullptr;   // B^T / Abar^T: bf3_presplit16
-    int dma = 0;                      // fp32 mode: apply tiles by LDS-DMA (option apply_dma: 1 = 128 wide, 2 = 256 wide); needs no planes
+    int dma = 0;                      // fp32 mode: apply tiles by LDS-DMA (1 = 128 wide, 2 = 256 wide, 3 = 256 for Phi.B and 128 for Phibar); needs no planes
 };
 
 template <typename T>

@@ -956,7 +956,9 @@ static int apply_launch(const Geom& g, const T* Phi, const T* Bm, T* V, double* 
         if (planes && planes->dma && pl.count[0] > 0 && Tune<T>::APPLY_BN == 128 && Tune<T>::APPLY_BM == 256) {
             // the full tiles by LDS-DMA (Bm symmetric): option value 1 = 128 wide, 2 = 256 wide with a 128-wide one for an odd
             // count; the 64-wide remainder by the loader-staged kernel, whose mu slices then are column bands too (ntot = 0)
-            const int n256 = planes->dma >= 2 ? pl.count[0] / 2 : 0, n128 = pl.count[0] - 2 * n256;
+            // 3: 256-wide for V = Phi.B (EPI 0), 128-wide for Phibar (EPI 1: its epilogue wants a second resident workgroup)
+            const bool wide = planes->dma == 2 || (planes->dma == 3 && EPI == 0);
+            const int n256 = wide ? pl.count[0] / 2 : 0, n128 = pl.count[0] - 2 * n256;
             nb += apply_dma_launch<EPI, 256>(g, n256, 0, 0, nb, Phi, Bm, V, vpart, p, q, y, alpha, ut, bpart, mu, st);
             nb += apply_dma_launch<EPI, 128>(g, n128, 256 * n256, 2 * n256, nb, Phi, Bm, V, vpart, p, q, y, alpha, ut, bpart, mu, st);
             typedef typename ApplyCfg<T, 64>::type RCfg;

@@ -71,7 +71,7 @@ struct scfgp_ctx {
     double *d_x1 = nullptr, *d_x2 = nullptr, *d_x3 = nullptr; int64_t n_x1 = 0, n_x2 = 0, n_x3 = 0; int Dpp = 0;
     double *d_Li = nullptr, *d_B = nullptr, *d_T1 = nullptr, *d_T2 = nullptr, *d_Abar = nullptr;
     void *d_BT = nullptr, *d_AbarT = nullptr, *d_M3 = nullptr;     // d_M3: B / Abar split into bf16 planes (SCFGP_BF16X3)
-    void *d_M16 = nullptr, *d_P3 = nullptr; int64_t p3_cap = 0; int bf3_dma = 0, apply_dma = 0;   // 16-deep planes of B / Abar; row planes of Phi (DMA-fed tiles)
+    void *d_M16 = nullptr, *d_P3 = nullptr; int64_t p3_cap = 0; int bf3_dma = 0, apply_dma = -1;   // apply_dma: -1 = by problem size   // 16-deep planes of B / Abar; row planes of Phi (DMA-fed tiles)
     double *d_vecs = nullptr;            // beta, alpha, u, ut, alpha_pred (Kp each)
     double *d_scalars = nullptr, *d_yy = nullptr; int* d_flag = nullptr;
     double *d_slabs = nullptr; size_t slabs_bytes = 0;
@@ -86,7 +86,7 @@ struct scfgp_ctx {
     hipGraph_t graph = nullptr; hipGraphExec_t gexec = nullptr; int64_t graph_N = -1; bool in_train = false, warm = false;
     int use_graph = 1;
     // options
-    int gram_nsplit = 0, gram_taper = 1, xtz_nsplit = 0; int64_t gram_chunk = 16384;
+    int gram_nsplit = 0, gram_taper = 1, xtz_nsplit = 0; int64_t gram_chunk = 4096;
     int fuse_fmap = 0; void* d_Z = nullptr; int64_t z_cap = 0;         // experiment: Gram of pass 1 fed from the phases
     RowSplits splits{};
     // profiling
@@ -98,7 +98,11 @@ struct scfgp_ctx {
     Bf3Planes planes() const {                                  // valid after pass 1 of the current working set
         Bf3Planes pl;
         if (bf3 && bf3_dma && g.K > 256 && d_P3 && p3_cap >= g.Np) { pl.rows = d_P3; pl.matrix16 = d_M16; }
-        pl.dma = !bf3 && dtype == SCFGP_F32 ? apply_dma : 0;
+        // fp32 apply products by LDS-DMA (kernels_sweep.hip: apply_dma_kernel).  Auto: large problems only (profiles/r02_tuning.md:
+        // V = Phi.B as 256-wide tiles, Phibar as 128-wide ones, -1.2 ms per evaluation at the headline shape); the small ones keep the
+        // loader-staged tiles, whose single 64-wide launch per product matters more there
+        const int auto_dma = g.K >= 1024 && g.Np >= 65536 ? 3 : 0;
+        pl.dma = !bf3 && dtype == SCFGP_F32 ? (apply_dma < 0 ? auto_dma : apply_dma) : 0;
         return pl;
     }
     double* u() { return d_vecs + 2 * g.Kp; }

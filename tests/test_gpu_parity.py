@@ -262,9 +262,8 @@ def test_headline_size_fp32_properties():
     e64.set_params(params); e64.set_data(X, y)
     c64, g64, a64, L64 = e64.eval(want_grad=True)
     e64.close()
-    # measured at this size (bench.py `parity_at_size`, round 2, 16384-row flush interval of the Gram accumulators): cost
-    # 3e-11...7e-11, gradient blocks (a,b,c) 6e-11...1e-10, l_F 4.0e-6, r_F 3.3e-6, alpha 7.5e-7, Li 1.2e-7; the bounds are
-    # ten times that at most
+    # measured at this size (bench.py `parity_at_size`, round 2): cost 2e-11...7e-11, gradient blocks (a,b,c) 3e-11...1e-10,
+    # l_F 2.8e-6, r_F 2.3e-6, alpha 4.0e-7, Li 4.5e-8; the bounds are about ten times that
     measured = dict(cost=abs(float(cost) - float(c64)) / abs(float(c64)), alpha=rel(alpha, a64), Li=rel(Li, L64))
     for nm, u, v in zip(('grad_abc', 'grad_lF', 'grad_rF'), grad_blocks(grad, D, S, M), grad_blocks(g64, D, S, M)):
         measured[nm] = rel(u, v)
