@@ -26,6 +26,10 @@ def short(name):
     m2 = re.search(r'>, ([\w, ]+)>\s*(\(|$)', name)
     if m2:
         tail = '_' + m2.group(1).replace(', ', '_')
+    elif not tiles:
+        m3 = re.match(r'[a-z_0-9]+<([\w, ]+)>\(', name)          # plain template arguments: apply_dma_kernel<0, 256>(...)
+        if m3:
+            tail = '_' + m3.group(1).replace(', ', '_')
     return base + ('_' + tag if tag else '') + tail
 
 
@@ -83,7 +87,7 @@ def main():
     res = {'kernels': kernels,
            'correction': 'GB_corrected = (2 x FETCH_SIZE + WRITE_SIZE) KB: gfx950 tallies 128-B read requests at 64 B '
                          '(MI355X_MICROARCH.md, HBM); Infinity-Cache hits are included in both counters; one counter group per pass'}
-    ap = [v for k, v in kernels.items() if k.startswith('apply_kernel') and 'GB_corrected' in v]
+    ap = [v for k, v in kernels.items() if (k.startswith('apply_kernel') or k.startswith('apply_dma_kernel')) and 'GB_corrected' in v]
     if ap:
         # one product = the full-tile launch + the ragged-remainder launch; two products per evaluation (EPI 0 and 1)
         res['apply_kernel_mean_GB_per_launch'] = sum(v['GB_corrected'] * v['launches_per_eval'] for v in ap) / 2.0
