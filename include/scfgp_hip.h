@@ -12,7 +12,8 @@
  * remains user-extensible; the library returns the exact gradient it needs.
  *
  * Conventions
- *   - every function returns 0 or a negative error code; nothing throws across the ABI;
+ *   - every function returns 0 or a negative error code (scfgp_finish may also return SCFGP_REDO = 1); nothing throws
+ *     across the ABI;
  *     scfgp_last_error() gives a message for the last failure on that context
  *   - the caller owns every host buffer; the library owns all device memory
  *   - host matrices are row-major, C-contiguous float64 regardless of compute dtype
@@ -40,6 +41,10 @@ typedef struct scfgp_ctx scfgp_ctx;
                                    the reference raises numpy.linalg.LinAlgError from its
                                    Cholesky op (SCFGP/SCFGP.py:106)                      */
 #define SCFGP_ENONFINITE   -4   /* cost is NaN/Inf                                       */
+#define SCFGP_REDO          1   /* not an error, staged API only (scfgp_finish): the evaluation
+                                   ran at a lower precision level than its own condition estimate
+                                   asks for; the level has been raised -- run the stages again
+                                   (scfgp_eval / scfgp_eval_rows do that themselves)      */
 
 #define SCFGP_F64 0             /* fp64 MFMA everywhere (reference numerics)             */
 #define SCFGP_F32 1             /* N-sized products in exact-fp32 MFMA, fp64 projection,
@@ -168,6 +173,22 @@ int scfgp_opt_init(scfgp_ctx* ctx, int algo, const double* hyper, int nhyper, do
 int scfgp_opt_state(scfgp_ctx* ctx, int set, int which, double* buf);
 int scfgp_train(scfgp_ctx* ctx, int n_iters, double* cost_hist, double* alpha, double* Li);
 
+/* ---- conditioning and precision level (no reference counterpart) -----------------------------------
+ * The reference computes in float64 throughout (SCFGP/SCFGP.py:95-96) and factors A = Phi^T Phi + (e^{2a}+1e-6) I
+ * (SCFGP/SCFGP.py:104-107) whatever its conditioning.  In SCFGP_F32 / SCFGP_BF16X3 mode the Gram products carry a
+ * relative error of ~6e-8, which reaches alpha and Li multiplied by the condition of A (measured: about 3e-7 times the
+ * estimate below).  The K x K stage therefore reports a condition estimate with every evaluation, and by default (option
+ * "gram64" = 2, auto) the library raises the precision of the two Gram products when it is high:
+ *   level 1 (estimate > 10):   pass 1 -- G and Phi^T y by the fp64 kernels from fp64 features; alpha and Li then equal fp64
+ *                               mode's bit for bit, cost / mu* / sigma* to ~1e-8
+ *   level 2 (estimate > 1000): also pass 2 -- V^T diag(q) V and V^T p in fp64 MFMA (gradient blocks to ~1e-4)
+ * "gram64" = 0 never (plain fp32: the caller reads out[3] to know what alpha is worth), 1 / 3 = always level 1 / 2.
+ * out (n >= 4, up to 9 values): [0] condition estimate max_i L_ii^2 * max_j (A^-1)_jj of the last finished evaluation (a lower
+ * bound of cond_2(A)), [1] level it ran at, [2] 1 if G was formed in fp64 from fp64 features, [3] predicted relative error
+ * of alpha / Li for an fp32 Gram at this estimate, [4] / [5] thresholds of levels 1 / 2, [6..8] min L_ii^2, max L_ii^2,
+ * max_j (A^-1)_jj. */
+int scfgp_get_condition(scfgp_ctx* ctx, double* out, int n);
+
 /* ---- introspection ------------------------------------------------------------------------ */
 /* padded sizes the device buffers use: out[0]=K, out[1]=Kp, out[2]=Jp, out[3]=Dp, out[4]=Np, out[5]=P, out[6]=tile */
 int scfgp_get_dims(scfgp_ctx* ctx, int64_t* out, int n);
@@ -182,7 +203,9 @@ int64_t scfgp_debug_read(scfgp_ctx* ctx, const char* name, void* host, int64_t m
  * XCD group is cut into 1/2, 1/4, 1/8, 1/8; t >= 2: into t + 3 pieces down to 1/2^(t+2)), "gram_chunk" (fp32 flush interval in rows), "xtz_nsplit", "use_graph", "fuse_fmap" (experiment, profiles/r02_tuning.md: the
  * Gram of pass 1 reads the phases and evaluates cos / sin inside its operand loaders instead of reading Phi), "apply_dma" (experiment, fp32 mode: the full tiles of the apply products staged by LDS-DMA
  * instead of through registers, 1 = 128 wide, 2 = 256 wide; measured equal), "bf3_dma"
- * (experiment, SCFGP_BF16X3 only: 256-wide apply tiles fed by LDS-DMA from pre-split planes of Phi, 6 bytes per element more) */
+ * (experiment, SCFGP_BF16X3 only: 256-wide apply tiles fed by LDS-DMA from pre-split planes of Phi, 6 bytes per element more),
+ * "gram64" (precision level policy, see scfgp_get_condition), "cond_threshold" / "cond_threshold_w" (its two thresholds),
+ * "roctx" (1: push a roctx range per stage for `rocprofv3 --marker-trace`; off by default, also SCFGP_ROCTX=1) */
 int scfgp_set_option(scfgp_ctx* ctx, const char* name, int64_t value);
 
 /* host-only self-test of the row splits of the Gram products (how the N rows are cut into the splits whose partial

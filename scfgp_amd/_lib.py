@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libscfgp_hip%s.so' % os.environ.get('SCFGP_LIB_VARIANT', ''))
 
 SCFGP_F64, SCFGP_F32, SCFGP_BF16X3 = 0, 1, 2
+SCFGP_REDO = 1                           # scfgp_finish: run the stages again (precision level raised), not an error
 ERRORS = {-1: 'bad argument', -2: 'HIP error', -3: 'not positive definite', -4: 'non-finite cost'}
 
 _c_double_p = C.POINTER(C.c_double)
@@ -47,6 +48,7 @@ SIGNATURES = {
     'scfgp_opt_init': (C.c_int, [C.c_void_p, C.c_int, _c_double_p, C.c_int, C.c_double]),
     'scfgp_opt_state': (C.c_int, [C.c_void_p, C.c_int, C.c_int, _c_double_p]),
     'scfgp_train': (C.c_int, [C.c_void_p, C.c_int, _c_double_p, _c_double_p, _c_double_p]),
+    'scfgp_get_condition': (C.c_int, [C.c_void_p, _c_double_p, C.c_int]),
     'scfgp_get_dims': (C.c_int, [C.c_void_p, _c_i64_p, C.c_int]),
     'scfgp_set_profiling': (C.c_int, [C.c_void_p, C.c_int]),
     'scfgp_get_timings': (C.c_int, [C.c_void_p, _c_double_p, C.POINTER(C.c_char_p), C.c_int]),

@@ -26,7 +26,9 @@ struct Scal {
 
 // slots of the small scalar reduction vector kept on the device
 enum {
-    R_YY = 0, R_LOGDET, R_T2, R_KBAR, R_BBAR, R_TRABAR, R_GTALPHA, R_PEN, R_COST, R_FLAG, R_COUNT
+    R_YY = 0, R_LOGDET, R_T2, R_KBAR, R_BBAR, R_TRABAR, R_GTALPHA, R_PEN, R_COST, R_FLAG,
+    R_LMIN2, R_LMAX2, R_BMAX,      // min / max of L_ii^2 and max_j (A^-1)_jj of the last factorisation (condition estimate)
+    R_COUNT
 };
 
 // Dynamic LDS above 64 KiB needs an explicit opt-in per kernel on HIP.

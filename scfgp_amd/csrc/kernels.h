@@ -86,6 +86,14 @@ struct SweepKernels {
     // triangular product Phi . LiT, LiT[k][j] = Li[j][k] (convert_transposed); mupart as apply_v.  Half the flops of apply_v.
     static void apply_predict(const Geom& g, const T* Phi, const T* LiT, double* vpart, const double* alpha, double* mupart,
                               hipStream_t st, bool bf3 = false);
+    // Factor form of pass 2 (the reference's own products, SCFGP/SCFGP.py:112: v = rowsum((Phi Li^T)^2)): C = Phi . LiT
+    // (triangular: half the flops), vpart = slices of rowsum(C^2), mupart as apply_v; then V = C . Li = Phi B (triangular).
+    // Li / LiT: the typed K x K copies of L^-1 and its transpose (padding zeroed).  Rounding errors of C are amplified by
+    // cond(L) = sqrt(cond(A)) where those of V = Phi . B computed directly are amplified by cond(A)
+    // (profiles/r03_c3_owner.md); planes: only `dma` is used.
+    static void apply_c(const Geom& g, const T* Phi, const T* LiT, const T* Li, T* C, double* vpart, const double* alpha,
+                        double* mupart, hipStream_t st, const Bf3Planes* planes = nullptr);
+    static void apply_vc(const Geom& g, const T* C, const T* Li, const T* LiT, T* V, hipStream_t st, const Bf3Planes* planes = nullptr);
     // Phibar = 2 Phi.Abar + 2 q V + p alpha^T + y ut^T  (in place over V); bpart[block] = partial of
     // bbar = sum Phibar o Phi.  Returns the number of blocks (= partials written).
     static int apply_phibar(const Geom& g, const T* Phi, const T* Abar, T* V, const double* p, const double* q,
@@ -177,4 +185,5 @@ struct KStage {
 };
 void kstage_factor(const KStage& k, const Scal* sc, hipStream_t st);          // SCFGP.py:105-110,125
 void kstage_adjoint(const KStage& k, const double* BWB, double* Abar, const Scal* sc, hipStream_t st);
+void kstage_adjoint_factor_form(const KStage& k, double* McBWB, double* Abar, const Scal* sc, hipStream_t st);
 void kstage_gram_li(const KStage& k, hipStream_t st);                         // B = Li^T Li only (predict)

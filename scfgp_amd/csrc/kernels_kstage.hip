@@ -23,7 +23,8 @@ struct GemmArgs {
     double alpha, beta;
     int tri;        // 1: skip tiles strictly above the diagonal; 2: also store every tile's transpose (C symmetric)
     int kskip;      // contraction range by the operands' triangular shape: 0 all of K; 1 both Li^T-shaped: from max(m0, n0);
-                    // 2 B lower triangular (B[k][n] = 0 for k < n): from n0; 3 A lower triangular (A[m][k] = 0 for k > m): up to m0 + 64
+                    // 2 B lower triangular (B[k][n] = 0 for k < n): from n0; 3 A lower triangular (A[m][k] = 0 for k > m): up to m0 + 64;
+                    // 4 A stored [k][m] lower triangular (A[k][m] = 0 for k < m): from m0
 };
 
 // C[m][n] = alpha * sum_k Aop[k][m] Bop[k][n] + beta * C[m][n]
@@ -33,7 +34,7 @@ __device__ __forceinline__ void gemm64_body(const GemmArgs& a, int tm, int tn, d
     typedef KCfg Cfg;
     if (tm * Cfg::BM >= a.M || tn * Cfg::BN >= a.N) return;
     if (a.tri && tn > tm) return;
-    const int k0 = a.kskip == 1 ? (tm > tn ? tm : tn) * Cfg::BM : (a.kskip == 2 ? tn * Cfg::BN : 0);
+    const int k0 = a.kskip == 1 ? (tm > tn ? tm : tn) * Cfg::BM : (a.kskip == 2 ? tn * Cfg::BN : (a.kskip == 4 ? tm * Cfg::BM : 0));
     const int k1 = a.kskip == 3 && (tm + 1) * Cfg::BM < a.K ? (tm + 1) * Cfg::BM : a.K;
     const int nkt = (k1 - k0) / Cfg::BK;
     v4d acc[Cfg::TM][Cfg::TN];
@@ -431,20 +432,34 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const double* __restrict
     for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
     if (lane == 0) out[i] = s;
 }
-// scalars: logdet = 2 sum_{i<K} log L_ii ; g.alpha
-__global__ __launch_bounds__(256) void factor_scalars_kernel(const double* __restrict__ L, int64_t ld, int K,
+// scalars: logdet = 2 sum_{i<K} log L_ii ; g.alpha ; and the condition estimate's ingredients: min / max of L_ii^2 and
+// max_j B_jj, B = A^-1.  max L_ii^2 <= max A_ii <= lam_max(A) and max B_jj <= 1 / lam_min(A), so their product is a LOWER
+// bound of cond_2(A) -- and at least the usual diagonal ratio max L_ii^2 / min L_ii^2, since B_jj >= 1 / L_jj^2.
+__global__ __launch_bounds__(256) void factor_scalars_kernel(const double* __restrict__ L, const double* __restrict__ B, int64_t ld, int K,
                                                              const double* __restrict__ g, const double* __restrict__ alpha,
                                                              double* __restrict__ scalars) {
-    __shared__ double r1[256], r2[256];
-    double s1 = 0, s2 = 0;
-    for (int i = threadIdx.x; i < K; i += 256) { s1 += log(L[(int64_t)i * ld + i]); s2 += g[i] * alpha[i]; }
-    r1[threadIdx.x] = s1; r2[threadIdx.x] = s2;
+    __shared__ double r1[256], r2[256], r3[256], r4[256], r5[256];
+    double s1 = 0, s2 = 0, lmin = 1.0 / 0.0, lmax = 0, bmax = 0;
+    for (int i = threadIdx.x; i < K; i += 256) {
+        const double l = L[(int64_t)i * ld + i], b = B[(int64_t)i * ld + i];
+        s1 += log(l); s2 += g[i] * alpha[i];
+        lmin = fmin(lmin, l * l); lmax = fmax(lmax, l * l); bmax = fmax(bmax, b);
+    }
+    r1[threadIdx.x] = s1; r2[threadIdx.x] = s2; r3[threadIdx.x] = lmin; r4[threadIdx.x] = lmax; r5[threadIdx.x] = bmax;
     __syncthreads();
     for (int m = 128; m >= 1; m >>= 1) {
-        if (threadIdx.x < m) { r1[threadIdx.x] += r1[threadIdx.x + m]; r2[threadIdx.x] += r2[threadIdx.x + m]; }
+        if (threadIdx.x < m) {
+            r1[threadIdx.x] += r1[threadIdx.x + m]; r2[threadIdx.x] += r2[threadIdx.x + m];
+            r3[threadIdx.x] = fmin(r3[threadIdx.x], r3[threadIdx.x + m]);
+            r4[threadIdx.x] = fmax(r4[threadIdx.x], r4[threadIdx.x + m]);
+            r5[threadIdx.x] = fmax(r5[threadIdx.x], r5[threadIdx.x + m]);
+        }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { scalars[R_LOGDET] = 2.0 * r1[0]; scalars[R_GTALPHA] = r2[0]; }
+    if (threadIdx.x == 0) {
+        scalars[R_LOGDET] = 2.0 * r1[0]; scalars[R_GTALPHA] = r2[0];
+        scalars[R_LMIN2] = r3[0]; scalars[R_LMAX2] = r4[0]; scalars[R_BMAX] = r5[0];
+    }
 }
 
 // Abar = B - BWB - (u a^T + a u^T)/2 + e^{-2a} a a^T  on the K x K block (padding: B - BWB = I)
@@ -518,7 +533,43 @@ void kstage_factor(const KStage& k, const Scal* sc, hipStream_t st) {
     kstage_gram_li(k, st);
     // alpha = Li^T (Li g) = B g  (SCFGP.py:108-110); B is symmetric, so one coalesced row-dot GEMV
     hipLaunchKernelGGL(gemv_rows_kernel, dim3((Kp + 3) / 4), dim3(256), 0, st, k.B, ld, k.g, k.alpha, Kp);
-    hipLaunchKernelGGL(factor_scalars_kernel, dim3(1), dim3(256), 0, st, k.T2, ld, k.K, k.g, k.alpha, k.scalars);
+    hipLaunchKernelGGL(factor_scalars_kernel, dim3(1), dim3(256), 0, st, k.T2, k.B, ld, k.K, k.g, k.alpha, k.scalars);
+}
+
+// out[i] = sum_k M[k][i] v[k]  (M^T v; M lower triangular: k >= i only).  blockIdx.y cuts k into gridDim.y parts whose partial
+// sums go to part[y][i]; the second kernel adds them in order (deterministic, no atomics).
+__global__ __launch_bounds__(256) void gemv_cols_part_kernel(const double* __restrict__ M, int64_t ld, const double* __restrict__ v,
+                                                             double* __restrict__ part, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int per = (n + gridDim.y - 1) / gridDim.y, k0 = blockIdx.y * per, k1 = k0 + per < n ? k0 + per : n;
+    if (i >= n) return;
+    double s = 0;
+    for (int k = k0 > i ? k0 : i; k < k1; ++k) s += M[(int64_t)k * ld + i] * v[k];
+    part[(int64_t)blockIdx.y * n + i] = s;
+}
+__global__ __launch_bounds__(256) void gemv_cols_sum_kernel(const double* __restrict__ part, int nparts, double* __restrict__ out, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double s = 0;
+    for (int p = 0; p < nparts; ++p) s += part[(int64_t)p * n + i];
+    out[i] = s;
+}
+
+// Factor form of pass 2 (SweepKernels::apply_c): the sweep delivers Mc = C^T diag(q) C and s = C^T p with C = Phi Li^T, so
+//   B W B = Li^T Mc Li   (two K x K products, triangular ranges)      u = B Phi^T p = Li^T s
+// McBWB: Mc on entry, B W B on return; k.h: s on entry; u goes to k.u.  Then as kstage_adjoint.
+void kstage_adjoint_factor_form(const KStage& k, double* McBWB, double* Abar, const Scal* sc, hipStream_t st) {
+    const int Kp = k.Kp;
+    const int64_t ld = Kp;
+    GemmArgs a1 = {McBWB, k.Li, k.T1, ld, ld, ld, Kp, Kp, Kp, 1.0, 0.0, 0, 2};       // T1 = Mc Li (Mc symmetric: stored [k][m] too)
+    gemm64<false, false>(a1, st);
+    GemmArgs a2 = {k.Li, k.T1, McBWB, ld, ld, ld, Kp, Kp, Kp, 1.0, 0.0, 2, 4};        // B W B = Li^T T1: lower tiles, mirrored
+    gemm64<false, false>(a2, st);
+    constexpr int PARTS = 32;
+    hipLaunchKernelGGL(gemv_cols_part_kernel, dim3((Kp + 255) / 256, PARTS), dim3(256), 0, st, k.Li, ld, k.h, k.T1, Kp);
+    hipLaunchKernelGGL(gemv_cols_sum_kernel, dim3((Kp + 255) / 256), dim3(256), 0, st, k.T1, PARTS, k.u, Kp);
+    hipLaunchKernelGGL(abar_kernel, dim3(1024), dim3(256), 0, st, k.B, McBWB, Abar, k.u, k.alpha, Kp, sc);
+    hipLaunchKernelGGL(adjoint_vec_kernel, dim3(1), dim3(256), 0, st, Abar, ld, k.K, Kp, k.u, k.alpha, k.ut, sc, k.scalars);
 }
 
 // BWB = V^T diag(q) V and u = B h = V^T p arrive ready from the row sweep (V = Phi B is resident), so the adjoint

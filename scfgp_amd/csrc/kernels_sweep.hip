@@ -361,18 +361,19 @@ __device__ __forceinline__ void slab_flush(const typename Cfg::MTr::acc_t (&acc)
 // s = p: Phi^T p) for their columns from the rows they stream anyway: sidepart[split][col].
 // One launch covers everything; the job order is described at the decode in gram_kernel.
 // ZSRC (experiment): Phi points to the phase matrix Z (leading dimension ld = Jp) and the loaders form s cos / s sin
-template <class Cfg, bool WEIGHT, bool STRIP, bool ZSRC = false>
+//   S: element type of the operand in memory (T, or float under T = double: the resident fp32 V multiplied in fp64)
+template <class Cfg, bool WEIGHT, bool STRIP, bool ZSRC = false, typename S = typename Cfg::T>
 __device__ __forceinline__ void gram_body(
-    const typename Cfg::T* __restrict__ Phi, int64_t ld, const double* __restrict__ w, const double* __restrict__ side,
+    const S* __restrict__ Phi, int64_t ld, const double* __restrict__ w, const double* __restrict__ side,
     int64_t r0, int64_t r1, int64_t chunk, int acol, int bcol, bool diag, double* __restrict__ sideout,
     double* __restrict__ slab, double* __restrict__ slab_hi, char* smem_raw, int zJ = 0, typename Cfg::T zs = 0) {
     typedef typename Cfg::T T;
     T* smem = reinterpret_cast<T*>(smem_raw);
     typename Cfg::MTr::acc_t acc[Cfg::TM][Cfg::TN];
     // consecutive chunks are consecutive k-tiles, so one pair of loaders walks the whole row range
-    NatLoader<T, T, Cfg::BM, Cfg::BK, Cfg::LDA, Cfg::THREADS, WEIGHT, false, true, ZSRC> la(
+    NatLoader<S, T, Cfg::BM, Cfg::BK, Cfg::LDA, Cfg::THREADS, WEIGHT, false, true, ZSRC> la(
         Phi + r0 * ld + (ZSRC ? 0 : acol), ld, threadIdx.x, WEIGHT ? w + r0 : nullptr, 0, diag ? side + r0 : nullptr);
-    NatLoader<T, T, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS, false, false, false, ZSRC> lb(Phi + r0 * ld + (ZSRC ? 0 : bcol), ld, threadIdx.x);
+    NatLoader<S, T, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS, false, false, false, ZSRC> lb(Phi + r0 * ld + (ZSRC ? 0 : bcol), ld, threadIdx.x);
     if (ZSRC) { la.z_source(Phi + r0 * ld, ld, zJ, acol, zs); lb.z_source(Phi + r0 * ld, ld, zJ, bcol, zs); }
     bool first = true;
     for (int64_t c0 = r0; c0 < r1 || first; c0 += chunk) {
@@ -404,11 +405,11 @@ template <bool BIG> __host__ __device__ inline int gram_jobs_per_split(int nfull
     const int R = nfull / 2, odd = nfull & 1, nsb = nstrip * (nfull + 1);
     return R * R + nsb / 4 + R + odd * nfull + nsb % 4;          // tall, wide (4 strip tiles each), small, single strips
 }
-template <class Cfg, class SCfg, class BCfg, class WCfg, bool WEIGHT, bool BIG, bool ZSRC = false>
+template <class Cfg, class SCfg, class BCfg, class WCfg, bool WEIGHT, bool BIG, bool ZSRC = false, typename S = typename Cfg::T>
 __global__ __launch_bounds__(Cfg::THREADS)
 __attribute__((amdgpu_waves_per_eu(4, 4)))       // two 8-wave workgroups per CU: the compiler would take up to 256 VGPRs
 void gram_kernel(
-    const typename Cfg::T* __restrict__ Phi, int64_t ld, const double* __restrict__ w, const double* __restrict__ side,
+    const S* __restrict__ Phi, int64_t ld, const double* __restrict__ w, const double* __restrict__ side,
     RowSplits rs, int64_t chunk, int nfull, int nstrip, double* __restrict__ sidepart, double* __restrict__ slabs,
     int64_t zld, int zJ, double zscale) {                     // ZSRC: Phi is the phase matrix Z (leading dimension zld)
     static_assert(Cfg::THREADS == SCfg::THREADS && Cfg::THREADS == BCfg::THREADS && Cfg::THREADS == WCfg::THREADS &&
@@ -471,12 +472,12 @@ void gram_kernel(
     typedef typename Cfg::T T;
     const int64_t sld = ZSRC ? zld : ld;                       // leading dimension of the operand source
     const T zs = (T)zscale;
-    if (kind == 1) { gram_body<SCfg, WEIGHT, true, ZSRC>(Phi, sld, w, side, r0, r1, chunk, acol, bcol, diag, sideout, slab, nullptr, smem_raw, zJ, zs); TRACE_END(kind); return; }
+    if (kind == 1) { gram_body<SCfg, WEIGHT, true, ZSRC, S>(Phi, sld, w, side, r0, r1, chunk, acol, bcol, diag, sideout, slab, nullptr, smem_raw, zJ, zs); TRACE_END(kind); return; }
     if constexpr (BIG) {
-        if (kind == 2) { gram_body<BCfg, WEIGHT, false, ZSRC>(Phi, sld, w, side, r0, r1, chunk, acol, bcol, diag, sideout, slab, slab2, smem_raw, zJ, zs); TRACE_END(kind); return; }
-        if (kind == 3) { gram_body<WCfg, WEIGHT, true, ZSRC>(Phi, sld, w, side, r0, r1, chunk, acol, bcol, diag, sideout, slab, nullptr, smem_raw, zJ, zs); TRACE_END(kind); return; }
+        if (kind == 2) { gram_body<BCfg, WEIGHT, false, ZSRC, S>(Phi, sld, w, side, r0, r1, chunk, acol, bcol, diag, sideout, slab, slab2, smem_raw, zJ, zs); TRACE_END(kind); return; }
+        if (kind == 3) { gram_body<WCfg, WEIGHT, true, ZSRC, S>(Phi, sld, w, side, r0, r1, chunk, acol, bcol, diag, sideout, slab, nullptr, smem_raw, zJ, zs); TRACE_END(kind); return; }
     }
-    gram_body<Cfg, WEIGHT, false, ZSRC>(Phi, sld, w, side, r0, r1, chunk, acol, bcol, diag, sideout, slab, nullptr, smem_raw, zJ, zs);
+    gram_body<Cfg, WEIGHT, false, ZSRC, S>(Phi, sld, w, side, r0, r1, chunk, acol, bcol, diag, sideout, slab, nullptr, smem_raw, zJ, zs);
     TRACE_END(kind);
 }
 
@@ -609,6 +610,9 @@ void SweepKernels<T>::xtz(const Geom& g, const double* Xt, const T* Phi, const T
 //   EPI 2 (predict): Bm = Li^T, so C = Phi Li^T is the reference's own product (SCFGP/SCFGP.py:144) and
 //          vpart[jt][n] = sum_j C[n][j]^2; nothing is stored, and since Li^T[k][j] = 0 for k > j the contraction of column
 //          tile jt stops at its last column: half the flops of the symmetric product
+//   EPI 3 (factor form of pass 2, SCFGP/SCFGP.py:112): as EPI 2 but C is stored (in V's place) and mu rides along
+//   EPI 4 (factor form): V = C . Li, Bm = Li lower triangular (Bm[k][j] = 0 for k < j): the contraction of column tile jt
+//          STARTS at its first column; plain store, no row sums
 // --------------------------------------------------------------------------
 // epilogues of the apply product: V and the row dots (EPI 0) or Phibar and bbar (EPI 1) from the accumulators
 //   MU (EPI 0 only): also mupart[jtg][n] = sum_{j in tile} Phi[n][j] alpha[j] from the Phi values the row dot reads anyway
@@ -621,7 +625,16 @@ __device__ __forceinline__ void apply_epilogue(
     double* __restrict__ bpart, char* smem_raw, double* __restrict__ mupart = nullptr) {
     typedef typename Cfg::T T;
     AccCoord<Cfg> co;
-    if (EPI == 0 || EPI == 2) {
+    if (EPI == 4) {
+#pragma unroll
+        for (int tm = 0; tm < Cfg::TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < Cfg::MTr::NACC; ++r) {
+                const int64_t off = (rb * Cfg::BM + co.row(tm, r)) * Kp + cbase;
+#pragma unroll
+                for (int tn = 0; tn < Cfg::TN; ++tn) V[off + co.col(tn)] = acc[tm][tn][r];
+            }
+    } else if (EPI == 0 || EPI == 2 || EPI == 3) {
         double* red = reinterpret_cast<double*>(smem_raw);          // [WGN][BM] (MU: twice); main loop ended with a barrier
         double* red2 = red + Cfg::WGN * Cfg::BM;
         const int wn = (threadIdx.x >> 6) % Cfg::WGN;
@@ -640,9 +653,11 @@ __device__ __forceinline__ void apply_epilogue(
 #pragma unroll
                 for (int tn = 0; tn < Cfg::TN; ++tn) {
                     const T c = acc[tm][tn][r];
-                    if (EPI == 2) { part += (double)c * (double)c; continue; }
-                    V[off + co.col(tn)] = c;
-                    if (cbase + co.col(tn) < K) {
+                    if (EPI != 2) V[off + co.col(tn)] = c;
+                    if (EPI != 0) {                                   // v_n = || Li phi_n ||^2
+                        part += (double)c * (double)c;
+                        if (MU && cbase + co.col(tn) < K) mup += (double)Phi[off + co.col(tn)] * al[tn];
+                    } else if (cbase + co.col(tn) < K) {              // v_n = phi_n . (B phi_n)
                         const double ph = (double)Phi[off + co.col(tn)];
                         part += ph * (double)c;
                         if (MU) mup += ph * al[tn];
@@ -715,13 +730,14 @@ void apply_kernel(
     const int64_t rb = wid / njt;
     const int cbase = col0 + jt * Cfg::BN;
     // EPI 0: column tile t of ntot also forms the slice kt % ntot == t of mu = Phi.alpha for its rows
-    const bool want_mu = (EPI == 0 || EPI == 2) && mu != nullptr;
+    const bool want_mu = (EPI == 0 || EPI == 2 || EPI == 3) && mu != nullptr;
     // rows >= K of the operand matrix are zero padding, so the contraction stops at K rounded up to the k-tile;
     // EPI 2: the operand is lower-triangular-transposed, column tile jt needs k < cbase + BN only, and forms the slice
     // k in [cbase, cbase + BN) of mu (the k-tiles no earlier column tile visits)
     const int nkt_all = (K + Cfg::BK - 1) / Cfg::BK;
     const int nkt_tri = (cbase + Cfg::BN + Cfg::BK - 1) / Cfg::BK;
-    const int nkt = EPI == 2 && nkt_tri < nkt_all ? nkt_tri : nkt_all;
+    const int kt0 = EPI == 4 ? cbase / Cfg::BK : 0;                 // EPI 4: Bm[k][j] = 0 for k < j
+    const int nkt = ((EPI == 2 || EPI == 3) && nkt_tri < nkt_all ? nkt_tri : nkt_all) - kt0;
     if constexpr (IsBf3<Cfg>::value) {                         // split-precision tiles; Bm: the matrix pre-split by bf3_presplit()
         typename Cfg::MTr::acc_t acc[Cfg::TM][Cfg::TN];
         acc_zero<Cfg>(acc);
@@ -738,16 +754,16 @@ void apply_kernel(
     } else {
         typename Cfg::MTr::acc_t acc[Cfg::TM][Cfg::TN];
         acc_zero<Cfg>(acc);
-        TrLoader<T, T, Cfg::BM, Cfg::BK, Cfg::LDA, Cfg::THREADS, EPI != 1, Cfg::SWZA> la(Phi + rb * Cfg::BM * Kp, Kp, threadIdx.x,
-                                                                            want_mu ? alpha : nullptr, jt0 + jt, ntot);
-        if (EPI == 2) la.dot_range(cbase / Cfg::BK, nkt);
+        TrLoader<T, T, Cfg::BM, Cfg::BK, Cfg::LDA, Cfg::THREADS, EPI != 1 && EPI != 4, Cfg::SWZA> la(
+            Phi + rb * Cfg::BM * Kp + kt0 * Cfg::BK, Kp, threadIdx.x, want_mu ? alpha : nullptr, jt0 + jt, ntot);
+        if (EPI == 2 || EPI == 3) la.dot_range(cbase / Cfg::BK, nkt);
         else if (ntot == 0) {                                   // beside DMA-fed tiles: mu slices are the tiles' own column bands
             const int hi = (cbase + Cfg::BN) / Cfg::BK;
             la.dot_range(cbase / Cfg::BK, hi < nkt ? hi : nkt);
         }
-        NatLoader<T, T, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS, false, false> lb(Bm + cbase, Kp, threadIdx.x);
+        NatLoader<T, T, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS, false, false> lb(Bm + (int64_t)kt0 * Cfg::BK * Kp + cbase, Kp, threadIdx.x);
         tile_mainloop<Cfg>(la, lb, nkt, acc, smem);
-        if (EPI != 1 && want_mu) la.dot_reduce(mu + (int64_t)(jt0 + jt) * Np + rb * Cfg::BM);
+        if constexpr (EPI != 1 && EPI != 4) { if (want_mu) la.dot_reduce(mu + (int64_t)(jt0 + jt) * Np + rb * Cfg::BM); }
         apply_epilogue<Cfg, EPI>(acc, Phi, V, vpart, p, q, y, alpha, ut, K, Kp, Np, rb, cbase, jt0 + jt, bpart, smem_raw);
     }
 }
@@ -760,6 +776,8 @@ void apply_kernel(
 //   c ^ ((x >> 2) & 3) (source-side swizzle, the DMA writes linearly): the 16 lanes of an MFMA row group read 64 banks.
 //   Lane group q of the 16x16x4 shape takes chunk q -- k = 4q .. 4q+3 -- and feeds component e to k-step e: both
 //   operands use the same permutation of the 16 k, so the sum is unchanged and a fragment is ONE ds_read_b128 per stage.
+//   EPI 3 / 4 (factor form): Bm holds the k-contiguous COLUMNS of the triangular operand as its rows (Li for C = Phi Li^T,
+//   Li^T for V = C Li); the stages run over k < cbase + BN (EPI 3) or k >= cbase (EPI 4) only.
 template <int BN_>
 struct ApplyDma {
     static constexpr int BM = 256, BN = BN_, WAVES = 4 * (BN / 64), STAGE = (BM + BN) * 64, STAGES = 3, LDS_BYTES = STAGES * STAGE,
@@ -790,7 +808,7 @@ void apply_dma_kernel(const float* __restrict__ Phi, const float* __restrict__ B
     for (int u = 0; u < D::DMA_PER_WAVE; ++u) {
         const int t = wave * D::DMA_PER_WAVE + u, x = 16 * t + (lane >> 2), c = (lane & 3) ^ ((x >> 2) & 3);
         const float* rowp = x < D::BM ? Phi + (rb * D::BM + x) * Kp : Bm + (int64_t)(cbase + x - D::BM) * Kp;
-        src[u] = reinterpret_cast<const char*>(rowp) + c * 16;
+        src[u] = reinterpret_cast<const char*>(rowp) + c * 16 + (EPI == 4 ? (cbase / 16) * 64 : 0);
         dst[u] = t * 1024;
     }
     const auto issue = [&](int slot) {
@@ -806,7 +824,8 @@ void apply_dma_kernel(const float* __restrict__ Phi, const float* __restrict__ B
     const int aoff = (wm0 + i) * 64 + sw, boff = D::BM * 64 + (wn0 + i) * 64 + sw;
     typename Cfg::MTr::acc_t acc[Cfg::TM][Cfg::TN];
     acc_zero<Cfg>(acc);
-    const int nst = (K + 15) / 16;
+    const int nst_all = (K + 15) / 16, nst_tri = (cbase + D::BN + 15) / 16;
+    const int nst = (EPI == 3 && nst_tri < nst_all ? nst_tri : nst_all) - (EPI == 4 ? cbase / 16 : 0);
     issue(0);
     if (nst > 1) issue(1);
     int slot = 0, fill = 2;
@@ -835,8 +854,8 @@ void apply_dma_kernel(const float* __restrict__ Phi, const float* __restrict__ B
     __syncthreads();
     constexpr int SLOTS = BN / 128;                            // vpart / mupart slots are 128 columns wide
     const int vslot = slot0 + SLOTS * jt;
-    apply_epilogue<Cfg, EPI, EPI == 0>(acc, Phi, V, vpart, p, q, y, alpha, ut, K, Kp, Np, rb, cbase, vslot, bpart, smem_raw, mu);
-    if (SLOTS == 2 && EPI == 0 && threadIdx.x < D::BM) {
+    apply_epilogue<Cfg, EPI, EPI == 0 || EPI == 3>(acc, Phi, V, vpart, p, q, y, alpha, ut, K, Kp, Np, rb, cbase, vslot, bpart, smem_raw, mu);
+    if (SLOTS == 2 && (EPI == 0 || EPI == 3) && threadIdx.x < D::BM) {
         vpart[(int64_t)(vslot + 1) * Np + rb * D::BM + threadIdx.x] = 0.0;
         if (mu) mu[(int64_t)(vslot + 1) * Np + rb * D::BM + threadIdx.x] = 0.0;
     }
@@ -917,7 +936,9 @@ static int apply_dma_launch(const Geom& g, int njt, int col0, int slot0, int bof
 template <typename T, int EPI>
 static int apply_launch(const Geom& g, const T* Phi, const T* Bm, T* V, double* vpart, const double* p, const double* q,
                         const double* y, const double* alpha, const double* ut, double* bpart, double* mu, hipStream_t st, bool bf3 = false,
-                        const Bf3Planes* planes = nullptr) {
+                        const Bf3Planes* planes = nullptr, const T* BmT = nullptr) {
+    // BmT: the operand with its k-contiguous columns as rows (what the DMA-fed tiles read); NULL: Bm is symmetric
+    if (!BmT) BmT = Bm;
     const ApplyPlan<T> pl(g.K);
     int nb = 0;
     if constexpr (sizeof(T) == 4) {
@@ -957,10 +978,10 @@ static int apply_launch(const Geom& g, const T* Phi, const T* Bm, T* V, double* 
             // the full tiles by LDS-DMA (Bm symmetric): option value 1 = 128 wide, 2 = 256 wide with a 128-wide one for an odd
             // count; the 64-wide remainder by the loader-staged kernel, whose mu slices then are column bands too (ntot = 0)
             // 3: 256-wide for V = Phi.B (EPI 0), 128-wide for Phibar (EPI 1: its epilogue wants a second resident workgroup)
-            const bool wide = planes->dma == 2 || (planes->dma == 3 && EPI == 0);
+            const bool wide = planes->dma == 2 || (planes->dma == 3 && EPI != 1);
             const int n256 = wide ? pl.count[0] / 2 : 0, n128 = pl.count[0] - 2 * n256;
-            nb += apply_dma_launch<EPI, 256>(g, n256, 0, 0, nb, Phi, Bm, V, vpart, p, q, y, alpha, ut, bpart, mu, st);
-            nb += apply_dma_launch<EPI, 128>(g, n128, 256 * n256, 2 * n256, nb, Phi, Bm, V, vpart, p, q, y, alpha, ut, bpart, mu, st);
+            nb += apply_dma_launch<EPI, 256>(g, n256, 0, 0, nb, Phi, BmT, V, vpart, p, q, y, alpha, ut, bpart, mu, st);
+            nb += apply_dma_launch<EPI, 128>(g, n128, 256 * n256, 2 * n256, nb, Phi, BmT, V, vpart, p, q, y, alpha, ut, bpart, mu, st);
             typedef typename ApplyCfg<T, 64>::type RCfg;
             if (pl.count[2] > 0) {
                 const int64_t nr = g.Np / RCfg::BM;
@@ -1002,6 +1023,15 @@ template <typename T>
 void SweepKernels<T>::apply_predict(const Geom& g, const T* Phi, const T* LiT, double* vpart, const double* alpha, double* mu,
                                     hipStream_t st, bool bf3) {
     apply_launch<T, 2>(g, Phi, LiT, (T*)nullptr, vpart, nullptr, nullptr, nullptr, alpha, nullptr, nullptr, mu, st, bf3);
+}
+template <typename T>
+void SweepKernels<T>::apply_c(const Geom& g, const T* Phi, const T* LiT, const T* Li, T* C, double* vpart, const double* alpha,
+                              double* mu, hipStream_t st, const Bf3Planes* planes) {
+    apply_launch<T, 3>(g, Phi, LiT, C, vpart, nullptr, nullptr, nullptr, alpha, nullptr, nullptr, mu, st, false, planes, Li);
+}
+template <typename T>
+void SweepKernels<T>::apply_vc(const Geom& g, const T* C, const T* Li, const T* LiT, T* V, hipStream_t st, const Bf3Planes* planes) {
+    apply_launch<T, 4>(g, C, Li, V, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, st, false, planes, LiT);
 }
 template <typename T>
 int SweepKernels<T>::apply_phibar(const Geom& g, const T* Phi, const T* Abar, T* V, const double* p, const double* q,

@@ -23,12 +23,27 @@
 
 static constexpr int XT = 128;              // tile of the X~^T Zbar product and padding unit of J (kernels_sweep.hip)
 static constexpr int64_t PRED_ROWS = 32768; // predict processes test rows in chunks of this size
+// Thresholds of the automatic precision escalation and the error model behind them (profiles/r03_c3_owner.md): with the
+// fp32 Gram products (4096-row flush interval) the relative error of alpha / Li, and of the frequency gradient blocks,
+// against fp64 mode is about SCFGP_ERR_PER_COND times the condition estimate (measured 2.6e-7 .. 3.3e-7 at estimates
+// 58 .. 6.4e3).  Level 1 keeps the predicted alpha error under 3e-6 (north star: 1e-5), level 2 the predicted gradient
+// error under 3e-4 (SURVEY App. E acceptance: 1e-3 per block).
+#ifndef SCFGP_COND_THRESHOLD
+#define SCFGP_COND_THRESHOLD 10.0
+#endif
+#ifndef SCFGP_COND_THRESHOLD_W
+#define SCFGP_COND_THRESHOLD_W 1000.0
+#endif
+#ifndef SCFGP_ERR_PER_COND
+#define SCFGP_ERR_PER_COND 3.0e-7
+#endif
 static void derive_geom(Geom& g, int D, int S, int M);
 
 thread_local bool g_scfgp_capturing = false;
 
-// roctx ranges around every stage (visible in `rocprofv3 --marker-trace`): resolved at run time so the library has no
-// link-time dependency on the profiler SDK; without it the calls are no-ops
+// roctx ranges around every stage (visible in `rocprofv3 --marker-trace`): OPT-IN (environment SCFGP_ROCTX=1 at context
+// creation or option "roctx"); only then is the profiler's roctx library looked up, at run time, so the product has no
+// link-time dependency on the profiler SDK and an ordinary process never loads it
 struct Roctx {
     int (*push)(const char*) = nullptr; int (*pop)() = nullptr;
     Roctx() {
@@ -89,7 +104,31 @@ struct scfgp_ctx {
     int gram_nsplit = 0, gram_taper = 1, xtz_nsplit = 0; int64_t gram_chunk = 4096;
     int fuse_fmap = 0; void* d_Z = nullptr; int64_t z_cap = 0;         // experiment: Gram of pass 1 fed from the phases
     RowSplits splits{};
+    // Precision escalation (fp32 / bf16x3 modes; profiles/r03_c3_owner.md).  The fp32 Gram products carry a relative error
+    // of ~6e-8 that reaches alpha / Li (pass 1) and the gradient (pass 2's V^T diag(q) V) multiplied by the condition of A,
+    // so the K x K stage's free condition estimate decides how the two TN products are formed:
+    //   level 0  both in fp32 MFMA (fp64 across 4096-row chunks)
+    //   level 1  pass 1: G = Phi^T Phi and Phi^T y by the fp64 kernels from fp64 features (alpha, Li, cost, mu*, sigma* then
+    //            equal fp64 mode's to ~1e-8; alpha and Li bit for bit)
+    //   level 2  also pass 2 in its factor form (C = Phi Li^T, v = rowsum(C^2), B W B = Li^T (C^T diag(q) C) Li, V = C Li):
+    //            rounding errors amplified by sqrt(cond) instead of cond (gradient blocks)
+    // option gram64: 0 never, 1 always level 1, 2 auto (default), 3 always level 2.  Auto is sticky: when the estimate of a
+    // finished evaluation asks for a higher level that evaluation is repeated (scfgp_finish returns SCFGP_REDO; scfgp_eval
+    // does so itself) and the following ones start at that level; the level drops when the estimate falls below a quarter
+    // of the threshold.  Inside one scfgp_train call the level is fixed (the iteration may be a captured graph).
+    int gram64 = 2, esc_level = 0; double esc_thr = SCFGP_COND_THRESHOLD, escw_thr = SCFGP_COND_THRESHOLD_W; bool last_used64 = false;
+    int last_level = 0; bool cond_valid = false;               // cond_valid: cond[] describes the current parameters and rows
+    double cond[3] = {0, 0, 0};                                         // min L_ii^2, max L_ii^2, max_j (A^-1)_jj of the last factorisation
+    void* d_Phi64 = nullptr; int64_t phi64_cap = 0; RowSplits splits64{};
+    // factor form of pass 2 (C = Phi Li^T, V = C Li: SweepKernels::apply_c): -1 auto (precision level 2), 0 never, 1 always
+    int factor_form = -1; bool last_cform = false; void* d_C = nullptr; int64_t c_cap = 0;
+    bool want_cform() const { return factor_form == 1 || (factor_form < 0 && level() >= 2); }
+    int level() const { return dtype != SCFGP_F32 || gram64 == 0 ? 0 : (gram64 == 1 ? 1 : (gram64 == 3 ? 2 : esc_level)); }
+    bool use64() const { return level() >= 1; }
+    double cond_est() const { return cond[1] * cond[2]; }
+    int want_level(double est, double slack) const { return est > escw_thr * slack ? 2 : (est > esc_thr * slack ? 1 : 0); }
     // profiling
+    bool roctx_on = false;
     bool prof = false; std::vector<ProfRec> recs; std::vector<hipEvent_t> pool; size_t pool_used = 0;
     std::string err;
 
@@ -123,7 +162,7 @@ struct ProfScope {
     scfgp_ctx* c; size_t idx = (size_t)-1; bool ranged = false;
     ProfScope(scfgp_ctx* c_, const char* name) : c(c_) {
         if (g_scfgp_capturing) return;
-        if (roctx().push) { roctx().push(name); ranged = true; }
+        if (c->roctx_on && roctx().push) { roctx().push(name); ranged = true; }
         if (!c->prof) return;
         auto get = [&]() {
             if (c->pool_used == c->pool.size()) { hipEvent_t e; hipEventCreate(&e); c->pool.push_back(e); }
@@ -166,6 +205,35 @@ static void free_rows(scfgp_ctx* c) {
     c->Ncap = 0; c->slabs_bytes = 0;
 }
 
+// optional row buffers (fp64 features of an escalated pass 1, the experiments' phase matrix and bf16 row planes): sized
+// for the current working set, allocated HERE and never inside a pass -- a pass may be running under graph capture
+static int ensure_aux_rows(scfgp_ctx* c) {
+    const Geom& g = c->g;
+    if (c->use64() && c->phi64_cap < g.Np) {
+        dfree(c->d_Phi64); c->phi64_cap = 0;
+        if (int rc = dmalloc(c, &c->d_Phi64, sizeof(double) * g.Np * g.Kp)) return rc;
+        HIPCHK(c, hipMemsetAsync(c->d_Phi64, 0, sizeof(double) * g.Np * g.Kp, c->st));      // columns >= K stay zero
+        c->phi64_cap = g.Np;
+    }
+    if (c->want_cform() && c->c_cap < g.Np) {
+        dfree(c->d_C); c->c_cap = 0;
+        if (int rc = dmalloc(c, &c->d_C, c->tsize() * g.Np * g.Kp)) return rc;
+        HIPCHK(c, hipMemsetAsync(c->d_C, 0, c->tsize() * g.Np * g.Kp, c->st));
+        c->c_cap = g.Np;
+    }
+    if (c->fuse_fmap && c->z_cap < g.Np) {
+        dfree(c->d_Z); c->z_cap = 0;
+        if (int rc = dmalloc(c, &c->d_Z, c->tsize() * g.Np * g.Jp)) return rc;
+        c->z_cap = g.Np;
+    }
+    if (c->bf3 && c->bf3_dma && g.K > 256 && c->p3_cap < g.Np) {
+        dfree(c->d_P3); c->p3_cap = 0;
+        if (int rc = dmalloc(c, &c->d_P3, (size_t)6 * g.Np * g.Kp)) return rc;
+        c->p3_cap = g.Np;
+    }
+    return SCFGP_OK;
+}
+
 // (re)allocate every buffer whose size depends on the number of local rows
 static int ensure_rows(scfgp_ctx* c, int64_t N) {
     Geom& g = c->g;
@@ -177,7 +245,11 @@ static int ensure_rows(scfgp_ctx* c, int64_t N) {
     const int ntx = ((g.Dp + XT - 1) / XT) * (g.Jp / XT);
     const int gjobs = c->dtype == SCFGP_F32 ? SweepKernels<float>::gram_jobs(g) : SweepKernels<double>::gram_jobs(g);
     c->splits = gram_row_splits(gjobs, Np, c->dtype == SCFGP_F32, c->gram_nsplit, c->gram_taper);
-    const int gs = c->splits.nsplit;
+    int gs = c->splits.nsplit;
+    if (c->dtype == SCFGP_F32 && c->gram64 != 0) {              // the fp64 job list of an escalated pass 1 has its own row splits
+        c->splits64 = gram_row_splits(SweepKernels<double>::gram_jobs(g), Np, false, c->gram_nsplit, c->gram_taper);
+        gs = std::max(gs, c->splits64.nsplit);
+    }
     const int xs = c->xtz_nsplit > 0 ? (int)std::min<int64_t>(c->xtz_nsplit, Np / 64) : xtz_split(ntx, Np);
     // Gram slabs are followed by the per-split side-vector partials (gs x Kp)
     const size_t need = sizeof(double) * std::max<size_t>((size_t)gs * ntiles * g.tile * g.tile + (size_t)gs * g.Kp, (size_t)xs * ntx * XT * XT);
@@ -186,6 +258,7 @@ static int ensure_rows(scfgp_ctx* c, int64_t N) {
         if (int rc = dmalloc(c, &c->d_slabs, need)) return rc;
         c->slabs_bytes = need;
     }
+    if (int rc = ensure_aux_rows(c)) return rc;
     if (Np <= c->Ncap) return SCFGP_OK;
     dfree(c->d_Xt); dfree(c->d_y); dfree(c->d_p); dfree(c->d_q); dfree(c->d_mu); dfree(c->d_vpart); dfree(c->d_Tt);
     dfree(c->d_Phi); dfree(c->d_V); dfree(c->d_bpart);
@@ -217,6 +290,7 @@ extern "C" int scfgp_create(scfgp_ctx** out, int D, int S, int M, int dtype, int
     Geom& g = c->g;
     derive_geom(g, D, S, M);
     if (const char* e = getenv("SCFGP_LOWRANK")) g.lowrank = atoi(e) != 0;                       // tuning override
+    if (const char* e = getenv("SCFGP_ROCTX")) c->roctx_on = atoi(e) != 0;
     c->Dpp = (int)round_up(g.Dp, XT);
     HIPCHK(c, hipSetDevice(device));
     if (stream) c->st = (hipStream_t)stream;
@@ -272,7 +346,7 @@ extern "C" void scfgp_destroy(scfgp_ctx* c) {
     hipSetDevice(c->device);
     if (c->st) hipStreamSynchronize(c->st);
     free_rows(c);
-    dfree(c->d_Z); dfree(c->d_Xraw); dfree(c->d_yraw); dfree(c->d_idx); dfree(c->d_xscale); dfree(c->d_yscale);
+    dfree(c->d_Z); dfree(c->d_Phi64); dfree(c->d_C); dfree(c->d_Xraw); dfree(c->d_yraw); dfree(c->d_idx); dfree(c->d_xscale); dfree(c->d_yscale);
     dfree(c->d_params); dfree(c->d_F); dfree(c->d_Fall); dfree(c->d_Lall); dfree(c->d_Rall); dfree(c->d_sc); dfree(c->p_Tt);
     dfree(c->d_xp1); dfree(c->d_xp2); dfree(c->d_x1); dfree(c->d_x2); dfree(c->d_x3); dfree(c->d_Li); dfree(c->d_B); dfree(c->d_T1); dfree(c->d_T2);
     dfree(c->d_Abar); dfree(c->d_BT); dfree(c->d_AbarT); dfree(c->d_M3); dfree(c->d_M16); dfree(c->d_P3); dfree(c->d_vecs); dfree(c->d_scalars); dfree(c->d_yy);
@@ -299,7 +373,7 @@ extern "C" int scfgp_set_params(scfgp_ctx* c, const double* params, int P) {
     HIPCHK(c, hipMemcpyAsync(c->d_params, c->h_params.data(), sizeof(double) * P, hipMemcpyHostToDevice, c->st));
     unpack_params(c->g, c->d_params, c->d_F, c->d_Fall, c->d_Lall, c->d_Rall, c->d_sc, c->st);
     HIPCHK(c, hipGetLastError());
-    c->have_params = true;
+    c->have_params = true; c->cond_valid = false;
     return SCFGP_OK;
 }
 
@@ -317,7 +391,7 @@ static int load_working_set(scfgp_ctx* c, const int64_t* d_idx, int64_t n, int64
     sum_squares(c->d_y, c->g.Np, c->d_yy, 0, c->d_partial, c->st);
     HIPCHK(c, hipGetLastError());
     c->work_full = d_idx == nullptr;
-    c->have_data = true; c->stage = 0;
+    c->have_data = true; c->stage = 0; c->cond_valid = false;
     return SCFGP_OK;
 }
 
@@ -381,26 +455,35 @@ template <typename T> struct Impl {
     static int pass1(scfgp_ctx* c) {
         const Geom& g = c->g;
         if (!c->in_train) HIPCHK(c, hipMemsetAsync(c->d_flag, 0, sizeof(int) * 4, c->st));
-        const bool fuse = c->fuse_fmap && g.J % (16 / (int)sizeof(T)) == 0;
-        if (fuse && c->z_cap < g.Np) {
-            dfree(c->d_Z);
-            if (int rc = dmalloc(c, &c->d_Z, sizeof(T) * g.Np * g.Jp)) return rc;
-            c->z_cap = g.Np;
+        const bool use64 = sizeof(T) == 4 && c->use64();
+        const bool fuse = !use64 && c->fuse_fmap && g.J % (16 / (int)sizeof(T)) == 0;
+        c->last_cform = c->want_cform();
+        if ((fuse && c->z_cap < g.Np) || (use64 && c->phi64_cap < g.Np) || (c->last_cform && c->c_cap < g.Np)) {
+            c->err = "pass1: auxiliary row buffer missing"; return SCFGP_EARG;
         }
-        { ProfScope ps(c, "featuremap"); SK::featuremap(g, c->d_Xt, Projection{c->d_Fall, c->d_Lall, c->d_Rall, c->d_Tt}, c->d_sc, (T*)c->d_Phi, c->st,
-                                                        fuse ? (T*)c->d_Z : nullptr); }
+        const Projection proj{c->d_Fall, c->d_Lall, c->d_Rall, c->d_Tt};
         if constexpr (sizeof(T) == 4) {
-            if (c->bf3 && c->bf3_dma && g.K > 256) {           // row planes of Phi for the DMA-fed apply tiles
-                if (c->p3_cap < g.Np) {
-                    dfree(c->d_P3); c->p3_cap = 0;
-                    if (int rc = dmalloc(c, &c->d_P3, (size_t)6 * g.Np * g.Kp)) return rc;
-                    c->p3_cap = g.Np;
-                }
+            if (use64) {                                       // escalated pass 1: fp64 features, fp64 Gram and Phi^T y
+                typedef SweepKernels<double> SK64;
+                const int nts = g.Kp / g.tile, ntiles = nts * (nts + 1) / 2, gs = c->splits64.nsplit;
+                double* sidepart = c->d_slabs + (size_t)gs * ntiles * g.tile * g.tile;
+                { ProfScope ps(c, "featuremap64"); SK64::featuremap(g, c->d_Xt, proj, c->d_sc, (double*)c->d_Phi64, c->st); }
+                { ProfScope ps(c, "gram64");
+                  SK64::gram(g, (const double*)c->d_Phi64, nullptr, c->d_y, c->splits64, 0, c->d_slabs, sidepart, c->st); }
+                { ProfScope ps(c, "reduce_tiles"); reduce_tri_tiles(c->d_slabs, gs, nts, g.tile, c->d_xp1, c->st);
+                  reduce_side(sidepart, gs, g.Kp, g.gfull * g.tile + g.gstrip * 64, c->d_xp1 + c->n_pk, c->st); }
+            }
+        }
+        { ProfScope ps(c, "featuremap"); SK::featuremap(g, c->d_Xt, proj, c->d_sc, (T*)c->d_Phi, c->st, fuse ? (T*)c->d_Z : nullptr); }
+        if constexpr (sizeof(T) == 4) {
+            if (c->bf3 && c->bf3_dma && g.K > 256 && c->p3_cap >= g.Np) {           // row planes of Phi for the DMA-fed apply tiles
                 ProfScope ps(c, "split_rows");
                 bf3_split_rows((const float*)c->d_Phi, g.Kp, c->d_P3, g.Np, g.Kp, c->st);
             }
         }
-        gram_to(c, (const T*)c->d_Phi, nullptr, c->d_y, c->d_xp1, fuse ? "gram_fused" : "gram", fuse ? (const T*)c->d_Z : nullptr);
+        if (!use64)
+            gram_to(c, (const T*)c->d_Phi, nullptr, c->d_y, c->d_xp1, fuse ? "gram_fused" : "gram", fuse ? (const T*)c->d_Z : nullptr);
+        c->last_used64 = use64 || sizeof(T) == 8; c->last_level = sizeof(T) == 8 ? 0 : c->level();
         HIPCHK(c, hipMemcpyAsync(c->d_xp1 + c->n_pk + g.Kp, c->d_yy, sizeof(double), hipMemcpyDeviceToDevice, c->st));
         HIPCHK(c, hipGetLastError());
         return SCFGP_OK;
@@ -408,27 +491,42 @@ template <typename T> struct Impl {
     static int factor(scfgp_ctx* c) {
         const Geom& g = c->g;
         { ProfScope ps(c, "kstage_factor"); unpack_exchange(c, c->d_xp1, c->d_x1); kstage_factor(c->kstage(), c->d_sc, c->st); }
-        SK::convert(c->d_B, (T*)c->d_BT, g.K, g.Kp, c->st);
+        if (c->last_cform) {                                   // factor form: the typed operands are Li (in B's place) and Li^T (scratch)
+            SK::convert(c->d_Li, (T*)c->d_BT, g.K, g.Kp, c->st);
+            SK::convert_transposed(c->d_Li, (T*)c->d_AbarT, g.K, g.Kp, c->st);
+        } else
+            SK::convert(c->d_B, (T*)c->d_BT, g.K, g.Kp, c->st);
         HIPCHK(c, hipGetLastError());
         return SCFGP_OK;
     }
     static int pass2(scfgp_ctx* c, int want_grad) {
         const Geom& g = c->g;
-        { ProfScope ps(c, "apply_v"); const Bf3Planes pl = c->planes();
-          SK::apply_v(g, (const T*)c->d_Phi, BT(c), (T*)c->d_V, c->d_vpart, c->alpha(), c->d_mu, c->st, c->bf3, &pl); }
+        if (c->last_cform) {
+            Bf3Planes pl; pl.dma = c->planes().dma;
+            { ProfScope ps(c, "apply_c");
+              SK::apply_c(g, (const T*)c->d_Phi, (const T*)c->d_AbarT, (const T*)c->d_BT, (T*)c->d_C, c->d_vpart, c->alpha(), c->d_mu, c->st, &pl); }
+            { ProfScope ps(c, "apply_vc");
+              SK::apply_vc(g, (const T*)c->d_C, (const T*)c->d_BT, (const T*)c->d_AbarT, (T*)c->d_V, c->st, &pl); }
+        } else {
+            ProfScope ps(c, "apply_v"); const Bf3Planes pl = c->planes();
+            SK::apply_v(g, (const T*)c->d_Phi, BT(c), (T*)c->d_V, c->d_vpart, c->alpha(), c->d_mu, c->st, c->bf3, &pl);
+        }
         const int nb = (int)std::min<int64_t>(g.Np / 4, 2048);
         { ProfScope ps(c, "rowstats");
           SK::rowstats(g, c->d_mu, c->d_vpart, c->d_y, c->d_sc, c->d_p, c->d_q, c->d_partial, nb, c->st);
           reduce_scalars(c->d_partial, nb, 2, c->d_xp2 + c->n_pk + g.Kp, 0, c->st); }
         if (want_grad) {
-            gram_to(c, (const T*)c->d_V, c->d_q, c->d_p, c->d_xp2, "gram_w");      // V^T diag(q) V = B W B, V^T p = B Phi^T p
+            // factor form: C^T diag(q) C and C^T p (the K x K stage turns them into B W B and u); else V^T diag(q) V = B W B, V^T p = u
+            gram_to(c, c->last_cform ? (const T*)c->d_C : (const T*)c->d_V, c->d_q, c->d_p, c->d_xp2, "gram_w");
         }
         HIPCHK(c, hipGetLastError());
         return SCFGP_OK;
     }
     static int adjoint(scfgp_ctx* c) {
         const Geom& g = c->g;
-        { ProfScope ps(c, "kstage_adjoint"); unpack_exchange(c, c->d_xp2, c->d_x2); kstage_adjoint(c->kstage(), c->d_x2, c->d_Abar, c->d_sc, c->st); }
+        { ProfScope ps(c, "kstage_adjoint"); unpack_exchange(c, c->d_xp2, c->d_x2);
+          if (c->last_cform) kstage_adjoint_factor_form(c->kstage(), c->d_x2, c->d_Abar, c->d_sc, c->st);
+          else kstage_adjoint(c->kstage(), c->d_x2, c->d_Abar, c->d_sc, c->st); }
         SK::convert(c->d_Abar, (T*)c->d_AbarT, g.K, g.Kp, c->st);
         HIPCHK(c, hipGetLastError());
         return SCFGP_OK;
@@ -562,6 +660,41 @@ static void enqueue_epilogue(scfgp_ctx* c, int want_grad) {
                   c->Nglobal, c->d_grad, want_grad, c->st);
 }
 
+// Automatic precision level for the NEXT evaluation from the condition estimate of the one just finished (and, when that
+// one ran below the level its own estimate asks for, SCFGP_REDO).  A Cholesky that failed on the fp32 Gram is retried on
+// the fp64 one before it is reported.
+static int update_level(scfgp_ctx* c, bool notpd, bool want_grad, bool may_redo = true) {
+    if (c->dtype != SCFGP_F32 || c->gram64 != 2) return SCFGP_OK;
+    const double est = c->cond_est();
+    const int want = notpd || !std::isfinite(est) ? 2 : c->want_level(est, 1.0);
+    if (want > c->esc_level) c->esc_level = want;
+    // level 2 only serves the gradient: a forward-only evaluation at level 1 is final
+    if (may_redo && (want_grad ? want : std::min(want, 1)) > c->last_level) {
+        if (c->gexec) { hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
+        if (c->graph) { hipGraphDestroy(c->graph); c->graph = nullptr; }
+        c->warm = false;
+        if (int rc = ensure_aux_rows(c)) return rc;
+        if (notpd) HIPCHK(c, hipMemsetAsync(c->d_flag, 0, sizeof(int) * 4, c->st));
+        return SCFGP_REDO;
+    }
+    if ((c->use64() && c->phi64_cap < c->g.Np) || (c->want_cform() && c->c_cap < c->g.Np)) {   // level raised without a repeat (scfgp_train, forward-only)
+        if (c->gexec) { hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
+        if (c->graph) { hipGraphDestroy(c->graph); c->graph = nullptr; }
+        c->warm = false;
+        if (int rc = ensure_aux_rows(c)) return rc;
+    }
+    if (!notpd) {
+        const int keep = c->want_level(est, 0.25);             // hysteresis: drop only well below the threshold
+        if (keep < c->esc_level) {
+            c->esc_level = keep;
+            if (c->gexec) { hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
+            if (c->graph) { hipGraphDestroy(c->graph); c->graph = nullptr; }
+            c->warm = false;
+        }
+    }
+    return SCFGP_OK;
+}
+
 extern "C" int scfgp_finish(scfgp_ctx* c, int want_grad, double* cost, double* grad, double* alpha, double* Li) {
     if (int rc = ready(c)) return rc;
     if ((want_grad && c->stage != 5) || (!want_grad && c->stage != 3)) { c->err = "finish: evaluation incomplete"; return SCFGP_EARG; }
@@ -571,6 +704,7 @@ extern "C" int scfgp_finish(scfgp_ctx* c, int want_grad, double* cost, double* g
     {
         ProfScope ps(c, "d2h");
         HIPCHK(c, hipMemcpyAsync(&h_cost, c->d_scalars + R_COST, sizeof(double), hipMemcpyDeviceToHost, c->st));
+        HIPCHK(c, hipMemcpyAsync(c->cond, c->d_scalars + R_LMIN2, sizeof(double) * 3, hipMemcpyDeviceToHost, c->st));
         HIPCHK(c, hipMemcpyAsync(h_flag, c->d_flag, sizeof(int) * 4, hipMemcpyDeviceToHost, c->st));
         if (want_grad && grad) HIPCHK(c, hipMemcpyAsync(grad, c->d_grad, sizeof(double) * g.P, hipMemcpyDeviceToHost, c->st));
         if (alpha) HIPCHK(c, hipMemcpyAsync(alpha, c->alpha(), sizeof(double) * g.K, hipMemcpyDeviceToHost, c->st));
@@ -581,6 +715,8 @@ extern "C" int scfgp_finish(scfgp_ctx* c, int want_grad, double* cost, double* g
     HIPCHK(c, hipGetLastError());
     c->stage = 0; c->warm = true;
     if (cost) *cost = h_cost;
+    if (int rc = update_level(c, h_flag[0] != 0, want_grad != 0)) return rc;    // SCFGP_REDO: repeat the evaluation at the higher level
+    c->cond_valid = true;
     if (h_flag[0]) { c->err = "Phi^T Phi + (e^{2a}+1e-6) I is not positive definite"; return SCFGP_ENOTPD; }
     if (!std::isfinite(h_cost)) { c->err = "non-finite cost"; return SCFGP_ENONFINITE; }
     return SCFGP_OK;
@@ -593,17 +729,21 @@ static int pass1_current(scfgp_ctx* c) {                  // pass 1 on the worki
     c->stage = 1; return SCFGP_OK;
 }
 static int run_eval(scfgp_ctx* c, int want_grad, double* cost, double* grad, double* alpha, double* Li, bool subset = false) {
-    int rc;
-    if ((rc = subset ? pass1_current(c) : scfgp_pass1(c))) return rc;
-    if ((rc = scfgp_factor(c))) return rc;
-    if ((rc = scfgp_pass2(c, want_grad))) return rc;
-    if (want_grad) {
-        if ((rc = scfgp_adjoint(c))) return rc;
-        if ((rc = scfgp_pass3(c))) return rc;
+    int rc = SCFGP_OK;
+    for (int attempt = 0; attempt < 3; ++attempt) {              // at most two escalations (levels 0 -> 1 -> 2)
+        if ((rc = subset ? pass1_current(c) : scfgp_pass1(c))) return rc;
+        if ((rc = scfgp_factor(c))) return rc;
+        if ((rc = scfgp_pass2(c, want_grad))) return rc;
+        if (want_grad) {
+            if ((rc = scfgp_adjoint(c))) return rc;
+            if ((rc = scfgp_pass3(c))) return rc;
+        }
+        // everything is queued: the factor outputs now stream to the host beside passes 2 and 3
+        if ((alpha || Li) && (rc = scfgp_fetch_factors(c, alpha, Li))) return rc;
+        rc = scfgp_finish(c, want_grad, cost, grad, nullptr, nullptr);
+        if (rc != SCFGP_REDO) return rc;
     }
-    // everything is queued: the factor outputs now stream to the host beside passes 2 and 3
-    if ((alpha || Li) && (rc = scfgp_fetch_factors(c, alpha, Li))) return rc;
-    return scfgp_finish(c, want_grad, cost, grad, nullptr, nullptr);
+    return rc;
 }
 
 extern "C" int scfgp_eval(scfgp_ctx* c, const double* X, const double* y, int64_t N, int want_grad,
@@ -826,6 +966,18 @@ extern "C" int scfgp_train(scfgp_ctx* c, int n_iters, double* cost_hist, double*
         if (c->gexec) { hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
         if (c->graph) { hipGraphDestroy(c->graph); c->graph = nullptr; }
     }
+    // auto precision level, condition of the current parameters unknown (no evaluation since they or the rows were set):
+    // one pass 1 + factor stage as a probe, so that the iterations of this call run at the level their first one needs
+    if (c->dtype == SCFGP_F32 && c->gram64 == 2 && !c->cond_valid) {
+        int rc;
+        if ((rc = DISPATCH(c, pass1, c))) return rc;
+        if ((rc = DISPATCH(c, factor, c))) return rc;
+        int h_flag[4] = {0, 0, 0, 0};
+        HIPCHK(c, hipMemcpyAsync(c->cond, c->d_scalars + R_LMIN2, sizeof(double) * 3, hipMemcpyDeviceToHost, c->st));
+        HIPCHK(c, hipMemcpyAsync(h_flag, c->d_flag, sizeof(int) * 4, hipMemcpyDeviceToHost, c->st));
+        HIPCHK(c, hipStreamSynchronize(c->st));
+        if ((rc = update_level(c, h_flag[0] != 0, true, false))) return rc;
+    }
     HIPCHK(c, hipMemsetAsync(c->d_flag, 0, sizeof(int) * 4, c->st));
     HIPCHK(c, hipMemsetAsync(c->d_tctr + 1, 0, sizeof(double), c->st));
     c->in_train = true;
@@ -869,9 +1021,13 @@ extern "C" int scfgp_train(scfgp_ctx* c, int n_iters, double* cost_hist, double*
     if (alpha) HIPCHK(c, hipMemcpyAsync(alpha, c->alpha(), sizeof(double) * g.K, hipMemcpyDeviceToHost, c->st));
     if (Li) HIPCHK(c, hipMemcpy2DAsync(Li, sizeof(double) * g.K, c->d_Li, sizeof(double) * g.Kp, sizeof(double) * g.K, g.K,
                                        hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipMemcpyAsync(c->cond, c->d_scalars + R_LMIN2, sizeof(double) * 3, hipMemcpyDeviceToHost, c->st));
     HIPCHK(c, hipStreamSynchronize(c->st));
     HIPCHK(c, hipGetLastError());
     c->stage = 0;
+    // the precision level is fixed inside one call; the last iteration's condition estimate sets it for the next call
+    if (int rc = update_level(c, h_flag[0] != 0, true, false)) return rc;
+    c->cond_valid = true;
     if (h_flag[0]) { c->err = "Phi^T Phi + (e^{2a}+1e-6) I is not positive definite"; return SCFGP_ENOTPD; }
     if (cost_hist) for (int i = 0; i < n_iters; ++i) if (!std::isfinite(cost_hist[i])) { c->err = "non-finite cost"; return SCFGP_ENONFINITE; }
     return SCFGP_OK;
@@ -944,8 +1100,32 @@ extern "C" int scfgp_set_option(scfgp_ctx* c, const char* name, int64_t value) {
     else if (s == "gram_chunk") c->gram_chunk = value;
     else if (s == "xtz_nsplit") c->xtz_nsplit = (int)value;
     else if (s == "use_graph") c->use_graph = (int)value;
+    else if (s == "gram64") { if (value < 0 || value > 3) { c->err = "gram64: 0 never, 1 always level 1, 2 auto, 3 always level 2"; return SCFGP_EARG; }
+                              c->gram64 = (int)value; c->esc_level = 0; }
+    else if (s == "factor_form") { if (value < -1 || value > 1) { c->err = "factor_form: -1 auto, 0 never, 1 always"; return SCFGP_EARG; } c->factor_form = (int)value; }
+    else if (s == "cond_threshold") c->esc_thr = (double)value;
+    else if (s == "cond_threshold_w") c->escw_thr = (double)value;
+    else if (s == "roctx") c->roctx_on = value != 0;
     else { c->err = "unknown option " + s; return SCFGP_EARG; }
+    // kernels not run so far, buffers not allocated so far: the next scfgp_train starts with an eager iteration again
+    c->warm = false; c->cond_valid = false;
+    if (c->gexec) { hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
+    if (c->graph) { hipGraphDestroy(c->graph); c->graph = nullptr; }
     if (c->have_data) return ensure_rows(c, c->g.N);
+    return SCFGP_OK;
+}
+
+// out[0] condition estimate of A = Phi^T Phi + lam I from the last finished evaluation: max_i L_ii^2 * max_j (A^-1)_jj, a
+//        LOWER bound of cond_2(A) (>= the diagonal ratio max L_ii^2 / min L_ii^2)
+// out[1] precision level that evaluation ran at (0, 1, 2: see scfgp_ctx; fp64 mode reports 0)
+// out[2] 1 if its G and Phi^T y were formed in fp64 from fp64 features (always in fp64 mode), else 0
+// out[3] predicted relative error of alpha / Li had the Gram been formed in fp32: SCFGP_ERR_PER_COND * out[0]
+// out[4] threshold of level 1, out[5] threshold of level 2 (auto policy), out[6] min L_ii^2, out[7] max L_ii^2, out[8] max_j (A^-1)_jj
+extern "C" int scfgp_get_condition(scfgp_ctx* c, double* out, int n) {
+    if (!c || !out || n < 4) return SCFGP_EARG;
+    const double v[9] = {c->cond_est(), (double)c->last_level, c->last_used64 ? 1.0 : 0.0, SCFGP_ERR_PER_COND * c->cond_est(),
+                         c->esc_thr, c->escw_thr, c->cond[0], c->cond[1], c->cond[2]};
+    for (int i = 0; i < n && i < 9; ++i) out[i] = v[i];
     return SCFGP_OK;
 }
 

@@ -37,7 +37,9 @@ class HipEngine(object):
         rc = self.lib.scfgp_create(C.byref(self.ctx), self.D, self.S, self.M, self.dtype, int(device),
                                    C.c_void_p(stream) if stream else None)
         if rc != 0:
+            # a failed create still hands back the half-built context (for its error message): it must be destroyed
             msg = self.lib.scfgp_last_error(self.ctx).decode() if self.ctx else ''
+            self.close()
             raise RuntimeError('scfgp_create failed (%d): %s' % (rc, msg))
         self.N = 0
         self.n_global = 0
@@ -224,6 +226,9 @@ class HipEngine(object):
         self._check(self.lib.scfgp_pass3(self.ctx), 'pass3')
 
     def finish(self, want_grad=True):
+        """(cost, grad, alpha, Li) -- or None when the library asks for the stages to be run again at the precision level
+        it has just raised (SCFGP_REDO, include/scfgp_hip.h: the condition estimate of this evaluation was too high
+        for the level it ran at)."""
         cost, grad, alpha, Li = self._outputs(want_grad)
         early = getattr(self, '_early', None)
         if early is not None:
@@ -232,6 +237,8 @@ class HipEngine(object):
         else:
             rc = self.lib.scfgp_finish(self.ctx, int(bool(want_grad)), dptr(cost), dptr(grad), dptr(alpha), dptr(Li))
         self._early = None
+        if rc == _lib.SCFGP_REDO:
+            return None
         self._check(rc, 'finish')
         return cost.reshape(()), grad, alpha, Li
 
@@ -284,6 +291,14 @@ class HipEngine(object):
         out = (C.c_int64 * 7)()
         self._check(self.lib.scfgp_get_dims(self.ctx, out, 7), 'get_dims')
         return dict(zip(('K', 'Kp', 'Jp', 'Dp', 'Np', 'P', 'tile'), [int(v) for v in out]))
+
+    CONDITION = ('cond_est', 'level', 'gram_fp64', 'alpha_err_fp32', 'threshold', 'threshold_w', 'Lmin2', 'Lmax2', 'Bmax')
+
+    def condition(self):
+        """Condition estimate of A and the precision level of the last finished evaluation (scfgp_get_condition)."""
+        out = np.zeros(len(self.CONDITION))
+        self._check(self.lib.scfgp_get_condition(self.ctx, dptr(out), out.size), 'get_condition')
+        return dict(zip(self.CONDITION, out.tolist()))
 
     def set_profiling(self, on=True):
         self._check(self.lib.scfgp_set_profiling(self.ctx, int(bool(on))), 'set_profiling')

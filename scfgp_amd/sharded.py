@@ -81,12 +81,18 @@ class ShardedEvaluator(object):
 
     def eval(self, want_grad=True):
         e = self.engine
-        e.pass1(); self._sum(1)
-        e.factor()
-        e.pass2(want_grad); self._sum(2)
-        if want_grad:
-            e.adjoint()
-            e.pass3(); self._sum(3)
-        if hasattr(e, 'fetch_factors'):
-            e.fetch_factors()               # everything is queued: alpha / Li reach the host beside the remaining sweeps
-        return e.finish(want_grad)
+        for _ in range(3):
+            e.pass1(); self._sum(1)
+            e.factor()
+            e.pass2(want_grad); self._sum(2)
+            if want_grad:
+                e.adjoint()
+                e.pass3(); self._sum(3)
+            if hasattr(e, 'fetch_factors'):
+                e.fetch_factors()           # everything is queued: alpha / Li reach the host beside the remaining sweeps
+            out = e.finish(want_grad)
+            # None: the library raised its precision level (condition estimate of A too high for an fp32 Gram) and wants
+            # the stages again.  Every rank factors the same summed matrix, so every rank takes the same decision.
+            if out is not None:
+                return out
+        raise RuntimeError('precision escalation did not settle')

@@ -416,7 +416,8 @@ def test_facade_fit_predict_save_load(tmp_path):
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('algo,kw', [('adam', {'learning_rate': 0.02, 'beta1': 0.9, 'beta2': 0.999, 'epsilon': 1e-8}),
                                       ('adamax', {'learning_rate': 0.02}), ('sgd', {'learning_rate': 1e-3}),
-                                      ('adagrad', {'learning_rate': 0.05}), ('adadelta', {'learning_rate': 1.0})])
+                                      ('adagrad', {'learning_rate': 0.05}), ('adadelta', {'learning_rate': 1.0}),
+                                      ('rmsprop', {'learning_rate': 0.01, 'rho': 0.9, 'epsilon': 1e-6})])
 def test_device_optimizer_matches_host_rules(algo, kw):
     """n iterations with the update rule on the device (one hipGraph launch per iteration) follow the
     host-side rule (the reference's Optimizer arithmetic incl. its Nesterov placement) step for step."""

@@ -237,6 +237,7 @@ def test_gram_row_splits_uniform_and_tapered_give_the_same_gram(dtype, tol):
     c0, gr0, a0, L0 = O.value_and_grad(X, y, params, S, M)
     for nsplit, taper in ((0, 1), (1, 0), (3, 1), (16, 1), (16, 0), (40, 1), (40, 2), (48, 3)):
         eng = HipEngine(D, S, M, dtype=dtype); eng.set_params(params)
+        eng.set_option('gram64', 0)                              # the fp32 product itself is under test
         eng.set_option('gram_nsplit', nsplit); eng.set_option('gram_taper', taper)
         eng.set_data(X, y)
         eng.pass1()
