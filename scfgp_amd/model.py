@@ -84,10 +84,11 @@ class SCFGP(object):
         self.params = Shared(np.concatenate([a, b, c, l_f, r_f, l_p, p]))
 
     # -- "compilation" ------------------------------------------------------------------------
-    def build_hip_models(self, algo, algo_params):
+    def build_hip_models(self, algo, algo_params, momentum=0.9):
         """Counterpart of build_theano_models (SCFGP/SCFGP.py:92-148): creates the GPU context
-        and optimiser state bound to self.params; no symbolic build, no C compile."""
-        self._compiled = CompiledFuncs(self.D, self.S, self.M, self.params, algo, algo_params,
+        and optimiser state bound to self.params; no symbolic build, no C compile.  momentum: the Nesterov
+        momentum the reference hard-codes at SCFGP/SCFGP.py:131 (negative: none)."""
+        self._compiled = CompiledFuncs(self.D, self.S, self.M, self.params, algo, algo_params, momentum=momentum,
                                        dtype=self.dtype, device=self.device,
                                        device_optimizer=self.device_optimizer)
         self.train_func, self.train_iter_func, self.pred_func = self._compiled.triple()
@@ -272,7 +273,8 @@ class SCFGP(object):
         if isinstance(owner, CompiledFuncs):
             cf = owner                                     # a reused triple owns the state that is being trained
         if cf is not None:
-            opt = {'opt_algo': cf.algo, 'opt_kwargs': json.dumps(cf.algo_params, sort_keys=True),
+            plain = {k: (v.item() if isinstance(v, np.generic) else v) for k, v in cf.algo_params.items()}   # np.float32(0.01) etc.
+            opt = {'opt_algo': cf.algo, 'opt_kwargs': json.dumps(plain, sort_keys=True),
                    'opt_momentum': float(cf.momentum), 'opt_device': bool(cf.device_optimizer), 'dtype': str(cf.dtype)}
             for i, a in enumerate(cf.get_opt_state()):
                 opt['opt_state_%d' % i] = a
@@ -282,7 +284,7 @@ class SCFGP(object):
 
     def load(self, path):
         import json
-        algo, kwargs, opt_state = 'adam', dict(_ADAM_DEFAULTS), None
+        algo, kwargs, opt_state, momentum = 'adam', dict(_ADAM_DEFAULTS), None, 0.9
         with np.load(path, allow_pickle=False) as z:
             self.ID = str(z['ID']); self.S = int(z['S']); self.M = int(z['M']); self.D = int(z['D'])
             self.params = Shared(z['params'])
@@ -301,10 +303,11 @@ class SCFGP(object):
             if 'opt_algo' in z.files:                       # checkpoints written before the optimiser was saved lack these
                 algo, kwargs = str(z['opt_algo']), json.loads(str(z['opt_kwargs']))
                 self.device_optimizer = bool(z['opt_device']); self.dtype = str(z['dtype'])
+                momentum = float(z['opt_momentum']) if 'opt_momentum' in z.files else 0.9
                 n = len([k for k in z.files if k.startswith('opt_state_')])
                 opt_state = [z['opt_state_%d' % i] for i in range(n)]
         self.NAME = "SCFGP (Sparsity=%d, Fourier Features=%d)" % (self.S, self.M)
-        self.build_hip_models(algo, kwargs)
+        self.build_hip_models(algo, kwargs, momentum)
         if opt_state is not None:
             self._compiled.set_opt_state(opt_state)
 

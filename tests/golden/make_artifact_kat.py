@@ -16,6 +16,8 @@ Fixture contents (float64):
   Li, alpha Theano-computed outputs stored by the reference
   cost      evals['COST'][1][-1] recorded by optimize() (SCFGP/SCFGP.py:265-266)
   S, M, D
+  Xraw, yraw           the raw rows of that split (scikit-learn's Boston table)
+  xs_*, ys_*, *_algo   the fitted X / y scaler dictionaries stored in the pickle (SCFGP/Scaler.py:23-24,39-97)
 """
 import collections
 import os
@@ -23,7 +25,6 @@ import pickle
 import sys
 
 import numpy as np
-from scipy.stats import norm
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, '..', '..'))
@@ -73,15 +74,14 @@ def _walk_arrays(obj, out, seen):
         _walk_arrays(obj.__dict__, out, seen)
 
 
-def _forward_scale(Xraw, data, inv_normal):
-    """Scaler.forward_transform for the two 'auto-*' modes (SCFGP/Scaler.py:107-116)."""
-    tX = Xraw[:, data['cols']]
-    tX = (tX - data['min']) / (data['max'] - data['min'])
-    lm = data['boxcox'][None, :]
-    bc = (np.sign(tX) * np.abs(tX) ** lm - 1) / lm
-    if inv_normal:
-        return norm.cdf(bc, data['mu'], data['std'])
-    return (bc - data['mu']) / data['std']
+def _artifact_scaler(state):
+    """The product's own host Scaler (scfgp_amd/scaler.py) carrying the FITTED dictionary of the reference's pickled Scaler
+    (SCFGP/Scaler.py:23-24: `algo`, `data` with cols/min/max/boxcox/mu/std): what reproduces Theano's Li / alpha / COST below is
+    therefore scaler.py's forward_transform itself, not a private restatement."""
+    from scfgp_amd.scaler import Scaler
+    sc = Scaler(str(state['algo']))
+    sc.data = {k: ([int(c) for c in v] if k == 'cols' else np.asarray(v, np.float64)) for k, v in state['data'].items()}
+    return sc
 
 
 def main():
@@ -101,8 +101,10 @@ def main():
 
     raw = np.loadtxt(CSV, delimiter=',', skiprows=2)
     Xraw, yraw = raw[:, :13], raw[:, 13:14]
-    Xs = _forward_scale(Xraw, xs['data'], True)
-    ysc = _forward_scale(yraw, ys['data'], False)
+    x_scaler, y_scaler = _artifact_scaler(xs), _artifact_scaler(ys)
+    assert x_scaler.algo == 'auto-inv-normal' and y_scaler.algo == 'auto-normal'
+    Xs = x_scaler.forward_transform(Xraw)
+    ysc = y_scaler.forward_transform(yraw)
 
     best = None
     for params in cands:
@@ -127,8 +129,15 @@ def main():
     print('rows', len(tr), 'split deviation', dev)
     print('oracle vs artifact: Li %.2e alpha %.2e cost %.2e' % (
         rel(Li_o, Li), rel(al, alpha), abs(cost - cost_rec) / abs(cost_rec)))
+    # the fitted scaler dictionaries (numbers from the pickle) and the raw rows of the split (scikit-learn's Boston table, not
+    # part of the reference): tests/test_oracle_golden.py drives scfgp_amd/scaler.py with them and must land on X, y above
+    sc = {}
+    for tag, sd in (('xs', x_scaler), ('ys', y_scaler)):
+        for k, v in sd.data.items():
+            sc['%s_%s' % (tag, k)] = np.asarray(v)
     np.savez_compressed(os.path.join(HERE, 'artifact_kat.npz'), X=X, y=y, params=params,
-                        Li=Li, alpha=alpha, cost=cost_rec, S=S, M=M, D=D, train_rows=tr)
+                        Li=Li, alpha=alpha, cost=cost_rec, S=S, M=M, D=D, train_rows=tr,
+                        Xraw=Xraw[tr], yraw=yraw[tr], xs_algo=x_scaler.algo, ys_algo=y_scaler.algo, **sc)
 
 
 if __name__ == '__main__':

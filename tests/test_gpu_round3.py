@@ -259,3 +259,37 @@ def test_factor_form_of_pass2_matches_oracle(dtype, dma, ctol, gtol):
             c2, g2, _, _ = eng.eval()
             assert float(c2) == float(c) and np.array_equal(g2, g)
             eng.close()
+
+
+def test_checkpoint_keeps_a_non_default_momentum_and_numpy_scalar_kwargs(tmp_path):
+    """save() wrote opt_momentum but load() ignored it, and numpy-scalar keyword arguments broke json.dumps.
+    A triple built with momentum 0.5 and learning_rate = np.float32(0.02): 3 iterations + save + load + 3 == 6."""
+    import os
+    from scfgp_amd import SCFGP
+    rng = np.random.default_rng(31)
+    X = rng.uniform(-2, 2, (200, 3))
+    y = np.sin(X[:, :1]) + 0.3 * X[:, 1:2] + 0.05 * rng.standard_normal((200, 1))
+    kw = {'learning_rate': np.float32(0.02), 'beta2': np.float64(0.999)}
+
+    def fresh():
+        np.random.seed(5)
+        m = SCFGP(sparsity=3, nfeats=8)
+        m.set_data(X, y)
+        m.build_hip_models('adam', kw, momentum=0.5)
+        return m
+
+    def iters(m, n):
+        for _ in range(n):
+            c, a, L = m.train_iter_func(m.X, m.y)
+        m.alpha, m.Li = a, L
+
+    full = fresh(); iters(full, 6)
+    first = fresh(); iters(first, 3)
+    path = os.path.join(str(tmp_path), 'mom.npz')
+    first.save(path)
+    second = SCFGP(sparsity=1, nfeats=1); second.set_data(X, y); second.load(path)
+    assert second._compiled.momentum == 0.5 and abs(second._compiled.algo_params['learning_rate'] - 0.02) < 1e-8
+    iters(second, 3)
+    assert np.array_equal(second.params.get_value(), full.params.get_value())
+    default = fresh(); default.build_hip_models('adam', kw); iters(default, 6)
+    assert not np.array_equal(default.params.get_value(), full.params.get_value())     # the momentum does matter

@@ -131,8 +131,9 @@ def test_synth_is_counter_based():
 
 
 def test_residency_fingerprint_sees_every_element():
-    """Arrays up to 2^24 elements are hashed completely: any in-place edit changes the fingerprint; above that
-    the sample + writeable flag + version token are the key."""
+    """Writeable arrays are hashed completely at EVERY size (an in-place edit of one element of a 1e6 x 64 array
+    must change the fingerprint); only read-only arrays, or arrays under a caller-maintained version token, are sampled, and
+    two read-only arrays at unchanged addresses are not hashed at all."""
     from scfgp_amd import funcs
     rng = np.random.default_rng(0)
     X = rng.random((5000, 7)); y = rng.random((5000, 1))
@@ -143,21 +144,22 @@ def test_residency_fingerprint_sees_every_element():
     assert f1 != f0
     y[17, 0] += 1e-13
     assert funcs._fingerprint(X, y) != f1
-    big = rng.random((3 << 20,))                               # > 4 MiB: the threaded path
-    k0 = funcs._content_key(big)
-    big[(3 << 20) - 5] += 1e-9
-    assert funcs._content_key(big) != k0
-    old = funcs.FULL_HASH_ELEMS
-    funcs.FULL_HASH_ELEMS = 1024
-    try:
-        s0 = funcs._content_key(X)
-        assert s0[0] == 'sampled' and s0[1] is True
-        X.flags.writeable = False
-        assert funcs._content_key(X)[1] is False
-        X.flags.writeable = True
-        assert funcs._fingerprint(X, y, version=1) != funcs._fingerprint(X, y, version=2)
-    finally:
-        funcs.FULL_HASH_ELEMS = old
+    big = rng.random((1 << 24) + 12345)                        # above the old 2^24 sampling limit, threaded path
+    k0 = funcs._content_key(big, False)
+    assert k0[0] == 'full'
+    big[5 * 64 + 7] += 1e-9                                    # an element no sample block of the old scheme contained
+    assert funcs._content_key(big, False) != k0
+    s0 = funcs._content_key(big, True)                         # trusted: sampled
+    assert s0[0] == 'sampled'
+    Xb = rng.random((70000, 3)); yb = rng.random((70000, 1))
+    assert funcs._fingerprint(Xb, yb)[4][0] == 'full'
+    assert funcs._fingerprint(Xb, yb, version=1)[4][0] == 'sampled'
+    assert funcs._fingerprint(Xb, yb, version=1) != funcs._fingerprint(Xb, yb, version=2)
+    assert funcs._frozen_identity(Xb, yb, None) is None
+    Xb.flags.writeable = False; yb.flags.writeable = False
+    assert funcs._fingerprint(Xb, yb)[4][0] == 'sampled'
+    fid = funcs._frozen_identity(Xb, yb, None)
+    assert fid is not None and fid == funcs._frozen_identity(Xb, yb, None) and fid != funcs._frozen_identity(Xb[1:], yb[1:], None)
 
 
 def test_scaler_key_follows_contents_not_identity():

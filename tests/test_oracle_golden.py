@@ -86,3 +86,34 @@ def test_invariances():
     e.pass1(); e.factor(); e.pass2(True); e.adjoint(); e.pass3()
     c3, g3, al3, Li3 = e.finish(True)
     assert abs(c3 - c0) < 1e-12 * abs(c0) and rel(g3, g0) < 1e-10
+
+
+def test_host_scaler_is_pinned_by_the_artifacts_fitted_dictionaries():
+    """scfgp_amd/scaler.py (the comparator of every device-scaler test) fed with the FITTED dictionaries stored in the
+    reference's artifact lands on the scaled rows that reproduce Theano's Li / alpha / COST: pins forward_transform of
+    'auto-inv-normal' (X) and 'auto-normal' (y), SCFGP/Scaler.py:107-116; the backward transform (:126-135) must invert
+    it, and fit() on the same raw rows must find the same min / max and nearly the same Box-Cox exponents (:39-97)."""
+    from scfgp_amd.scaler import Scaler
+    z = np.load(os.path.join(GOLD, 'artifact_kat.npz'))
+
+    def scaler(tag):
+        sc = Scaler(str(z[tag + '_algo']))
+        sc.data = {k[3:]: ([int(c) for c in z[k]] if k.endswith('cols') else z[k]) for k in z.files
+                   if k.startswith(tag + '_') and not k.endswith('algo')}
+        return sc
+
+    xs, ys = scaler('xs'), scaler('ys')
+    assert xs.algo == 'auto-inv-normal' and ys.algo == 'auto-normal'
+    X = xs.forward_transform(z['Xraw']); y = ys.forward_transform(z['yraw'])
+    assert np.array_equal(X, z['X']) and np.array_equal(y, z['y'])
+    # ... and these rows, through the oracle, are the artifact's Theano outputs (same assertion as above, end to end)
+    cost, alpha, Li = O.forward(X, y, z['params'], int(z['S']), int(z['M']), True)
+    assert rel(Li, z['Li']) < 1e-12 and abs(cost - float(z['cost'])) < 1e-13 * abs(float(z['cost']))
+    assert rel(ys.backward_transform(y), z['yraw']) < 1e-13
+    assert rel(xs.backward_transform(X), z['Xraw'][:, xs.data['cols']]) < 1e-8      # column B: exponent 5 of values near the minimum
+    # the dictionaries are what fit() finds on these 400 rows: min / max exactly, exponents to the optimiser's tolerance
+    for tag, raw, ref in (('X', z['Xraw'], xs), ('y', z['yraw'], ys)):
+        f = Scaler(ref.algo); f.fit(raw)
+        assert f.data['cols'] == ref.data['cols']
+        assert np.array_equal(f.data['min'], ref.data['min']) and np.array_equal(f.data['max'], ref.data['max'])
+        assert np.allclose(f.data['boxcox'], ref.data['boxcox'], rtol=2e-2), (tag, f.data['boxcox'], ref.data['boxcox'])
