@@ -14,6 +14,11 @@ and exits with the child's code.  Under torchrun (the driver's launch) every ran
 one rank per GPU over RCCL, the N rows sharded over the ranks (strong scaling -- total work fixed, as
 the metric is quoted at fixed N), three all-reduces per evaluation.  Rank 0 prints ONE JSON line.
 
+Before the timed loop a ~100 ms BOX PROBE (scfgp_box_probe: register-only fp32 MFMA loop, sustained clock, streaming copy)
+is printed as `secondary.box`, so lines from different leases of the pool can be normalised.  With more than one rank the
+three sums over ranks are bracketed by events on the stream they run on: `stages_ms.exchange1..3`, `comm_share`, and
+`stages_ms_max_over_ranks` (one small all-reduce after the loop).
+
 In the default single-GPU run at config H the same process then also runs the fp64 engine (the
 reference's arithmetic, SCFGP/SCFGP.py:95-96,138) on the same rows: `secondary.f64` and the
 fp32-vs-fp64 `parity_at_size` block, and times the CPU restatements on a bounded sample (`cpu_baseline`).
@@ -147,6 +152,20 @@ def cpu_baseline(X, y, params, S, M, N_full, budget_rows):
                                "element-wise numpy on one) on the same %d rows: %.1f s" % (n, dt_np)}}
 
 
+def box_probe(device):
+    """What this device delivers: fp32 MFMA TFLOP/s of a register-only loop, the clock it held, streaming copy GB/s."""
+    import ctypes as C
+    from scfgp_amd import _lib
+    out = (C.c_double * 3)()
+    rc = _lib.load().scfgp_box_probe(int(device), out, 3)
+    if rc != 0:
+        return {"error": rc}
+    return {"mfma_f32_TFLOPs": out[0], "mfma_f32_frac_of_peak": out[0] / PEAK_TFLOPS['f32'], "mfma_clock_GHz": out[1],
+            "copy_GBs": out[2], "copy_frac_of_8TBs": out[2] / HBM_PEAK_GBS,
+            "what": "scfgp_box_probe before the timed loop: register-only v_mfma_f32_16x16x4_f32 loop on random operands "
+                    "(no memory traffic), shader clock held during it, 1 GiB -> 1 GiB streaming copy (read + write)"}
+
+
 def rel(a, b):
     return float(np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(np.asarray(b)), 1e-300))
 
@@ -182,6 +201,29 @@ def _parity(out, ref, eng, eng_ref, D, S, M, what):
             "alpha": rel(a, a64), "Li": rel(L, L64), "mu": rel(mu, mu64), "std": rel(sd, sd64)}
 
 
+def through_triple(X, y, params, D, S, M, local, n=3):
+    """One train_iter_func call of the reference-shaped triple (scfgp_amd/funcs.py: residency check of X and y, evaluation,
+    host update rule, parameter upload) -- what a user of SCFGP.optimize pays per iteration on top of `value`'s bare
+    evaluation.  Writeable arrays are hashed completely on every call; read-only ones are not hashed at all."""
+    from scfgp_amd.funcs import CompiledFuncs
+    cf = CompiledFuncs(D, S, M, params.copy(), 'adam', {'learning_rate': 1e-3}, dtype='f32', device=local)
+    res = {}
+    for tag, frozen in (('writeable_arrays', False), ('read_only_arrays', True)):
+        Xc, yc = X, y
+        if frozen:
+            Xc = X.view(); yc = y.view(); Xc.flags.writeable = False; yc.flags.writeable = False
+        cf.train_iter_func(Xc, yc)                                  # upload + first touch
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            cf.train_iter_func(Xc, yc)
+            ts.append(time.perf_counter() - t0)
+        res[tag] = {"ms_per_call": float(np.median(ts)) * 1e3}
+    cf.engine.close()
+    res["note"] = "CompiledFuncs.train_iter_func (host adam + Nesterov), median of %d calls; never `value`" % n
+    return res
+
+
 def f64_leg_and_parity(X, y, params, D, S, M, local, f32_out, f32_eng, steps=5, warmup=2):
     """The reference's arithmetic is float64: run the fp64 engine on the SAME resident rows, time it, and report how far
     the fp32-mode outputs are from it at this size (relative, norm-wise; gradient per block).  Then the experimental
@@ -200,7 +242,7 @@ def f64_leg_and_parity(X, y, params, D, S, M, local, f32_out, f32_eng, steps=5, 
            "stages_ms": stages, "cost": float(ref[0])}
     base = "mode of this library on the same %d rows (fp64 mode equals the oracle to 1e-12 wherever the oracle is run: " \
            "tests/test_gpu_parity.py); relative, norm-wise" % N
-    parity = _parity(f32_out, ref, f32_eng, e64, D, S, M, "fp32 mode vs fp64 " + base)
+    parity = _parity(f32_out, ref, f32_eng, e64, D, S, M, "fp32 mode (precision level %d) vs fp64 " % int(f32_eng.condition()['level']) + base)
     eb = HipEngine(D, S, M, dtype='bf16x3', device=local)
     eb.set_params(params); eb.set_data(X, y, n_global=N)
     msb, stb, outb = _timed_leg(eb, steps, warmup)
@@ -212,8 +254,22 @@ def f64_leg_and_parity(X, y, params, D, S, M, local, f32_out, f32_eng, steps=5, 
            "stages_ms": stb, "cost": float(outb[0]),
            "parity_at_size": _parity(outb, ref, eb, e64, D, S, M, "bf16x3 mode vs fp64 " + base)}
     eb.close()
+    plain = None
+    if f32_eng.condition()['level'] > 0:
+        # the headline engine escalated its Gram products (ill-conditioned A): the same rows in PLAIN fp32 mode (option gram64 = 0),
+        # its rate and how far its outputs are from fp64 mode -- both modes in one line
+        ep = HipEngine(D, S, M, dtype='f32', device=local)
+        ep.set_option('gram64', 0)
+        ep.set_params(params); ep.set_data(X, y, n_global=N)
+        msp, stp, outp = _timed_leg(ep, steps, warmup)
+        cdp = ep.condition()
+        plain = {"what": "fp32 mode with the precision escalation switched off (option gram64 = 0): every product in fp32 MFMA",
+                 "evals_per_s": 1e3 / msp, "ms_per_step": msp, "steps": steps, "statistic": "median", "stages_ms": stp,
+                 "cost": float(outp[0]), "cond_est": cdp['cond_est'], "alpha_err_predicted": cdp['alpha_err_fp32'],
+                 "parity_at_size": _parity(outp, ref, ep, e64, D, S, M, "plain fp32 (gram64 = 0) vs fp64 " + base)}
+        ep.close()
     e64.close()
-    return sec, parity, bf3
+    return sec, parity, bf3, plain
 
 
 def main(a):
@@ -244,7 +300,8 @@ def main(a):
     X, y, params = build_problem(eng, N, D, S, M, lo, hi, allreduce)
     eng.set_params(params)
     eng.set_data(X, y, n_global=N)
-    ev = ShardedEvaluator(eng, allreduce)
+    ev = ShardedEvaluator(eng, allreduce, time_exchanges=use_dist)
+    box = box_probe(local) if rank == 0 else None
 
     def barrier():
         torch.cuda.synchronize()
@@ -264,12 +321,22 @@ def main(a):
         step_s.append(time.perf_counter() - t1)
         for name, ms in eng.timings():
             per_kernel.setdefault(name, []).append(ms)
+        for st_, ms in ev.exchange_ms().items():
+            per_kernel.setdefault('exchange%d' % st_, []).append(ms)
     barrier()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt, float(np.median(step_s))], device='cuda' if a.backend == 'nccl' else 'cpu', dtype=torch.float64)
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt, med_s = float(tmax[0].item()), float(tmax[1].item())
+    # slowest rank per stage: the same code path on every rank gives the same stage names in the same order
+    stage_names = sorted(per_kernel)
+    stage_max = None
+    if use_dist and world > 1:
+        smax = torch.tensor([float(np.median(per_kernel[k])) for k in stage_names], device=tmax.device, dtype=torch.float64)
+        dist.all_reduce(smax, op=dist.ReduceOp.MAX)
+        stage_max = dict(zip(stage_names, [float(v) for v in smax.tolist()]))
+    cond = eng.condition()
 
     if rank == 0:
         ms_step = dt / a.steps * 1e3
@@ -282,14 +349,16 @@ def main(a):
         peak = PEAK_TFLOPS[a.dtype]
         falg = 10.0 * N * K * K + 4.0 * N * D * J
         traffic, traffic_src, pmc = None, None, {}
-        tp = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')
+        tp = os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json')
+        if not os.path.exists(tp):
+            tp = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')
         if os.path.exists(tp) and not a.custom and world == 1:
             # HBM-side bytes per launch of the same kernels on the same workload, from rocprofv3 PMC passes
             # (FETCH_SIZE x2 + WRITE_SIZE, one counter per pass): they cannot be collected inside this process
             pmc = json.load(open(tp)).get(a.config + '_' + a.dtype, {})
             if 'apply_kernel_mean_GB_per_launch' in pmc:
                 traffic = pmc['apply_kernel_mean_GB_per_launch'] * 1e9
-                traffic_src = 'profiles/r02_pmc_traffic.json'
+                traffic_src = os.path.relpath(tp, ROOT)
         out = {
             "metric": "NLML+grad evals/sec", "value": a.steps / dt, "unit": "evals/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
@@ -310,7 +379,16 @@ def main(a):
             "stages_ms": {k: float(np.median(v)) for k, v in per_kernel.items()},
             "stages_statistic": "median over the timed steps",
             "cost": float(cost),
+            # conditioning of A and the precision level the evaluations ran at (include/scfgp_hip.h: scfgp_get_condition)
+            "condition": {"cond_est": cond['cond_est'], "precision_level": int(cond['level']), "gram_fp64": bool(cond['gram_fp64']),
+                          "alpha_err_if_plain_fp32": cond['alpha_err_fp32'], "thresholds": [cond['threshold'], cond['threshold_w']]},
         }
+        if world > 1:
+            ex = sum(float(np.median(per_kernel.get('exchange%d' % i, [0.0]))) for i in (1, 2, 3))
+            out["comm_share"] = ex / ms_step if ms_step > 0 else 0.0
+            out["comm_note"] = ("exchange1..3 in stages_ms: stream time of each sum over ranks, from the end of this rank's sweep to the "
+                                "summed buffer (transfer + wait for the slowest rank); comm_share = their sum / ms_per_step, rank 0")
+            out["stages_ms_max_over_ranks"] = stage_max
         # the two other figures the north star asks for: the feature map against the HBM roof (it writes Phi once:
         # rows x K x element size, SURVEY 8(d) kernel K3) and the Gram build against the MFMA peak (executed flops:
         # lower triangle in 64-column blocks, so about 1.06 x N K^2 rather than the algorithmic 2 N K^2)
@@ -332,6 +410,7 @@ def main(a):
         }
         for v in out["secondary"].values():
             v["frac"] = v["achieved"] / v["peak"]
+        out["secondary"]["box"] = box
         if world == 1 and not a.no_secondary:
             # the same evaluation when the caller hands over HOST arrays every call (what the reference's Theano functions
             # receive, SCFGP/SCFGP.py:237): upload of X, y over PCIe from pageable memory + packing + evaluation.  Never `value`.
@@ -346,8 +425,12 @@ def main(a):
         # the fp64 leg and the fp32-vs-fp64 parity block: at the headline shape and at the two other 1e6-row fp32 configs (C3's
         # D = 8 makes A ill-conditioned: that is where fp32 products cost the most accuracy, and the line says so)
         if world == 1 and a.config in ('H', 'C3', 'C5') and a.dtype == 'f32' and not a.custom and not a.no_secondary:
-            out["secondary"]["f64"], out["parity_at_size"], out["secondary"]["bf16x3"] = f64_leg_and_parity(
+            out["secondary"]["f64"], out["parity_at_size"], out["secondary"]["bf16x3"], plain = f64_leg_and_parity(
                 X, y, params, D, S, M, local, (cost, grad, alpha, Li), eng)
+            if plain is not None:
+                out["secondary"]["plain_fp32"] = plain
+        if world == 1 and not a.no_secondary and a.dtype == 'f32' and not a.custom:
+            out["secondary"]["through_triple"] = through_triple(X, y, params, D, S, M, local)
         if not a.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(X, y, params, S, M, N, a.cpu_rows)
         sys.stdout.flush()

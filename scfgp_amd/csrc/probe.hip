@@ -1,0 +1,92 @@
+// Box probe: what THIS device delivers on the two resources the hot path lives on, measured in ~100 ms so that two bench
+// lines taken on two leases of the pool can be normalised instead of argued about (boxes differ by several percent in
+// sustained MFMA clock and in memory bandwidth).  No reference counterpart; bench.py prints it as `secondary.box`.
+//   out[0] fp32 MFMA rate of a register-only loop (v_mfma_f32_16x16x4_f32, 8 independent accumulators per wave, one
+//          4-wave workgroup per SIMD set, 8 workgroups per CU), TFLOP/s
+//   out[1] shader clock held during that loop, GHz (s_memtime ticks per s_memrealtime tick of the 100 MHz constant clock,
+//          median over workgroups)
+//   out[2] streaming copy of 2 GiB (16 bytes per lane, read + write counted), GB/s
+#include "../../include/scfgp_hip.h"
+#include "common.h"
+
+#include <algorithm>
+#include <vector>
+
+__global__ __launch_bounds__(256) void probe_mfma_kernel(float* __restrict__ sink, unsigned long long* __restrict__ stamps, int iters) {
+    const int lane = threadIdx.x & 63;
+    v4f acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = v4f{0.f, 0.f, 0.f, 0.f};
+    // full-range pseudo-random operands, different for every lane and every MFMA of the 8: constant or trivial operands
+    // let the chip hold a higher clock than real data does (MI355X_MICROARCH.md, DVFS give-back)
+    float a[8], b[8];
+    unsigned h = (blockIdx.x * 256u + threadIdx.x) * 2654435761u + 12345u;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        h = h * 1664525u + 1013904223u; a[j] = (float)(int)(h >> 8) * (1.0f / 8388608.0f) - 1.0f;
+        h = h * 1664525u + 1013904223u; b[j] = (float)(int)(h >> 8) * (1.0f / 8388608.0f) - 1.0f;
+    }
+    (void)lane;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc[j], 0, 0, 0);
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3];
+    if (s == 123.456f) sink[0] = s;                               // never true: keeps the loop alive
+    if (threadIdx.x == 0) { stamps[2 * blockIdx.x] = c1 - c0; stamps[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
+__global__ __launch_bounds__(256) void probe_copy_kernel(const v4f* __restrict__ src, v4f* __restrict__ dst, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
+}
+
+extern "C" int scfgp_box_probe(int device, double* out, int n) {
+    if (!out || n < 3) return SCFGP_EARG;
+    if (hipSetDevice(device) != hipSuccess) return SCFGP_EHIP;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return SCFGP_EHIP;
+    const int ncu = prop.multiProcessorCount, nwg = ncu * 8, iters = 40000;
+    float* sink = nullptr; unsigned long long* stamps = nullptr; char* buf = nullptr;
+    const size_t half = (size_t)1 << 30;                          // 1 GiB in, 1 GiB out
+    hipEvent_t e0, e1;
+    int rc = SCFGP_OK;
+    if (hipMalloc((void**)&sink, 64) != hipSuccess || hipMalloc((void**)&stamps, sizeof(unsigned long long) * 2 * nwg) != hipSuccess ||
+        hipMalloc((void**)&buf, 2 * half) != hipSuccess || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+        rc = SCFGP_EHIP;
+    } else {
+        float ms = 0;
+        (void)hipMemset(buf, 1, 2 * half);
+        hipLaunchKernelGGL(probe_mfma_kernel, dim3(nwg), dim3(256), 0, 0, sink, stamps, 2000);      // warm-up
+        (void)hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(probe_mfma_kernel, dim3(nwg), dim3(256), 0, 0, sink, stamps, iters);
+        (void)hipEventRecord(e1, 0);
+        (void)hipEventSynchronize(e1);
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        out[0] = (double)nwg * 4 * iters * 8 * 2048.0 / (ms * 1e-3) / 1e12;
+        std::vector<unsigned long long> h(2 * nwg);
+        (void)hipMemcpy(h.data(), stamps, sizeof(unsigned long long) * 2 * nwg, hipMemcpyDeviceToHost);
+        std::vector<double> ghz(nwg);
+        for (int i = 0; i < nwg; ++i) ghz[i] = h[2 * i + 1] ? (double)h[2 * i] / (double)h[2 * i + 1] * 0.1 : 0.0;
+        std::nth_element(ghz.begin(), ghz.begin() + nwg / 2, ghz.end());
+        out[1] = ghz[nwg / 2];
+        double best = 0;
+        for (int rep = 0; rep < 4; ++rep) {
+            (void)hipEventRecord(e0, 0);
+            hipLaunchKernelGGL(probe_copy_kernel, dim3(ncu * 16), dim3(256), 0, 0, (const v4f*)buf, (v4f*)(buf + half), (int64_t)(half / 16));
+            (void)hipEventRecord(e1, 0);
+            (void)hipEventSynchronize(e1);
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            if (rep > 0) best = std::max(best, 2.0 * half / (ms * 1e-3) / 1e9);
+        }
+        out[2] = best;
+        if (hipGetLastError() != hipSuccess) rc = SCFGP_EHIP;
+    }
+    if (sink) (void)hipFree(sink);
+    if (stamps) (void)hipFree(stamps);
+    if (buf) (void)hipFree(buf);
+    return rc;
+}

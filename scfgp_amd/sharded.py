@@ -49,9 +49,15 @@ def shard_rows(N, rank, world):
 
 class ShardedEvaluator(object):
 
-    def __init__(self, engine, allreduce=None):
+    def __init__(self, engine, allreduce=None, time_exchanges=False):
         self.engine = engine
         self.allreduce = allreduce
+        # time_exchanges: bracket every sum over ranks with events on the stream it runs on (inside the two fences), so
+        # that a scaling record can say how much of a step the three exchanges -- transfer AND the wait for the slowest
+        # rank -- took (bench.py: stages_ms exchange1..3, comm_share); exchange_ms() reads them after the evaluation
+        self.time_exchanges = bool(time_exchanges)
+        self._ex_events = {}
+        self._ex_wall = {}
 
     def _sum(self, stage):
         """Sum exchange buffer `stage` over the ranks, in place.  The collective runs on torch's current stream,
@@ -64,9 +70,38 @@ class ShardedEvaluator(object):
         fenced = peer is not False and hasattr(e, 'stream_fence')
         if fenced:
             e.stream_fence(peer, 0)
-        self.allreduce(e.exchange(stage))
+        buf = e.exchange(stage)
+        timed = self.time_exchanges
+        if timed:
+            import time
+            if fenced:
+                import torch
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
+            t0 = time.perf_counter()
+        self.allreduce(buf)
+        if timed:
+            self._ex_wall[stage] = (time.perf_counter() - t0) * 1e3
+            if fenced:
+                ev[1].record()
+                self._ex_events[stage] = ev
         if fenced:
             e.stream_fence(peer, 1)
+
+    def exchange_ms(self):
+        """{stage: milliseconds} of the sums of the last evaluation: stream time between the two events that bracket the
+        collective (GPU side; it starts when the rank's own sweep is done and ends when the summed buffer is back, so it
+        contains the wait for the slowest rank), host wall time of the call where there is no GPU side.  Call after
+        finish() -- the events have completed by then."""
+        out = {}
+        for stage, ms in self._ex_wall.items():
+            ev = self._ex_events.get(stage)
+            if ev is not None:
+                ev[1].synchronize()
+                ms = ev[0].elapsed_time(ev[1])
+            out[stage] = float(ms)
+        self._ex_events.clear(); self._ex_wall.clear()
+        return out
 
     @staticmethod
     def _peer_stream():
