@@ -156,11 +156,12 @@ def box_probe(device):
     """What this device delivers: fp32 MFMA TFLOP/s of a register-only loop, the clock it held, streaming copy GB/s."""
     import ctypes as C
     from scfgp_amd import _lib
-    out = (C.c_double * 3)()
-    rc = _lib.load().scfgp_box_probe(int(device), out, 3)
+    out = (C.c_double * 6)()
+    rc = _lib.load().scfgp_box_probe(int(device), out, 6)
     if rc != 0:
         return {"error": rc}
     return {"mfma_f32_TFLOPs": out[0], "mfma_f32_frac_of_peak": out[0] / PEAK_TFLOPS['f32'], "mfma_clock_GHz": out[1],
+            "mfma_f32_TFLOPs_at_1_2_8_waves_per_simd": [out[3], out[4], out[5]],
             "copy_GBs": out[2], "copy_frac_of_8TBs": out[2] / HBM_PEAK_GBS,
             "what": "scfgp_box_probe before the timed loop: register-only v_mfma_f32_16x16x4_f32 loop on random operands "
                     "(no memory traffic), shader clock held during it, 1 GiB -> 1 GiB streaming copy (read + write)"}

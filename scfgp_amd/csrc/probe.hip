@@ -1,8 +1,8 @@
 // Box probe: what THIS device delivers on the two resources the hot path lives on, measured in ~100 ms so that two bench
 // lines taken on two leases of the pool can be normalised instead of argued about (boxes differ by several percent in
 // sustained MFMA clock and in memory bandwidth).  No reference counterpart; bench.py prints it as `secondary.box`.
-//   out[0] fp32 MFMA rate of a register-only loop (v_mfma_f32_16x16x4_f32, 8 independent accumulators per wave, one
-//          4-wave workgroup per SIMD set, 8 workgroups per CU), TFLOP/s
+//   out[0] fp32 MFMA rate of a register-only loop (v_mfma_f32_16x16x4_f32, 8 independent accumulators per wave; the best of
+//          1, 2 and 8 waves per SIMD, whose individual rates are out[3], out[4], out[5] when n >= 6), TFLOP/s
 //   out[1] shader clock held during that loop, GHz (s_memtime ticks per s_memrealtime tick of the 100 MHz constant clock,
 //          median over workgroups)
 //   out[2] streaming copy of 2 GiB (16 bytes per lane, read + write counted), GB/s
@@ -28,9 +28,9 @@ __global__ __launch_bounds__(256) void probe_mfma_kernel(float* __restrict__ sin
     }
     (void)lane;
     const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
-    for (int i = 0; i < iters; ++i) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc[j], 0, 0, 0);
+    for (int i = 0; i < iters; ++i) {                            // inline asm: the builtin form made hipcc shuffle accumulators
+#pragma unroll                                                   // between misaligned AGPR tuples inside the loop
+        for (int j = 0; j < 8; ++j) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[j]) : "v"(a[j]), "v"(b[j]));
     }
     const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     float s = 0;
@@ -49,7 +49,7 @@ extern "C" int scfgp_box_probe(int device, double* out, int n) {
     if (hipSetDevice(device) != hipSuccess) return SCFGP_EHIP;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return SCFGP_EHIP;
-    const int ncu = prop.multiProcessorCount, nwg = ncu * 8, iters = 40000;
+    const int ncu = prop.multiProcessorCount, nwg = ncu * 8;
     float* sink = nullptr; unsigned long long* stamps = nullptr; char* buf = nullptr;
     const size_t half = (size_t)1 << 30;                          // 1 GiB in, 1 GiB out
     hipEvent_t e0, e1;
@@ -61,18 +61,27 @@ extern "C" int scfgp_box_probe(int device, double* out, int n) {
         float ms = 0;
         (void)hipMemset(buf, 1, 2 * half);
         hipLaunchKernelGGL(probe_mfma_kernel, dim3(nwg), dim3(256), 0, 0, sink, stamps, 2000);      // warm-up
-        (void)hipEventRecord(e0, 0);
-        hipLaunchKernelGGL(probe_mfma_kernel, dim3(nwg), dim3(256), 0, 0, sink, stamps, iters);
-        (void)hipEventRecord(e1, 0);
-        (void)hipEventSynchronize(e1);
-        (void)hipEventElapsedTime(&ms, e0, e1);
-        out[0] = (double)nwg * 4 * iters * 8 * 2048.0 / (ms * 1e-3) / 1e12;
-        std::vector<unsigned long long> h(2 * nwg);
-        (void)hipMemcpy(h.data(), stamps, sizeof(unsigned long long) * 2 * nwg, hipMemcpyDeviceToHost);
-        std::vector<double> ghz(nwg);
-        for (int i = 0; i < nwg; ++i) ghz[i] = h[2 * i + 1] ? (double)h[2 * i] / (double)h[2 * i + 1] * 0.1 : 0.0;
-        std::nth_element(ghz.begin(), ghz.begin() + nwg / 2, ghz.end());
-        out[1] = ghz[nwg / 2];
+        out[0] = 0; out[1] = 0;
+        const int wps[3] = {1, 2, 8};                                 // waves per SIMD = 4-wave workgroups per CU
+        for (int v = 0; v < 3; ++v) {
+            const int g = ncu * wps[v], iters = 240000 / wps[v];       // ~25-30 ms each
+            (void)hipEventRecord(e0, 0);
+            hipLaunchKernelGGL(probe_mfma_kernel, dim3(g), dim3(256), 0, 0, sink, stamps, iters);
+            (void)hipEventRecord(e1, 0);
+            (void)hipEventSynchronize(e1);
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            const double tf = (double)g * 4 * iters * 8 * 2048.0 / (ms * 1e-3) / 1e12;
+            if (n >= 6) out[3 + v] = tf;
+            if (tf > out[0]) {
+                out[0] = tf;
+                std::vector<unsigned long long> h(2 * g);
+                (void)hipMemcpy(h.data(), stamps, sizeof(unsigned long long) * 2 * g, hipMemcpyDeviceToHost);
+                std::vector<double> ghz(g);
+                for (int i = 0; i < g; ++i) ghz[i] = h[2 * i + 1] ? (double)h[2 * i] / (double)h[2 * i + 1] * 0.1 : 0.0;
+                std::nth_element(ghz.begin(), ghz.begin() + g / 2, ghz.end());
+                out[1] = ghz[g / 2];
+            }
+        }
         double best = 0;
         for (int rep = 0; rep < 4; ++rep) {
             (void)hipEventRecord(e0, 0);

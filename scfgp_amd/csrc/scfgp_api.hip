@@ -24,10 +24,10 @@
 static constexpr int XT = 128;              // tile of the X~^T Zbar product and padding unit of J (kernels_sweep.hip)
 static constexpr int64_t PRED_ROWS = 32768; // predict processes test rows in chunks of this size
 // Thresholds of the automatic precision escalation and the error model behind them (profiles/r03_c3_owner.md): with the
-// fp32 Gram products (4096-row flush interval) the relative error of alpha / Li, and of the frequency gradient blocks,
-// against fp64 mode is about SCFGP_ERR_PER_COND times the condition estimate (measured 2.6e-7 .. 3.3e-7 at estimates
-// 58 .. 6.4e3).  Level 1 keeps the predicted alpha error under 3e-6 (north star: 1e-5), level 2 the predicted gradient
-// error under 3e-4 (SURVEY App. E acceptance: 1e-3 per block).
+// fp32 Gram products (4096-row flush interval, relative error 6e-8 from 1e5 rows up) the relative error of alpha / Li, and
+// of the frequency gradient blocks, against fp64 mode is about SCFGP_ERR_PER_COND times the condition estimate (measured
+// 1.2e-7 .. 3.0e-7 at estimates 4 .. 6.4e3).  Level 1 keeps the predicted alpha error under 3e-6 (north star: 1e-5), level 2
+// the predicted gradient error under 3e-4 (SURVEY App. E acceptance: 1e-3 per block).
 #ifndef SCFGP_COND_THRESHOLD
 #define SCFGP_COND_THRESHOLD 10.0
 #endif
@@ -126,7 +126,19 @@ struct scfgp_ctx {
     int level() const { return dtype != SCFGP_F32 || gram64 == 0 ? 0 : (gram64 == 1 ? 1 : (gram64 == 3 ? 2 : esc_level)); }
     bool use64() const { return level() >= 1; }
     double cond_est() const { return cond[1] * cond[2]; }
-    int want_level(double est, double slack) const { return est > escw_thr * slack ? 2 : (est > esc_thr * slack ? 1 : 0); }
+    // relative error of the fp32 Gram against the fp64 one (profiles/r03_c3_owner.md): chains of up to 4096 rows in fp32, fp64
+    // across them -- 4e-7 for one full chain, falling with the square root of the number of chains down to the 6e-8 measured
+    // from 1e5 rows up, and in proportion to the chain length below one chunk
+    double gram_rel_err() const {
+        const double n = (double)(Nglobal > 0 ? Nglobal : 1), ch = (double)(gram_chunk > 0 ? gram_chunk : 4096);
+        return n >= ch ? std::max(6e-8, 4e-7 * std::sqrt(ch / n)) * (ch / 4096.0) : std::max(3e-8, 4e-7 * n / 4096.0);
+    }
+    double alpha_err_fp32() const { return 5.0 * gram_rel_err() * cond_est(); }      // == SCFGP_ERR_PER_COND * estimate from 1e5 rows up
+    // thresholds are quoted for the 6e-8 regime; fewer rows (a noisier Gram) scale the estimate up accordingly
+    int want_level(double est, double slack) const {
+        est *= gram_rel_err() / 6e-8;
+        return est > escw_thr * slack ? 2 : (est > esc_thr * slack ? 1 : 0);
+    }
     // profiling
     bool roctx_on = false;
     bool prof = false; std::vector<ProfRec> recs; std::vector<hipEvent_t> pool; size_t pool_used = 0;
@@ -502,7 +514,9 @@ template <typename T> struct Impl {
     static int pass2(scfgp_ctx* c, int want_grad) {
         const Geom& g = c->g;
         if (c->last_cform) {
-            Bf3Planes pl; pl.dma = c->planes().dma;
+            // triangular products: the loader-staged 256 x 128 tiles (two workgroups per CU) ride out the unequal k ranges best
+            // (C3: 41.7 / 40.1 ms against 43.9 / 41.6 by LDS-DMA 128 wide and 49.8 / 46.9 by 256-wide tiles); LDS-DMA on request only
+            Bf3Planes pl; pl.dma = c->apply_dma > 0 ? c->planes().dma : 0;
             { ProfScope ps(c, "apply_c");
               SK::apply_c(g, (const T*)c->d_Phi, (const T*)c->d_AbarT, (const T*)c->d_BT, (T*)c->d_C, c->d_vpart, c->alpha(), c->d_mu, c->st, &pl); }
             { ProfScope ps(c, "apply_vc");
@@ -1119,11 +1133,12 @@ extern "C" int scfgp_set_option(scfgp_ctx* c, const char* name, int64_t value) {
 //        LOWER bound of cond_2(A) (>= the diagonal ratio max L_ii^2 / min L_ii^2)
 // out[1] precision level that evaluation ran at (0, 1, 2: see scfgp_ctx; fp64 mode reports 0)
 // out[2] 1 if its G and Phi^T y were formed in fp64 from fp64 features (always in fp64 mode), else 0
-// out[3] predicted relative error of alpha / Li had the Gram been formed in fp32: SCFGP_ERR_PER_COND * out[0]
+// out[3] predicted relative error of alpha / Li had the Gram been formed in fp32: 5 x (relative error of the fp32 Gram at this
+//        number of rows) x out[0]  (= SCFGP_ERR_PER_COND * out[0] from 1e5 rows up)
 // out[4] threshold of level 1, out[5] threshold of level 2 (auto policy), out[6] min L_ii^2, out[7] max L_ii^2, out[8] max_j (A^-1)_jj
 extern "C" int scfgp_get_condition(scfgp_ctx* c, double* out, int n) {
     if (!c || !out || n < 4) return SCFGP_EARG;
-    const double v[9] = {c->cond_est(), (double)c->last_level, c->last_used64 ? 1.0 : 0.0, SCFGP_ERR_PER_COND * c->cond_est(),
+    const double v[9] = {c->cond_est(), (double)c->last_level, c->last_used64 ? 1.0 : 0.0, c->alpha_err_fp32(),
                          c->esc_thr, c->escw_thr, c->cond[0], c->cond[1], c->cond[2]};
     for (int i = 0; i < n && i < 9; ++i) out[i] = v[i];
     return SCFGP_OK;
