@@ -52,6 +52,26 @@ struct RowSplits {
 };
 RowSplits gram_row_splits(int jobs_per_split, int64_t Np, bool f32, int nsplit_override, int taper);
 
+// Table-driven schedule of the fp32 Gram products ("lock-step plan", option gram_plan).  The split plan above lets every
+// workgroup stream its own rows: its re-reads of Phi miss the 4 MB L2 of its XCD (98 GB of fabric traffic per launch against
+// 8.45 GB of Phi at the headline shape, profiles/r03_pmc_gram_jobs.json).  Here every XCD owns 1/8 of the rows and its 64
+// resident workgroups sweep those rows TOGETHER, one tall tile each from the first row to the last, so a row fetched by the
+// leading workgroup is an L2 hit for the 63 behind it (a workgroup that runs ahead pays the misses and falls back: the pack
+// holds itself together).  Tiles beyond the 64 x (number of full waves) tall ones are cut into row slices and follow,
+// slice-major.  A job is one entry; entries are XCD-major in launch order (xcd_remap hands XCD x the x-th contiguous share).
+struct GramJob {
+    int acol, bcol;        // first column of the A panel (tile rows) and of the B panel (tile columns)
+    int kind;              // 0: 128 x 128, 1: 64 x 128 strip, 2: 256 x 128 tall, 3: 64 x 512 wide strip
+    int diag;              // carries the side vector for its A columns
+    int64_t r0, r1;        // rows
+    int part;              // partial index: slabs[part][tile], sidepart[part][.]
+    int tile, tile2;       // output tile(s) in packed lower-triangle numbering (tile2: second row block of a tall tile)
+    int pad;
+};
+struct GramPlan { const GramJob* jobs = nullptr; int njobs = 0, nparts = 0; const int* cnt = nullptr; };     // device pointers
+// host side: the plan for the fp32 job list; cnt[t] = partials of output tile t.  False when the problem is too small for it.
+bool gram_lockstep_plan(const Geom& g, int64_t Np, std::vector<GramJob>& jobs, std::vector<int>& cnt, int& nparts);
+
 // operands of the phase projection: Fall (Dp x Jp); Lall (Dp x round_up(Sp,64)) = [l_F | e_D], Rall (Sp x Jp) =
 // [[I_S | r_F^T]; phase offsets], Tt (Np x Sp) scratch for T~
 struct Projection { const double* Fall; const double* Lall; const double* Rall; double* Tt; };
@@ -75,6 +95,9 @@ struct SweepKernels {
     static void gram(const Geom& g, const T* Phi, const double* w, const double* side, const RowSplits& rs, int64_t chunk,
                      double* slabs, double* sidepart, hipStream_t st, const T* Zsrc = nullptr, double zscale = 0.0);
     static int gram_jobs(const Geom& g);        // workgroups per row split of gram() (sizes the row split)
+    // the same products scheduled by a job table (fp32 list only); slabs[part][tile], sidepart[part][Kp] (zeroed here)
+    static void gram_planned(const Geom& g, const T* Phi, const double* w, const double* side, const GramPlan& plan, int64_t chunk,
+                             double* slabs, double* sidepart, hipStream_t st);
     // V = Phi . Bm, vpart[jt][n] = sum_{j in tile} Phi[n][j] V[n][j]    (SCFGP.py:112); column tile jt also forms
     // mupart[jt][n] = its slice of mu = Phi . alpha (SCFGP.py:111 / :143) from the rows it stages
     //   bf3 (fp32 only): split-precision MFMA tiles (tile_bf16x3.h), compute mode SCFGP_BF16X3; Bm / Abar then point to
@@ -129,6 +152,8 @@ void bf3_split_rows(const float* S, int64_t ld, void* out, int64_t Np, int Kp, h
 // ---- reductions ------------------------------------------------------------
 // packed lower tiles = sum over splits of the per-split lower-tile slabs (tile t = ti(ti+1)/2+tj, row-major)
 void reduce_tri_tiles(const double* slabs, int nsplit, int nts, int tile, double* packed, hipStream_t st);
+// the same with cnt[t] partials for output tile t (slabs[part][tile], parts 0 .. cnt[t]-1)
+void reduce_tri_tiles_cnt(const double* slabs, const int* cnt, int nts, int tile, double* packed, hipStream_t st);
 // packed lower tiles -> full symmetric Kp x Kp matrix
 void unpack_tri_tiles(const double* packed, int nts, int tile, double* full, int64_t ld, hipStream_t st);
 // out (ldo) = sum over splits of a full ntm x ntn tile grid of slabs

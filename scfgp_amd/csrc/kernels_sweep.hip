@@ -481,6 +481,28 @@ void gram_kernel(
     TRACE_END(kind);
 }
 
+// The same bodies driven by a job table (kernels.h: GramPlan); fp32 job list.
+template <class Cfg, class SCfg, class BCfg, class WCfg, bool WEIGHT>
+__global__ __launch_bounds__(Cfg::THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void gram_table_kernel(const typename Cfg::T* __restrict__ Phi, int64_t ld, const double* __restrict__ w, const double* __restrict__ side,
+                       const GramJob* __restrict__ jobs, int64_t chunk, int ntile_all, double* __restrict__ sidepart,
+                       double* __restrict__ slabs) {
+    SMEM_DECL;
+    TRACE_BEGIN();
+    constexpr int B = Cfg::BN;
+    const GramJob jb = jobs[xcd_remap(blockIdx.x, gridDim.x)];
+    const int kind = jb.kind;
+    const bool diag = side != nullptr && jb.diag;
+    double* slab = slabs + ((int64_t)jb.part * ntile_all + jb.tile) * (B * B);
+    double* slab2 = slabs + ((int64_t)jb.part * ntile_all + jb.tile2) * (B * B);
+    double* sideout = sidepart + (int64_t)jb.part * ld + jb.acol;
+    if (kind == 1) gram_body<SCfg, WEIGHT, true>(Phi, ld, w, side, jb.r0, jb.r1, chunk, jb.acol, jb.bcol, diag, sideout, slab, nullptr, smem_raw);
+    else if (kind == 2) gram_body<BCfg, WEIGHT, false>(Phi, ld, w, side, jb.r0, jb.r1, chunk, jb.acol, jb.bcol, diag, sideout, slab, slab2, smem_raw);
+    else if (kind == 3) gram_body<WCfg, WEIGHT, true>(Phi, ld, w, side, jb.r0, jb.r1, chunk, jb.acol, jb.bcol, diag, sideout, slab, nullptr, smem_raw);
+    else gram_body<Cfg, WEIGHT, false>(Phi, ld, w, side, jb.r0, jb.r1, chunk, jb.acol, jb.bcol, diag, sideout, slab, nullptr, smem_raw);
+    TRACE_END(kind);
+}
+
 // Row tile ti0 + (t / ntn) of the output (tiles are 128 rows apart whatever Cfg::BM is: a narrower Cfg multiplies only the
 // first BM rows of its tile and zeroes the rest of the 128 x 128 slab)
 template <class Cfg, typename S>
@@ -577,6 +599,78 @@ void SweepKernels<T>::gram(const Geom& g, const T* Phi, const double* w, const d
     else
         hipLaunchKernelGGL((gram_kernel<Cfg, SCfg, BCfg, WCfg, false, BIG>), dim3(njobs), dim3(Cfg::THREADS), LDS, st,
                            Phi, (int64_t)g.Kp, w, side, rs, chunk, g.gfull, g.gstrip, sidepart, slabs, (int64_t)0, 0, 0.0);
+}
+
+bool gram_lockstep_plan(const Geom& g, int64_t Np, std::vector<GramJob>& jobs, std::vector<int>& cnt, int& nparts) {
+    constexpr int B = 128, XCDS = 8, SLOTS = 64;               // 32 CUs x 2 resident workgroups per XCD
+    const int nfull = g.gfull, nstrip = g.gstrip, nall = nfull + nstrip;
+    const int64_t nrb = Np / 256;
+    if (nrb / XCDS < 32) return false;                          // under 8192 rows per XCD the split plan's small-problem rules win
+    const auto tri = [](int ti, int tj) { return ti * (ti + 1) / 2 + tj; };
+    struct Tile { int acol, bcol, kind, diag, tile, tile2; };
+    std::vector<Tile> tall, rest;
+    const int R = nfull / 2;
+    for (int a = 0; a < R; ++a)
+        for (int b = 0; b <= 2 * a; ++b) tall.push_back({2 * a * B, b * B, 2, b == 2 * a, tri(2 * a, b), tri(2 * a + 1, b)});
+    const int nwide = nstrip * (nfull + 1) / 4;
+    for (int q = 0; q < nwide; ++q) rest.push_back({nfull * B, 4 * q * B, 3, nfull >= 4 * q && nfull < 4 * q + 4, tri(nfull, 4 * q), 0});
+    for (int k = 0; k < R; ++k) rest.push_back({(2 * k + 1) * B, (2 * k + 1) * B, 0, 0, tri(2 * k + 1, 2 * k + 1), 0});
+    if (nfull & 1)
+        for (int b = 0; b < nfull; ++b) rest.push_back({(nfull - 1) * B, b * B, 0, b == nfull - 1, tri(nfull - 1, b), 0});
+    for (int tj = 4 * nwide; nstrip && tj <= nfull; ++tj) rest.push_back({nfull * B, tj * B, 1, tj == nfull, tri(nfull, tj), 0});
+    // full waves of SLOTS tall tiles sweep the XCD's rows in lock step; what is left over is cut into row slices
+    const int nwaves = (int)tall.size() / SLOTS;
+    std::vector<Tile> sliced(tall.begin() + nwaves * SLOTS, tall.end());
+    sliced.insert(sliced.end(), rest.begin(), rest.end());
+    int S = sliced.empty() ? 0 : std::max(1, (3 * SLOTS + (int)sliced.size() - 1) / (int)sliced.size());     // >= 3 rounds of jobs
+    const int64_t rows_x = nrb / XCDS * 256;
+    while (S > 1 && rows_x / S < 4096) --S;
+    nparts = XCDS * std::max(S, 1);
+    cnt.assign(nall * (nall + 1) / 2, 0);
+    jobs.clear();
+    for (int x = 0; x < XCDS; ++x) {
+        const int64_t g0 = nrb * x / XCDS * 256, g1 = nrb * (x + 1) / XCDS * 256;
+        for (int i = 0; i < nwaves * SLOTS; ++i) {
+            const Tile& t = tall[i];
+            jobs.push_back({t.acol, t.bcol, t.kind, t.diag, g0, g1, x, t.tile, t.tile2, 0});
+        }
+        for (int sl = 0; sl < S; ++sl) {
+            const int64_t len = (g1 - g0) / 256, r0 = g0 + len * sl / S * 256, r1 = g0 + len * (sl + 1) / S * 256;
+            for (const Tile& t : sliced) jobs.push_back({t.acol, t.bcol, t.kind, t.diag, r0, r1, x * S + sl, t.tile, t.tile2, 0});
+        }
+    }
+    for (int i = 0; i < nwaves * SLOTS; ++i) { cnt[tall[i].tile] = XCDS; cnt[tall[i].tile2] = XCDS; }
+    for (const Tile& t : sliced) {
+        const int n = t.kind == 3 ? 4 : 1;
+        for (int k = 0; k < n; ++k) cnt[t.tile + k] = XCDS * S;
+        if (t.kind == 2) cnt[t.tile2] = XCDS * S;
+    }
+    return true;
+}
+
+template <typename T>
+void SweepKernels<T>::gram_planned(const Geom& g, const T* Phi, const double* w, const double* side, const GramPlan& plan, int64_t chunk,
+                                   double* slabs, double* sidepart, hipStream_t st) {
+    if constexpr (sizeof(T) == 4) {
+        typedef typename GramCfg<T, 128>::type Cfg;
+        typedef typename GramStripCfg<T>::type SCfg;
+        typedef typename GramBigCfg<T>::type BCfg;
+        typedef typename GramWideCfg<T>::type WCfg;
+        if (chunk <= 0 || chunk > g.Np) chunk = g.Np;
+        chunk = round_up(chunk, 256);
+        constexpr int L1 = Cfg::LDS_BYTES > SCfg::LDS_BYTES ? Cfg::LDS_BYTES : SCfg::LDS_BYTES;
+        constexpr int L2 = BCfg::LDS_BYTES > L1 ? BCfg::LDS_BYTES : L1;
+        constexpr int LDS = WCfg::LDS_BYTES > L2 ? WCfg::LDS_BYTES : L2;
+        const int nall = g.gfull + g.gstrip, ntile_all = nall * (nall + 1) / 2;
+        if (side) (void)hipMemsetAsync(sidepart, 0, sizeof(double) * (size_t)plan.nparts * g.Kp, st);   // parts a column's diagonal job does not use
+        const auto launch = [&](auto kernel) {
+            allow_big_lds(kernel, LDS);
+            hipLaunchKernelGGL(kernel, dim3(plan.njobs), dim3(Cfg::THREADS), LDS, st, Phi, (int64_t)g.Kp, w, side, plan.jobs, chunk, ntile_all,
+                               sidepart, slabs);
+        };
+        if (w) launch(gram_table_kernel<Cfg, SCfg, BCfg, WCfg, true>);
+        else launch(gram_table_kernel<Cfg, SCfg, BCfg, WCfg, false>);
+    }
 }
 
 template <typename T>
@@ -778,21 +872,23 @@ void apply_kernel(
 //   operands use the same permutation of the 16 k, so the sum is unchanged and a fragment is ONE ds_read_b128 per stage.
 //   EPI 3 / 4 (factor form): Bm holds the k-contiguous COLUMNS of the triangular operand as its rows (Li for C = Phi Li^T,
 //   Li^T for V = C Li); the stages run over k < cbase + BN (EPI 3) or k >= cbase (EPI 4) only.
-template <int BN_>
+//   WGM_ = 2 (experiment, BN = 256 only): 8 waves of 128 x 64 instead of 16 of 64 x 64 -- 12 fragment reads per 128 MFMAs instead of
+//   8 per 64, one workgroup per CU at two waves per SIMD
+template <int BN_, int WGM_ = 4>
 struct ApplyDma {
-    static constexpr int BM = 256, BN = BN_, WAVES = 4 * (BN / 64), STAGE = (BM + BN) * 64, STAGES = 3, LDS_BYTES = STAGES * STAGE,
+    static constexpr int BM = 256, BN = BN_, WAVES = WGM_ * (BN / 64), STAGE = (BM + BN) * 64, STAGES = 3, LDS_BYTES = STAGES * STAGE,
                          DMA_PER_WAVE = STAGE / 1024 / WAVES;
-    typedef TileCfg<float, BM, BN, 16, 4, BN / 64, 16, true> Cfg;         // wave grid / accumulator map of the epilogue: 64 x 64 wave tiles
+    typedef TileCfg<float, BM, BN, 16, WGM_, BN / 64, 16, true> Cfg;      // wave grid / accumulator map of the epilogue: (256 / WGM_) x 64 wave tiles
     static_assert(STAGE / 1024 % WAVES == 0, "whole DMA instructions per wave");
 };
 // BN = 128: 8 waves, two workgroups per CU, 48 operand bytes per MFMA; BN = 256: 16 waves, one workgroup per CU, 32 bytes per MFMA
-template <int EPI, int BN>
-__global__ __launch_bounds__(64 * ApplyDma<BN>::WAVES) __attribute__((amdgpu_waves_per_eu(4, 4)))
+template <int EPI, int BN, int WGM = 4>
+__global__ __launch_bounds__((64 * ApplyDma<BN, WGM>::WAVES)) __attribute__((amdgpu_waves_per_eu(WGM == 2 ? 2 : 4, WGM == 2 ? 2 : 4)))
 void apply_dma_kernel(const float* __restrict__ Phi, const float* __restrict__ Bm, float* V,
                       double* __restrict__ vpart, const double* __restrict__ p, const double* __restrict__ q,
                       const double* __restrict__ y, const double* __restrict__ alpha, const double* __restrict__ ut,
                       int K, int Kp, int64_t Np, int njt, double* __restrict__ bpart, double* __restrict__ mu, int col0, int slot0) {
-    typedef ApplyDma<BN> D;
+    typedef ApplyDma<BN, WGM> D;
     typedef typename D::Cfg Cfg;
     SMEM_DECL;
     char* smem = smem_raw;
@@ -831,7 +927,11 @@ void apply_dma_kernel(const float* __restrict__ Phi, const float* __restrict__ B
     int slot = 0, fill = 2;
     for (int s = 0; s < nst; ++s) {
         // this wave's share of stage s has landed when only the DMAs of stage s+1 are outstanding
-        if (s + 1 < nst) { if (D::DMA_PER_WAVE == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+        if (s + 1 < nst) {
+            if (D::DMA_PER_WAVE == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (D::DMA_PER_WAVE == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        }
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                          // everybody's has; nobody reads the slot of stage s-1 any more
         asm volatile("" ::: "memory");
@@ -919,15 +1019,15 @@ static int apply_launch_cfg(const Geom& g, int njt, int col0, int jt0, int boff,
                        Phi, Bm, V, vpart, p, q, y, alpha, ut, g.K, g.Kp, g.Np, njt, bpart ? bpart + boff : nullptr, col0, jt0, mu, ApplyPlan<T>(g.K).total);
     return (int)(njt * nrb);
 }
-template <int EPI, int BN>
+template <int EPI, int BN, int WGM = 4>
 static int apply_dma_launch(const Geom& g, int njt, int col0, int slot0, int boff, const float* Phi, const float* Bm, float* V, double* vpart,
                             const double* p, const double* q, const double* y, const double* alpha, const double* ut,
                             double* bpart, double* mu, hipStream_t st) {
     if (njt <= 0) return 0;
-    typedef ApplyDma<BN> D;
+    typedef ApplyDma<BN, WGM> D;
     const int64_t nrb = g.Np / D::BM;
-    allow_big_lds(apply_dma_kernel<EPI, BN>, D::LDS_BYTES);
-    hipLaunchKernelGGL((apply_dma_kernel<EPI, BN>), dim3((unsigned)(njt * nrb)), dim3(64 * D::WAVES), D::LDS_BYTES, st,
+    allow_big_lds(apply_dma_kernel<EPI, BN, WGM>, D::LDS_BYTES);
+    hipLaunchKernelGGL((apply_dma_kernel<EPI, BN, WGM>), dim3((unsigned)(njt * nrb)), dim3(64 * D::WAVES), D::LDS_BYTES, st,
                        Phi, Bm, V, vpart, p, q, y, alpha, ut, g.K, g.Kp, g.Np, njt, bpart ? bpart + boff : nullptr, mu, col0, slot0);
     return (int)(njt * nrb);
 }
@@ -978,9 +1078,12 @@ static int apply_launch(const Geom& g, const T* Phi, const T* Bm, T* V, double* 
             // the full tiles by LDS-DMA (Bm symmetric): option value 1 = 128 wide, 2 = 256 wide with a 128-wide one for an odd
             // count; the 64-wide remainder by the loader-staged kernel, whose mu slices then are column bands too (ntot = 0)
             // 3: 256-wide for V = Phi.B (EPI 0), 128-wide for Phibar (EPI 1: its epilogue wants a second resident workgroup)
-            const bool wide = planes->dma == 2 || (planes->dma == 3 && EPI != 1);
+            const bool wide = planes->dma == 2 || planes->dma == 4 || (planes->dma == 3 && EPI != 1);
             const int n256 = wide ? pl.count[0] / 2 : 0, n128 = pl.count[0] - 2 * n256;
-            nb += apply_dma_launch<EPI, 256>(g, n256, 0, 0, nb, Phi, BmT, V, vpart, p, q, y, alpha, ut, bpart, mu, st);
+            if (planes->dma == 4 && EPI < 2)                       // experiment: 8 waves of 128 x 64
+                nb += apply_dma_launch<EPI, 256, 2>(g, n256, 0, 0, nb, Phi, BmT, V, vpart, p, q, y, alpha, ut, bpart, mu, st);
+            else
+                nb += apply_dma_launch<EPI, 256>(g, n256, 0, 0, nb, Phi, BmT, V, vpart, p, q, y, alpha, ut, bpart, mu, st);
             nb += apply_dma_launch<EPI, 128>(g, n128, 256 * n256, 2 * n256, nb, Phi, BmT, V, vpart, p, q, y, alpha, ut, bpart, mu, st);
             typedef typename ApplyCfg<T, 64>::type RCfg;
             if (pl.count[2] > 0) {
@@ -1152,6 +1255,19 @@ __global__ __launch_bounds__(256) void reduce_tri_kernel(const double* __restric
         for (int sp = 0; sp < nsplit; ++sp) s += slabs[((int64_t)sp * ntiles + t) * (B * B) + e];
         packed[(int64_t)t * B * B + e] = s;
     }
+}
+__global__ __launch_bounds__(256) void reduce_tri_cnt_kernel(const double* __restrict__ slabs, const int* __restrict__ cnt, int ntiles, int B,
+                                                             double* __restrict__ packed) {
+    const int t = blockIdx.x, n = cnt[t];
+    for (int e = blockIdx.y * 256 + threadIdx.x; e < B * B; e += gridDim.y * 256) {
+        double s = 0;
+        for (int sp = 0; sp < n; ++sp) s += slabs[((int64_t)sp * ntiles + t) * (B * B) + e];
+        packed[(int64_t)t * B * B + e] = s;
+    }
+}
+void reduce_tri_tiles_cnt(const double* slabs, const int* cnt, int nts, int tile, double* packed, hipStream_t st) {
+    const int ntiles = nts * (nts + 1) / 2;
+    hipLaunchKernelGGL(reduce_tri_cnt_kernel, dim3(ntiles, 16), dim3(256), 0, st, slabs, cnt, ntiles, tile, packed);
 }
 void reduce_tri_tiles(const double* slabs, int nsplit, int nts, int tile, double* packed, hipStream_t st) {
     const int ntiles = nts * (nts + 1) / 2;

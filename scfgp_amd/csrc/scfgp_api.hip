@@ -28,6 +28,12 @@ static constexpr int64_t PRED_ROWS = 32768; // predict processes test rows in ch
 // of the frequency gradient blocks, against fp64 mode is about SCFGP_ERR_PER_COND times the condition estimate (measured
 // 1.2e-7 .. 3.0e-7 at estimates 4 .. 6.4e3).  Level 1 keeps the predicted alpha error under 3e-6 (north star: 1e-5), level 2
 // the predicted gradient error under 3e-4 (SURVEY App. E acceptance: 1e-3 per block).
+#ifndef SCFGP_PASS3_PARTS
+#define SCFGP_PASS3_PARTS 1        // default number of row parts of pass 3 from 262144 rows up (1: off)
+#endif
+#ifndef SCFGP_GRAM_PLAN_DEFAULT
+#define SCFGP_GRAM_PLAN_DEFAULT 0
+#endif
 #ifndef SCFGP_COND_THRESHOLD
 #define SCFGP_COND_THRESHOLD 10.0
 #endif
@@ -64,6 +70,7 @@ struct scfgp_ctx {
     int dtype = 0, device = 0;
     hipStream_t st = nullptr; bool own_stream = false;
     hipStream_t copy_st = nullptr; hipEvent_t ev_factor = nullptr;          // alpha/Li D2H beside pass 2/3 ...
+    hipStream_t aux_st = nullptr; std::vector<hipEvent_t> ev_p3; int pass3_parts = -1;      // pass 3 in row parts (pass3_pipelined)
     hipEvent_t ev_fence = nullptr;                                          // scfgp_stream_fence
     double* h_pin = nullptr;                                                // ... through pinned staging (K*K + K doubles)
     int64_t Ncap = 0, Nglobal = 0, Nglobal_full = 0;        // Nglobal_full: n_global given to scfgp_set_data
@@ -104,6 +111,8 @@ struct scfgp_ctx {
     int gram_nsplit = 0, gram_taper = 1, xtz_nsplit = 0; int64_t gram_chunk = 4096;
     int fuse_fmap = 0; void* d_Z = nullptr; int64_t z_cap = 0;         // experiment: Gram of pass 1 fed from the phases
     RowSplits splits{};
+    // lock-step schedule of the fp32 Gram products (kernels.h: GramPlan); option gram_plan: 0 split plan, 1 lock-step plan
+    int gram_plan = SCFGP_GRAM_PLAN_DEFAULT; GramPlan plan{}; GramJob* d_gjobs = nullptr; int* d_gcnt = nullptr; int64_t plan_Np = -1;
     // Precision escalation (fp32 / bf16x3 modes; profiles/r03_c3_owner.md).  The fp32 Gram products carry a relative error
     // of ~6e-8 that reaches alpha / Li (pass 1) and the gradient (pass 2's V^T diag(q) V) multiplied by the condition of A,
     // so the K x K stage's free condition estimate decides how the two TN products are formed:
@@ -262,6 +271,23 @@ static int ensure_rows(scfgp_ctx* c, int64_t N) {
         c->splits64 = gram_row_splits(SweepKernels<double>::gram_jobs(g), Np, false, c->gram_nsplit, c->gram_taper);
         gs = std::max(gs, c->splits64.nsplit);
     }
+    // lock-step plan of the fp32 Gram products: (re)built when the row count changes
+    if (c->dtype == SCFGP_F32 && c->gram_plan == 1) {
+        if (c->plan_Np != Np) {
+            std::vector<GramJob> jobs; std::vector<int> cnt; int nparts = 0;
+            c->plan = GramPlan{}; c->plan_Np = Np;
+            if (gram_lockstep_plan(g, Np, jobs, cnt, nparts)) {
+                HIPCHK(c, hipStreamSynchronize(c->st));
+                dfree(c->d_gjobs); dfree(c->d_gcnt);
+                if (int rc = dmalloc(c, &c->d_gjobs, sizeof(GramJob) * jobs.size())) return rc;
+                if (int rc = dmalloc(c, &c->d_gcnt, sizeof(int) * cnt.size())) return rc;
+                HIPCHK(c, hipMemcpy(c->d_gjobs, jobs.data(), sizeof(GramJob) * jobs.size(), hipMemcpyHostToDevice));
+                HIPCHK(c, hipMemcpy(c->d_gcnt, cnt.data(), sizeof(int) * cnt.size(), hipMemcpyHostToDevice));
+                c->plan.jobs = c->d_gjobs; c->plan.njobs = (int)jobs.size(); c->plan.nparts = nparts; c->plan.cnt = c->d_gcnt;
+            }
+        }
+        if (c->plan.jobs) gs = std::max(gs, c->plan.nparts);
+    } else { c->plan = GramPlan{}; c->plan_Np = -1; }
     const int xs = c->xtz_nsplit > 0 ? (int)std::min<int64_t>(c->xtz_nsplit, Np / 64) : xtz_split(ntx, Np);
     // Gram slabs are followed by the per-split side-vector partials (gs x Kp)
     const size_t need = sizeof(double) * std::max<size_t>((size_t)gs * ntiles * g.tile * g.tile + (size_t)gs * g.Kp, (size_t)xs * ntx * XT * XT);
@@ -358,7 +384,7 @@ extern "C" void scfgp_destroy(scfgp_ctx* c) {
     hipSetDevice(c->device);
     if (c->st) hipStreamSynchronize(c->st);
     free_rows(c);
-    dfree(c->d_Z); dfree(c->d_Phi64); dfree(c->d_C); dfree(c->d_Xraw); dfree(c->d_yraw); dfree(c->d_idx); dfree(c->d_xscale); dfree(c->d_yscale);
+    dfree(c->d_Z); dfree(c->d_Phi64); dfree(c->d_C); dfree(c->d_gjobs); dfree(c->d_gcnt); dfree(c->d_Xraw); dfree(c->d_yraw); dfree(c->d_idx); dfree(c->d_xscale); dfree(c->d_yscale);
     dfree(c->d_params); dfree(c->d_F); dfree(c->d_Fall); dfree(c->d_Lall); dfree(c->d_Rall); dfree(c->d_sc); dfree(c->p_Tt);
     dfree(c->d_xp1); dfree(c->d_xp2); dfree(c->d_x1); dfree(c->d_x2); dfree(c->d_x3); dfree(c->d_Li); dfree(c->d_B); dfree(c->d_T1); dfree(c->d_T2);
     dfree(c->d_Abar); dfree(c->d_BT); dfree(c->d_AbarT); dfree(c->d_M3); dfree(c->d_M16); dfree(c->d_P3); dfree(c->d_vecs); dfree(c->d_scalars); dfree(c->d_yy);
@@ -369,6 +395,8 @@ extern "C" void scfgp_destroy(scfgp_ctx* c) {
     dfree(c->d_opt); dfree(c->d_tctr); dfree(c->d_hist);
     for (hipEvent_t e : c->pool) hipEventDestroy(e);
     if (c->copy_st) { hipStreamSynchronize(c->copy_st); hipStreamDestroy(c->copy_st); }
+    if (c->aux_st) { hipStreamSynchronize(c->aux_st); hipStreamDestroy(c->aux_st); }
+    for (hipEvent_t e : c->ev_p3) hipEventDestroy(e);
     if (c->ev_factor) hipEventDestroy(c->ev_factor);
     if (c->ev_fence) hipEventDestroy(c->ev_fence);
     if (c->h_pin) hipHostFree(c->h_pin);
@@ -456,6 +484,16 @@ template <typename T> struct Impl {
                         const T* Zsrc = nullptr) {
         const Geom& g = c->g;
         const int nts = g.Kp / g.tile, ntiles = nts * (nts + 1) / 2;
+        if constexpr (sizeof(T) == 4) {
+            if (c->plan.jobs && !Zsrc) {                           // lock-step plan (kernels.h)
+                const int np = c->plan.nparts;
+                double* sidepart = c->d_slabs + (size_t)np * ntiles * g.tile * g.tile;
+                { ProfScope ps(c, name); SK::gram_planned(g, Mx, w, side, c->plan, c->gram_chunk, c->d_slabs, sidepart, c->st); }
+                { ProfScope ps(c, "reduce_tiles"); reduce_tri_tiles_cnt(c->d_slabs, c->plan.cnt, nts, g.tile, out, c->st);
+                  reduce_side(sidepart, np, g.Kp, g.gfull * g.tile + g.gstrip * 64, out + c->n_pk, c->st); }
+                return;
+            }
+        }
         const int gs = c->splits.nsplit;
         double* sidepart = c->d_slabs + (size_t)gs * ntiles * g.tile * g.tile;
         { ProfScope ps(c, name);
@@ -545,8 +583,49 @@ template <typename T> struct Impl {
         HIPCHK(c, hipGetLastError());
         return SCFGP_OK;
     }
+    // Pass 3 in row parts: X~^T Zbar of part i (HBM-bound: it streams Phi and Phibar once) runs on a second stream while the
+    // MFMA-bound Phibar product of part i+1 runs on the first (option pass3_parts; off in bf16x3 mode, whose row planes of Phi
+    // are not addressed by row offsets)
+    static int pass3_pipelined(scfgp_ctx* c, int Q) {
+        const Geom& g = c->g;
+        const int ntm = c->Dpp / XT, ntn = g.Jp / XT;
+        const int xs_all = c->xtz_nsplit > 0 ? (int)std::min<int64_t>(c->xtz_nsplit, g.Np / 64) : xtz_split(ntm * ntn, g.Np);
+        const int xs_q = std::max(1, xs_all / Q);
+        const int64_t nrb = g.Np / 256;
+        if (!c->aux_st) HIPCHK(c, hipStreamCreateWithFlags(&c->aux_st, hipStreamNonBlocking));
+        while ((int)c->ev_p3.size() < Q + 1) { hipEvent_t e; HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->ev_p3.push_back(e); }
+        const T* Ab = AbarT(c);
+        const Bf3Planes pl = c->planes();
+        int nb = 0;
+        {
+            ProfScope ps(c, "apply_phibar");
+            for (int i = 0; i < Q; ++i) {
+                const int64_t r0 = nrb * i / Q * 256, r1 = nrb * (i + 1) / Q * 256;
+                Geom gq = g; gq.Np = r1 - r0; gq.N = std::max<int64_t>(0, std::min<int64_t>(g.N, r1) - r0);
+                nb += SK::apply_phibar(gq, (const T*)c->d_Phi + r0 * g.Kp, Ab, (T*)c->d_V + r0 * g.Kp, c->d_p + r0, c->d_q + r0, c->d_y + r0,
+                                       c->alpha(), c->ut(), c->d_bpart + nb, c->st, false, &pl);
+                HIPCHK(c, hipEventRecord(c->ev_p3[i], c->st));
+                HIPCHK(c, hipStreamWaitEvent(c->aux_st, c->ev_p3[i], 0));
+                SK::xtz(gq, c->d_Xt + r0 * g.Dp, (const T*)c->d_Phi + r0 * g.Kp, (const T*)c->d_V + r0 * g.Kp, xs_q,
+                        c->dtype == SCFGP_F32 ? c->gram_chunk : 0, c->d_slabs + (size_t)i * xs_q * ntm * ntn * XT * XT, c->aux_st);
+            }
+            reduce_scalars(c->d_bpart, nb, 1, c->d_x3 + (int64_t)c->Dpp * g.Jp, 0, c->st);
+        }
+        {
+            ProfScope ps(c, "xtz");                             // what is left of it after the last product: its last part and the slab sum
+            HIPCHK(c, hipEventRecord(c->ev_p3[Q], c->aux_st));
+            HIPCHK(c, hipStreamWaitEvent(c->st, c->ev_p3[Q], 0));
+            reduce_full_tiles(c->d_slabs, xs_q * Q, ntm, ntn, c->d_x3, g.Jp, c->st);
+        }
+        HIPCHK(c, hipGetLastError());
+        return SCFGP_OK;
+    }
     static int pass3(scfgp_ctx* c) {
         const Geom& g = c->g;
+        {
+            const int Q = c->pass3_parts >= 0 ? c->pass3_parts : (g.Np >= 262144 ? SCFGP_PASS3_PARTS : 1);
+            if (Q > 1 && !c->bf3 && g.Np / 256 >= 4 * Q) return pass3_pipelined(c, Q);
+        }
         { ProfScope ps(c, "apply_phibar"); const Bf3Planes pl = c->planes();
           const int nb = SK::apply_phibar(g, (const T*)c->d_Phi, AbarT(c), (T*)c->d_V, c->d_p, c->d_q, c->d_y, c->alpha(), c->ut(),
                                           c->d_bpart, c->st, c->bf3, &pl);
@@ -1112,6 +1191,8 @@ extern "C" int scfgp_set_option(scfgp_ctx* c, const char* name, int64_t value) {
     else if (s == "bf3_dma") c->bf3_dma = (int)value;
     else if (s == "apply_dma") c->apply_dma = (int)value;
     else if (s == "gram_chunk") c->gram_chunk = value;
+    else if (s == "gram_plan") { c->gram_plan = (int)value; c->plan_Np = -1; }
+    else if (s == "pass3_parts") c->pass3_parts = (int)value;
     else if (s == "xtz_nsplit") c->xtz_nsplit = (int)value;
     else if (s == "use_graph") c->use_graph = (int)value;
     else if (s == "gram64") { if (value < 0 || value > 3) { c->err = "gram64: 0 never, 1 always level 1, 2 auto, 3 always level 2"; return SCFGP_EARG; }

@@ -293,3 +293,73 @@ def test_checkpoint_keeps_a_non_default_momentum_and_numpy_scalar_kwargs(tmp_pat
     assert np.array_equal(second.params.get_value(), full.params.get_value())
     default = fresh(); default.build_hip_models('adam', kw); iters(default, 6)
     assert not np.array_equal(default.params.get_value(), full.params.get_value())     # the momentum does matter
+
+
+@pytest.mark.parametrize('N,D,S,M', [(70000, 64, 32, 1024),      # headline tile list: 64 tall tiles = one full lock-step wave + sliced leftovers
+                                     (66000, 6, 3, 285),        # K = 576: nfull 4, strip: no full wave, everything sliced
+                                     (67000, 9, 20, 428)])      # K = 896: nfull 7 (odd: unpaired last block row), no strip
+def test_lockstep_gram_plan_equals_the_split_plan(N, D, S, M):
+    """Option gram_plan = 1 (kernels.h: GramPlan, job table + counted slab reduction): same G, Phi^T y, weighted Gram and
+    gradient as the split plan and as fp64 mode; deterministic."""
+    from scfgp_amd.engine import HipEngine
+    seed = 0x5CF63800 + M
+    X = synth.make_X(seed, N, D)
+    y = synth.normal(seed + 9, 0, N).reshape(-1, 1)
+    params = synth.make_params(seed + 0x0202, D, S, M, abc=(1.5, 0.0, -1.0))      # lam = e^3: well conditioned, so that the second
+    K = 2 * (S + M)                                                                 # Gram (on V = Phi B) sees the same B in every run
+    res = {}
+    for tag, dtype, plan in (('f64', 'f64', 0), ('split', 'f32', 0), ('lock', 'f32', 1)):
+        eng = HipEngine(D, S, M, dtype); eng.set_option('gram64', 0); eng.set_option('gram_plan', plan)
+        eng.set_params(params); eng.set_data(X, y)
+        eng.pass1()
+        Kp = eng.dims()['Kp']
+        x1 = eng.debug_read('G', (Kp * Kp + Kp,))
+        G = x1[:Kp * Kp].reshape(Kp, Kp)[:K, :K].copy(); g = x1[Kp * Kp:Kp * Kp + K].copy()
+        eng.factor(); eng.pass2(True)
+        x2 = eng.debug_read('W', (Kp * Kp + Kp,))
+        W = x2[:Kp * Kp].reshape(Kp, Kp)[:K, :K].copy(); u = x2[Kp * Kp:Kp * Kp + K].copy()
+        eng.adjoint(); eng.pass3()
+        out = eng.finish(True)
+        out2 = eng.eval()
+        assert float(out2[0]) == float(out[0]) and np.array_equal(out2[1], out[1])
+        res[tag] = (G, g, W, u, out)
+        eng.close()
+    for tag in ('split', 'lock'):
+        G, g, W, u, out = res[tag]; G0, g0, W0, u0, out0 = res['f64']
+        assert np.array_equal(G, G.T)
+        # W and u are formed from the fp32 V = Phi B: their distance from fp64 mode is V's (the D = 6 case is ill-conditioned)
+        assert rel(G, G0) < 5e-7 and rel(g, g0) < 5e-6 and rel(W, W0) < 2e-3 and rel(u, u0) < 2e-3, (tag, rel(G, G0), rel(g, g0), rel(W, W0), rel(u, u0))
+        assert abs(float(out[0]) - float(out0[0])) < 1e-6 * max(1.0, abs(float(out0[0])))
+        for a, b in zip(grad_blocks(out[1], D, S, M), grad_blocks(out0[1], D, S, M)):
+            assert rel(a, b) < 1e-3
+    for k, tol in enumerate((5e-7, 5e-6, 5e-4, 1e-3)):          # W = V^T diag(q) V: q has both signs, its sum cancels          # the two schedules differ by the fp32 chains' row partition only
+        assert rel(res['lock'][k], res['split'][k]) < tol, (k, rel(res['lock'][k], res['split'][k]))
+
+
+@pytest.mark.parametrize('dtype,tol', [('f64', 1e-12), ('f32', 2e-6)])
+def test_pass3_in_row_parts_overlapping_xtz(dtype, tol):
+    """Option pass3_parts: the Phibar product and X~^T Zbar run part by part on two streams (scfgp_api.hip: pass3_pipelined);
+    same cost and gradient as the one-piece pass, also through the captured training iteration."""
+    from scfgp_amd.engine import HipEngine
+    N, D, S, M = 9000, 12, 6, 90
+    seed = 0x5CF63900
+    X = synth.make_X(seed, N, D)
+    y = synth.normal(seed + 9, 0, N).reshape(-1, 1)
+    params = synth.make_params(seed + 0x0202, D, S, M, abc=(-0.5, 0.0, -1.0))
+    ref = None
+    for parts in (1, 2, 4, 7):
+        eng = HipEngine(D, S, M, dtype); eng.set_option('gram64', 0); eng.set_option('pass3_parts', parts)
+        eng.set_params(params); eng.set_data(X, y)
+        c, g, a, L = eng.eval()
+        c2, g2, _, _ = eng.eval()
+        assert float(c2) == float(c) and np.array_equal(g2, g)
+        eng.opt_init('adam', learning_rate=0.01)
+        hist, _, _ = eng.train(4)                                  # eager first iteration, then the captured graph
+        if ref is None:
+            ref = (float(c), g, hist)
+            c0, g0, _, _ = O.value_and_grad(X, y, params, S, M)
+            assert abs(float(c) - c0) < max(tol, 1e-10) * 10 * abs(c0) and rel(g, g0) < (1e-8 if dtype == 'f64' else 1e-3)
+        else:
+            assert abs(float(c) - ref[0]) < tol * abs(ref[0]) and rel(g, ref[1]) < tol * 10, (parts, rel(g, ref[1]))
+            assert np.allclose(hist, ref[2], rtol=tol * 100, atol=0)
+        eng.close()
