@@ -205,7 +205,11 @@ int64_t scfgp_debug_read(scfgp_ctx* ctx, const char* name, void* host, int64_t m
  * instead of through registers, 1 = 128 wide, 2 = 256 wide; measured equal), "bf3_dma"
  * (experiment, SCFGP_BF16X3 only: 256-wide apply tiles fed by LDS-DMA from pre-split planes of Phi, 6 bytes per element more),
  * "gram64" (precision level policy, see scfgp_get_condition), "cond_threshold" / "cond_threshold_w" (its two thresholds),
- * "roctx" (1: push a roctx range per stage for `rocprofv3 --marker-trace`; off by default, also SCFGP_ROCTX=1) */
+ * "roctx" (1: push a roctx range per stage for `rocprofv3 --marker-trace`; off by default, also SCFGP_ROCTX=1),
+ * "factor_form" (-1 auto = precision level 2, 0 never, 1 always: pass 2 as C = Phi Li^T, V = C Li),
+ * "gram_plan" (experiment: 1 = lock-step schedule of the fp32 Gram products from a job table; measured equal, profiles/r03_tuning.md),
+ * "pass3_parts" (experiment: pass 3 in row parts with X~^T Zbar on a second stream; measured slower),
+ * "apply_dma" = 4 (experiment: 256-wide LDS-DMA tiles on 8 waves of 128 x 64; measured slower) */
 int scfgp_set_option(scfgp_ctx* ctx, const char* name, int64_t value);
 
 /* Box probe (no reference counterpart; bench.py's `secondary.box`): ~100 ms of device work on `device`, no context needed.
@@ -218,6 +222,11 @@ int scfgp_box_probe(int device, double* out, int n);
  * sums the reduction adds; `nsplit` 0 = default, `taper` as the option): returns 0 when the splits tile [0, Np) in
  * order on 256-row blocks.  Needs no GPU. */
 int scfgp_selftest_row_splits(int D, int S, int M, int64_t N, int dtype, int nsplit, int taper);
+
+/* host-only self-test of the lock-step schedule of the fp32 Gram products (option "gram_plan" = 1): 0 when, for every output
+ * tile, the jobs that write it use its partial slots once each and their row ranges tile [0, Np); 1 when the problem is too
+ * small for that schedule.  Needs no GPU. */
+int scfgp_selftest_gram_plan(int D, int S, int M, int64_t N);
 
 #ifdef __cplusplus
 }

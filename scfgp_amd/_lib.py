@@ -54,6 +54,7 @@ SIGNATURES = {
     'scfgp_get_timings': (C.c_int, [C.c_void_p, _c_double_p, C.POINTER(C.c_char_p), C.c_int]),
     'scfgp_debug_read': (C.c_int64, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]),
     'scfgp_box_probe': (C.c_int, [C.c_int, _c_double_p, C.c_int]),
+    'scfgp_selftest_gram_plan': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int64]),
     'scfgp_selftest_row_splits': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int]),
     'scfgp_set_option': (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
 }

@@ -1182,6 +1182,38 @@ extern "C" int scfgp_selftest_row_splits(int D, int S, int M, int64_t N, int dty
     return at == g.Np ? 0 : 3;
 }
 
+// host-only: the lock-step plan of the fp32 Gram products (kernels.h) for this shape and its invariants: the jobs fill the
+// 8 XCD shares evenly, and for every output tile the jobs that write it use the partial slots 0 .. cnt-1 exactly once with
+// row ranges that tile [0, Np).  1: the problem is too small for the plan (the split plan is used), 0: ok.
+extern "C" int scfgp_selftest_gram_plan(int D, int S, int M, int64_t N) {
+    if (D < 1 || S < 1 || M < 1 || N < 1) return SCFGP_EARG;
+    Geom g{};
+    derive_geom(g, D, S, M);
+    g.N = N; g.Np = round_up(N, 256);
+    std::vector<GramJob> jobs; std::vector<int> cnt; int nparts = 0;
+    if (!gram_lockstep_plan(g, g.Np, jobs, cnt, nparts)) return 1;
+    if (jobs.empty() || jobs.size() % 8 != 0) return 2;
+    const int ntile = (int)cnt.size();
+    std::vector<std::vector<std::pair<int, std::pair<int64_t, int64_t>>>> cover(ntile);
+    for (const GramJob& j : jobs) {
+        if (j.r0 % 256 || j.r1 % 256 || j.r1 < j.r0 || j.part < 0 || j.part >= nparts) return 3;
+        const int n = j.kind == 3 ? 4 : 1;
+        for (int k = 0; k < n; ++k) { if (j.tile + k >= ntile) return 4; cover[j.tile + k].push_back({j.part, {j.r0, j.r1}}); }
+        if (j.kind == 2) { if (j.tile2 >= ntile) return 4; cover[j.tile2].push_back({j.part, {j.r0, j.r1}}); }
+    }
+    for (int t = 0; t < ntile; ++t) {
+        auto& v = cover[t];
+        if ((int)v.size() != cnt[t] || cnt[t] < 1) return 5;
+        std::sort(v.begin(), v.end());
+        for (int i = 0; i < (int)v.size(); ++i) if (v[i].first != i) return 6;          // partial slots 0 .. cnt-1, once each
+        std::sort(v.begin(), v.end(), [](const auto& a, const auto& b) { return a.second < b.second; });
+        int64_t at = 0;
+        for (const auto& e : v) { if (e.second.first != at) return 7; at = e.second.second; }
+        if (at != g.Np) return 8;
+    }
+    return 0;
+}
+
 extern "C" int scfgp_set_option(scfgp_ctx* c, const char* name, int64_t value) {
     if (!c || !name) return SCFGP_EARG;
     const std::string s(name);

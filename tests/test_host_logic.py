@@ -185,3 +185,15 @@ def test_gram_row_splits_tile_the_rows(D, S, M):
                 for taper in (0, 1, 2, 3):
                     assert lib.scfgp_selftest_row_splits(D, S, M, N, dtype, nsplit, taper) == 0, (N, dtype, nsplit, taper)
     assert lib.scfgp_selftest_row_splits(0, 1, 1, 5, 0, 0, 0) == -1
+
+
+def test_lockstep_gram_plan_invariants_without_a_gpu():
+    """scfgp_selftest_gram_plan (host only): for every output tile of the fp32 Gram's job table the jobs that write it use
+    the tile's partial slots once each and their row ranges tile [0, Np); small problems decline the plan."""
+    from scfgp_amd import _lib
+    lib = _lib.load()
+    for (D, S, M) in [(64, 32, 1024), (512, 64, 2048), (8, 32, 1024), (6, 3, 285), (9, 20, 428), (13, 8, 64), (3, 2, 3), (40, 17, 130)]:
+        for N in (65536, 66000, 70001, 250000, 1000000, 4000000):
+            assert lib.scfgp_selftest_gram_plan(D, S, M, N) == 0, (D, S, M, N)
+        assert lib.scfgp_selftest_gram_plan(D, S, M, 60000) == 1
+    assert lib.scfgp_selftest_gram_plan(0, 1, 1, 100000) == -1
