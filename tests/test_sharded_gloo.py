@@ -33,9 +33,30 @@ def _worker(rank, world, port, q):
     lo, hi = shard_rows(N, rank, world)
     eng = O.OracleEngine(D, S, M)
     eng.set_params(params); eng.set_data(X[lo:hi], y[lo:hi], n_global=N)
-    ev = ShardedEvaluator(eng, torch_allreduce())
+    ev = ShardedEvaluator(eng, torch_allreduce(), time_exchanges=True)
     cost, grad, alpha, Li = ev.eval(True)
+    ex = ev.exchange_ms()
+    assert sorted(ex) == [1, 2, 3] and all(v >= 0 for v in ex.values()) and ev.exchange_ms() == {}
     cost_f, _, _, _ = ev.eval(False)
+    assert sorted(ev.exchange_ms()) == [1, 2]                      # forward only: two sums
+
+    class RedoOnce(object):
+        """An engine whose first finish() asks for the stages again, like HipEngine after SCFGP_REDO (the library raised its
+        precision level): every rank sees it at the same evaluation, so the ranks repeat the three sums together."""
+        def __init__(self, inner):
+            self.inner, self.calls = inner, 0
+
+        def __getattr__(self, name):
+            return getattr(self.inner, name)
+
+        def finish(self, want_grad=True):
+            self.calls += 1
+            out = self.inner.finish(want_grad)
+            return None if self.calls == 1 else out
+
+    redo = RedoOnce(eng)
+    c2, g2, _, _ = ShardedEvaluator(redo, torch_allreduce()).eval(True)
+    assert redo.calls == 2 and float(c2) == float(cost) and np.array_equal(g2, grad)
     if rank == 0:
         q.put((float(cost), grad, alpha, float(cost_f)))
     dist.barrier()
