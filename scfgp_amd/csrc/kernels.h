@@ -133,6 +133,17 @@ struct SweepKernels {
     // formed inside the operand loader
     static void xtz(const Geom& g, const double* Xt, const T* Phi, const T* Phibar, int nsplit, int64_t chunk, double* slabs,
                     hipStream_t st);
+    // ---- rank-S form of the backward projection (F = l_F r_F^T, SCFGP.py:83,100: the reverse sweep needs only
+    //      T~^T Zbar (S+1 x J) and X~^T (Zbar_L + Zbar_M r_F) (D+1 x S) instead of X~^T Zbar (D+1 x J)) -------------
+    // Zbar over the cosine half of Phibar, in place
+    static void zbar_inplace(const Geom& g, const T* Phi, T* Phibar, hipStream_t st);
+    // Rsel = [I_S ; r_F] as a typed Kp x Kp-strided operand (round_up(S,64) columns written)
+    static void rsel(const Geom& g, const double* params, T* out, hipStream_t st);
+    // Out = A . Bm over k < Kc for ncols columns (64-wide tiles, leading dimension Kp everywhere; Bm[k][c] = 0 for k < c)
+    static void apply_plain(const Geom& g, const T* A, const T* Bm, T* Out, int Kc, int ncols, hipStream_t st);
+    // A^T Bm over the rows into per-split slabs: A (Np x Dp fp64), Bm (Np x J live columns, leading dimension ldb)
+    static void tn_plain(const double* A, int Dp, const T* Bm, int64_t ldb, int J, int64_t Np, int nsplit, int64_t chunk, double* slabs,
+                         hipStream_t st);
     // fp64 Kp x Kp matrix -> sweep operand (type T, rows/cols >= K zeroed)
     static void convert(const double* src, T* dst, int K, int Kp, hipStream_t st);
     static void convert_transposed(const double* src, T* dst, int K, int Kp, hipStream_t st);      // dst = src^T on the K x K block
@@ -169,8 +180,11 @@ void sum_squares(const double* y, int64_t n, double* scalars, int slot, double* 
 
 // ---- parameter unpack / gradient epilogue -----------------------------------
 void unpack_params(const Geom& g, const double* params, double* F, double* Fall, double* Lall, double* Rall, Scal* sc, hipStream_t st);
+//   rank-S form (TZ != NULL): XZ is not used; TZ (ld ldtz) rows s < S hold l_F^T X^T Zbar and row S the column sums of Zbar,
+//   XU (ld ldxu) holds X~^T (Zbar_L + Zbar_M r_F)
 void grad_epilogue(const Geom& g, const double* params, const double* F, const double* XZ, int64_t ldxz,
-                   double* work, double* scalars, int64_t Nglobal, double* grad, hipStream_t st);
+                   double* work, double* scalars, int64_t Nglobal, double* grad, hipStream_t st,
+                   const double* TZ = nullptr, int64_t ldtz = 0, const double* XU = nullptr, int64_t ldxu = 0);
 // yy -> y^T y, t2kb -> (T2, kbar), bbar -> bbar: device scalars living in the exchange buffers
 void finalize_cost(const Geom& g, const Scal* sc, double* scalars, const double* yy, const double* t2kb, const double* bbar,
                    int64_t Nglobal, double* grad, int want_grad, hipStream_t st);

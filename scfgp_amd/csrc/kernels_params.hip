@@ -125,19 +125,23 @@ __global__ void pen_sums_kernel(int D, int S, int M, double* __restrict__ work, 
     scalars[R_PEN] = ((sig_w + mu_w * mu_w - log(sig_w)) * M + (sig_l + mu_l * mu_l - log(sig_l)) * S) / (S + M);
 }
 // Fbar[d][m] = dcost*N / dF[d][m]  (data term, centring correction, penalty)
+//   rank-S form (TZ != NULL): the data term stays factored (it reaches the gradient through TZ and XU), so Fbar holds the centring
+//   correction and the penalty only; the column sums of Zbar are row S of TZ
 __global__ void fbar_kernel(const double* __restrict__ F, const double* __restrict__ XZ, int64_t ldxz, int D, int S, int M,
-                            double* __restrict__ work) {
+                            double* __restrict__ work, const double* __restrict__ TZ, int64_t ldtz) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)D * M) return;
     const int d = (int)(i / M), m = (int)(i % M);
     const double mu_w = work[4 * D + 0], sig_w = work[4 * D + 1];
     const double wgt = (double)M / (S + M);
     const double pen = wgt * ((1.0 - 1.0 / sig_w) * (F[i] - work[d]) / (M * work[D + d]) + 2.0 * mu_w / M);
-    work[4 * D + 4 + i] = XZ[(int64_t)d * ldxz + S + m] - XZ[(int64_t)D * ldxz + S + m] / D + pen;
+    if (TZ) work[4 * D + 4 + i] = -TZ[(int64_t)S * ldtz + S + m] / D + pen;
+    else work[4 * D + 4 + i] = XZ[(int64_t)d * ldxz + S + m] - XZ[(int64_t)D * ldxz + S + m] / D + pen;
 }
 // grad[3..] = [lbar_F, rbar_F, lbar_P, Pbar] / N
 __global__ void grad_tail_kernel(const double* __restrict__ params, const double* __restrict__ XZ, int64_t ldxz, int D, int S, int M,
-                                 const double* __restrict__ work, double invN, double* __restrict__ grad) {
+                                 const double* __restrict__ work, double invN, double* __restrict__ grad,
+                                 const double* __restrict__ TZ, int64_t ldtz) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t nDS = (int64_t)D * S, nMS = (int64_t)M * S;
     const double* lF = params + 3;
@@ -149,17 +153,19 @@ __global__ void grad_tail_kernel(const double* __restrict__ params, const double
         const int m = (int)(t / S), s = (int)(t % S);
         double v = 0;
         for (int d = 0; d < D; ++d) v += Fbar[(int64_t)d * M + m] * lF[(int64_t)d * S + s];
+        if (TZ) v += TZ[(int64_t)s * ldtz + S + m];                   // (l_F^T X^T Zbar_M)[s][m]: the data term of Fbar^T l_F
         grad[3 + i] = v * invN;
     } else if (i < nDS + nMS + S + M) {
         const int j = (int)(i - nDS - nMS);                           // column of X~^T Zbar's ones row
-        grad[3 + i] = XZ[(int64_t)D * ldxz + j] * invN;
+        grad[3 + i] = (TZ ? TZ[(int64_t)S * ldtz + j] : XZ[(int64_t)D * ldxz + j]) * invN;
     }
 }
 
 // lbar_F[d][s] = direct term + penalty + sum_m Fbar[d][m] r_F[m][s]: one wave per entry (the sum over M is the long one)
 __global__ __launch_bounds__(256) void lbar_kernel(const double* __restrict__ params, const double* __restrict__ XZ, int64_t ldxz, int D,
                                                    int S, int M, const double* __restrict__ work, double invN,
-                                                   double* __restrict__ grad) {
+                                                   double* __restrict__ grad, const double* __restrict__ TZ, int64_t ldtz,
+                                                   const double* __restrict__ XU, int64_t ldxu) {
     const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= (int64_t)D * S) return;
     const int lane = threadIdx.x & 63, d = (int)(i / S), s = (int)(i % S);
@@ -172,24 +178,26 @@ __global__ __launch_bounds__(256) void lbar_kernel(const double* __restrict__ pa
     if (lane == 0) {
         const double mu_l = work[4 * D + 2], sig_l = work[4 * D + 3];
         const double wgt = (double)S / (S + M);
-        v += XZ[(int64_t)d * ldxz + s] - XZ[(int64_t)D * ldxz + s] / D
+        // rank-S form: XU = X^T (Zbar_L + Zbar_M r_F) already holds the direct term and the data part of Fbar r_F
+        v += (TZ ? XU[(int64_t)d * ldxu + s] - TZ[(int64_t)S * ldtz + s] / D : XZ[(int64_t)d * ldxz + s] - XZ[(int64_t)D * ldxz + s] / D)
            + wgt * ((1.0 - 1.0 / sig_l) * (params[3 + i] - work[2 * D + d]) / (S * work[3 * D + d]) + 2.0 * mu_l / S);
         grad[3 + i] = v * invN;
     }
 }
 
 void grad_epilogue(const Geom& g, const double* params, const double* F, const double* XZ, int64_t ldxz, double* work,
-                   double* scalars, int64_t Nglobal, double* grad, hipStream_t st) {
+                   double* scalars, int64_t Nglobal, double* grad, hipStream_t st, const double* TZ, int64_t ldtz, const double* XU,
+                   int64_t ldxu) {
     const int D = g.D, S = g.S, M = g.M;
     hipLaunchKernelGGL(pen_rows_kernel, dim3(D), dim3(256), 0, st, params, F, D, S, M, work);
     hipLaunchKernelGGL(pen_sums_kernel, dim3(1), dim3(64), 0, st, D, S, M, work, scalars);
     if (!grad) return;
     const int64_t nf = (int64_t)D * M, nt = (int64_t)g.P - 3;
-    hipLaunchKernelGGL(fbar_kernel, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, st, F, XZ, ldxz, D, S, M, work);
+    hipLaunchKernelGGL(fbar_kernel, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, st, F, XZ, ldxz, D, S, M, work, TZ, ldtz);
     hipLaunchKernelGGL(grad_tail_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, params, XZ, ldxz, D, S, M, work,
-                       1.0 / (double)Nglobal, grad);
+                       1.0 / (double)Nglobal, grad, TZ, ldtz);
     hipLaunchKernelGGL(lbar_kernel, dim3((unsigned)(((int64_t)D * S + 3) / 4)), dim3(256), 0, st, params, XZ, ldxz, D, S, M, work,
-                       1.0 / (double)Nglobal, grad);
+                       1.0 / (double)Nglobal, grad, TZ, ldtz, XU, ldxu);
 }
 
 // cost and the three scalar gradient entries  (SCFGP.py:125-128)

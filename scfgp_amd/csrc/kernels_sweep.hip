@@ -505,7 +505,8 @@ void gram_table_kernel(const typename Cfg::T* __restrict__ Phi, int64_t ld, cons
 
 // Row tile ti0 + (t / ntn) of the output (tiles are 128 rows apart whatever Cfg::BM is: a narrower Cfg multiplies only the
 // first BM rows of its tile and zeroes the rest of the 128 x 128 slab)
-template <class Cfg, typename S>
+//   PLAIN: the B operand is a stored matrix (Phi[n][j], j < J; Pb unused) instead of Zbar formed from Phi and Phibar
+template <class Cfg, typename S, bool PLAIN = false>
 __global__ __launch_bounds__(Cfg::THREADS) void xtz_kernel(
     const double* __restrict__ Xt, int Dp, const S* __restrict__ Phi, const S* __restrict__ Pb, int64_t ld, int J, int64_t Np,
     int64_t rows_per_split, int64_t chunk, int ntn, int ntile, int ntile_all, int ti0, double* __restrict__ slabs) {
@@ -527,8 +528,14 @@ __global__ __launch_bounds__(Cfg::THREADS) void xtz_kernel(
         if (c0 < r1) {
             NatLoader<double, T, Cfg::BM, Cfg::BK, Cfg::LDA, Cfg::THREADS, false, true> la(
                 Xt + c0 * Dp + (int64_t)ti * 128, Dp, threadIdx.x, nullptr, Dp - ti * 128);
-            ZbarLoader<S, T, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS> lb(Phi + c0 * ld, Pb + c0 * ld, ld, J, tj * Cfg::BN, threadIdx.x);
-            tile_mainloop<Cfg>(la, lb, (int)((c1 - c0) / Cfg::BK), acc, smem);
+            if constexpr (PLAIN) {
+                NatLoader<S, T, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS, false, true> lb(Phi + c0 * ld + tj * Cfg::BN, ld, threadIdx.x, nullptr,
+                                                                                         J - tj * Cfg::BN);
+                tile_mainloop<Cfg>(la, lb, (int)((c1 - c0) / Cfg::BK), acc, smem);
+            } else {
+                ZbarLoader<S, T, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS> lb(Phi + c0 * ld, Pb + c0 * ld, ld, J, tj * Cfg::BN, threadIdx.x);
+                tile_mainloop<Cfg>(la, lb, (int)((c1 - c0) / Cfg::BK), acc, smem);
+            }
         }
         slab_flush<Cfg>(acc, slab, first);
         first = false;
@@ -673,28 +680,81 @@ void SweepKernels<T>::gram_planned(const Geom& g, const T* Phi, const double* w,
     }
 }
 
-template <typename T>
-void SweepKernels<T>::xtz(const Geom& g, const double* Xt, const T* Phi, const T* Phibar, int nsplit, int64_t chunk, double* slabs,
-                          hipStream_t st) {
-    const int ntm = (g.Dp + 127) / 128, ntn = g.Jp / 128;
-    const int64_t rps = round_up((g.Np + nsplit - 1) / nsplit, 64);
+// A^T B over the rows, A (Np x Dp, fp64) and B either Zbar formed in the loader (PLAIN false: Bsrc = Phi, Bsrc2 = Phibar) or the
+// stored matrix Bsrc (Np x J live columns, leading dimension ldb); slabs: nsplit x (ceil(Dp/128) x ceil(J/128)) tiles
+template <typename T, bool PLAIN>
+static void tn_product(const double* A, int Dp, const T* Bsrc, const T* Bsrc2, int64_t ldb, int J, int64_t Np, int nsplit, int64_t chunk,
+                       double* slabs, hipStream_t st) {
+    const int ntm = (Dp + 127) / 128, ntn = (J + 127) / 128;
+    const int64_t rps = round_up((Np + nsplit - 1) / nsplit, 64);
     if (chunk <= 0 || chunk > rps) chunk = rps;
     chunk = round_up(chunk, 16);
     const auto launch = [&](auto cfg, int ti0, int nti) {
         typedef typename decltype(cfg)::type Cfg;
         if (nti <= 0) return;
-        allow_big_lds(xtz_kernel<Cfg, T>, Cfg::LDS_BYTES);
-        hipLaunchKernelGGL((xtz_kernel<Cfg, T>), dim3(nti * ntn * nsplit), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st,
-                           Xt, g.Dp, Phi, Phibar, (int64_t)g.Kp, g.J, g.Np, rps, chunk, ntn, nti * ntn, ntm * ntn, ti0, slabs);
+        allow_big_lds(xtz_kernel<Cfg, T, PLAIN>, Cfg::LDS_BYTES);
+        hipLaunchKernelGGL((xtz_kernel<Cfg, T, PLAIN>), dim3(nti * ntn * nsplit), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st,
+                           A, Dp, Bsrc, Bsrc2, ldb, J, Np, rps, chunk, ntn, nti * ntn, ntm * ntn, ti0, slabs);
     };
-    // the last row tile holds Dp - 128 (ntm - 1) live rows: a 64- or 96-row tile when that is enough
-    const int last = g.Dp - 128 * (ntm - 1);
+    const int last = Dp - 128 * (ntm - 1);
     const int nfull = last > 96 ? ntm : ntm - 1;
     launch(XtzCfg<T>{}, 0, nfull);
     if (nfull < ntm) {
         if (last <= 64) launch(Xtz64Cfg<T>{}, nfull, 1);
         else launch(Xtz96Cfg<T>{}, nfull, 1);
     }
+}
+template <typename T>
+void SweepKernels<T>::tn_plain(const double* A, int Dp, const T* Bm, int64_t ldb, int J, int64_t Np, int nsplit, int64_t chunk, double* slabs,
+                               hipStream_t st) {
+    tn_product<T, true>(A, Dp, Bm, nullptr, ldb, J, Np, nsplit, chunk, slabs, st);
+}
+
+// Zbar[n][j] = Phi[n][j] Phibar[n][J+j] - Phi[n][J+j] Phibar[n][j], j < J, written over Phibar[n][j] (the cosine half of Phibar
+// is dead afterwards; its sine half stays until the caller overwrites it)
+template <typename T>
+__global__ __launch_bounds__(256) void zbar_kernel(const T* __restrict__ Phi, T* Pb, int64_t ld, int J, int64_t Np) {
+    const int jv = (J + 3) / 4;                                        // four columns per thread where J allows vector access
+    const int64_t total = Np * jv;
+    const bool vec = (J % 4 == 0) && sizeof(T) == 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t n = i / jv; const int j0 = (int)(i - n * jv) * 4;
+        const T* f = Phi + n * ld; T* b = Pb + n * ld;
+        if (vec) {
+            typedef T t4 __attribute__((ext_vector_type(4)));
+            const t4 fc = *reinterpret_cast<const t4*>(f + j0), fs = *reinterpret_cast<const t4*>(f + J + j0);
+            const t4 bc = *reinterpret_cast<const t4*>(b + j0), bs = *reinterpret_cast<const t4*>(b + J + j0);
+            *reinterpret_cast<t4*>(b + j0) = fc * bs - fs * bc;
+        } else {
+            for (int e = 0; e < 4 && j0 + e < J; ++e) { const int j = j0 + e; b[j] = f[j] * b[J + j] - f[J + j] * b[j]; }
+        }
+    }
+}
+template <typename T>
+void SweepKernels<T>::zbar_inplace(const Geom& g, const T* Phi, T* Phibar, hipStream_t st) {
+    hipLaunchKernelGGL(zbar_kernel<T>, dim3(8192), dim3(256), 0, st, Phi, Phibar, (int64_t)g.Kp, g.J, g.Np);
+}
+// Rsel (typed, leading dimension Kp, Kp rows): rows j < S the identity, rows S + m the row m of r_F, zero elsewhere -- the operand of
+// U = Zbar . Rsel = Zbar_L + Zbar_M r_F
+template <typename T>
+__global__ void rsel_kernel(const double* __restrict__ params, int D, int S, int M, T* __restrict__ out, int Kp, int ncol) {
+    const int64_t total = (int64_t)Kp * ncol;
+    const double* rF = params + 3 + (int64_t)D * S;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int k = (int)(i / ncol), c = (int)(i % ncol);
+        T v = 0;
+        if (c < S) { if (k < S) v = k == c ? (T)1 : (T)0; else if (k < S + M) v = (T)rF[(int64_t)(k - S) * S + c]; }
+        out[(int64_t)k * Kp + c] = v;
+    }
+}
+template <typename T>
+void SweepKernels<T>::rsel(const Geom& g, const double* params, T* out, hipStream_t st) {
+    hipLaunchKernelGGL(rsel_kernel<T>, dim3(1024), dim3(256), 0, st, params, g.D, g.S, g.M, out, g.Kp, (int)round_up(g.S, 64));
+}
+template <typename T>
+void SweepKernels<T>::xtz(const Geom& g, const double* Xt, const T* Phi, const T* Phibar, int nsplit, int64_t chunk, double* slabs,
+                          hipStream_t st) {
+    tn_product<T, false>(Xt, g.Dp, Phi, Phibar, (int64_t)g.Kp, g.J, g.Np, nsplit, chunk, slabs, st);
 }
 
 // --------------------------------------------------------------------------
@@ -1127,6 +1187,15 @@ void SweepKernels<T>::apply_predict(const Geom& g, const T* Phi, const T* LiT, d
                                     hipStream_t st, bool bf3) {
     apply_launch<T, 2>(g, Phi, LiT, (T*)nullptr, vpart, nullptr, nullptr, nullptr, alpha, nullptr, nullptr, mu, st, bf3);
 }
+// Out[n][c] = sum_{k < Kc} A[n][k] Bm[k][c] for c < ncols (rounded up to 64-wide tiles), everything with leading dimension Kp;
+// Bm[k][c] = 0 for k < c is assumed (the contraction of a column tile starts at its first column)
+template <typename T>
+void SweepKernels<T>::apply_plain(const Geom& g, const T* A, const T* Bm, T* Out, int Kc, int ncols, hipStream_t st) {
+    Geom gk = g; gk.K = Kc;
+    apply_launch_cfg<typename ApplyCfg<T, 64>::type, 4, T>(gk, (ncols + 63) / 64, 0, 0, 0, A, Bm, Out, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                                           nullptr, nullptr, nullptr, st);
+}
+
 template <typename T>
 void SweepKernels<T>::apply_c(const Geom& g, const T* Phi, const T* LiT, const T* Li, T* C, double* vpart, const double* alpha,
                               double* mu, hipStream_t st, const Bf3Planes* planes) {

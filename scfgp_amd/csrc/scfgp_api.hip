@@ -24,9 +24,9 @@
 static constexpr int XT = 128;              // tile of the X~^T Zbar product and padding unit of J (kernels_sweep.hip)
 static constexpr int64_t PRED_ROWS = 32768; // predict processes test rows in chunks of this size
 // Thresholds of the automatic precision escalation and the error model behind them (profiles/r03_c3_owner.md): with the
-// fp32 Gram products (4096-row flush interval, relative error 6e-8 from 1e5 rows up) the relative error of alpha / Li, and
-// of the frequency gradient blocks, against fp64 mode is about SCFGP_ERR_PER_COND times the condition estimate (measured
-// 1.2e-7 .. 3.0e-7 at estimates 4 .. 6.4e3).  Level 1 keeps the predicted alpha error under 3e-6 (north star: 1e-5), level 2
+// fp32 Gram products (4096-row flush interval, relative error ~6e-8) the relative error of alpha / Li, and of the frequency
+// gradient blocks, against fp64 mode is about SCFGP_ERR_PER_COND times the condition estimate (measured 7e-8 .. 2e-6 times
+// the estimate at estimates 4 .. 6.4e3: the estimate is a lower bound of cond_2 of varying tightness).  Level 1 keeps the predicted alpha error under 3e-6 (north star: 1e-5), level 2
 // the predicted gradient error under 3e-4 (SURVEY App. E acceptance: 1e-3 per block).
 #ifndef SCFGP_PASS3_PARTS
 #define SCFGP_PASS3_PARTS 1        // default number of row parts of pass 3 from 262144 rows up (1: off)
@@ -71,6 +71,14 @@ struct scfgp_ctx {
     hipStream_t st = nullptr; bool own_stream = false;
     hipStream_t copy_st = nullptr; hipEvent_t ev_factor = nullptr;          // alpha/Li D2H beside pass 2/3 ...
     hipStream_t aux_st = nullptr; std::vector<hipEvent_t> ev_p3; int pass3_parts = -1;      // pass 3 in row parts (pass3_pipelined)
+    // rank-S form of the backward projection: exchange 3 = [T~^T Zbar (Spp x Jp) ... | 8 scalars at Dpp*Jp | X~^T U (Dpp x Sq)]
+    int lowrank_bwd = -1; int Spp = 0, Sq = 0; bool last_lrb = false;
+    bool want_lrb() const {
+        const bool fits = g.Jp + (int)round_up(g.S, 64) <= g.Kp;
+        return fits && (lowrank_bwd == 1 || (lowrank_bwd < 0 && g.lowrank && g.Dp >= 4 * g.Sp));
+    }
+    double* x3_scalars() { return d_x3 + (int64_t)Dpp * g.Jp; }
+    double* x3_xu() { return d_x3 + (int64_t)Dpp * g.Jp + 8; }
     hipEvent_t ev_fence = nullptr;                                          // scfgp_stream_fence
     double* h_pin = nullptr;                                                // ... through pinned staging (K*K + K doubles)
     int64_t Ncap = 0, Nglobal = 0, Nglobal_full = 0;        // Nglobal_full: n_global given to scfgp_set_data
@@ -135,19 +143,11 @@ struct scfgp_ctx {
     int level() const { return dtype != SCFGP_F32 || gram64 == 0 ? 0 : (gram64 == 1 ? 1 : (gram64 == 3 ? 2 : esc_level)); }
     bool use64() const { return level() >= 1; }
     double cond_est() const { return cond[1] * cond[2]; }
-    // relative error of the fp32 Gram against the fp64 one (profiles/r03_c3_owner.md): chains of up to 4096 rows in fp32, fp64
-    // across them -- 4e-7 for one full chain, falling with the square root of the number of chains down to the 6e-8 measured
-    // from 1e5 rows up, and in proportion to the chain length below one chunk
-    double gram_rel_err() const {
-        const double n = (double)(Nglobal > 0 ? Nglobal : 1), ch = (double)(gram_chunk > 0 ? gram_chunk : 4096);
-        return n >= ch ? std::max(6e-8, 4e-7 * std::sqrt(ch / n)) * (ch / 4096.0) : std::max(3e-8, 4e-7 * n / 4096.0);
-    }
-    double alpha_err_fp32() const { return 5.0 * gram_rel_err() * cond_est(); }      // == SCFGP_ERR_PER_COND * estimate from 1e5 rows up
-    // thresholds are quoted for the 6e-8 regime; fewer rows (a noisier Gram) scale the estimate up accordingly
-    int want_level(double est, double slack) const {
-        est *= gram_rel_err() / 6e-8;
-        return est > escw_thr * slack ? 2 : (est > esc_thr * slack ? 1 : 0);
-    }
+    // predicted relative error of alpha / Li behind an fp32 Gram: SCFGP_ERR_PER_COND x estimate.  The estimate is a lower bound
+    // of cond_2(A) whose tightness varies (cond_2 / estimate: 30 .. 330 over the measured cases), so the prediction is an order
+    // of magnitude: measured error / prediction lies in 0.2 .. 7 (profiles/r03_c3_owner.md)
+    double alpha_err_fp32() const { return SCFGP_ERR_PER_COND * cond_est(); }
+    int want_level(double est, double slack) const { return est > escw_thr * slack ? 2 : (est > esc_thr * slack ? 1 : 0); }
     // profiling
     bool roctx_on = false;
     bool prof = false; std::vector<ProfRec> recs; std::vector<hipEvent_t> pool; size_t pool_used = 0;
@@ -290,7 +290,11 @@ static int ensure_rows(scfgp_ctx* c, int64_t N) {
     } else { c->plan = GramPlan{}; c->plan_Np = -1; }
     const int xs = c->xtz_nsplit > 0 ? (int)std::min<int64_t>(c->xtz_nsplit, Np / 64) : xtz_split(ntx, Np);
     // Gram slabs are followed by the per-split side-vector partials (gs x Kp)
-    const size_t need = sizeof(double) * std::max<size_t>((size_t)gs * ntiles * g.tile * g.tile + (size_t)gs * g.Kp, (size_t)xs * ntx * XT * XT);
+    // the two row-contracted products of the rank-S backward projection (pass3): (Spp x Jp) and (Dpp x Sq) tile grids
+    const int nt1 = (c->Spp / XT) * (g.Jp / XT), nt2 = (c->Dpp / XT) * (c->Sq / XT);
+    const size_t lrb = std::max<size_t>((size_t)xtz_split(nt1, Np) * nt1, (size_t)xtz_split(nt2, Np) * nt2);
+    const size_t need = sizeof(double) * std::max<size_t>((size_t)gs * ntiles * g.tile * g.tile + (size_t)gs * g.Kp,
+                                                          std::max<size_t>((size_t)xs * ntx, lrb) * XT * XT);
     if (need > c->slabs_bytes) {
         dfree(c->d_slabs);
         if (int rc = dmalloc(c, &c->d_slabs, need)) return rc;
@@ -337,7 +341,8 @@ extern "C" int scfgp_create(scfgp_ctx** out, int D, int S, int M, int dtype, int
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_factor, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_fence, hipEventDisableTiming));
     const int64_t Kp = g.Kp, K2 = Kp * Kp;
-    c->n_x1 = K2 + Kp + 8; c->n_x2 = K2 + Kp + 8; c->n_x3 = (int64_t)c->Dpp * g.Jp + 8;
+    c->Spp = (int)round_up(g.Sp, XT); c->Sq = (int)round_up(g.S, XT);
+    c->n_x1 = K2 + Kp + 8; c->n_x2 = K2 + Kp + 8; c->n_x3 = (int64_t)std::max(c->Dpp, c->Spp) * g.Jp + 8 + (int64_t)c->Dpp * c->Sq;
     { const int64_t nts = Kp / g.tile; c->n_pk = nts * (nts + 1) / 2 * g.tile * g.tile; c->n_xp = c->n_pk + Kp + 8; }
     int rc;
     if ((rc = dmalloc(c, &c->d_params, sizeof(double) * g.P))) return rc;
@@ -609,7 +614,7 @@ template <typename T> struct Impl {
                 SK::xtz(gq, c->d_Xt + r0 * g.Dp, (const T*)c->d_Phi + r0 * g.Kp, (const T*)c->d_V + r0 * g.Kp, xs_q,
                         c->dtype == SCFGP_F32 ? c->gram_chunk : 0, c->d_slabs + (size_t)i * xs_q * ntm * ntn * XT * XT, c->aux_st);
             }
-            reduce_scalars(c->d_bpart, nb, 1, c->d_x3 + (int64_t)c->Dpp * g.Jp, 0, c->st);
+            reduce_scalars(c->d_bpart, nb, 1, c->x3_scalars(), 0, c->st);
         }
         {
             ProfScope ps(c, "xtz");                             // what is left of it after the last product: its last part and the slab sum
@@ -624,16 +629,36 @@ template <typename T> struct Impl {
         const Geom& g = c->g;
         {
             const int Q = c->pass3_parts >= 0 ? c->pass3_parts : (g.Np >= 262144 ? SCFGP_PASS3_PARTS : 1);
-            if (Q > 1 && !c->bf3 && g.Np / 256 >= 4 * Q) return pass3_pipelined(c, Q);
+            if (Q > 1 && !c->bf3 && !c->want_lrb() && g.Np / 256 >= 4 * Q) { c->last_lrb = false; return pass3_pipelined(c, Q); }
         }
         { ProfScope ps(c, "apply_phibar"); const Bf3Planes pl = c->planes();
           const int nb = SK::apply_phibar(g, (const T*)c->d_Phi, AbarT(c), (T*)c->d_V, c->d_p, c->d_q, c->d_y, c->alpha(), c->ut(),
                                           c->d_bpart, c->st, c->bf3, &pl);
-          reduce_scalars(c->d_bpart, nb, 1, c->d_x3 + (int64_t)c->Dpp * g.Jp, 0, c->st); }
+          reduce_scalars(c->d_bpart, nb, 1, c->x3_scalars(), 0, c->st); }
         const int ntm = c->Dpp / XT, ntn = g.Jp / XT;
+        const int64_t chunk = c->dtype == SCFGP_F32 ? c->gram_chunk : 0;
+        c->last_lrb = c->want_lrb();
+        if (c->last_lrb) {
+            // rank-S form of the backward projection (F = l_F r_F^T, SCFGP.py:83,100): Zbar once, in place over Phibar's cosine half;
+            // T~^T Zbar (T~ = [X l_F | 1] is resident from the forward projection); U = Zbar_L + Zbar_M r_F into Phibar's dead
+            // sine half; X~^T U.  2 N (S+1) J + 2 N J S + 2 N (D+1) S flops instead of 2 N (D+1) J.
+            ProfScope ps(c, "xtz");
+            T* Zb = (T*)c->d_V; T* U = (T*)c->d_V + g.Jp;
+            SK::zbar_inplace(g, (const T*)c->d_Phi, Zb, c->st);
+            SK::rsel(g, c->d_params, (T*)c->d_AbarT, c->st);                       // Abar's typed copy is dead after the product above
+            SK::apply_plain(g, Zb, (const T*)c->d_AbarT, U, g.J, g.S, c->st);
+            const int nt1 = (c->Spp / XT) * ntn, xs1 = xtz_split(nt1, g.Np);
+            SK::tn_plain(c->d_Tt, g.Sp, Zb, g.Kp, g.J, g.Np, xs1, chunk, c->d_slabs, c->st);
+            reduce_full_tiles(c->d_slabs, xs1, c->Spp / XT, ntn, c->d_x3, g.Jp, c->st);
+            const int nt2 = ntm * (c->Sq / XT), xs2 = xtz_split(nt2, g.Np);
+            SK::tn_plain(c->d_Xt, g.Dp, U, g.Kp, g.S, g.Np, xs2, chunk, c->d_slabs, c->st);
+            reduce_full_tiles(c->d_slabs, xs2, ntm, c->Sq / XT, c->x3_xu(), c->Sq, c->st);
+            HIPCHK(c, hipGetLastError());
+            return SCFGP_OK;
+        }
         const int xs = c->xtz_nsplit > 0 ? (int)std::min<int64_t>(c->xtz_nsplit, g.Np / 64) : xtz_split(ntm * ntn, g.Np);
         { ProfScope ps(c, "xtz");
-          SK::xtz(g, c->d_Xt, (const T*)c->d_Phi, (const T*)c->d_V, xs, c->dtype == SCFGP_F32 ? c->gram_chunk : 0, c->d_slabs, c->st);
+          SK::xtz(g, c->d_Xt, (const T*)c->d_Phi, (const T*)c->d_V, xs, chunk, c->d_slabs, c->st);
           reduce_full_tiles(c->d_slabs, xs, ntm, ntn, c->d_x3, g.Jp, c->st); }
         HIPCHK(c, hipGetLastError());
         return SCFGP_OK;
@@ -748,8 +773,11 @@ extern "C" int scfgp_fetch_factors(scfgp_ctx* c, double* alpha, double* Li) {
 static void enqueue_epilogue(scfgp_ctx* c, int want_grad) {
     const Geom& g = c->g;
     ProfScope ps(c, "epilogue");
-    grad_epilogue(g, c->d_params, c->d_F, c->d_x3, g.Jp, c->d_work, c->d_scalars, c->Nglobal, want_grad ? c->d_grad : nullptr, c->st);
-    finalize_cost(g, c->d_sc, c->d_scalars, c->d_xp1 + c->n_pk + g.Kp, c->d_xp2 + c->n_pk + g.Kp, c->d_x3 + (int64_t)c->Dpp * g.Jp,
+    if (want_grad && c->last_lrb)
+        grad_epilogue(g, c->d_params, c->d_F, nullptr, 0, c->d_work, c->d_scalars, c->Nglobal, c->d_grad, c->st, c->d_x3, g.Jp, c->x3_xu(), c->Sq);
+    else
+        grad_epilogue(g, c->d_params, c->d_F, c->d_x3, g.Jp, c->d_work, c->d_scalars, c->Nglobal, want_grad ? c->d_grad : nullptr, c->st);
+    finalize_cost(g, c->d_sc, c->d_scalars, c->d_xp1 + c->n_pk + g.Kp, c->d_xp2 + c->n_pk + g.Kp, c->x3_scalars(),
                   c->Nglobal, c->d_grad, want_grad, c->st);
 }
 
@@ -1225,6 +1253,7 @@ extern "C" int scfgp_set_option(scfgp_ctx* c, const char* name, int64_t value) {
     else if (s == "gram_chunk") c->gram_chunk = value;
     else if (s == "gram_plan") { c->gram_plan = (int)value; c->plan_Np = -1; }
     else if (s == "pass3_parts") c->pass3_parts = (int)value;
+    else if (s == "lowrank_bwd") c->lowrank_bwd = (int)value;
     else if (s == "xtz_nsplit") c->xtz_nsplit = (int)value;
     else if (s == "use_graph") c->use_graph = (int)value;
     else if (s == "gram64") { if (value < 0 || value > 3) { c->err = "gram64: 0 never, 1 always level 1, 2 auto, 3 always level 2"; return SCFGP_EARG; }
@@ -1246,8 +1275,8 @@ extern "C" int scfgp_set_option(scfgp_ctx* c, const char* name, int64_t value) {
 //        LOWER bound of cond_2(A) (>= the diagonal ratio max L_ii^2 / min L_ii^2)
 // out[1] precision level that evaluation ran at (0, 1, 2: see scfgp_ctx; fp64 mode reports 0)
 // out[2] 1 if its G and Phi^T y were formed in fp64 from fp64 features (always in fp64 mode), else 0
-// out[3] predicted relative error of alpha / Li had the Gram been formed in fp32: 5 x (relative error of the fp32 Gram at this
-//        number of rows) x out[0]  (= SCFGP_ERR_PER_COND * out[0] from 1e5 rows up)
+// out[3] predicted relative error of alpha / Li had the Gram been formed in fp32: SCFGP_ERR_PER_COND * out[0] (an order of
+//        magnitude: measured / predicted = 0.2 .. 7)
 // out[4] threshold of level 1, out[5] threshold of level 2 (auto policy), out[6] min L_ii^2, out[7] max L_ii^2, out[8] max_j (A^-1)_jj
 extern "C" int scfgp_get_condition(scfgp_ctx* c, double* out, int n) {
     if (!c || !out || n < 4) return SCFGP_EARG;

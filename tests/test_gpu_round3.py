@@ -363,3 +363,34 @@ def test_pass3_in_row_parts_overlapping_xtz(dtype, tol):
             assert abs(float(c) - ref[0]) < tol * abs(ref[0]) and rel(g, ref[1]) < tol * 10, (parts, rel(g, ref[1]))
             assert np.allclose(hist, ref[2], rtol=tol * 100, atol=0)
         eng.close()
+
+
+@pytest.mark.parametrize('dtype,gtol', [('f64', 1e-9), ('f32', 1e-3)])
+def test_rank_s_backward_projection_matches_the_dense_one(dtype, gtol):
+    """Option lowrank_bwd (automatic when D >> S): the reverse sweep of F = l_F r_F^T (SCFGP/SCFGP.py:83,100) through
+    T~^T Zbar and X~^T (Zbar_L + Zbar_M r_F) instead of the dense X~^T Zbar.  Same gradient (all blocks, phases included) as
+    the dense form and the oracle; odd J (scalar Zbar path), J a multiple of 4 (vector path), S + 1 > 64 (two tiles of T~)."""
+    from scfgp_amd.engine import HipEngine
+    for N, D, S, M in ((1500, 200, 8, 232), (1100, 150, 5, 200), (900, 300, 70, 250)):
+        seed = 0x5CF63A00 + D
+        X = synth.make_X(seed, N, D)
+        y = synth.normal(seed + 9, 0, N).reshape(-1, 1)
+        params = synth.make_params(seed + 0x0202, D, S, M, abc=(0.5, 0.0, -1.0))
+        params[3:3 + D * S] *= 0.3                                 # |Z| stays moderate at D = 300
+        c0, g0, a0, L0 = O.value_and_grad(X, y, params, S, M)
+        outs = {}
+        for lrb in (0, 1):
+            eng = HipEngine(D, S, M, dtype); eng.set_option('gram64', 0); eng.set_option('lowrank_bwd', lrb)
+            eng.set_params(params); eng.set_data(X, y)
+            c, g, a, L = eng.eval()
+            c2, g2, _, _ = eng.eval()
+            assert float(c2) == float(c) and np.array_equal(g2, g)
+            outs[lrb] = (float(c), g)
+            assert abs(float(c) - c0) < (1e-10 if dtype == 'f64' else 2e-5) * max(1.0, abs(c0))
+            for u, v in zip(grad_blocks(g, D, S, M), grad_blocks(g0, D, S, M)):
+                assert rel(u, v) < gtol, (lrb, D, rel(u, v))
+            J = S + M
+            assert np.abs(g[-J:]).max() < (1e-9 if dtype == 'f64' else 1e-3) * np.abs(g).max()      # phases: zero gradient
+            eng.close()
+        assert outs[0][0] == outs[1][0]
+        assert rel(outs[1][1], outs[0][1]) < (1e-11 if dtype == 'f64' else 1e-4)
