@@ -385,7 +385,9 @@ def test_rank_s_backward_projection_matches_the_dense_one(dtype, gtol):
             c, g, a, L = eng.eval()
             c2, g2, _, _ = eng.eval()
             assert float(c2) == float(c) and np.array_equal(g2, g)
-            outs[lrb] = (float(c), g)
+            eng.opt_init('adam', learning_rate=0.005)
+            hist, _, _ = eng.train(3)                              # the same pass 3 inside the captured training iteration
+            outs[lrb] = (float(c), g, hist)
             assert abs(float(c) - c0) < (1e-10 if dtype == 'f64' else 2e-5) * max(1.0, abs(c0))
             for u, v in zip(grad_blocks(g, D, S, M), grad_blocks(g0, D, S, M)):
                 assert rel(u, v) < gtol, (lrb, D, rel(u, v))
@@ -394,3 +396,4 @@ def test_rank_s_backward_projection_matches_the_dense_one(dtype, gtol):
             eng.close()
         assert outs[0][0] == outs[1][0]
         assert rel(outs[1][1], outs[0][1]) < (1e-11 if dtype == 'f64' else 1e-4)
+        assert np.allclose(outs[1][2], outs[0][2], rtol=1e-10 if dtype == 'f64' else 1e-5, atol=0)
