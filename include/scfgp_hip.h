@@ -59,7 +59,10 @@ typedef struct scfgp_ctx scfgp_ctx;
  * Replaces SCFGP.build_theano_models (SCFGP/SCFGP.py:92-148): "compile" becomes "create a
  * context".  D,S,M as in SCFGP.__init__/set_data (SCFGP/SCFGP.py:36-37,164).
  * `stream` is a hipStream_t (NULL = the context creates its own); passing the stream of
- * the host framework keeps the library's work ordered with that framework's collectives. */
+ * the host framework keeps the library's work ordered with that framework's collectives.
+ * On failure (negative return) *out is still set whenever the context object itself could be made -- so that
+ * scfgp_last_error(*out) can say which allocation or HIP call failed -- and holds whatever was allocated up to that point:
+ * the caller must hand it to scfgp_destroy (scfgp_amd/engine.py does). */
 int  scfgp_create(scfgp_ctx** out, int D, int S, int M, int dtype, int device, void* stream);
 void scfgp_destroy(scfgp_ctx* ctx);
 const char* scfgp_last_error(const scfgp_ctx* ctx);
