@@ -402,7 +402,7 @@ def main(a):
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "avg_launch_ms": fm_ms,
                            "rocprof_WRITE_SIZE_GBs": pmc.get('featuremap_WRITE_SIZE_GBs'),
                            "note": "Phi written once / time of project+featuremap kernels (hipEvents); rocprof_WRITE_SIZE_GBs is the "
-                                   "same quantity from the rocprofv3 WRITE_SIZE counter (profiles/r02_pmc_traffic.json)"},
+                                   "same quantity from the rocprofv3 WRITE_SIZE counter (the traffic_source file of `roofline`)"},
             "gram": {"bound": "mfma", "achieved": gram_exec / (gr_ms * 1e-3) / 1e12 if gr_ms > 0 else 0.0, "peak": peak,
                      "unit": "TFLOP/s (executed)", "avg_launch_ms": gr_ms,
                      "MFMA_BUSY": pmc.get('gram_MFMA_BUSY')},
