@@ -7,6 +7,7 @@ and turns error codes into the exceptions the reference raises
 (numpy.linalg.LinAlgError for a failed Cholesky, SCFGP/SCFGP.py:106).
 """
 import ctypes as C
+import sys
 
 import numpy as np
 
@@ -34,6 +35,7 @@ class HipEngine(object):
         self.dtype = _DTYPES[dtype]
         self.device = int(device)
         self.ctx = C.c_void_p()
+        self._pool = {}
         rc = self.lib.scfgp_create(C.byref(self.ctx), self.D, self.S, self.M, self.dtype, int(device),
                                    C.c_void_p(stream) if stream else None)
         if rc != 0:
@@ -43,6 +45,8 @@ class HipEngine(object):
             raise RuntimeError('scfgp_create failed (%d): %s' % (rc, msg))
         self.N = 0
         self.n_global = 0
+
+    _pool = None
 
     def close(self):
         if getattr(self, 'ctx', None):
@@ -100,11 +104,26 @@ class HipEngine(object):
         self._check(self.lib.scfgp_set_data(self.ctx, dptr(X), dptr(y), N, self.n_global), 'set_data')
 
     # -- whole evaluations ------------------------------------------------------------------
-    def _outputs(self, want_grad):
+    def _fresh(self, shape):
+        """An output array nobody else holds.  The reference's functions return freshly allocated arrays on every call; a
+        fresh K x K float64 array (35.7 MB at K = 2112) costs the host ~1.4 ms per call in page faults and their release
+        (measured against reused buffers, tests/gpu_wall.py).  So arrays handed out earlier are kept in a small pool and one
+        is used again only once the caller has dropped every reference to it (views hold one through .base): from the
+        caller's side it cannot be told from a new array."""
+        pool = self._pool.setdefault(shape, [])
+        for i in range(len(pool)):
+            if sys.getrefcount(pool[i]) == 2:                  # the pool's reference + getrefcount's argument
+                return pool[i]
+        a = np.empty(shape)
+        if len(pool) < 4:
+            pool.append(a)
+        return a
+
+    def _outputs(self, want_grad, factors=True):
         cost = np.zeros(1)
         grad = np.empty(self.P) if want_grad else None
-        alpha = np.empty((self.K, 1))
-        Li = np.empty((self.K, self.K))
+        alpha = self._fresh((self.K, 1)) if factors else None
+        Li = self._fresh((self.K, self.K)) if factors else None
         return cost, grad, alpha, Li
 
     def eval(self, X=None, y=None, want_grad=True):
@@ -212,7 +231,7 @@ class HipEngine(object):
 
     def fetch_factors(self):
         """Fetch alpha / Li as soon as the factor stage is done (overlaps the sweeps already queued); finish() returns them."""
-        alpha = np.empty((self.K, 1)); Li = np.empty((self.K, self.K))
+        alpha = self._fresh((self.K, 1)); Li = self._fresh((self.K, self.K))
         self._check(self.lib.scfgp_fetch_factors(self.ctx, dptr(alpha), dptr(Li)), 'fetch_factors')
         self._early = (alpha, Li)
 
@@ -229,8 +248,8 @@ class HipEngine(object):
         """(cost, grad, alpha, Li) -- or None when the library asks for the stages to be run again at the precision level
         it has just raised (SCFGP_REDO, include/scfgp_hip.h: the condition estimate of this evaluation was too high
         for the level it ran at)."""
-        cost, grad, alpha, Li = self._outputs(want_grad)
         early = getattr(self, '_early', None)
+        cost, grad, alpha, Li = self._outputs(want_grad, factors=early is None)
         if early is not None:
             alpha, Li = early
             rc = self.lib.scfgp_finish(self.ctx, int(bool(want_grad)), dptr(cost), dptr(grad), None, None)
