@@ -866,22 +866,15 @@ __device__ __forceinline__ void apply_epilogue(
 #ifndef SCFGP_BF3_WAVES
 #define SCFGP_BF3_WAVES 2        // waves per SIMD the split-precision apply kernel is compiled for (2: one workgroup per CU)
 #endif
+// one output tile (column tile jt of this launch, row block rb) of the apply product
 template <class Cfg, int EPI>
-__global__ __launch_bounds__(Cfg::THREADS)
-__attribute__((amdgpu_waves_per_eu(IsBf3<Cfg>::value ? SCFGP_BF3_WAVES : (sizeof(typename Cfg::T) == 4 && SCFGP_APPLY_WAVES_F32 != 8 ? SCFGP_APPLY_WAVES_F32 : 1),
-                                   IsBf3<Cfg>::value ? SCFGP_BF3_WAVES : (sizeof(typename Cfg::T) == 4 ? SCFGP_APPLY_WAVES_F32 : 8))))
-void apply_kernel(
+__device__ __forceinline__ void apply_tile(
     const typename Cfg::T* __restrict__ Phi, const typename Cfg::T* __restrict__ Bm, typename Cfg::T* V,
     double* __restrict__ vpart, const double* __restrict__ p, const double* __restrict__ q, const double* __restrict__ y,
     const double* __restrict__ alpha, const double* __restrict__ ut, int K, int Kp, int64_t Np, int njt,
-    double* __restrict__ bpart, int col0, int jt0, double* __restrict__ mu, int ntot) {
-    // this launch covers columns [col0, col0 + njt*BN); jt0 = index of its first tile in vpart
+    double* __restrict__ bpart, int col0, int jt0, double* __restrict__ mu, int ntot, int jt, int64_t rb, char* smem_raw) {
     typedef typename Cfg::T T;
-    SMEM_DECL;
     T* smem = reinterpret_cast<T*>(smem_raw);
-    const unsigned wid = xcd_remap(blockIdx.x, gridDim.x);
-    const int jt = wid % njt;
-    const int64_t rb = wid / njt;
     const int cbase = col0 + jt * Cfg::BN;
     // EPI 0: column tile t of ntot also forms the slice kt % ntot == t of mu = Phi.alpha for its rows
     const bool want_mu = (EPI == 0 || EPI == 2 || EPI == 3) && mu != nullptr;
@@ -920,6 +913,32 @@ void apply_kernel(
         if constexpr (EPI != 1 && EPI != 4) { if (want_mu) la.dot_reduce(mu + (int64_t)(jt0 + jt) * Np + rb * Cfg::BM); }
         apply_epilogue<Cfg, EPI>(acc, Phi, V, vpart, p, q, y, alpha, ut, K, Kp, Np, rb, cbase, jt0 + jt, bpart, smem_raw);
     }
+}
+
+template <class Cfg, int EPI>
+__global__ __launch_bounds__(Cfg::THREADS)
+__attribute__((amdgpu_waves_per_eu(IsBf3<Cfg>::value ? SCFGP_BF3_WAVES : (sizeof(typename Cfg::T) == 4 && SCFGP_APPLY_WAVES_F32 != 8 ? SCFGP_APPLY_WAVES_F32 : 1),
+                                   IsBf3<Cfg>::value ? SCFGP_BF3_WAVES : (sizeof(typename Cfg::T) == 4 ? SCFGP_APPLY_WAVES_F32 : 8))))
+void apply_kernel(
+    const typename Cfg::T* __restrict__ Phi, const typename Cfg::T* __restrict__ Bm, typename Cfg::T* V,
+    double* __restrict__ vpart, const double* __restrict__ p, const double* __restrict__ q, const double* __restrict__ y,
+    const double* __restrict__ alpha, const double* __restrict__ ut, int K, int Kp, int64_t Np, int njt,
+    double* __restrict__ bpart, int col0, int jt0, double* __restrict__ mu, int ntot) {
+    // this launch covers columns [col0, col0 + njt*BN); jt0 = index of its first tile in vpart
+    SMEM_DECL;
+    const unsigned wid = xcd_remap(blockIdx.x, gridDim.x);
+    if constexpr (EPI == 3 || EPI == 4) {
+        // triangular operand: column tile jt contracts over (jt + 1) / njt (EPI 3) or (njt - jt) / njt (EPI 4) of the k range, so a
+        // workgroup takes tile t AND tile njt - 1 - t -- every workgroup of the launch then does the same amount of work
+        const int np = (njt + 1) / 2, t = (int)(wid % np), o = njt - 1 - t;
+        const int64_t rb = wid / np;
+        apply_tile<Cfg, EPI>(Phi, Bm, V, vpart, p, q, y, alpha, ut, K, Kp, Np, njt, bpart, col0, jt0, mu, ntot, t, rb, smem_raw);
+        if (o != t) {
+            __syncthreads();                                     // the first tile's epilogue is done with the LDS
+            apply_tile<Cfg, EPI>(Phi, Bm, V, vpart, p, q, y, alpha, ut, K, Kp, Np, njt, bpart, col0, jt0, mu, ntot, o, rb, smem_raw);
+        }
+    } else
+        apply_tile<Cfg, EPI>(Phi, Bm, V, vpart, p, q, y, alpha, ut, K, Kp, Np, njt, bpart, col0, jt0, mu, ntot, (int)(wid % njt), wid / njt, smem_raw);
 }
 
 // fp32 apply product with LDS-DMA staging (option apply_dma): both operands go global -> LDS by global_load_lds_dwordx4
@@ -1074,8 +1093,9 @@ static int apply_launch_cfg(const Geom& g, int njt, int col0, int jt0, int boff,
                             double* bpart, double* mu, hipStream_t st) {
     if (njt <= 0) return 0;
     const int64_t nrb = g.Np / Cfg::BM;
+    const int wgs_per_rb = EPI == 3 || EPI == 4 ? (njt + 1) / 2 : njt;          // triangular products pair their column tiles
     allow_big_lds(apply_kernel<Cfg, EPI>, Cfg::LDS_BYTES);
-    hipLaunchKernelGGL((apply_kernel<Cfg, EPI>), dim3((unsigned)(njt * nrb)), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st,
+    hipLaunchKernelGGL((apply_kernel<Cfg, EPI>), dim3((unsigned)(wgs_per_rb * nrb)), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st,
                        Phi, Bm, V, vpart, p, q, y, alpha, ut, g.K, g.Kp, g.Np, njt, bpart ? bpart + boff : nullptr, col0, jt0, mu, ApplyPlan<T>(g.K).total);
     return (int)(njt * nrb);
 }
@@ -1149,7 +1169,8 @@ static int apply_launch(const Geom& g, const T* Phi, const T* Bm, T* V, double* 
             if (pl.count[2] > 0) {
                 const int64_t nr = g.Np / RCfg::BM;
                 allow_big_lds(apply_kernel<RCfg, EPI>, RCfg::LDS_BYTES);
-                hipLaunchKernelGGL((apply_kernel<RCfg, EPI>), dim3((unsigned)(pl.count[2] * nr)), dim3(RCfg::THREADS), RCfg::LDS_BYTES, st,
+                hipLaunchKernelGGL((apply_kernel<RCfg, EPI>), dim3((unsigned)((EPI == 3 || EPI == 4 ? (pl.count[2] + 1) / 2 : pl.count[2]) * nr)),
+                                   dim3(RCfg::THREADS), RCfg::LDS_BYTES, st,
                                    Phi, Bm, V, vpart, p, q, y, alpha, ut, g.K, g.Kp, g.Np, pl.count[2], bpart ? bpart + nb : nullptr,
                                    pl.col0[2], pl.jt0[2], mu, 0);
                 nb += (int)(pl.count[2] * nr);

@@ -629,7 +629,8 @@ template <typename T> struct Impl {
         const Geom& g = c->g;
         {
             const int Q = c->pass3_parts >= 0 ? c->pass3_parts : (g.Np >= 262144 ? SCFGP_PASS3_PARTS : 1);
-            if (Q > 1 && !c->bf3 && !c->want_lrb() && g.Np / 256 >= 4 * Q) { c->last_lrb = false; return pass3_pipelined(c, Q); }
+            // not inside scfgp_train: a captured two-stream iteration crashed the graph runtime once in a dozen runs (ROCm 7.2)
+            if (Q > 1 && !c->bf3 && !c->in_train && !c->want_lrb() && g.Np / 256 >= 4 * Q) { c->last_lrb = false; return pass3_pipelined(c, Q); }
         }
         { ProfScope ps(c, "apply_phibar"); const Bf3Planes pl = c->planes();
           const int nb = SK::apply_phibar(g, (const T*)c->d_Phi, AbarT(c), (T*)c->d_V, c->d_p, c->d_q, c->d_y, c->alpha(), c->ut(),

@@ -339,7 +339,7 @@ def test_lockstep_gram_plan_equals_the_split_plan(N, D, S, M):
 @pytest.mark.parametrize('dtype,tol', [('f64', 1e-12), ('f32', 2e-6)])
 def test_pass3_in_row_parts_overlapping_xtz(dtype, tol):
     """Option pass3_parts: the Phibar product and X~^T Zbar run part by part on two streams (scfgp_api.hip: pass3_pipelined);
-    same cost and gradient as the one-piece pass, also through the captured training iteration."""
+    same cost and gradient as the one-piece pass; scfgp_train ignores the option (its iteration is one captured stream)."""
     from scfgp_amd.engine import HipEngine
     N, D, S, M = 9000, 12, 6, 90
     seed = 0x5CF63900
