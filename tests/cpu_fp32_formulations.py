@@ -3,7 +3,7 @@ exact (fp64) Gram, in two formulations:
   V-form: V = Phi B,      v = rowsum(Phi o V), BWB = V^T diag(q) V,            Phibar = 2 Phi Abar + 2 q o V + ...
   C-form: C = Phi Li^T,   v = rowsum(C^2),     BWB = Li^T (C^T diag(q) C) Li,  Phibar = 2 Phi Abar + 2 q o (C Li) + ...
 (the reference's own graph is the C-form: SCFGP/SCFGP.py:112).  Prints per-block gradient errors against float64.
-    python tools/fp32_formulations.py [N] [D] [S] [M]
+    python tests/cpu_fp32_formulations.py [N] [D] [S] [M]
 """
 import os
 import sys
