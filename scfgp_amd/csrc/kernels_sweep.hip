@@ -1014,7 +1014,9 @@ void apply_dma_kernel(const float* __restrict__ Phi, const float* __restrict__ B
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                          // everybody's has; nobody reads the slot of stage s-1 any more
         asm volatile("" ::: "memory");
+#ifndef SCFGP_DIAG_DMA_NODMA                                   // timing diagnostic only (wrong numbers): no operand traffic after the prologue
         if (s + 2 < nst) issue(fill);
+#endif
         const char* base = smem + slot * D::STAGE;
         v4f a[Cfg::TM], b[Cfg::TN];
 #pragma unroll
