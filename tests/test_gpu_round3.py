@@ -397,3 +397,48 @@ def test_rank_s_backward_projection_matches_the_dense_one(dtype, gtol):
         assert outs[0][0] == outs[1][0]
         assert rel(outs[1][1], outs[0][1]) < (1e-11 if dtype == 'f64' else 1e-4)
         assert np.allclose(outs[1][2], outs[0][2], rtol=1e-10 if dtype == 'f64' else 1e-5, atol=0)
+
+
+def test_level_drops_again_and_a_failed_fp32_cholesky_is_retried_in_fp64():
+    """The automatic level is sticky with hysteresis: after the parameters move to a well-conditioned point the next
+    evaluation still runs escalated, the one after it at level 0.  And when the fp32 Gram's error exceeds the jitter
+    (lam = e^{2a} + 1e-6 tiny, duplicated frequencies: A numerically singular) the Cholesky of the fp32 Gram fails; the library
+    retries on the fp64 Gram before it reports anything, and only fp64's own failure surfaces as LinAlgError."""
+    from scfgp_amd.engine import HipEngine
+    N, D, S, M = 5000, 8, 32, 256
+    X, y, params = _c3_like(N, D, S, M, seed=0x5CF63B00)
+    eng = HipEngine(D, S, M, 'f32'); eng.set_params(params); eng.set_data(X, y)
+    eng.eval()
+    assert eng.condition()['level'] >= 1
+    easy = params.copy(); easy[0] = 1.5                            # lam = e^3
+    eng.set_params(easy)
+    c1, g1, a1, L1 = eng.eval()
+    cd1 = eng.condition()
+    assert cd1['level'] >= 1 and cd1['cond_est'] < cd1['threshold'] / 4       # ran escalated, asks for less
+    c2, g2, a2, L2 = eng.eval()
+    assert eng.condition()['level'] == 0
+    assert abs(float(c2) - float(c1)) < 1e-6 * max(1.0, abs(float(c1))) and rel(a2, a1) < 1e-4
+    eng.close()
+    # numerically singular A: two identical blocks of frequencies and a tiny jitter
+    N, D, S, M = 6000, 6, 4, 124
+    seed = 0x5CF63C00
+    X = synth.make_X(seed, N, D)
+    y = synth.normal(seed + 9, 0, N).reshape(-1, 1)
+    p = synth.make_params(seed + 0x0202, D, S, M, abc=(-5.5, 0.0, -1.0))      # lam = e^-11 + 1e-6 = 1.8e-5
+    o = 3 + D * S
+    rf = p[o:o + M * S].reshape(M, S); rf[M // 2:] = rf[:M // 2]              # F's columns come in identical pairs ...
+    ph = p[o + M * S + S:]; ph[M // 2:] = ph[:M // 2]                         # ... with identical phases
+    c0, g0, a0, L0 = O.value_and_grad(X, y, p, S, M)                          # float64 copes (lam I keeps A positive definite)
+    e64 = HipEngine(D, S, M, 'f64'); e64.set_params(p); e64.set_data(X, y)
+    c64 = float(e64.eval()[0]); e64.close()
+    assert abs(c64 - c0) < 1e-6 * max(1.0, abs(c0))
+    e32 = HipEngine(D, S, M, 'f32'); e32.set_params(p); e32.set_data(X, y)
+    c, g, a, L = e32.eval()                                                   # whatever the fp32 Gram did, the answer is fp64's
+    assert e32.condition()['level'] >= 1 and abs(float(c) - c64) < 1e-6 * max(1.0, abs(c64))
+    e32.set_option('gram64', 0)                                               # plain fp32 on request: fails loudly or is visibly off
+    try:
+        cp = float(e32.eval()[0])
+        assert e32.condition()['alpha_err_fp32'] > 1e-2 or abs(cp - c64) < 1e-2 * max(1.0, abs(c64))
+    except np.linalg.LinAlgError:
+        pass
+    e32.close()
