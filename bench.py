@@ -373,7 +373,7 @@ def main(a):
             "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "apply product (Phi.B / Phi.Abar): one N x K x K product = 2*N*K^2 flops, issued as one launch for the "
-                                   "full column tiles (fp32 at this size: apply_dma_kernel, 256x256 tiles for Phi.B and 256x128 for Phi.Abar; "
+                                   "full column tiles (fp32 at this size: apply_dma_kernel, 256x256 tiles for both products; "
                                    "otherwise apply_kernel, 256x128 tiles) plus a 256x64-tile apply_kernel launch for the ragged remainder; "
                                    "avg_launch_ms is the median hipEvent time of that pair (rocprof: sum of the two kernels)",
                          "avg_launch_ms": ap_ms},

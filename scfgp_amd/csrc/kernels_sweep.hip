@@ -771,7 +771,11 @@ void SweepKernels<T>::xtz(const Geom& g, const double* Xt, const T* Phi, const T
 // epilogues of the apply product: V and the row dots (EPI 0) or Phibar and bbar (EPI 1) from the accumulators
 //   MU (EPI 0 only): also mupart[jtg][n] = sum_{j in tile} Phi[n][j] alpha[j] from the Phi values the row dot reads anyway
 //   (the DMA-fed kernel has no operand values in registers for the loader-side dot)
-template <class Cfg, int EPI, bool MU = false>
+//   VEC4 (the LDS-DMA kernels, fp32, 64-wide wave tiles of four 16-column MFMA tiles): the B operand's rows were staged in a
+//   permuted order, so that MFMA tile tn, lane column i IS output column 4 i + tn of the wave tile -- a lane then holds four
+//   ADJACENT columns of each of its rows and the epilogue moves V, Phi and Phibar 16 bytes per lane (256 contiguous bytes per
+//   row and 16-lane group) instead of 4 (four 64-byte pieces per instruction)
+template <class Cfg, int EPI, bool MU = false, bool VEC4 = false>
 __device__ __forceinline__ void apply_epilogue(
     const typename Cfg::MTr::acc_t (&acc)[Cfg::TM][Cfg::TN], const typename Cfg::T* __restrict__ Phi, typename Cfg::T* V,
     double* __restrict__ vpart, const double* __restrict__ p, const double* __restrict__ q, const double* __restrict__ y,
@@ -779,6 +783,93 @@ __device__ __forceinline__ void apply_epilogue(
     double* __restrict__ bpart, char* smem_raw, double* __restrict__ mupart = nullptr) {
     typedef typename Cfg::T T;
     AccCoord<Cfg> co;
+    if constexpr (VEC4) {
+        static_assert(Cfg::TN == 4 && Cfg::MS == 16 && sizeof(T) == 4 && (EPI == 0 || EPI == 1 || EPI == 3 || EPI == 4), "VEC4 layout");
+        const int c4 = co.wn0 + 4 * (co.lane & 15);               // first of this lane's four adjacent columns
+        const int jg = cbase + c4;
+        if constexpr (EPI == 4) {
+#pragma unroll
+            for (int tm = 0; tm < Cfg::TM; ++tm)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    *reinterpret_cast<v4f*>(V + (rb * Cfg::BM + co.row(tm, r)) * Kp + jg) = v4f{acc[tm][0][r], acc[tm][1][r], acc[tm][2][r], acc[tm][3][r]};
+        } else if constexpr (EPI == 0 || EPI == 3) {
+            double* red = reinterpret_cast<double*>(smem_raw);
+            double* red2 = red + Cfg::WGN * Cfg::BM;
+            const int wn = (threadIdx.x >> 6) % Cfg::WGN;
+            double al[4], live[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { live[k] = jg + k < K ? 1.0 : 0.0; al[k] = MU && jg + k < K ? alpha[jg + k] : 0.0; }
+#pragma unroll
+            for (int tm = 0; tm < Cfg::TM; ++tm)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = co.row(tm, r);
+                    const int64_t off = (rb * Cfg::BM + row) * Kp + jg;
+                    const v4f c = v4f{acc[tm][0][r], acc[tm][1][r], acc[tm][2][r], acc[tm][3][r]};
+                    *reinterpret_cast<v4f*>(V + off) = c;
+                    double part = 0, mup = 0;
+                    if (EPI == 3) {
+                        part = (double)(c[0] * c[0]) + (double)(c[1] * c[1]) + (double)(c[2] * c[2]) + (double)(c[3] * c[3]);
+                        if (MU) { const v4f ph = *reinterpret_cast<const v4f*>(Phi + off);
+                                  mup = (double)ph[0] * al[0] + (double)ph[1] * al[1] + (double)ph[2] * al[2] + (double)ph[3] * al[3]; }
+                    } else {
+                        const v4f ph = *reinterpret_cast<const v4f*>(Phi + off);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { part += (double)ph[k] * (double)c[k] * live[k]; if (MU) mup += (double)ph[k] * al[k]; }
+                    }
+#pragma unroll
+                    for (int m = 1; m < 16; m <<= 1) part += __shfl_xor(part, m);
+                    if ((co.lane & 15) == 0) red[wn * Cfg::BM + row] = part;
+                    if (MU) {
+#pragma unroll
+                        for (int m = 1; m < 16; m <<= 1) mup += __shfl_xor(mup, m);
+                        if ((co.lane & 15) == 0) red2[wn * Cfg::BM + row] = mup;
+                    }
+                }
+            __syncthreads();
+            if (threadIdx.x < Cfg::BM) {
+                double s = 0, s2 = 0;
+#pragma unroll
+                for (int k = 0; k < Cfg::WGN; ++k) { s += red[k * Cfg::BM + threadIdx.x]; if (MU) s2 += red2[k * Cfg::BM + threadIdx.x]; }
+                vpart[(int64_t)jtg * Np + rb * Cfg::BM + threadIdx.x] = s;
+                if (MU && mupart) mupart[(int64_t)jtg * Np + rb * Cfg::BM + threadIdx.x] = s2;
+            }
+        } else {                                                    // EPI 1
+            double bb = 0;
+            double al[4], u4[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { al[k] = alpha[jg + k]; u4[k] = ut[jg + k]; }
+#pragma unroll
+            for (int tm = 0; tm < Cfg::TM; ++tm)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t n = rb * Cfg::BM + co.row(tm, r);
+                    const int64_t off = n * Kp + jg;
+                    const double qn = 2.0 * q[n], pn = p[n], yn = y[n];
+                    const v4f vv = *reinterpret_cast<const v4f*>(V + off), ph = *reinterpret_cast<const v4f*>(Phi + off);
+                    v4f o;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const double v = 2.0 * (double)acc[tm][k][r] + qn * (double)vv[k] + pn * al[k] + yn * u4[k];
+                        o[k] = (float)v;
+                        if (jg + k < K) bb += v * (double)ph[k];
+                    }
+                    *reinterpret_cast<v4f*>(V + off) = o;
+                }
+            double* red = reinterpret_cast<double*>(smem_raw);
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) bb += __shfl_xor(bb, m);
+            if (co.lane == 0) red[threadIdx.x >> 6] = bb;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                double s = 0;
+                for (int k = 0; k < Cfg::THREADS / 64; ++k) s += red[k];
+                bpart[blockIdx.x] = s;
+            }
+        }
+        return;
+    }
     if (EPI == 4) {
 #pragma unroll
         for (int tm = 0; tm < Cfg::TM; ++tm)
@@ -982,7 +1073,9 @@ void apply_dma_kernel(const float* __restrict__ Phi, const float* __restrict__ B
 #pragma unroll
     for (int u = 0; u < D::DMA_PER_WAVE; ++u) {
         const int t = wave * D::DMA_PER_WAVE + u, x = 16 * t + (lane >> 2), c = (lane & 3) ^ ((x >> 2) & 3);
-        const float* rowp = x < D::BM ? Phi + (rb * D::BM + x) * Kp : Bm + (int64_t)(cbase + x - D::BM) * Kp;
+        // B rows in the VEC4 order (apply_epilogue): LDS row tn*16 + i of a 64-wide wave tile holds operand row 4 i + tn
+        const int xb = x - D::BM, xcol = (xb & ~63) + 4 * (xb & 15) + ((xb >> 4) & 3);
+        const float* rowp = x < D::BM ? Phi + (rb * D::BM + x) * Kp : Bm + (int64_t)(cbase + xcol) * Kp;
         src[u] = reinterpret_cast<const char*>(rowp) + c * 16 + (EPI == 4 ? (cbase / 16) * 64 : 0);
         dst[u] = t * 1024;
     }
@@ -1035,7 +1128,7 @@ void apply_dma_kernel(const float* __restrict__ Phi, const float* __restrict__ B
     __syncthreads();
     constexpr int SLOTS = BN / 128;                            // vpart / mupart slots are 128 columns wide
     const int vslot = slot0 + SLOTS * jt;
-    apply_epilogue<Cfg, EPI, EPI == 0 || EPI == 3>(acc, Phi, V, vpart, p, q, y, alpha, ut, K, Kp, Np, rb, cbase, vslot, bpart, smem_raw, mu);
+    apply_epilogue<Cfg, EPI, EPI == 0 || EPI == 3, true>(acc, Phi, V, vpart, p, q, y, alpha, ut, K, Kp, Np, rb, cbase, vslot, bpart, smem_raw, mu);
     if (SLOTS == 2 && (EPI == 0 || EPI == 3) && threadIdx.x < D::BM) {
         vpart[(int64_t)(vslot + 1) * Np + rb * D::BM + threadIdx.x] = 0.0;
         if (mu) mu[(int64_t)(vslot + 1) * Np + rb * D::BM + threadIdx.x] = 0.0;

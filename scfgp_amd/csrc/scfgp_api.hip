@@ -158,10 +158,11 @@ struct scfgp_ctx {
     Bf3Planes planes() const {                                  // valid after pass 1 of the current working set
         Bf3Planes pl;
         if (bf3 && bf3_dma && g.K > 256 && d_P3 && p3_cap >= g.Np) { pl.rows = d_P3; pl.matrix16 = d_M16; }
-        // fp32 apply products by LDS-DMA (kernels_sweep.hip: apply_dma_kernel).  Auto: large problems only (profiles/r02_tuning.md:
-        // V = Phi.B as 256-wide tiles, Phibar as 128-wide ones, -1.2 ms per evaluation at the headline shape); the small ones keep the
-        // loader-staged tiles, whose single 64-wide launch per product matters more there
-        const int auto_dma = g.K >= 1024 && g.Np >= 65536 ? 3 : 0;
+        // fp32 apply products by LDS-DMA (kernels_sweep.hip: apply_dma_kernel).  Auto: large problems only, 256-wide tiles for both
+        // products (round 2 shipped 128-wide tiles for Phibar, whose epilogue then wanted a second resident workgroup to hide
+        // behind; with the 16-byte epilogue of round 3 the 256-wide tile wins there too: profiles/r03_tuning.md); the small ones
+        // keep the loader-staged tiles, whose single 64-wide launch per product matters more there
+        const int auto_dma = g.K >= 1024 && g.Np >= 65536 ? 2 : 0;
         pl.dma = !bf3 && dtype == SCFGP_F32 ? (apply_dma < 0 ? auto_dma : apply_dma) : 0;
         return pl;
     }
