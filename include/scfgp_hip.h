@@ -204,8 +204,9 @@ int scfgp_get_timings(scfgp_ctx* ctx, double* ms, const char** names, int n);
 int64_t scfgp_debug_read(scfgp_ctx* ctx, const char* name, void* host, int64_t max_bytes);
 /* tuning knobs: "gram_nsplit" (row-split units of the Gram products, 0 = default), "gram_taper" (1: the last unit of every
  * XCD group is cut into 1/2, 1/4, 1/8, 1/8; t >= 2: into t + 3 pieces down to 1/2^(t+2)), "gram_chunk" (fp32 flush interval in rows), "xtz_nsplit", "use_graph", "fuse_fmap" (experiment, profiles/r02_tuning.md: the
- * Gram of pass 1 reads the phases and evaluates cos / sin inside its operand loaders instead of reading Phi), "apply_dma" (experiment, fp32 mode: the full tiles of the apply products staged by LDS-DMA
- * instead of through registers, 1 = 128 wide, 2 = 256 wide; measured equal), "bf3_dma"
+ * Gram of pass 1 reads the phases and evaluates cos / sin inside its operand loaders instead of reading Phi), "apply_dma" (fp32 mode: the full tiles of the apply products staged by LDS-DMA instead of through
+ * registers; -1 = automatic: 256-wide tiles from K >= 1024 and 65536 rows up, else off; 0 off, 1 = 128 wide, 2 = 256 wide, 3 = 256 wide
+ * for Phi.B and 128 wide for Phibar), "bf3_dma"
  * (experiment, SCFGP_BF16X3 only: 256-wide apply tiles fed by LDS-DMA from pre-split planes of Phi, 6 bytes per element more),
  * "gram64" (precision level policy, see scfgp_get_condition), "cond_threshold" / "cond_threshold_w" (its two thresholds),
  * "roctx" (1: push a roctx range per stage for `rocprofv3 --marker-trace`; off by default, also SCFGP_ROCTX=1),
