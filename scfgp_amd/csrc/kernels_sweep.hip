@@ -1052,7 +1052,28 @@ struct ApplyDma {
     static_assert(STAGE / 1024 % WAVES == 0, "whole DMA instructions per wave");
 };
 // BN = 128: 8 waves, two workgroups per CU, 48 operand bytes per MFMA; BN = 256: 16 waves, one workgroup per CU, 32 bytes per MFMA
-template <int EPI, int BN, int WGM = 4>
+// one 8-byte LDS read at a literal offset, as inline asm: the compiler can neither merge two of them into a half-rate ds_read2st64_b64
+// nor replace the counted waits of the pipelined loop by lgkmcnt(0)
+typedef float v2f __attribute__((ext_vector_type(2)));
+template <int OFF> __device__ __forceinline__ v2f lds_read_b64(unsigned addr) {
+    v2f r;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+    return r;
+}
+// in-place MFMA as inline asm: between the scheduling barriers of the pipelined loop the register allocator otherwise gives every
+// MFMA a fresh destination tuple (two live copies of the 64 accumulator registers: spills)
+__device__ __forceinline__ void mfma_inplace(v4f& c, float a, float b) {
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+#define SCFGP_RD4(dst, base, half)                                                                                 \
+    do { dst[0] = lds_read_b64<0 + half>(base); dst[1] = lds_read_b64<1024 + half>(base);                        \
+         dst[2] = lds_read_b64<2048 + half>(base); dst[3] = lds_read_b64<3072 + half>(base); } while (0)
+
+//   PIPE (experiment, option apply_dma = 5): fragment reads software-pipelined at half-stage granularity -- the 16 k of a stage are
+//   consumed as two halves (the first and the last 8 bytes of every lane's 16-byte chunk), each half is fetched while the other is
+//   multiplied, the stage's barrier sits between the halves and the ring runs three stages ahead, so neither LDS latency nor
+//   the DMA issue stands between a wave's MFMAs; same registers.  Reads and waits are inline asm (see lds_read_b64).
+template <int EPI, int BN, int WGM = 4, int PIPE = 0>
 __global__ __launch_bounds__((64 * ApplyDma<BN, WGM>::WAVES)) __attribute__((amdgpu_waves_per_eu(WGM == 2 ? 2 : 4, WGM == 2 ? 2 : 4)))
 void apply_dma_kernel(const float* __restrict__ Phi, const float* __restrict__ Bm, float* V,
                       double* __restrict__ vpart, const double* __restrict__ p, const double* __restrict__ q,
@@ -1094,6 +1115,58 @@ void apply_dma_kernel(const float* __restrict__ Phi, const float* __restrict__ B
     acc_zero<Cfg>(acc);
     const int nst_all = (K + 15) / 16, nst_tri = (cbase + D::BN + 15) / 16;
     const int nst = (EPI == 3 && nst_tri < nst_all ? nst_tri : nst_all) - (EPI == 4 ? cbase / 16 : 0);
+    if constexpr (PIPE) {
+        static_assert(Cfg::TM == 4 && Cfg::TN == 4 && (D::DMA_PER_WAVE == 2 || D::DMA_PER_WAVE == 3), "pipelined loop: 64 x 64 wave tiles");
+        const auto wait_landed = [&](int after) {                 // all but the youngest `after` stages of this wave's DMAs are done
+            constexpr int P = D::DMA_PER_WAVE;
+            if (after >= 2) { if (P == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+            else if (after == 1) { if (P == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+        const unsigned lds0 = (unsigned)(size_t)(lds_void*)smem;
+        issue(0);
+        if (nst > 1) issue(1);
+        if (nst > 2) issue(2);
+        wait_landed(nst > 2 ? 2 : (nst > 1 ? 1 : 0));
+        asm volatile("s_barrier" ::: "memory");
+        v2f ax[4], bx[4], ay[4], by[4];
+        SCFGP_RD4(ax, lds0 + aoff, 0); SCFGP_RD4(bx, lds0 + boff, 0);
+        int slot = 0;
+        for (int s = 0; s < nst; ++s) {
+            const unsigned cur = lds0 + slot * D::STAGE;
+            const int nslot = slot == 2 ? 0 : slot + 1;
+            SCFGP_RD4(ay, cur + aoff, 8); SCFGP_RD4(by, cur + boff, 8);
+            asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");   // the first half (issued half a stage ago) is in; the second is in flight
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < 4; ++tn) mfma_inplace(acc[tm][tn], ax[tm][e], bx[tn][e]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 1 < nst) {
+                // stage s+1 has landed (stage s+2 may still be in flight); this wave's reads of slot `slot` are complete
+                wait_landed(s + 2 < nst ? 1 : 0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                asm volatile("s_barrier" ::: "memory");
+                if (s + 3 < nst) issue(slot);                    // everybody is done with stage s: its slot takes stage s+3
+                const unsigned nxt = lds0 + nslot * D::STAGE;
+                SCFGP_RD4(ax, nxt + aoff, 0); SCFGP_RD4(bx, nxt + boff, 0);
+            } else
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < 4; ++tn) mfma_inplace(acc[tm][tn], ay[tm][e], by[tn][e]);
+            __builtin_amdgcn_sched_barrier(0);
+            slot = nslot;
+        }
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // the last MFMA results before ordinary code reads them
+    } else {
     issue(0);
     if (nst > 1) issue(1);
     int slot = 0, fill = 2;
@@ -1124,6 +1197,7 @@ void apply_dma_kernel(const float* __restrict__ Phi, const float* __restrict__ B
                 for (int tn = 0; tn < Cfg::TN; ++tn) Cfg::MTr::mfma(acc[tm][tn], a[tm][e], b[tn][e]);
         slot = slot == 2 ? 0 : slot + 1;
         fill = fill == 2 ? 0 : fill + 1;
+    }
     }
     __syncthreads();
     constexpr int SLOTS = BN / 128;                            // vpart / mupart slots are 128 columns wide
@@ -1194,15 +1268,15 @@ static int apply_launch_cfg(const Geom& g, int njt, int col0, int jt0, int boff,
                        Phi, Bm, V, vpart, p, q, y, alpha, ut, g.K, g.Kp, g.Np, njt, bpart ? bpart + boff : nullptr, col0, jt0, mu, ApplyPlan<T>(g.K).total);
     return (int)(njt * nrb);
 }
-template <int EPI, int BN, int WGM = 4>
+template <int EPI, int BN, int WGM = 4, int PIPE = 0>
 static int apply_dma_launch(const Geom& g, int njt, int col0, int slot0, int boff, const float* Phi, const float* Bm, float* V, double* vpart,
                             const double* p, const double* q, const double* y, const double* alpha, const double* ut,
                             double* bpart, double* mu, hipStream_t st) {
     if (njt <= 0) return 0;
     typedef ApplyDma<BN, WGM> D;
     const int64_t nrb = g.Np / D::BM;
-    allow_big_lds(apply_dma_kernel<EPI, BN, WGM>, D::LDS_BYTES);
-    hipLaunchKernelGGL((apply_dma_kernel<EPI, BN, WGM>), dim3((unsigned)(njt * nrb)), dim3(64 * D::WAVES), D::LDS_BYTES, st,
+    allow_big_lds(apply_dma_kernel<EPI, BN, WGM, PIPE>, D::LDS_BYTES);
+    hipLaunchKernelGGL((apply_dma_kernel<EPI, BN, WGM, PIPE>), dim3((unsigned)(njt * nrb)), dim3(64 * D::WAVES), D::LDS_BYTES, st,
                        Phi, Bm, V, vpart, p, q, y, alpha, ut, g.K, g.Kp, g.Np, njt, bpart ? bpart + boff : nullptr, mu, col0, slot0);
     return (int)(njt * nrb);
 }
@@ -1253,13 +1327,19 @@ static int apply_launch(const Geom& g, const T* Phi, const T* Bm, T* V, double* 
             // the full tiles by LDS-DMA (Bm symmetric): option value 1 = 128 wide, 2 = 256 wide with a 128-wide one for an odd
             // count; the 64-wide remainder by the loader-staged kernel, whose mu slices then are column bands too (ntot = 0)
             // 3: 256-wide for V = Phi.B (EPI 0), 128-wide for Phibar (EPI 1: its epilogue wants a second resident workgroup)
-            const bool wide = planes->dma == 2 || planes->dma == 4 || (planes->dma == 3 && EPI != 1);
+            const bool wide = planes->dma == 2 || planes->dma == 4 || planes->dma == 5 || (planes->dma == 3 && EPI != 1);
             const int n256 = wide ? pl.count[0] / 2 : 0, n128 = pl.count[0] - 2 * n256;
-            if (planes->dma == 4 && EPI < 2)                       // experiment: 8 waves of 128 x 64
-                nb += apply_dma_launch<EPI, 256, 2>(g, n256, 0, 0, nb, Phi, BmT, V, vpart, p, q, y, alpha, ut, bpart, mu, st);
-            else
-                nb += apply_dma_launch<EPI, 256>(g, n256, 0, 0, nb, Phi, BmT, V, vpart, p, q, y, alpha, ut, bpart, mu, st);
-            nb += apply_dma_launch<EPI, 128>(g, n128, 256 * n256, 2 * n256, nb, Phi, BmT, V, vpart, p, q, y, alpha, ut, bpart, mu, st);
+            bool done256 = false, done128 = false;
+            if constexpr (EPI < 2) {
+                if (planes->dma == 4) {                            // experiment: 8 waves of 128 x 64
+                    nb += apply_dma_launch<EPI, 256, 2>(g, n256, 0, 0, nb, Phi, BmT, V, vpart, p, q, y, alpha, ut, bpart, mu, st); done256 = true;
+                } else if (planes->dma == 5) {                     // experiment: half-stage pipelined fragment reads
+                    nb += apply_dma_launch<EPI, 256, 4, 1>(g, n256, 0, 0, nb, Phi, BmT, V, vpart, p, q, y, alpha, ut, bpart, mu, st); done256 = true;
+                    nb += apply_dma_launch<EPI, 128, 4, 1>(g, n128, 256 * n256, 2 * n256, nb, Phi, BmT, V, vpart, p, q, y, alpha, ut, bpart, mu, st); done128 = true;
+                }
+            }
+            if (!done256) nb += apply_dma_launch<EPI, 256>(g, n256, 0, 0, nb, Phi, BmT, V, vpart, p, q, y, alpha, ut, bpart, mu, st);
+            if (!done128) nb += apply_dma_launch<EPI, 128>(g, n128, 256 * n256, 2 * n256, nb, Phi, BmT, V, vpart, p, q, y, alpha, ut, bpart, mu, st);
             typedef typename ApplyCfg<T, 64>::type RCfg;
             if (pl.count[2] > 0) {
                 const int64_t nr = g.Np / RCfg::BM;

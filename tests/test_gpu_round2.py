@@ -342,12 +342,12 @@ def test_fp32_apply_tiles_fed_by_lds_dma_match(N, D, S, M):
     params = synth.make_params(seed + 0x0202, D, S, M, abc=(-1.0, 0.0, -1.0))
     c0, g0, a0, _ = O.value_and_grad(X, y, params, S, M)
     out = {}
-    for dma in (0, 1, 2, 4):                                   # 2: 256-wide tiles (16 waves), a 128-wide one for an odd count; 4: 256-wide on 8 waves of 128 x 64
+    for dma in (0, 1, 2, 4, 5):                                # 2: 256-wide tiles (16 waves), a 128-wide one for an odd count; 4: 256-wide on 8 waves of 128 x 64; 5: as 2, fragment reads pipelined by half stages
         eng = HipEngine(D, S, M, dtype='f32'); eng.set_params(params); eng.set_option('apply_dma', dma); eng.set_data(X, y)
         cost, grad, alpha, Li = eng.eval(want_grad=True)
         out[dma] = (float(cost), grad.copy(), alpha.copy(), eng.debug_read('p', (N,)).copy(), eng.debug_read('q', (N,)).copy())
         eng.close()
-    for dma in (1, 2, 4):
+    for dma in (1, 2, 4, 5):
         assert abs(out[dma][0] - out[0][0]) < 1e-7 * abs(out[0][0])
         for k in (1, 2, 3, 4):
             assert rel(out[dma][k], out[0][k]) < 2e-5, (dma, k, rel(out[dma][k], out[0][k]))

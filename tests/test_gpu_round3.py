@@ -223,7 +223,7 @@ def test_fp32_mode_against_fp64_mode_at_full_size(cfg):
     e32.close(); e64.close()
 
 
-@pytest.mark.parametrize('dtype,dma,ctol,gtol', [('f64', -1, 1e-10, 1e-8), ('f32', 0, 2e-5, 2e-3), ('f32', 3, 2e-5, 2e-3), ('f32', 1, 2e-5, 2e-3)])
+@pytest.mark.parametrize('dtype,dma,ctol,gtol', [('f64', -1, 1e-10, 1e-8), ('f32', 0, 2e-5, 2e-3), ('f32', 3, 2e-5, 2e-3), ('f32', 1, 2e-5, 2e-3), ('f32', 5, 2e-5, 2e-3)])
 def test_factor_form_of_pass2_matches_oracle(dtype, dma, ctol, gtol):
     """Option factor_form = 1: pass 2 as the reference writes it (SCFGP/SCFGP.py:112) -- C = Phi Li^T (triangular), v = rowsum(C^2),
     V = C Li (triangular), B W B = Li^T (C^T diag(q) C) Li, u = Li^T C^T p -- against the oracle: loader-staged tiles (f64, f32)
@@ -442,3 +442,33 @@ def test_level_drops_again_and_a_failed_fp32_cholesky_is_retried_in_fp64():
     except np.linalg.LinAlgError:
         pass
     e32.close()
+
+
+def test_one_rank_under_the_launcher_goes_through_rccl():
+    """The driver's multi-GPU command line with one rank (`python -m torch.distributed.run --nproc-per-node 1 ... bench.py`):
+    the rank creates an RCCL communicator and the three sums run as in-place `all_reduce` calls on torch tensors aliasing the
+    library's exchange buffers, fenced against the library's stream -- the code path of N > 1 with the only thing this one-GPU
+    box cannot supply, a second card.  Same fp64 cost as the plain single-process run, and the line carries the exchange
+    stages."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'TORCHELASTIC_RUN_ID')}
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    args = ['--config', 'C2', '--rows', '20000', '--steps', '2', '--warmup', '1', '--no-cpu', '--no-secondary']
+    one = subprocess.run([sys.executable, os.path.join(root, 'bench.py')] + args, env=env, stdout=subprocess.PIPE,
+                         universal_newlines=True, timeout=600)
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '1'] + args
+    rccl = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, universal_newlines=True, timeout=600)
+    assert one.returncode == 0 and rccl.returncode == 0
+    o1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith('{')][-1])
+    o2 = json.loads([ln for ln in rccl.stdout.splitlines() if ln.startswith('{')][-1])
+    assert o2['n_gpus'] == 1 and o2['cost'] == o1['cost']          # a sum over one rank changes nothing, bit for bit
+    st = o2['stages_ms']
+    assert all(('exchange%d' % k) in st and st['exchange%d' % k] >= 0 for k in (1, 2, 3))
+    assert 'exchange1' not in o1['stages_ms']
