@@ -4,6 +4,7 @@ escalation of the two Gram products in fp32 mode (include/scfgp_hip.h: scfgp_get
 and fp32 mode against fp64 mode at the FULL size of the ill-conditioned BASELINE config C3 (and of C5).
 The reference computes in float64 whatever the conditioning (SCFGP/SCFGP.py:95-96,104-110).
 """
+import os
 import numpy as np
 import pytest
 
