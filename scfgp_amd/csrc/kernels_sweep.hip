@@ -1053,7 +1053,9 @@ struct ApplyDma {
 };
 // BN = 128: 8 waves, two workgroups per CU, 48 operand bytes per MFMA; BN = 256: 16 waves, one workgroup per CU, 32 bytes per MFMA
 // one 8-byte LDS read at a literal offset, as inline asm: the compiler can neither merge two of them into a half-rate ds_read2st64_b64
-// nor replace the counted waits of the pipelined loop by lgkmcnt(0)
+// nor replace the counted waits of the pipelined loop by lgkmcnt(0).  The result register is only valid after the loop's own
+// s_waitcnt lgkmcnt: the compiler does not know that, so the value must reach its MFMA without an intermediate copy (checked in the
+// ISA of the three PIPE instantiations: the reads land in the registers the MFMAs name)
 typedef float v2f __attribute__((ext_vector_type(2)));
 template <int OFF> __device__ __forceinline__ v2f lds_read_b64(unsigned addr) {
     v2f r;
