@@ -215,7 +215,7 @@ int64_t scfgp_debug_read(scfgp_ctx* ctx, const char* name, void* host, int64_t m
  * "pass3_parts" (experiment: pass 3 in row parts with X~^T Zbar on a second stream; measured slower),
  * "apply_dma" = 4 (experiment: 256-wide LDS-DMA tiles on 8 waves of 128 x 64; measured slower), = 5 (experiment: the default
  * tiles with the fragment reads software-pipelined by half stages in inline assembly; measured slower),
- * "lowrank_bwd" (-1 auto: when D+1 >= 4 (S+1) padded, 0 never, 1 whenever it fits: the reverse sweep of F = l_F r_F^T through
+ * "lowrank_bwd" (-1 auto: when D+1 >= 4 (S+1) padded, 0 never, 1 whenever it can -- the forward projection goes through the S columns (S+1 < D+1, padded to 16) and U fits: the reverse sweep of F = l_F r_F^T through
  * T~^T Zbar and X~^T (Zbar_L + Zbar_M r_F) instead of the dense X~^T Zbar; exchange buffer 3 then holds those two) */
 int scfgp_set_option(scfgp_ctx* ctx, const char* name, int64_t value);
 

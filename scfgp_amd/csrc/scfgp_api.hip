@@ -74,8 +74,10 @@ struct scfgp_ctx {
     // rank-S form of the backward projection: exchange 3 = [T~^T Zbar (Spp x Jp) ... | 8 scalars at Dpp*Jp | X~^T U (Dpp x Sq)]
     int lowrank_bwd = -1; int Spp = 0, Sq = 0; bool last_lrb = false;
     bool want_lrb() const {
-        const bool fits = g.Jp + (int)round_up(g.S, 64) <= g.Kp;
-        return fits && (lowrank_bwd == 1 || (lowrank_bwd < 0 && g.lowrank && g.Dp >= 4 * g.Sp));
+        // T~ = [X l_F | 1] exists only when the forward projection goes through the S columns (g.lowrank), and U needs room in
+        // Phibar's dead sine half
+        const bool fits = g.lowrank && g.Jp + (int)round_up(g.S, 64) <= g.Kp;
+        return fits && (lowrank_bwd == 1 || (lowrank_bwd < 0 && g.Dp >= 4 * g.Sp));
     }
     double* x3_scalars() { return d_x3 + (int64_t)Dpp * g.Jp; }
     double* x3_xu() { return d_x3 + (int64_t)Dpp * g.Jp + 8; }

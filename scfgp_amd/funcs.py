@@ -102,6 +102,9 @@ class CompiledFuncs(object):
     def __init__(self, D, S, M, params, algo='adam', algo_params=None, momentum=0.9,
                  dtype='f64', device=0, stream=None, allreduce=None, n_global=None, device_optimizer=False):
         self.engine = HipEngine(D, S, M, dtype=dtype, device=device, stream=stream)
+        # Theano's functions return a NaN / Inf cost as a value and SCFGP.optimize reads it as "no improvement"
+        # (SCFGP/SCFGP.py:249-258); only a failed Cholesky raises (LinAlgError)
+        self.engine.nonfinite = 'return'
         self.evaluator = ShardedEvaluator(self.engine, allreduce)
         self.allreduce = allreduce
         self.n_global = n_global

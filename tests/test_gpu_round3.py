@@ -473,3 +473,61 @@ def test_one_rank_under_the_launcher_goes_through_rccl():
     st = o2['stages_ms']
     assert all(('exchange%d' % k) in st and st['exchange%d' % k] >= 0 for k in (1, 2, 3))
     assert 'exchange1' not in o1['stages_ms']
+
+
+@pytest.mark.parametrize('dtype,opts,ctol,gtol', [
+    ('f64', {'lowrank_bwd': 1}, 1e-10, 1e-8),
+    ('f64', {'factor_form': 1}, 1e-10, 1e-8),
+    ('f32', {'gram64': 3}, 2e-5, 3e-3),                              # level 2 forced: fp64 pass-1 Gram + factor form of pass 2
+    ('f32', {'gram64': 0, 'lowrank_bwd': 1, 'factor_form': 1}, 2e-5, 3e-3),
+])
+def test_random_shapes_with_the_optional_paths_forced(dtype, opts, ctol, gtol):
+    """The optional paths of this round (rank-S backward projection, factor form of pass 2, the escalated pass 1) forced on
+    24 seeded random (N, D, S, M) -- ragged K, one-row problems, D < S and D >> S -- against the oracle's cost and gradient:
+    every tile-edge combination of their kernels (triangular k ranges, T~ / U tile grids, fp64 Gram job list in an fp32 context)."""
+    from scfgp_amd.engine import HipEngine
+    rng0 = np.random.default_rng(20261005)
+    for _ in range(24):
+        N, D, S, M = (int(rng0.integers(1, 2500)), int(rng0.integers(1, 90)), int(rng0.integers(1, 40)), int(rng0.integers(1, 300)))
+        rng = np.random.default_rng(N * 131 + D * 17 + S * 3 + M)
+        X = rng.random((N, D)); y = rng.standard_normal((N, 1))
+        params = O.init_params(D, S, M, rng)
+        params[0] = -0.4; params[1] = 0.1; params[2] = -0.6; params[3:3 + D * S] *= 0.6
+        eng = HipEngine(D, S, M, dtype)
+        for k, v in opts.items():
+            eng.set_option(k, v)
+        eng.set_params(params); eng.set_data(X, y)
+        c0, g0, a0, L0 = O.value_and_grad(X, y, params, S, M)
+        if not np.isfinite(c0):                                    # S = 1 or M = 1: a row's std is 0, -log 0 in the penalty (SCFGP.py:94,114-117)
+            with pytest.raises(FloatingPointError):                # the engine reports it (SCFGP_ENONFINITE); the triple returns it
+                eng.eval(want_grad=True)
+            eng.close()
+            continue
+        cost, grad, alpha, Li = eng.eval(want_grad=True)
+        assert abs(float(cost) - c0) < ctol * max(1.0, abs(c0)), (N, D, S, M, float(cost), c0)
+        assert rel(grad, g0) < gtol, (N, D, S, M, rel(grad, g0))
+        eng.close()
+
+
+def test_non_finite_cost_comes_back_as_a_value_through_the_triple():
+    """With S = 1 the penalty's `sig_l` (sum over rows of the std along a one-element axis, SCFGP/SCFGP.py:116) is 0 and
+    kl's -log(sig) makes the cost +inf.  Theano's functions return that as a value, the reference's optimize loop reads a
+    non-finite objective as "no improvement" (SCFGP/SCFGP.py:249-258) -- so do train_func / train_iter_func here, with alpha and
+    Li as usual; the engine itself (the C ABI's SCFGP_ENONFINITE) raises."""
+    from scfgp_amd.engine import HipEngine
+    from scfgp_amd.funcs import CompiledFuncs
+    N, D, S, M = 300, 6, 1, 20
+    rng = np.random.default_rng(7)
+    X = rng.random((N, D)); y = rng.standard_normal((N, 1))
+    params = O.init_params(D, S, M, rng); params[:3] = (-0.5, 0.0, -1.0)
+    c0, g0, a0, L0 = O.value_and_grad(X, y, params, S, M)
+    assert np.isposinf(c0)
+    cf = CompiledFuncs(D, S, M, params.copy())
+    cost, alpha, Li = cf.train_func(X, y)
+    assert np.isposinf(float(cost)) and rel(alpha, a0) < 1e-9 and rel(Li, L0) < 1e-9
+    cost2, _, _ = cf.train_iter_func(X, y)                          # no exception either; the update then spreads the NaN gradient
+    assert np.isposinf(float(cost2))
+    eng = HipEngine(D, S, M); eng.set_params(params); eng.set_data(X, y)
+    with pytest.raises(FloatingPointError):
+        eng.eval()
+    eng.close()
