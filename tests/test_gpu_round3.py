@@ -531,3 +531,79 @@ def test_non_finite_cost_comes_back_as_a_value_through_the_triple():
     with pytest.raises(FloatingPointError):
         eng.eval()
     eng.close()
+
+
+@pytest.mark.parametrize('dtype,ctol,gtol,ptol', [('f64', 1e-10, 1e-8, 1e-9), ('f32', 2e-5, 3e-3, 2e-4)])
+@pytest.mark.parametrize('D,S,M', [(7, 3, 40), (40, 6, 150), (5, 12, 200)])
+def test_one_context_through_a_random_sequence_of_calls(D, S, M, dtype, ctol, gtol, ptol):
+    """Stale-state check: ONE context lives through 40 seeded random calls -- new rows (1 .. 3000, growing and shrinking), new
+    parameters, evaluations with and without gradient, minibatch evaluations on index lists (duplicates, one row, all rows),
+    predictions (1 .. 5000 rows), two device training iterations, and option changes between them (precision level, factor
+    form, rank-S backward projection, LDS-DMA tiles, row splits) -- and every result is compared with the oracle on the
+    inputs of that call.  Buffers that outlive a call (row buffers sized for an earlier, larger N; the factor-form and fp64
+    feature buffers; slabs; the captured training graph) must never leak into a later one."""
+    from scfgp_amd.engine import HipEngine
+    rng = np.random.default_rng(D * 1000 + S * 10 + M + (0 if dtype == 'f64' else 7))
+    eng = HipEngine(D, S, M, dtype)
+    sizes = [1, 37, 255, 256, 257, 700, 1500, 3000]
+
+    def new_params():
+        p = O.init_params(D, S, M, rng)
+        p[0] = -0.4 + 0.2 * rng.standard_normal(); p[1] = 0.1; p[2] = -0.6; p[3:3 + D * S] *= 0.6
+        return p
+
+    def new_data():
+        n = int(rng.choice(sizes))
+        return rng.random((n, D)), rng.standard_normal((n, 1))
+
+    params = new_params(); X, y = new_data()
+    eng.set_params(params); eng.set_data(X, y)
+    alpha = Li = None
+    options = [('gram64', (0, 2, 3)), ('factor_form', (-1, 1)), ('lowrank_bwd', (-1, 0, 1)), ('gram_nsplit', (0, 3)), ('gram_taper', (0, 1))]
+    if dtype == 'f32':
+        options.append(('apply_dma', (-1, 0, 1, 2)))
+    log = []
+    for step in range(40):
+        op = rng.choice(['data', 'params', 'eval', 'eval', 'rows', 'predict', 'option', 'train'])
+        log.append(str(op))
+        if op == 'data':
+            X, y = new_data(); eng.set_data(X, y)
+        elif op == 'params':
+            params = new_params(); eng.set_params(params)
+        elif op == 'option':
+            name, values = options[int(rng.integers(len(options)))]
+            v = int(rng.choice(values)); eng.set_option(name, v); log[-1] += ' %s=%d' % (name, v)
+        elif op == 'eval':
+            wg = bool(rng.integers(2))
+            c, g, alpha, Li = eng.eval(want_grad=wg)
+            c0, g0, a0, L0 = O.value_and_grad(X, y, params, S, M)
+            assert abs(float(c) - c0) < ctol * max(1.0, abs(c0)), (step, log)
+            assert rel(alpha, a0) < max(ptol, 1e-3 if dtype == 'f32' else 0), (step, log)
+            if wg:
+                assert rel(g, g0) < gtol, (step, log, rel(g, g0))
+        elif op == 'rows':
+            n = int(rng.choice([1, 10, max(1, X.shape[0] // 2), X.shape[0]]))
+            idx = rng.integers(0, X.shape[0], n)
+            c, g, alpha, Li = eng.eval_rows(idx, True)
+            c0, g0, a0, L0 = O.value_and_grad(X[idx], y[idx], params, S, M)
+            assert abs(float(c) - c0) < ctol * max(1.0, abs(c0)), (step, log)
+            assert rel(g, g0) < gtol, (step, log, rel(g, g0))
+        elif op == 'predict':
+            if alpha is None:
+                continue
+            T = int(rng.choice([1, 100, 5000]))
+            Xs = rng.random((T, D))
+            mu, sd = eng.predict(Xs, alpha, Li)
+            mu0, sd0 = O.predict(Xs, alpha, Li, params, S, M)
+            assert mu.shape == (T, 1) and sd.shape == (T,)
+            assert rel(mu, mu0) < ptol and rel(sd, sd0) < ptol, (step, log, rel(mu, mu0), rel(sd, sd0))
+        elif op == 'train':
+            eng.opt_init('adam', learning_rate=1e-3)
+            hist, alpha, Li = eng.train(2)
+            c0, g0, a0, L0 = O.value_and_grad(X, y, params, S, M)
+            assert abs(hist[0] - c0) < ctol * max(1.0, abs(c0)), (step, log)       # first iteration: cost at the parameters it started from
+            params = eng.get_params()
+            c1, _, _, _ = O.value_and_grad(X, y, params, S, M)                     # ... and the vector the device moved to evaluates consistently
+            c, _, alpha, Li = eng.eval(want_grad=False)
+            assert abs(float(c) - c1) < ctol * max(1.0, abs(c1)), (step, log)
+    eng.close()
