@@ -609,3 +609,26 @@ def test_one_context_through_a_random_sequence_of_calls(D, S, M, dtype, ctol, gt
             c, _, alpha, Li = eng.eval(want_grad=False)
             assert abs(float(c) - c1) < ctol * max(1.0, abs(c1)), (step, log)
     eng.close()
+
+
+@pytest.mark.parametrize('dma', [1, 2, 3])
+def test_lds_dma_apply_tiles_on_random_widths(dma):
+    """The LDS-DMA apply kernels (128- and 256-wide tiles, the narrower remainder on the loader-staged kernel) forced on 12
+    seeded random shapes with K from ~130 to ~1500 -- ragged K, odd and even tile counts, row counts that are no multiple of
+    256 -- against the oracle, with and without the factor form (triangular k ranges)."""
+    from scfgp_amd.engine import HipEngine
+    rng0 = np.random.default_rng(20261006 + dma)
+    for it in range(12):
+        N, D, S, M = (int(rng0.integers(1, 4000)), int(rng0.integers(1, 40)), int(rng0.integers(2, 30)), int(rng0.integers(60, 720)))
+        rng = np.random.default_rng(N * 131 + D * 17 + S * 3 + M)
+        X = rng.random((N, D)); y = rng.standard_normal((N, 1))
+        params = O.init_params(D, S, M, rng)
+        params[0] = -0.4; params[1] = 0.1; params[2] = -0.6; params[3:3 + D * S] *= 0.6
+        c0, g0, a0, L0 = O.value_and_grad(X, y, params, S, M)
+        eng = HipEngine(D, S, M, 'f32')
+        eng.set_option('apply_dma', dma); eng.set_option('factor_form', it % 2)
+        eng.set_params(params); eng.set_data(X, y)
+        cost, grad, alpha, Li = eng.eval(want_grad=True)
+        assert abs(float(cost) - c0) < 2e-5 * max(1.0, abs(c0)), (N, D, S, M, float(cost), c0)
+        assert rel(grad, g0) < 3e-3, (N, D, S, M, rel(grad, g0))
+        eng.close()
