@@ -1,6 +1,9 @@
 // Row-sweep kernels of the SCFGP objective: everything whose cost scales with N.
 // Built on tile_engine.h; templated on the compute type T (double | float).
 #include "kernels.h"
+#ifndef SCFGP_DIAG_EPI0
+#define SCFGP_DIAG_EPI0 0                 // timing diagnostics of the apply epilogue (wrong numbers): see apply_epilogue
+#endif
 #include "tile_engine.h"
 #include "tile_bf16x3.h"
 #include "tile_bf16x3_dma.h"
@@ -775,6 +778,22 @@ void SweepKernels<T>::xtz(const Geom& g, const double* Xt, const T* Phi, const T
 //   permuted order, so that MFMA tile tn, lane column i IS output column 4 i + tn of the wave tile -- a lane then holds four
 //   ADJACENT columns of each of its rows and the epilogue moves V, Phi and Phibar 16 bytes per lane (256 contiguous bytes per
 //   row and 16-lane group) instead of 4 (four 64-byte pieces per instruction)
+// Sum over the 16 lanes of a DPP row (the lanes that hold one output row of a 16 x 16 MFMA tile), result in every lane: two
+// quad permutes, row_half_mirror, row_mirror on the two halves of the double -- VALU moves instead of the eight LDS-crossbar
+// ds_bpermute_b32 a __shfl_xor butterfly costs (256 of them per lane in the 64 x 64 wave tile's epilogue: 0.9 ms of the product)
+template <int CTRL> __device__ __forceinline__ double dpp_mov_f64(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row16_sum(double x) {
+    x += dpp_mov_f64<0xB1>(x);                                  // quad_perm [1,0,3,2]
+    x += dpp_mov_f64<0x4E>(x);                                  // quad_perm [2,3,0,1]
+    x += dpp_mov_f64<0x141>(x);                                 // row_half_mirror
+    x += dpp_mov_f64<0x140>(x);                                 // row_mirror
+    return x;
+}
 template <class Cfg, int EPI, bool MU = false, bool VEC4 = false>
 __device__ __forceinline__ void apply_epilogue(
     const typename Cfg::MTr::acc_t (&acc)[Cfg::TM][Cfg::TN], const typename Cfg::T* __restrict__ Phi, typename Cfg::T* V,
@@ -807,7 +826,13 @@ __device__ __forceinline__ void apply_epilogue(
                     const int row = co.row(tm, r);
                     const int64_t off = (rb * Cfg::BM + row) * Kp + jg;
                     const v4f c = v4f{acc[tm][0][r], acc[tm][1][r], acc[tm][2][r], acc[tm][3][r]};
+#if SCFGP_DIAG_EPI0 != 3                                             // timing diagnostics (wrong numbers): 1 no row reduction, 2 stores only, 3 nothing
                     *reinterpret_cast<v4f*>(V + off) = c;
+#endif
+#if SCFGP_DIAG_EPI0 >= 2
+                    asm volatile("" :: "v"(c));
+                    continue;
+#endif
                     double part = 0, mup = 0;
                     if (EPI == 3) {
                         part = (double)(c[0] * c[0]) + (double)(c[1] * c[1]) + (double)(c[2] * c[2]) + (double)(c[3] * c[3]);
@@ -818,12 +843,14 @@ __device__ __forceinline__ void apply_epilogue(
 #pragma unroll
                         for (int k = 0; k < 4; ++k) { part += (double)ph[k] * (double)c[k] * live[k]; if (MU) mup += (double)ph[k] * al[k]; }
                     }
-#pragma unroll
-                    for (int m = 1; m < 16; m <<= 1) part += __shfl_xor(part, m);
+#if SCFGP_DIAG_EPI0 == 1
+                    asm volatile("" :: "v"(part), "v"(mup));
+                    continue;
+#endif
+                    part = row16_sum(part);
                     if ((co.lane & 15) == 0) red[wn * Cfg::BM + row] = part;
                     if (MU) {
-#pragma unroll
-                        for (int m = 1; m < 16; m <<= 1) mup += __shfl_xor(mup, m);
+                        mup = row16_sum(mup);
                         if ((co.lane & 15) == 0) red2[wn * Cfg::BM + row] = mup;
                     }
                 }
@@ -908,12 +935,18 @@ __device__ __forceinline__ void apply_epilogue(
                         if (MU) mup += ph * al[tn];
                     }
                 }
+                if constexpr (Cfg::MS == 16) part = row16_sum(part);                     // lanes of one MFMA row group
+                else {
 #pragma unroll
-                for (int m = 1; m < Cfg::MS; m <<= 1) part += __shfl_xor(part, m);      // lanes of one MFMA row group
+                    for (int m = 1; m < Cfg::MS; m <<= 1) part += __shfl_xor(part, m);
+                }
                 if ((co.lane % Cfg::MS) == 0) red[wn * Cfg::BM + row] = part;
                 if (MU) {
+                    if constexpr (Cfg::MS == 16) mup = row16_sum(mup);
+                    else {
 #pragma unroll
-                    for (int m = 1; m < Cfg::MS; m <<= 1) mup += __shfl_xor(mup, m);
+                        for (int m = 1; m < Cfg::MS; m <<= 1) mup += __shfl_xor(mup, m);
+                    }
                     if ((co.lane % Cfg::MS) == 0) red2[wn * Cfg::BM + row] = mup;
                 }
             }
