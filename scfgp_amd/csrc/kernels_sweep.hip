@@ -4,6 +4,9 @@
 #ifndef SCFGP_DIAG_EPI0
 #define SCFGP_DIAG_EPI0 0                 // timing diagnostics of the apply epilogue (wrong numbers): see apply_epilogue
 #endif
+#ifndef SCFGP_DIAG_EPI1
+#define SCFGP_DIAG_EPI1 0
+#endif
 #include "tile_engine.h"
 #include "tile_bf16x3.h"
 #include "tile_bf16x3_dma.h"
@@ -819,15 +822,25 @@ __device__ __forceinline__ void apply_epilogue(
             double al[4], live[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) { live[k] = jg + k < K ? 1.0 : 0.0; al[k] = MU && jg + k < K ? alpha[jg + k] : 0.0; }
+            // the re-read of Phi is issued for the four rows of an accumulator row group at once: written row by row, every row's
+            // load waited for the row before it (16 dependent round trips per tile; profiles/r03_tuning.md)
 #pragma unroll
-            for (int tm = 0; tm < Cfg::TM; ++tm)
+            for (int tm = 0; tm < Cfg::TM; ++tm) {
+                v4f ph[4];
+                int64_t off[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    off[r] = (rb * Cfg::BM + co.row(tm, r)) * Kp + jg;
+#if SCFGP_DIAG_EPI0 < 2                                              // timing diagnostics (wrong numbers): 1 no row reduction, 2 stores only, 3 nothing
+                    if (EPI == 0 || MU) ph[r] = *reinterpret_cast<const v4f*>(Phi + off[r]);
+#endif
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = co.row(tm, r);
-                    const int64_t off = (rb * Cfg::BM + row) * Kp + jg;
                     const v4f c = v4f{acc[tm][0][r], acc[tm][1][r], acc[tm][2][r], acc[tm][3][r]};
-#if SCFGP_DIAG_EPI0 != 3                                             // timing diagnostics (wrong numbers): 1 no row reduction, 2 stores only, 3 nothing
-                    *reinterpret_cast<v4f*>(V + off) = c;
+#if SCFGP_DIAG_EPI0 != 3
+                    *reinterpret_cast<v4f*>(V + off[r]) = c;
 #endif
 #if SCFGP_DIAG_EPI0 >= 2
                     asm volatile("" :: "v"(c));
@@ -836,12 +849,10 @@ __device__ __forceinline__ void apply_epilogue(
                     double part = 0, mup = 0;
                     if (EPI == 3) {
                         part = (double)(c[0] * c[0]) + (double)(c[1] * c[1]) + (double)(c[2] * c[2]) + (double)(c[3] * c[3]);
-                        if (MU) { const v4f ph = *reinterpret_cast<const v4f*>(Phi + off);
-                                  mup = (double)ph[0] * al[0] + (double)ph[1] * al[1] + (double)ph[2] * al[2] + (double)ph[3] * al[3]; }
+                        if (MU) mup = (double)ph[r][0] * al[0] + (double)ph[r][1] * al[1] + (double)ph[r][2] * al[2] + (double)ph[r][3] * al[3];
                     } else {
-                        const v4f ph = *reinterpret_cast<const v4f*>(Phi + off);
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) { part += (double)ph[k] * (double)c[k] * live[k]; if (MU) mup += (double)ph[k] * al[k]; }
+                        for (int k = 0; k < 4; ++k) { part += (double)ph[r][k] * (double)c[k] * live[k]; if (MU) mup += (double)ph[r][k] * al[k]; }
                     }
 #if SCFGP_DIAG_EPI0 == 1
                     asm volatile("" :: "v"(part), "v"(mup));
@@ -854,6 +865,7 @@ __device__ __forceinline__ void apply_epilogue(
                         if ((co.lane & 15) == 0) red2[wn * Cfg::BM + row] = mup;
                     }
                 }
+            }
             __syncthreads();
             if (threadIdx.x < Cfg::BM) {
                 double s = 0, s2 = 0;
@@ -867,24 +879,62 @@ __device__ __forceinline__ void apply_epilogue(
             double al[4], u4[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) { al[k] = alpha[jg + k]; u4[k] = ut[jg + k]; }
+            float alf[4], u4f[4];
 #pragma unroll
-            for (int tm = 0; tm < Cfg::TM; ++tm)
+            for (int k = 0; k < 4; ++k) { alf[k] = (float)al[k]; u4f[k] = (float)u4[k]; }
+            // per-row scalars (2 q, p, y) of the tile's rows through LDS (free after the loop's last barrier), and the re-reads of V
+            // and Phi issued for the four rows of an accumulator row group at once: written row by row, the in-place store of a row
+            // stood between the loads of the next one and its own (16 dependent round trips per tile; profiles/r03_tuning.md)
+            float* rowsc = reinterpret_cast<float*>(smem_raw);        // [BM][3]
+            for (int i = threadIdx.x; i < Cfg::BM; i += Cfg::THREADS) {
+                const int64_t n = rb * Cfg::BM + i;
+                rowsc[3 * i] = (float)(2.0 * q[n]); rowsc[3 * i + 1] = (float)p[n]; rowsc[3 * i + 2] = (float)y[n];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int tm = 0; tm < Cfg::TM; ++tm) {
+                v4f vv[4], ph[4];
+                int64_t off[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int64_t n = rb * Cfg::BM + co.row(tm, r);
-                    const int64_t off = n * Kp + jg;
-                    const double qn = 2.0 * q[n], pn = p[n], yn = y[n];
-                    const v4f vv = *reinterpret_cast<const v4f*>(V + off), ph = *reinterpret_cast<const v4f*>(Phi + off);
+                    off[r] = (rb * Cfg::BM + co.row(tm, r)) * Kp + jg;
+#if SCFGP_DIAG_EPI1 >= 2                                             // timing diagnostics (wrong numbers): 1 no Phi re-read / b-bar dot, 2 no V re-read either, 3 nothing
+                    vv[r] = v4f{0, 0, 0, 0};
+#else
+                    vv[r] = *reinterpret_cast<const v4f*>(V + off[r]);
+#endif
+#if SCFGP_DIAG_EPI1 >= 1
+                    ph[r] = v4f{0, 0, 0, 0};
+#else
+                    ph[r] = *reinterpret_cast<const v4f*>(Phi + off[r]);
+#endif
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+#if SCFGP_DIAG_EPI1 == 3
+                    asm volatile("" :: "v"(acc[tm][0][r]), "v"(acc[tm][1][r]), "v"(acc[tm][2][r]), "v"(acc[tm][3][r]));
+                    continue;
+#endif
+                    const int row = co.row(tm, r);
+                    // Phibar is stored in fp32: its four terms are combined in fp32 FMAs (one rounding per term instead of one at
+                    // the end; the accumulator itself carries ~1e-7 of the product), and the b-bar dot takes the four products of a
+                    // lane in fp32 and everything above them in fp64 -- the fp64 conversions and FMAs of the all-fp64 form were
+                    // ~1 ms of the launch (profiles/r03_tuning.md)
+                    const float qn = rowsc[3 * row], pn = rowsc[3 * row + 1], yn = rowsc[3 * row + 2];
                     v4f o;
+                    float dot = 0.f;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const double v = 2.0 * (double)acc[tm][k][r] + qn * (double)vv[k] + pn * al[k] + yn * u4[k];
-                        o[k] = (float)v;
-                        if (jg + k < K) bb += v * (double)ph[k];
+                        o[k] = fmaf(qn, vv[r][k], fmaf(pn, alf[k], fmaf(yn, u4f[k], 2.0f * acc[tm][k][r])));
+#if SCFGP_DIAG_EPI1 == 0
+                        dot = fmaf(o[k], jg + k < K ? ph[r][k] : 0.f, dot);
+#endif
                     }
-                    *reinterpret_cast<v4f*>(V + off) = o;
+                    bb += (double)dot;
+                    *reinterpret_cast<v4f*>(V + off[r]) = o;
                 }
-            double* red = reinterpret_cast<double*>(smem_raw);
+            }
+            double* red = reinterpret_cast<double*>(rowsc + 4 * Cfg::BM);
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1) bb += __shfl_xor(bb, m);
             if (co.lane == 0) red[threadIdx.x >> 6] = bb;
