@@ -1010,6 +1010,11 @@ __device__ __forceinline__ void apply_epilogue(
         }
     } else {
         double bb = 0;                                                  // bbar = sum Phibar o Phi  (d cost / d b)
+        [[maybe_unused]] float alf[Cfg::TN], utf[Cfg::TN];
+        if constexpr (sizeof(T) == 4) {
+#pragma unroll
+            for (int tn = 0; tn < Cfg::TN; ++tn) { alf[tn] = (float)alpha[cbase + co.col(tn)]; utf[tn] = (float)ut[cbase + co.col(tn)]; }
+        }
 #pragma unroll
         for (int tm = 0; tm < Cfg::TM; ++tm)
 #pragma unroll
@@ -1017,12 +1022,24 @@ __device__ __forceinline__ void apply_epilogue(
                 const int64_t n = rb * Cfg::BM + co.row(tm, r);
                 const int64_t off = n * Kp + cbase;
                 const double qn = 2.0 * q[n], pn = p[n], yn = y[n];
+                if constexpr (sizeof(T) == 4) {                     // fp32 storage: fp32 FMAs, as in the VEC4 path above
+                    const float qf = (float)qn, pf = (float)pn, yf = (float)yn;
+                    float dot = 0.f;
 #pragma unroll
-                for (int tn = 0; tn < Cfg::TN; ++tn) {
-                    const int j = cbase + co.col(tn);
-                    const double v = 2.0 * (double)acc[tm][tn][r] + qn * (double)V[off + co.col(tn)] + pn * alpha[j] + yn * ut[j];
-                    V[off + co.col(tn)] = (T)v;
-                    if (j < K) bb += v * (double)Phi[off + co.col(tn)];
+                    for (int tn = 0; tn < Cfg::TN; ++tn) {
+                        const float o = fmaf(qf, V[off + co.col(tn)], fmaf(pf, alf[tn], fmaf(yf, utf[tn], 2.0f * acc[tm][tn][r])));
+                        V[off + co.col(tn)] = o;
+                        if (cbase + co.col(tn) < K) dot = fmaf(o, Phi[off + co.col(tn)], dot);
+                    }
+                    bb += (double)dot;
+                } else {
+#pragma unroll
+                    for (int tn = 0; tn < Cfg::TN; ++tn) {
+                        const int j = cbase + co.col(tn);
+                        const double v = 2.0 * (double)acc[tm][tn][r] + qn * (double)V[off + co.col(tn)] + pn * alpha[j] + yn * ut[j];
+                        V[off + co.col(tn)] = (T)v;
+                        if (j < K) bb += v * (double)Phi[off + co.col(tn)];
+                    }
                 }
             }
         double* red = reinterpret_cast<double*>(smem_raw);
