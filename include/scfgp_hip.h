@@ -215,6 +215,8 @@ int64_t scfgp_debug_read(scfgp_ctx* ctx, const char* name, void* host, int64_t m
  * "pass3_parts" (experiment: pass 3 in row parts with X~^T Zbar on a second stream; measured slower),
  * "apply_dma" = 4 (experiment: 256-wide LDS-DMA tiles on 8 waves of 128 x 64; measured slower), = 5 (experiment: the default
  * tiles with the fragment reads software-pipelined by half stages in inline assembly; measured slower),
+ * "zbar_fused" (experiment: 1 = the Phibar product's epilogue writes Zbar instead of Phibar -- pass 3 without the Phibar round
+ * trip -- where the fp32 LDS-DMA tiles run and J % 4 == 0; measured slower, off by default),
  * "lowrank_bwd" (-1 auto: when D+1 >= 4 (S+1) padded, 0 never, 1 whenever it can -- the forward projection goes through the S columns (S+1 < D+1, padded to 16) and U fits: the reverse sweep of F = l_F r_F^T through
  * T~^T Zbar and X~^T (Zbar_L + Zbar_M r_F) instead of the dense X~^T Zbar; exchange buffer 3 then holds those two) */
 int scfgp_set_option(scfgp_ctx* ctx, const char* name, int64_t value);

@@ -122,6 +122,10 @@ struct SweepKernels {
     static int apply_phibar(const Geom& g, const T* Phi, const T* Abar, T* V, const double* p, const double* q,
                             const double* y, const double* alpha, const double* ut, double* bpart, hipStream_t st, bool bf3 = false,
                             const Bf3Planes* planes = nullptr);
+    // the same product with the Zbar epilogue (Zbar over V's cosine half, Phibar never stored): -1 when it does not apply
+    static int apply_zbar(const Geom& g, const T* Phi, const T* Abar, T* V, const double* p, const double* q,
+                          const double* y, const double* alpha, const double* ut, double* bpart, hipStream_t st,
+                          const Bf3Planes* planes);
     static int apply_blocks(const Geom& g);
     // per-row moments and adjoint scalars; block partials of (T2, kbar)  (SCFGP.py:111-113,121-124)
     static void rowstats(const Geom& g, const double* mupart, const double* vpart, const double* y,

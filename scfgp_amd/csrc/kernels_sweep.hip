@@ -1054,6 +1054,118 @@ __device__ __forceinline__ void apply_epilogue(
         }
     }
 }
+typedef float v2f __attribute__((ext_vector_type(2)));
+// --------------------------------------------------------------------------
+// EPI 5: the Phibar product writes Zbar instead of Phibar ("pass 3 without the Phibar round trip").  The column tiles of the launch
+// are tiles of j: a tile holds the cosine columns j and the sine columns J + j of the same j's, gathered through the operand's row
+// addresses, so that one lane ends up with Phibar[n][j] AND Phibar[n][J + j]:
+//   Zbar[n][j] = Phi[n][j] Phibar[n][J + j] - Phi[n][J + j] Phibar[n][j]          (zbar_kernel), written over V[n][j], j < J
+// Phibar itself never reaches memory (8.45 GB less written, Phi and Phibar not re-read by a Zbar pass or by the X~^T Zbar loader);
+// bbar = sum Phibar o Phi as in EPI 1.  fp32 storage only, J % 4 == 0.
+//   VEC4 form (LDS-DMA kernels): MFMA tile tn of a 64-wide wave tile w, lane column i: tn = 0, 1 -> cosine column jb + 32 w + 2 i + tn,
+//   tn = 2, 3 -> the sine column of the same j
+// --------------------------------------------------------------------------
+template <class Cfg>
+__device__ __forceinline__ void zbar_epilogue_vec4(
+    const typename Cfg::MTr::acc_t (&acc)[Cfg::TM][Cfg::TN], const float* __restrict__ Phi, float* V,
+    const double* __restrict__ p, const double* __restrict__ q, const double* __restrict__ y,
+    const double* __restrict__ alpha, const double* __restrict__ ut, int J, int Kp, int64_t rb, int jb,
+    double* __restrict__ bpart, char* smem_raw) {
+    static_assert(Cfg::TN == 4 && Cfg::MS == 16, "64-wide wave tiles");
+    AccCoord<Cfg> co;
+    const int j = jb + (co.wn0 >> 1) + 2 * (co.lane & 15);      // this lane's two j: j, j + 1 (full tiles only: j + 1 < J)
+    float alc[2], als[2], uc[2], us[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        alc[t] = (float)alpha[j + t]; als[t] = (float)alpha[J + j + t];
+        uc[t] = (float)ut[j + t]; us[t] = (float)ut[J + j + t];
+    }
+    float* rowsc = reinterpret_cast<float*>(smem_raw);          // [BM][3]: 2 q, p, y of the tile's rows (LDS is free after the loop)
+    for (int i = threadIdx.x; i < Cfg::BM; i += Cfg::THREADS) {
+        const int64_t n = rb * Cfg::BM + i;
+        rowsc[3 * i] = (float)(2.0 * q[n]); rowsc[3 * i + 1] = (float)p[n]; rowsc[3 * i + 2] = (float)y[n];
+    }
+    __syncthreads();
+    double bb = 0;
+#pragma unroll
+    for (int tm = 0; tm < Cfg::TM; ++tm) {
+        v2f vc[4], vs[4], fc[4], fs[4];
+        int64_t off[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            off[r] = (rb * Cfg::BM + co.row(tm, r)) * Kp + j;
+            vc[r] = *reinterpret_cast<const v2f*>(V + off[r]); vs[r] = *reinterpret_cast<const v2f*>(V + off[r] + J);
+            fc[r] = *reinterpret_cast<const v2f*>(Phi + off[r]); fs[r] = *reinterpret_cast<const v2f*>(Phi + off[r] + J);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = co.row(tm, r);
+            const float qn = rowsc[3 * row], pn = rowsc[3 * row + 1], yn = rowsc[3 * row + 2];
+            v2f z;
+            float dot = 0.f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const float bc = fmaf(qn, vc[r][t], fmaf(pn, alc[t], fmaf(yn, uc[t], 2.0f * acc[tm][t][r])));
+                const float bs = fmaf(qn, vs[r][t], fmaf(pn, als[t], fmaf(yn, us[t], 2.0f * acc[tm][2 + t][r])));
+                dot = fmaf(bc, fc[r][t], fmaf(bs, fs[r][t], dot));
+                z[t] = fc[r][t] * bs - fs[r][t] * bc;
+            }
+            bb += (double)dot;
+            *reinterpret_cast<v2f*>(V + off[r]) = z;
+        }
+    }
+    double* red = reinterpret_cast<double*>(rowsc + 4 * Cfg::BM);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) bb += __shfl_xor(bb, m);
+    if (co.lane == 0) red[threadIdx.x >> 6] = bb;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0;
+        for (int k = 0; k < Cfg::THREADS / 64; ++k) s += red[k];
+        bpart[blockIdx.x] = s;
+    }
+}
+//   pair form (the loader-staged 64-wide remainder tile, 32-wide wave tiles of two MFMA tiles): wave column w, lane column i:
+//   tn = 0 -> cosine column jb + 16 w + i, tn = 1 -> its sine column; j >= J (ragged last tile) contributes nothing
+template <class Cfg>
+__device__ __forceinline__ void zbar_epilogue_pair(
+    const typename Cfg::MTr::acc_t (&acc)[Cfg::TM][Cfg::TN], const float* __restrict__ Phi, float* V,
+    const double* __restrict__ p, const double* __restrict__ q, const double* __restrict__ y,
+    const double* __restrict__ alpha, const double* __restrict__ ut, int J, int Kp, int64_t rb, int jb,
+    double* __restrict__ bpart, char* smem_raw) {
+    static_assert(Cfg::TN == 2 && Cfg::MS == 16, "32-wide wave tiles");
+    AccCoord<Cfg> co;
+    const int j = jb + (co.wn0 >> 1) + (co.lane & 15);
+    const bool live = j < J;
+    const float alc = live ? (float)alpha[j] : 0.f, als = live ? (float)alpha[J + j] : 0.f;
+    const float uc = live ? (float)ut[j] : 0.f, us = live ? (float)ut[J + j] : 0.f;
+    double bb = 0;
+#pragma unroll
+    for (int tm = 0; tm < Cfg::TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < Cfg::MTr::NACC; ++r) {
+            const int64_t n = rb * Cfg::BM + co.row(tm, r);
+            const int64_t off = n * Kp + j;
+            if (live) {
+                const float qn = (float)(2.0 * q[n]), pn = (float)p[n], yn = (float)y[n];
+                const float fc = Phi[off], fs = Phi[off + J];
+                const float bc = fmaf(qn, V[off], fmaf(pn, alc, fmaf(yn, uc, 2.0f * acc[tm][0][r])));
+                const float bs = fmaf(qn, V[off + J], fmaf(pn, als, fmaf(yn, us, 2.0f * acc[tm][1][r])));
+                bb += (double)fmaf(bc, fc, bs * fs);
+                V[off] = fc * bs - fs * bc;
+            }
+        }
+    double* red = reinterpret_cast<double*>(smem_raw);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) bb += __shfl_xor(bb, m);
+    if (co.lane == 0) red[threadIdx.x >> 6] = bb;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0;
+        for (int k = 0; k < Cfg::THREADS / 64; ++k) s += red[k];
+        bpart[blockIdx.x] = s;
+    }
+}
 #ifndef SCFGP_BF3_WAVES
 #define SCFGP_BF3_WAVES 2        // waves per SIMD the split-precision apply kernel is compiled for (2: one workgroup per CU)
 #endif
@@ -1092,7 +1204,7 @@ __device__ __forceinline__ void apply_tile(
     } else {
         typename Cfg::MTr::acc_t acc[Cfg::TM][Cfg::TN];
         acc_zero<Cfg>(acc);
-        TrLoader<T, T, Cfg::BM, Cfg::BK, Cfg::LDA, Cfg::THREADS, EPI != 1 && EPI != 4, Cfg::SWZA> la(
+        TrLoader<T, T, Cfg::BM, Cfg::BK, Cfg::LDA, Cfg::THREADS, EPI != 1 && EPI != 4 && EPI != 5, Cfg::SWZA> la(
             Phi + rb * Cfg::BM * Kp + kt0 * Cfg::BK, Kp, threadIdx.x, want_mu ? alpha : nullptr, jt0 + jt, ntot);
         if (EPI == 2 || EPI == 3) la.dot_range(cbase / Cfg::BK, nkt);
         else if (ntot == 0) {                                   // beside DMA-fed tiles: mu slices are the tiles' own column bands
@@ -1100,8 +1212,20 @@ __device__ __forceinline__ void apply_tile(
             la.dot_range(cbase / Cfg::BK, hi < nkt ? hi : nkt);
         }
         NatLoader<T, T, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS, false, false> lb(Bm + (int64_t)kt0 * Cfg::BK * Kp + cbase, Kp, threadIdx.x);
+        if constexpr (EPI == 5) {
+            // col0 counts j here: tile jt covers j in [jb, jb + BN / 2); tile column x = 32 w + 16 tn + i is operand column
+            // jb + 16 w + i (tn = 0, cosine) or J + that (tn = 1, sine); j >= J: a zero padding column (K < Kp whenever a tile is ragged)
+            const int J = K / 2, jb = col0 + jt * (Cfg::BN / 2);
+            lb.remap_columns(Bm, Kp, [=](int x) {
+                const int jj = jb + 16 * (x >> 5) + (x & 15);
+                return jj < J ? ((x & 16) ? J + jj : jj) : K + (x & 3);
+            });
+            tile_mainloop<Cfg>(la, lb, nkt, acc, smem);
+            if constexpr (sizeof(T) == 4 && Cfg::TN == 2) zbar_epilogue_pair<Cfg>(acc, Phi, V, p, q, y, alpha, ut, J, Kp, rb, jb, bpart, smem_raw);
+            return;
+        }
         tile_mainloop<Cfg>(la, lb, nkt, acc, smem);
-        if constexpr (EPI != 1 && EPI != 4) { if (want_mu) la.dot_reduce(mu + (int64_t)(jt0 + jt) * Np + rb * Cfg::BM); }
+        if constexpr (EPI != 1 && EPI != 4 && EPI != 5) { if (want_mu) la.dot_reduce(mu + (int64_t)(jt0 + jt) * Np + rb * Cfg::BM); }
         apply_epilogue<Cfg, EPI>(acc, Phi, V, vpart, p, q, y, alpha, ut, K, Kp, Np, rb, cbase, jt0 + jt, bpart, smem_raw);
     }
 }
@@ -1156,7 +1280,6 @@ struct ApplyDma {
 // nor replace the counted waits of the pipelined loop by lgkmcnt(0).  The result register is only valid after the loop's own
 // s_waitcnt lgkmcnt: the compiler does not know that, so the value must reach its MFMA without an intermediate copy (checked in the
 // ISA of the three PIPE instantiations: the reads land in the registers the MFMAs name)
-typedef float v2f __attribute__((ext_vector_type(2)));
 template <int OFF> __device__ __forceinline__ v2f lds_read_b64(unsigned addr) {
     v2f r;
     asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
@@ -1198,7 +1321,11 @@ void apply_dma_kernel(const float* __restrict__ Phi, const float* __restrict__ B
         const int t = wave * D::DMA_PER_WAVE + u, x = 16 * t + (lane >> 2), c = (lane & 3) ^ ((x >> 2) & 3);
         // B rows in the VEC4 order (apply_epilogue): LDS row tn*16 + i of a 64-wide wave tile holds operand row 4 i + tn
         const int xb = x - D::BM, xcol = (xb & ~63) + 4 * (xb & 15) + ((xb >> 4) & 3);
-        const float* rowp = x < D::BM ? Phi + (rb * D::BM + x) * Kp : Bm + (int64_t)(cbase + xcol) * Kp;
+        // EPI 5 (zbar_epilogue_vec4): col0 counts j, tile jt covers j in [jb, jb + BN / 2); LDS row 64 w + 16 tn + i holds operand row
+        // jb + 32 w + 2 i + (tn & 1) for tn < 2 and J + that for tn >= 2
+        const int zj = col0 + jt * (D::BN / 2) + 32 * (xb >> 6) + 2 * (xb & 15) + ((xb >> 4) & 1);
+        const int brow = EPI == 5 ? (((xb >> 4) & 2) ? K / 2 + zj : zj) : cbase + xcol;
+        const float* rowp = x < D::BM ? Phi + (rb * D::BM + x) * Kp : Bm + (int64_t)brow * Kp;
         src[u] = reinterpret_cast<const char*>(rowp) + c * 16 + (EPI == 4 ? (cbase / 16) * 64 : 0);
         dst[u] = t * 1024;
     }
@@ -1304,7 +1431,8 @@ void apply_dma_kernel(const float* __restrict__ Phi, const float* __restrict__ B
     __syncthreads();
     constexpr int SLOTS = BN / 128;                            // vpart / mupart slots are 128 columns wide
     const int vslot = slot0 + SLOTS * jt;
-    apply_epilogue<Cfg, EPI, EPI == 0 || EPI == 3, true>(acc, Phi, V, vpart, p, q, y, alpha, ut, K, Kp, Np, rb, cbase, vslot, bpart, smem_raw, mu);
+    if constexpr (EPI == 5) zbar_epilogue_vec4<Cfg>(acc, Phi, V, p, q, y, alpha, ut, K / 2, Kp, rb, col0 + jt * (D::BN / 2), bpart, smem_raw);
+    else apply_epilogue<Cfg, EPI, EPI == 0 || EPI == 3, true>(acc, Phi, V, vpart, p, q, y, alpha, ut, K, Kp, Np, rb, cbase, vslot, bpart, smem_raw, mu);
     if (SLOTS == 2 && (EPI == 0 || EPI == 3) && threadIdx.x < D::BM) {
         vpart[(int64_t)(vslot + 1) * Np + rb * D::BM + threadIdx.x] = 0.0;
         if (mu) mu[(int64_t)(vslot + 1) * Np + rb * D::BM + threadIdx.x] = 0.0;
@@ -1508,6 +1636,36 @@ int SweepKernels<T>::apply_phibar(const Geom& g, const T* Phi, const T* Abar, T*
                                   const double* y, const double* alpha, const double* ut, double* bpart, hipStream_t st, bool bf3,
                                   const Bf3Planes* planes) {
     return apply_launch<T, 1>(g, Phi, Abar, V, nullptr, p, q, y, alpha, ut, bpart, nullptr, st, bf3, planes);
+}
+
+// Phibar product with the Zbar epilogue (EPI 5): Zbar[n][j], j < J, over V[n][j]; returns the number of bbar partials, or -1
+// when the fused form does not apply (fp64, split-precision mode, no LDS-DMA tiles at this size, J % 4 != 0) and the caller runs
+// apply_phibar + the Zbar pass instead.  j plan: 128 j per 256-wide LDS-DMA tile, 64 per 128-wide one, 32 per loader-staged
+// 64-wide tile (the last of those may be ragged).
+template <typename T>
+int SweepKernels<T>::apply_zbar(const Geom& g, const T* Phi, const T* Abar, T* V, const double* p, const double* q,
+                                const double* y, const double* alpha, const double* ut, double* bpart, hipStream_t st,
+                                const Bf3Planes* planes) {
+    if constexpr (sizeof(T) != 4) return -1;
+    else {
+        if (!planes || !planes->dma || planes->rows || g.J % 4 != 0 || g.K <= 256) return -1;
+        const bool wide = planes->dma != 1;
+        const int n256 = wide ? g.J / 128 : 0, n128 = (g.J - 128 * n256) / 64;
+        const int jrest = g.J - 128 * n256 - 64 * n128, n64 = (jrest + 31) / 32;
+        if (n256 + n128 == 0) return -1;
+        int nb = 0;
+        nb += apply_dma_launch<5, 256>(g, n256, 0, 0, nb, Phi, Abar, V, nullptr, p, q, y, alpha, ut, bpart, nullptr, st);
+        nb += apply_dma_launch<5, 128>(g, n128, 128 * n256, 0, nb, Phi, Abar, V, nullptr, p, q, y, alpha, ut, bpart, nullptr, st);
+        if (n64 > 0) {
+            typedef typename ApplyCfg<T, 64>::type RCfg;
+            const int64_t nr = g.Np / RCfg::BM;
+            allow_big_lds(apply_kernel<RCfg, 5>, RCfg::LDS_BYTES);
+            hipLaunchKernelGGL((apply_kernel<RCfg, 5>), dim3((unsigned)(n64 * nr)), dim3(RCfg::THREADS), RCfg::LDS_BYTES, st,
+                               Phi, Abar, V, nullptr, p, q, y, alpha, ut, g.K, g.Kp, g.Np, n64, bpart + nb, 128 * n256 + 64 * n128, 0, nullptr, 0);
+            nb += (int)(n64 * nr);
+        }
+        return nb;
+    }
 }
 // number of column tiles of the apply kernel (vpart leading count)
 template <typename T> static int apply_njt(const Geom& g) { return ApplyPlan<T>(g.K).total; }

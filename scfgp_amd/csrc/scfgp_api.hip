@@ -73,6 +73,10 @@ struct scfgp_ctx {
     hipStream_t aux_st = nullptr; std::vector<hipEvent_t> ev_p3; int pass3_parts = -1;      // pass 3 in row parts (pass3_pipelined)
     // rank-S form of the backward projection: exchange 3 = [T~^T Zbar (Spp x Jp) ... | 8 scalars at Dpp*Jp | X~^T U (Dpp x Sq)]
     int lowrank_bwd = -1; int Spp = 0, Sq = 0; bool last_lrb = false;
+    // pass 3 without the Phibar round trip: the Phibar product's epilogue writes Zbar (SweepKernels::apply_zbar) where it applies
+    // (fp32 LDS-DMA tiles, J % 4 == 0).  Option zbar_fused: 0 off (default: measured 0.6 ms SLOWER at the headline shape -- the
+    // epilogue gains 1.7 ms, X~^T Zbar loses 1.1; profiles/r03_tuning.md), 1 on
+    int zbar_fused = 0; bool last_zfused = false;
     bool want_lrb() const {
         // T~ = [X l_F | 1] exists only when the forward projection goes through the S columns (g.lowrank), and U needs room in
         // Phibar's dead sine half
@@ -633,11 +637,17 @@ template <typename T> struct Impl {
         {
             const int Q = c->pass3_parts >= 0 ? c->pass3_parts : (g.Np >= 262144 ? SCFGP_PASS3_PARTS : 1);
             // not inside scfgp_train: a captured two-stream iteration crashed the graph runtime once in a dozen runs (ROCm 7.2)
-            if (Q > 1 && !c->bf3 && !c->in_train && !c->want_lrb() && g.Np / 256 >= 4 * Q) { c->last_lrb = false; return pass3_pipelined(c, Q); }
+            if (Q > 1 && !c->bf3 && !c->in_train && !c->want_lrb() && g.Np / 256 >= 4 * Q) { c->last_lrb = false; c->last_zfused = false; return pass3_pipelined(c, Q); }
         }
         { ProfScope ps(c, "apply_phibar"); const Bf3Planes pl = c->planes();
-          const int nb = SK::apply_phibar(g, (const T*)c->d_Phi, AbarT(c), (T*)c->d_V, c->d_p, c->d_q, c->d_y, c->alpha(), c->ut(),
-                                          c->d_bpart, c->st, c->bf3, &pl);
+          int nb = -1;
+          if (c->zbar_fused > 0 && !c->bf3)
+              nb = SK::apply_zbar(g, (const T*)c->d_Phi, (const T*)c->d_AbarT, (T*)c->d_V, c->d_p, c->d_q, c->d_y, c->alpha(), c->ut(),
+                                  c->d_bpart, c->st, &pl);
+          c->last_zfused = nb >= 0;
+          if (nb < 0)
+              nb = SK::apply_phibar(g, (const T*)c->d_Phi, AbarT(c), (T*)c->d_V, c->d_p, c->d_q, c->d_y, c->alpha(), c->ut(),
+                                    c->d_bpart, c->st, c->bf3, &pl);
           reduce_scalars(c->d_bpart, nb, 1, c->x3_scalars(), 0, c->st); }
         const int ntm = c->Dpp / XT, ntn = g.Jp / XT;
         const int64_t chunk = c->dtype == SCFGP_F32 ? c->gram_chunk : 0;
@@ -648,7 +658,7 @@ template <typename T> struct Impl {
             // sine half; X~^T U.  2 N (S+1) J + 2 N J S + 2 N (D+1) S flops instead of 2 N (D+1) J.
             ProfScope ps(c, "xtz");
             T* Zb = (T*)c->d_V; T* U = (T*)c->d_V + g.Jp;
-            SK::zbar_inplace(g, (const T*)c->d_Phi, Zb, c->st);
+            if (!c->last_zfused) SK::zbar_inplace(g, (const T*)c->d_Phi, Zb, c->st);
             SK::rsel(g, c->d_params, (T*)c->d_AbarT, c->st);                       // Abar's typed copy is dead after the product above
             SK::apply_plain(g, Zb, (const T*)c->d_AbarT, U, g.J, g.S, c->st);
             const int nt1 = (c->Spp / XT) * ntn, xs1 = xtz_split(nt1, g.Np);
@@ -662,7 +672,8 @@ template <typename T> struct Impl {
         }
         const int xs = c->xtz_nsplit > 0 ? (int)std::min<int64_t>(c->xtz_nsplit, g.Np / 64) : xtz_split(ntm * ntn, g.Np);
         { ProfScope ps(c, "xtz");
-          SK::xtz(g, c->d_Xt, (const T*)c->d_Phi, (const T*)c->d_V, xs, chunk, c->d_slabs, c->st);
+          if (c->last_zfused) SK::tn_plain(c->d_Xt, g.Dp, (const T*)c->d_V, g.Kp, g.J, g.Np, xs, chunk, c->d_slabs, c->st);    // Zbar is there already
+          else SK::xtz(g, c->d_Xt, (const T*)c->d_Phi, (const T*)c->d_V, xs, chunk, c->d_slabs, c->st);
           reduce_full_tiles(c->d_slabs, xs, ntm, ntn, c->d_x3, g.Jp, c->st); }
         HIPCHK(c, hipGetLastError());
         return SCFGP_OK;
@@ -1258,6 +1269,7 @@ extern "C" int scfgp_set_option(scfgp_ctx* c, const char* name, int64_t value) {
     else if (s == "gram_plan") { c->gram_plan = (int)value; c->plan_Np = -1; }
     else if (s == "pass3_parts") c->pass3_parts = (int)value;
     else if (s == "lowrank_bwd") c->lowrank_bwd = (int)value;
+    else if (s == "zbar_fused") c->zbar_fused = (int)value;
     else if (s == "xtz_nsplit") c->xtz_nsplit = (int)value;
     else if (s == "use_graph") c->use_graph = (int)value;
     else if (s == "gram64") { if (value < 0 || value > 3) { c->err = "gram64: 0 never, 1 always level 1, 2 auto, 3 always level 2"; return SCFGP_EARG; }

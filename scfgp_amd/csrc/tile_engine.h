@@ -137,6 +137,15 @@ struct NatLoader {
 #pragma unroll
         for (int i = 0; i < NV; ++i) ptr[i] += delta;
     }
+    // gathered columns: tile column x (a multiple of VS) comes from source column f(x) .. f(x) + VS - 1 of row-major b
+    template <class F>
+    __device__ __forceinline__ void remap_columns(const S* b, int64_t l, F f) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int v = tid + i * THREADS;
+            ptr[i] = b + (int64_t)(v / VPR) * l + f((v % VPR) * VS);
+        }
+    }
     template <int SET = 0>
     __device__ __forceinline__ void load(int) {
 #pragma unroll

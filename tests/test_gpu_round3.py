@@ -397,6 +397,13 @@ def test_rank_s_backward_projection_matches_the_dense_one(dtype, gtol):
             eng.close()
         assert outs[0][0] == outs[1][0]
         assert rel(outs[1][1], outs[0][1]) < (1e-11 if dtype == 'f64' else 1e-4)
+        if dtype == 'f32':                                         # ... and with Zbar written by the Phibar product itself (J % 4 == 0 only)
+            eng = HipEngine(D, S, M, dtype); eng.set_option('gram64', 0); eng.set_option('lowrank_bwd', 1)
+            eng.set_option('apply_dma', 2); eng.set_option('zbar_fused', 1)
+            eng.set_params(params); eng.set_data(X, y)
+            c, g, _, _ = eng.eval()
+            assert rel(g, outs[1][1]) < 1e-4, (D, rel(g, outs[1][1]))
+            eng.close()
         assert np.allclose(outs[1][2], outs[0][2], rtol=1e-10 if dtype == 'f64' else 1e-5, atol=0)
 
 
@@ -631,4 +638,10 @@ def test_lds_dma_apply_tiles_on_random_widths(dma):
         cost, grad, alpha, Li = eng.eval(want_grad=True)
         assert abs(float(cost) - c0) < 2e-5 * max(1.0, abs(c0)), (N, D, S, M, float(cost), c0)
         assert rel(grad, g0) < 3e-3, (N, D, S, M, rel(grad, g0))
+        # option zbar_fused: the Phibar product writes Zbar (cosine and sine columns of a j gathered into one tile; applies when
+        # J % 4 == 0, otherwise the call is the unfused path again): same gradient, phases included
+        eng.set_option('zbar_fused', 1)
+        cost2, grad2, _, _ = eng.eval(want_grad=True)
+        assert float(cost2) == float(cost) and rel(grad2, grad) < 1e-5, (N, D, S, M, rel(grad2, grad))
+        assert rel(grad2, g0) < 3e-3
         eng.close()
