@@ -1,6 +1,10 @@
 // Row-sweep kernels of the SCFGP objective: everything whose cost scales with N.
 // Built on tile_engine.h; templated on the compute type T (double | float).
 #include "kernels.h"
+#ifndef SCFGP_GRAM_PERM
+#define SCFGP_GRAM_PERM 0                 // 1: Gram tiles with permuted tile rows (tile_engine.h: TileCfg PERM): 8 ds_read_b128 per 64 MFMAs
+                                          // instead of 32 ds_read_b32 -- measured equal (36.7 / 37.6 against 37.0 / 37.4 ms): the reads are not the bound
+#endif
 #ifndef SCFGP_DIAG_EPI0
 #define SCFGP_DIAG_EPI0 0                 // timing diagnostics of the apply epilogue (wrong numbers): see apply_epilogue
 #endif
@@ -80,20 +84,20 @@ template <> struct Tune<double> {
     static constexpr int apply_wgn(int) { return 4; }
 };
 template <typename T, int TILE> struct GramCfg {
-    typedef TileCfg<T, TILE, TILE, Tune<T>::GRAM_BK, Tune<T>::GRAM_WGM, Tune<T>::GRAM_WGN, Tune<T>::MS> type;
+    typedef TileCfg<T, TILE, TILE, Tune<T>::GRAM_BK, Tune<T>::GRAM_WGM, Tune<T>::GRAM_WGN, Tune<T>::MS, false, SCFGP_GRAM_PERM != 0> type;
 };
 // the 64-high strip below the square tiles: same workgroup size (one launch), 32 x 32 wave tiles
 template <typename T> struct GramStripCfg {
-    typedef TileCfg<T, 64, 128, Tune<T>::GRAM_BK, Tune<T>::GRAM_WGM / 2, Tune<T>::GRAM_WGN * 2, Tune<T>::MS> type;
+    typedef TileCfg<T, 64, 128, Tune<T>::GRAM_BK, Tune<T>::GRAM_WGM / 2, Tune<T>::GRAM_WGN * 2, Tune<T>::MS, false, SCFGP_GRAM_PERM != 0> type;
 };
 // fp32 only: the tall Gram tile (64 x 64 wave tiles); fp64 would need 16 waves for the same tile
 template <typename T> struct GramBigCfg {
-    typedef TileCfg<T, 256, 128, SCFGP_BK, Tune<T>::GRAM_WGM, Tune<T>::GRAM_WGN, Tune<T>::MS> type;
+    typedef TileCfg<T, 256, 128, SCFGP_BK, Tune<T>::GRAM_WGM, Tune<T>::GRAM_WGN, Tune<T>::MS, false, SCFGP_GRAM_PERM != 0> type;
 };
 // fp32 only: four strip tiles side by side as one 64 x 512 tile (eight 64 x 64 wave tiles: the MFMA-per-barrier ratio of
 // the tall tile; the 64 x 128 strip tiles ran at half its rate and were 6 % of the launch)
 template <typename T> struct GramWideCfg {
-    typedef TileCfg<T, 64, 512, SCFGP_BK, 1, 8, Tune<T>::MS> type;
+    typedef TileCfg<T, 64, 512, SCFGP_BK, 1, 8, Tune<T>::MS, false, SCFGP_GRAM_PERM != 0> type;
 };
 template <typename T, int TILE> struct ApplyCfg {
     typedef TileCfg<T, Tune<T>::APPLY_BM, TILE, SCFGP_BK, Tune<T>::APPLY_WGM, Tune<T>::apply_wgn(TILE), Tune<T>::MS,
@@ -368,16 +372,19 @@ __device__ __forceinline__ void slab_flush(const typename Cfg::MTr::acc_t (&acc)
 // One launch covers everything; the job order is described at the decode in gram_kernel.
 // ZSRC (experiment): Phi points to the phase matrix Z (leading dimension ld = Jp) and the loaders form s cos / s sin
 //   S: element type of the operand in memory (T, or float under T = double: the resident fp32 V multiplied in fp64)
-template <class Cfg, bool WEIGHT, bool STRIP, bool ZSRC = false, typename S = typename Cfg::T>
-__device__ __forceinline__ void gram_body(
+// DIAG is a compile-time property of the instantiation (the side sums cost a dozen registers that only the diagonal jobs need:
+// with them in every job the 64 x 64 wave tiles spilled inside the k-loop); gram_body dispatches on the job's flag
+template <class Cfg, bool WEIGHT, bool STRIP, bool ZSRC, typename S, bool DIAG>
+__device__ __forceinline__ void gram_body_impl(
     const S* __restrict__ Phi, int64_t ld, const double* __restrict__ w, const double* __restrict__ side,
-    int64_t r0, int64_t r1, int64_t chunk, int acol, int bcol, bool diag, double* __restrict__ sideout,
-    double* __restrict__ slab, double* __restrict__ slab_hi, char* smem_raw, int zJ = 0, typename Cfg::T zs = 0) {
+    int64_t r0, int64_t r1, int64_t chunk, int acol, int bcol, double* __restrict__ sideout,
+    double* __restrict__ slab, double* __restrict__ slab_hi, char* smem_raw, int zJ, typename Cfg::T zs) {
+    constexpr bool diag = DIAG;
     typedef typename Cfg::T T;
     T* smem = reinterpret_cast<T*>(smem_raw);
     typename Cfg::MTr::acc_t acc[Cfg::TM][Cfg::TN];
     // consecutive chunks are consecutive k-tiles, so one pair of loaders walks the whole row range
-    NatLoader<S, T, Cfg::BM, Cfg::BK, Cfg::LDA, Cfg::THREADS, WEIGHT, false, true, ZSRC> la(
+    NatLoader<S, T, Cfg::BM, Cfg::BK, Cfg::LDA, Cfg::THREADS, WEIGHT, false, DIAG, ZSRC> la(
         Phi + r0 * ld + (ZSRC ? 0 : acol), ld, threadIdx.x, WEIGHT ? w + r0 : nullptr, 0, diag ? side + r0 : nullptr);
     NatLoader<S, T, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS, false, false, false, ZSRC> lb(Phi + r0 * ld + (ZSRC ? 0 : bcol), ld, threadIdx.x);
     if (ZSRC) { la.z_source(Phi + r0 * ld, ld, zJ, acol, zs); lb.z_source(Phi + r0 * ld, ld, zJ, bcol, zs); }
@@ -387,14 +394,22 @@ __device__ __forceinline__ void gram_body(
         acc_zero<Cfg>(acc);
         if (c0 < r1) tile_mainloop<Cfg>(la, lb, (int)((c1 - c0) / Cfg::BK), acc, smem);
         slab_flush<Cfg>(acc, slab, first, slab_hi);
-        if (diag) la.side_flush();
+        if constexpr (DIAG) la.side_flush();
         first = false;
     }
     if constexpr (STRIP) {                                     // lower half of the 128 x 128 slab(s): rows the strip does not have
         constexpr int NB = Cfg::BN / 128, REST = (128 - Cfg::BM) * 128;
         for (int e = threadIdx.x; e < NB * REST; e += Cfg::THREADS) slab[(e / REST) * (128 * 128) + Cfg::BM * 128 + e % REST] = 0.0;
     }
-    if (diag) la.side_reduce(reinterpret_cast<double*>(smem_raw), sideout);
+    if constexpr (DIAG) la.side_reduce(reinterpret_cast<double*>(smem_raw), sideout);
+}
+template <class Cfg, bool WEIGHT, bool STRIP, bool ZSRC = false, typename S = typename Cfg::T>
+__device__ __forceinline__ void gram_body(
+    const S* __restrict__ Phi, int64_t ld, const double* __restrict__ w, const double* __restrict__ side,
+    int64_t r0, int64_t r1, int64_t chunk, int acol, int bcol, bool diag, double* __restrict__ sideout,
+    double* __restrict__ slab, double* __restrict__ slab_hi, char* smem_raw, int zJ = 0, typename Cfg::T zs = 0) {
+    if (diag) gram_body_impl<Cfg, WEIGHT, STRIP, ZSRC, S, true>(Phi, ld, w, side, r0, r1, chunk, acol, bcol, sideout, slab, slab_hi, smem_raw, zJ, zs);
+    else gram_body_impl<Cfg, WEIGHT, STRIP, ZSRC, S, false>(Phi, ld, w, side, r0, r1, chunk, acol, bcol, sideout, slab, slab_hi, smem_raw, zJ, zs);
 }
 
 // Job list of one row split (all kernels of the launch have 8 waves):

@@ -23,7 +23,7 @@ struct Bf3Cfg {
     typedef float T;
     typedef MT<float, 32> MTr;                                  // accumulator tile and C/D map of the 32x32 shapes
     static constexpr int BM = BM_, BN = BN_, BK = 32, WGM = WGM_, WGN = WGN_, MS = 32;
-    static constexpr bool SWZA = false;
+    static constexpr bool SWZA = false, PERM = false;
     static constexpr int THREADS = 64 * WGM * WGN;
     static constexpr int WM = BM / WGM, WN = BN / WGN;
     static constexpr int TM = WM / MS, TN = WN / MS;

@@ -20,6 +20,9 @@
 #ifndef SCFGP_DRY_LOOP
 #define SCFGP_DRY_LOOP 0
 #endif
+#ifndef SCFGP_PERM_AHEAD
+#define SCFGP_PERM_AHEAD 0               // PERM tiles: fragment reads this many k-steps ahead of their MFMAs (0 or 1)
+#endif
 
 // MFMA traits: element type T and instruction shape MS (16: 16x16x4, 32: 32x32x2, f32 only).
 //   lane l supplies A[i = l % MS][k = l / MS] and B[k = l / MS][j = l % MS]
@@ -52,12 +55,17 @@ template <> struct MT<float, 32> {
 };
 
 // SWZA: the A image is written by a TrLoader<..., SWZ = true> (column index XOR-swizzled, see there)
-template <typename T_, int BM_, int BN_, int BK_, int WGM_, int WGN_, int MS_ = 16, bool SWZA_ = false>
+// PERM (k-major images from NatLoaders, 16x16x4 shapes): MFMA tile tm, tile row rho of a wave IS output row TM rho + tm of the
+//   wave tile (columns likewise with TN), so a lane's TM fragment elements of one k row are TM CONSECUTIVE elements of the image:
+//   one 8- or 16-byte LDS read per k row and operand instead of TM (TN) 4-byte ones -- 8 ds_read_b128 per 64 MFMAs of a
+//   64 x 64 fp32 wave tile instead of 32 ds_read_b32 -- and a lane ends up with TN ADJACENT output columns (AccCoord).
+template <typename T_, int BM_, int BN_, int BK_, int WGM_, int WGN_, int MS_ = 16, bool SWZA_ = false, bool PERM_ = false>
 struct TileCfg {
     typedef T_ T;
     typedef MT<T_, MS_> MTr;
     static constexpr int BM = BM_, BN = BN_, BK = BK_, WGM = WGM_, WGN = WGN_, MS = MS_;
-    static constexpr bool SWZA = SWZA_;
+    static constexpr bool SWZA = SWZA_, PERM = PERM_;
+    static_assert(!PERM_ || (MS_ == 16 && !SWZA_), "permuted tile rows: 16x16x4 shapes, unswizzled images");
     static_assert(!SWZA_ || (BK_ == 16 && MS_ == 16), "swizzle is laid out for BK = 16 and the 16x16x4 shapes");
     static constexpr int THREADS = 64 * WGM * WGN;
     static constexpr int WM = BM / WGM, WN = BN / WGN;
@@ -387,6 +395,33 @@ __device__ __forceinline__ void tile_compute(const typename Cfg::T* sA, const ty
     constexpr int MS = Cfg::MS, KS = M::KS;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm0 = (wave / Cfg::WGN) * Cfg::WM, wn0 = (wave % Cfg::WGN) * Cfg::WN;
+    if constexpr (Cfg::PERM) {
+        typedef T va_t __attribute__((ext_vector_type(Cfg::TM)));
+        typedef T vb_t __attribute__((ext_vector_type(Cfg::TN)));
+        const T* a_p = sA + (lane / MS) * Cfg::LDA + wm0 + Cfg::TM * (lane % MS);
+        const T* b_p = sB + (lane / MS) * Cfg::LDB + wn0 + Cfg::TN * (lane % MS);
+#pragma unroll
+        for (int kk = 0; kk < Cfg::BK / KS; ++kk) {
+            const va_t a = *reinterpret_cast<const va_t*>(a_p + kk * KS * Cfg::LDA);
+            const vb_t b = *reinterpret_cast<const vb_t*>(b_p + kk * KS * Cfg::LDB);
+#pragma unroll
+            for (int tm = 0; tm < Cfg::TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < Cfg::TN; ++tn) M::mfma(acc[tm][tn], a[tm], b[tn]);
+        }
+        // fragment reads one k-step ahead of their MFMAs and no further: hoisted to the top of the k-tile, the BK / 4 pairs of
+        // 16-byte fragments and the loaders' staging registers pushed the 64 x 64 wave tile over its 128 registers (spills in the loop)
+        constexpr int NS = Cfg::BK / KS, NM = Cfg::TM * Cfg::TN;
+#if SCFGP_PERM_AHEAD
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#endif
+#pragma unroll
+        for (int kk = 0; kk < NS; ++kk) {
+            if (SCFGP_PERM_AHEAD == 0 || kk + 1 < NS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+        }
+        return;
+    }
     const T* a_s = sA + (lane / MS) * Cfg::LDA + wm0 + (lane % MS);
     const T* b_s = sB + (lane / MS) * Cfg::LDB + wn0 + (lane % MS);
     // SWZA: lane (q = lane/16, i = lane%16) reads row k = 4 kk + q of k-step kk at column (..+i) ^ SZ*(k/VS):
@@ -535,8 +570,12 @@ struct AccCoord {
         const int wave = threadIdx.x >> 6;
         wm0 = (wave / Cfg::WGN) * Cfg::WM; wn0 = (wave % Cfg::WGN) * Cfg::WN;
     }
-    __device__ __forceinline__ int row(int tm, int r) const { return wm0 + tm * Cfg::MS + Cfg::MTr::crow(lane, r); }
-    __device__ __forceinline__ int col(int tn) const { return wn0 + tn * Cfg::MS + (lane % Cfg::MS); }
+    __device__ __forceinline__ int row(int tm, int r) const {
+        return Cfg::PERM ? wm0 + Cfg::TM * Cfg::MTr::crow(lane, r) + tm : wm0 + tm * Cfg::MS + Cfg::MTr::crow(lane, r);
+    }
+    __device__ __forceinline__ int col(int tn) const {
+        return Cfg::PERM ? wn0 + Cfg::TN * (lane % Cfg::MS) + tn : wn0 + tn * Cfg::MS + (lane % Cfg::MS);
+    }
 };
 
 // XCD-aware work-item id (guide T1): hardware deals consecutive workgroup ids round-robin over
