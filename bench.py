@@ -37,7 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 SEED = 0x5CF600FF
-PEAK_TFLOPS = {'f32': 157.3, 'f64': 78.6, 'bf16x3': 157.3}     # dense MFMA peaks, MI355X_MICROARCH.md / datasheet (bf16x3: priced as fp32)
+PEAK_TFLOPS = {'f32': 157.3, 'f64': 78.6}     # dense MFMA peaks, MI355X_MICROARCH.md / datasheet
 HBM_PEAK_GBS = 8000.0
 
 # BASELINE.json `configs` (C1..C5) and the headline metric (H): N, D, S (rank), M, compute dtype
@@ -227,9 +227,7 @@ def through_triple(X, y, params, D, S, M, local, n=3):
 
 def f64_leg_and_parity(X, y, params, D, S, M, local, f32_out, f32_eng, steps=5, warmup=2):
     """The reference's arithmetic is float64: run the fp64 engine on the SAME resident rows, time it, and report how far
-    the fp32-mode outputs are from it at this size (relative, norm-wise; gradient per block).  Then the experimental
-    split-precision mode (dtype "bf16x3", include/scfgp_hip.h) on the same rows: its own rate and its own parity block --
-    a separately labelled figure, never the fp32 or fp64 line."""
+    the fp32-mode outputs are from it at this size (relative, norm-wise; gradient per block)."""
     from scfgp_amd.engine import HipEngine
     N = X.shape[0]; J = S + M; K = 2 * J
     e64 = HipEngine(D, S, M, dtype='f64', device=local)
@@ -239,22 +237,12 @@ def f64_leg_and_parity(X, y, params, D, S, M, local, f32_out, f32_eng, steps=5, 
     ach = 2.0 * N * K * K / (ap_ms * 1e-3) / 1e12 if ap_ms > 0 else 0.0
     sec = {"evals_per_s": 1e3 / ms, "ms_per_step": ms, "steps": steps, "statistic": "median",
            "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS['f64'], "unit": "TFLOP/s",
-                        "frac": ach / PEAK_TFLOPS['f64'], "kernel": "apply_kernel (fp64 MFMA 16x16x4)", "avg_launch_ms": ap_ms},
+                        "frac": ach / PEAK_TFLOPS['f64'], "kernel": "apply_dma_kernel<double> + 64-wide apply_kernel remainder (fp64 MFMA 16x16x4)",
+                        "avg_launch_ms": ap_ms},
            "stages_ms": stages, "cost": float(ref[0])}
     base = "mode of this library on the same %d rows (fp64 mode equals the oracle to 1e-12 wherever the oracle is run: " \
            "tests/test_gpu_parity.py); relative, norm-wise" % N
     parity = _parity(f32_out, ref, f32_eng, e64, D, S, M, "fp32 mode (precision level %d) vs fp64 " % int(f32_eng.condition()['level']) + base)
-    eb = HipEngine(D, S, M, dtype='bf16x3', device=local)
-    eb.set_params(params); eb.set_data(X, y, n_global=N)
-    msb, stb, outb = _timed_leg(eb, steps, warmup)
-    apb = float(np.median([stb.get('apply_v', 0), stb.get('apply_phibar', 0)]))
-    bf3 = {"dtype": "bf16x3", "evals_per_s": 1e3 / msb, "ms_per_step": msb, "steps": steps, "statistic": "median",
-           "what": "EXPERIMENTAL: fp32 mode with the two N x K x K apply products on split-precision MFMA (each fp32 operand = three "
-                   "bf16 pieces, six bf16 MFMAs per product, fp32 accumulate); everything else as fp32 mode",
-           "apply_product_ms": apb, "apply_fp32_equivalent_TFLOPs": 2.0 * N * K * K / (apb * 1e-3) / 1e12 if apb > 0 else 0.0,
-           "stages_ms": stb, "cost": float(outb[0]),
-           "parity_at_size": _parity(outb, ref, eb, e64, D, S, M, "bf16x3 mode vs fp64 " + base)}
-    eb.close()
     plain = None
     if f32_eng.condition()['level'] > 0:
         # the headline engine escalated its Gram products (ill-conditioned A): the same rows in PLAIN fp32 mode (option gram64 = 0),
@@ -270,7 +258,7 @@ def f64_leg_and_parity(X, y, params, D, S, M, local, f32_out, f32_eng, steps=5, 
                  "parity_at_size": _parity(outp, ref, ep, e64, D, S, M, "plain fp32 (gram64 = 0) vs fp64 " + base)}
         ep.close()
     e64.close()
-    return sec, parity, bf3, plain
+    return sec, parity, plain
 
 
 def main(a):
@@ -373,7 +361,7 @@ def main(a):
             "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "apply product (Phi.B / Phi.Abar): one N x K x K product = 2*N*K^2 flops, issued as one launch for the "
-                                   "full column tiles (fp32 at this size: apply_dma_kernel, 256x256 tiles for both products; "
+                                   "full column tiles (at this size: apply_dma_kernel, fp32 256x256 tiles / fp64 256x128 tiles, for both products; "
                                    "otherwise apply_kernel, 256x128 tiles) plus a 256x64-tile apply_kernel launch for the ragged remainder; "
                                    "avg_launch_ms is the median hipEvent time of that pair (rocprof: sum of the two kernels)",
                          "avg_launch_ms": ap_ms},
@@ -426,7 +414,7 @@ def main(a):
         # the fp64 leg and the fp32-vs-fp64 parity block: at the headline shape and at the two other 1e6-row fp32 configs (C3's
         # D = 8 makes A ill-conditioned: that is where fp32 products cost the most accuracy, and the line says so)
         if world == 1 and a.config in ('H', 'C3', 'C5') and a.dtype == 'f32' and not a.custom and not a.no_secondary:
-            out["secondary"]["f64"], out["parity_at_size"], out["secondary"]["bf16x3"], plain = f64_leg_and_parity(
+            out["secondary"]["f64"], out["parity_at_size"], plain = f64_leg_and_parity(
                 X, y, params, D, S, M, local, (cost, grad, alpha, Li), eng)
             if plain is not None:
                 out["secondary"]["plain_fp32"] = plain

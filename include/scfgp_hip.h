@@ -49,11 +49,6 @@ typedef struct scfgp_ctx scfgp_ctx;
 #define SCFGP_F64 0             /* fp64 MFMA everywhere (reference numerics)             */
 #define SCFGP_F32 1             /* N-sized products in exact-fp32 MFMA, fp64 projection,
                                    fp64 cross-chunk accumulation and fp64 K x K stage    */
-#define SCFGP_BF16X3 2          /* EXPERIMENTAL: as SCFGP_F32 (fp32 storage, everything else unchanged) but the N x K x K
-                                   products split every fp32 operand exactly into three bf16 pieces while staging it and
-                                   run six bf16 MFMAs per product term (fp32 accumulate): fp32-grade results at 2.67x the
-                                   MFMA rate.  Neither the reference's nor BASELINE.json's arithmetic: reported only as
-                                   its own dtype "bf16x3", never in place of the f32 / f64 figures                     */
 
 /* ---- life cycle --------------------------------------------------------------------
  * Replaces SCFGP.build_theano_models (SCFGP/SCFGP.py:92-148): "compile" becomes "create a
@@ -130,6 +125,8 @@ int scfgp_predict_y(scfgp_ctx* ctx, const double* Xs_raw, int64_t T, const doubl
  *   scfgp_pass1   -> exchange 1 = [G, packed lower 128x128 tiles | Phi^T y (Kp) | y^T y ...]
  *   scfgp_factor     (replicated: Cholesky, Li, alpha, log det)
  *   scfgp_pass2   -> exchange 2 = [B W B = V^T diag(q) V, packed lower tiles | B Phi^T p = V^T p (Kp) | T2, kbar ...]
+ *                    (at precision level 2 of fp32 mode, scfgp_get_condition: [C^T diag(q) C | C^T p | ...], C = Phi Li^T --
+ *                    still row sums, so the sum over ranks is the same operation)
  *   scfgp_adjoint    (replicated: Abar)                      [want_grad only]
  *   scfgp_pass3   -> exchange 3 = [X~^T Zbar | bbar ...]     [want_grad only]
  *   scfgp_finish  -> outputs on the host
@@ -178,13 +175,17 @@ int scfgp_train(scfgp_ctx* ctx, int n_iters, double* cost_hist, double* alpha, d
 
 /* ---- conditioning and precision level (no reference counterpart) -----------------------------------
  * The reference computes in float64 throughout (SCFGP/SCFGP.py:95-96) and factors A = Phi^T Phi + (e^{2a}+1e-6) I
- * (SCFGP/SCFGP.py:104-107) whatever its conditioning.  In SCFGP_F32 / SCFGP_BF16X3 mode the Gram products carry a
+ * (SCFGP/SCFGP.py:104-107) whatever its conditioning.  In SCFGP_F32 mode the Gram products carry a
  * relative error of ~6e-8, which reaches alpha and Li multiplied by the condition of A (measured: about 3e-7 times the
  * estimate below).  The K x K stage therefore reports a condition estimate with every evaluation, and by default (option
  * "gram64" = 2, auto) the library raises the precision of the two Gram products when it is high:
  *   level 1 (estimate > 10):   pass 1 -- G and Phi^T y by the fp64 kernels from fp64 features; alpha and Li then equal fp64
  *                               mode's bit for bit, cost / mu* / sigma* to ~1e-8
- *   level 2 (estimate > 1000): also pass 2 -- V^T diag(q) V and V^T p in fp64 MFMA (gradient blocks to ~1e-4)
+ *   level 2 (estimate > 1000): also pass 2 in the reference's own factor form (SCFGP/SCFGP.py:112): C = Phi Li^T,
+ *                               v = rowsum(C^2), V = C Li, all in fp32 MFMA; EXCHANGE BUFFER 2 THEN CARRIES C^T diag(q) C AND
+ *                               C^T p (not B W B and u): the K x K stage forms B W B = Li^T (C^T diag(q) C) Li and
+ *                               u = Li^T (C^T p) after the sum over ranks.  Rounding errors are amplified by sqrt(cond A)
+ *                               instead of cond A (gradient blocks to ~1e-4)
  * "gram64" = 0 never (plain fp32: the caller reads out[3] to know what alpha is worth), 1 / 3 = always level 1 / 2.
  * out (n >= 4, up to 9 values): [0] condition estimate max_i L_ii^2 * max_j (A^-1)_jj of the last finished evaluation (a lower
  * bound of cond_2(A)), [1] level it ran at, [2] 1 if G was formed in fp64 from fp64 features, [3] predicted relative error
@@ -202,23 +203,26 @@ int scfgp_get_timings(scfgp_ctx* ctx, double* ms, const char** names, int n);
 /* copy an internal device buffer to the host for tests ("Phi","V","G","W","XZ","Li","B","Abar",
  * "p","q","vecs","Fall","Xt","scalars"); returns the number of bytes copied or <0 */
 int64_t scfgp_debug_read(scfgp_ctx* ctx, const char* name, void* host, int64_t max_bytes);
-/* tuning knobs: "gram_nsplit" (row-split units of the Gram products, 0 = default), "gram_taper" (1: the last unit of every
- * XCD group is cut into 1/2, 1/4, 1/8, 1/8; t >= 2: into t + 3 pieces down to 1/2^(t+2)), "gram_chunk" (fp32 flush interval in rows), "xtz_nsplit", "use_graph", "fuse_fmap" (experiment, profiles/r02_tuning.md: the
- * Gram of pass 1 reads the phases and evaluates cos / sin inside its operand loaders instead of reading Phi), "apply_dma" (fp32 mode: the full tiles of the apply products staged by LDS-DMA instead of through
- * registers; -1 = automatic: 256-wide tiles from K >= 1024 and 65536 rows up, else off; 0 off, 1 = 128 wide, 2 = 256 wide, 3 = 256 wide
- * for Phi.B and 128 wide for Phibar), "bf3_dma"
- * (experiment, SCFGP_BF16X3 only: 256-wide apply tiles fed by LDS-DMA from pre-split planes of Phi, 6 bytes per element more),
- * "gram64" (precision level policy, see scfgp_get_condition), "cond_threshold" / "cond_threshold_w" (its two thresholds),
- * "roctx" (1: push a roctx range per stage for `rocprofv3 --marker-trace`; off by default, also SCFGP_ROCTX=1),
- * "factor_form" (-1 auto = precision level 2, 0 never, 1 always: pass 2 as C = Phi Li^T, V = C Li),
- * "gram_plan" (experiment: 1 = lock-step schedule of the fp32 Gram products from a job table; measured equal, profiles/r03_tuning.md),
- * "pass3_parts" (experiment: pass 3 in row parts with X~^T Zbar on a second stream; measured slower),
- * "apply_dma" = 4 (experiment: 256-wide LDS-DMA tiles on 8 waves of 128 x 64; measured slower), = 5 (experiment: the default
- * tiles with the fragment reads software-pipelined by half stages in inline assembly; measured slower),
- * "zbar_fused" (experiment: 1 = the Phibar product's epilogue writes Zbar instead of Phibar -- pass 3 without the Phibar round
- * trip -- where the fp32 LDS-DMA tiles run and J % 4 == 0; measured slower, off by default),
- * "lowrank_bwd" (-1 auto: when D+1 >= 4 (S+1) padded, 0 never, 1 whenever it can -- the forward projection goes through the S columns (S+1 < D+1, padded to 16) and U fits: the reverse sweep of F = l_F r_F^T through
- * T~^T Zbar and X~^T (Zbar_L + Zbar_M r_F) instead of the dense X~^T Zbar; exchange buffer 3 then holds those two) */
+/* options (name, value):
+ *   "gram_nsplit"  row-split units of the Gram products (0 = default)
+ *   "gram_taper"   1: the last unit of every XCD group is cut into 1/2, 1/4, 1/8, 1/8; t >= 2: into t + 3 pieces down to 1/2^(t+2)
+ *   "gram_chunk"   fp32 mode: rows between two flushes of the fp32 accumulators into the fp64 slabs (default 4096)
+ *   "xtz_nsplit"   row splits of X~^T Zbar (0 = default)
+ *   "use_graph"    0: scfgp_train launches every iteration eagerly instead of replaying a captured hipGraph
+ *   "apply_dma"    the full 128-column tiles of the apply products staged by LDS-DMA (global_load_lds) instead of through
+ *                  registers: -1 automatic (K >= 1024 and >= 65536 rows: fp32 256-wide tiles, fp64 128-wide), 0 off,
+ *                  1 = 128-wide tiles, 2 = 256-wide tiles (fp32; fp64 stays 128 wide)
+ *   "gram64"       precision level policy of fp32 mode (scfgp_get_condition): 0 never, 1 always level 1, 2 auto, 3 always level 2
+ *   "cond_threshold" / "cond_threshold_w"   the two thresholds of the auto policy
+ *   "factor_form"  -1 auto (= precision level 2), 0 never, 1 always: pass 2 as C = Phi Li^T, V = C Li
+ *   "lowrank_bwd"  -1 auto (D+1 >= 4 (S+1), padded), 0 never, 1 whenever it can (the forward projection goes through the S
+ *                  columns and U fits): the reverse sweep of F = l_F r_F^T through T~^T Zbar and X~^T (Zbar_L + Zbar_M r_F)
+ *                  instead of the dense X~^T Zbar; exchange buffer 3 then holds those two
+ *   "roctx"        1: push a roctx range per stage for `rocprofv3 --marker-trace` (off by default; also SCFGP_ROCTX=1)
+ * Experiments of earlier rounds that measured equal or slower (feature map fused into the Gram loaders, lock-step Gram
+ * schedule, pass 3 in row parts on two streams, Zbar written by the Phibar product, 8-wave and hand-pipelined LDS-DMA
+ * tiles, the bf16x3 split-precision dtype) are no longer part of the library: profiles/r02_tuning.md, r03_tuning.md hold
+ * their measurements, git history (tag of round 3: commit 757ac97) their code. */
 int scfgp_set_option(scfgp_ctx* ctx, const char* name, int64_t value);
 
 /* Box probe (no reference counterpart; bench.py's `secondary.box`): ~100 ms of device work on `device`, no context needed.
@@ -231,11 +235,6 @@ int scfgp_box_probe(int device, double* out, int n);
  * sums the reduction adds; `nsplit` 0 = default, `taper` as the option): returns 0 when the splits tile [0, Np) in
  * order on 256-row blocks.  Needs no GPU. */
 int scfgp_selftest_row_splits(int D, int S, int M, int64_t N, int dtype, int nsplit, int taper);
-
-/* host-only self-test of the lock-step schedule of the fp32 Gram products (option "gram_plan" = 1): 0 when, for every output
- * tile, the jobs that write it use its partial slots once each and their row ranges tile [0, Np); 1 when the problem is too
- * small for that schedule.  Needs no GPU. */
-int scfgp_selftest_gram_plan(int D, int S, int M, int64_t N);
 
 #ifdef __cplusplus
 }

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SCFGP_LIB_VARIANT selects an alternative build (tuning experiments only, e.g. '_bk32')
 LIB_PATH = os.path.join(_HERE, 'lib', 'libscfgp_hip%s.so' % os.environ.get('SCFGP_LIB_VARIANT', ''))
 
-SCFGP_F64, SCFGP_F32, SCFGP_BF16X3 = 0, 1, 2
+SCFGP_F64, SCFGP_F32 = 0, 1
 SCFGP_REDO = 1                           # scfgp_finish: run the stages again (precision level raised), not an error
 ERRORS = {-1: 'bad argument', -2: 'HIP error', -3: 'not positive definite', -4: 'non-finite cost'}
 
@@ -54,7 +54,6 @@ SIGNATURES = {
     'scfgp_get_timings': (C.c_int, [C.c_void_p, _c_double_p, C.POINTER(C.c_char_p), C.c_int]),
     'scfgp_debug_read': (C.c_int64, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]),
     'scfgp_box_probe': (C.c_int, [C.c_int, _c_double_p, C.c_int]),
-    'scfgp_selftest_gram_plan': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int64]),
     'scfgp_selftest_row_splits': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int]),
     'scfgp_set_option': (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
 }

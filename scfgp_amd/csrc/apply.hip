@@ -1,0 +1,823 @@
+// NT products of the SCFGP objective (contraction over the feature columns):  V = Phi B, Phibar = 2 Phi Abar + ...,
+// the triangular products of the factor form and of predict (SCFGP/SCFGP.py:111-113, :143-144 and their backward),
+// the per-row statistics that follow them, and the scalar reductions.  Built on tile_engine.h.
+#include "kernels.h"
+#include "tile_cfgs.h"
+
+#include <algorithm>
+
+// apply tiles: 256 rows x {256, 128, 64} columns (tile_cfgs.h)
+template <typename T, int TILE> struct ApplyCfg {
+    typedef TileCfg<T, Tune<T>::APPLY_BM, TILE, SCFGP_BK, Tune<T>::APPLY_WGM, Tune<T>::apply_wgn(TILE), Tune<T>::MS,
+                    SCFGP_BK == 16 && Tune<T>::MS == 16> type;                 // swizzled Phi image (TrLoader)
+};
+
+// --------------------------------------------------------------------------
+// NT products (contraction over feature columns):  C = Phi . Bm  with Bm symmetric
+//   EPI 0: V = C,  vpart[jt][n] = sum_j Phi[n][j] C[n][j]
+//   EPI 1: Phibar = 2 C + 2 q_n V[n][j] + p_n alpha_j + y_n ut_j   (in place over V)
+//   EPI 2 (predict): Bm = Li^T, so C = Phi Li^T is the reference's own product (SCFGP/SCFGP.py:144) and
+//          vpart[jt][n] = sum_j C[n][j]^2; nothing is stored, and since Li^T[k][j] = 0 for k > j the contraction of column
+//          tile jt stops at its last column: half the flops of the symmetric product
+//   EPI 3 (factor form of pass 2, SCFGP/SCFGP.py:112): as EPI 2 but C is stored (in V's place) and mu rides along
+//   EPI 4 (factor form): V = C . Li, Bm = Li lower triangular (Bm[k][j] = 0 for k < j): the contraction of column tile jt
+//          STARTS at its first column; plain store, no row sums
+// --------------------------------------------------------------------------
+// epilogues of the apply product: V and the row dots (EPI 0) or Phibar and bbar (EPI 1) from the accumulators
+//   MU (EPI 0 only): also mupart[jtg][n] = sum_{j in tile} Phi[n][j] alpha[j] from the Phi values the row dot reads anyway
+//   (the DMA-fed kernel has no operand values in registers for the loader-side dot)
+//   VEC4 (the LDS-DMA kernels, fp32, 64-wide wave tiles of four 16-column MFMA tiles): the B operand's rows were staged in a
+//   permuted order, so that MFMA tile tn, lane column i IS output column 4 i + tn of the wave tile -- a lane then holds four
+//   ADJACENT columns of each of its rows and the epilogue moves V, Phi and Phibar 16 bytes per lane (256 contiguous bytes per
+//   row and 16-lane group) instead of 4 (four 64-byte pieces per instruction)
+// Sum over the 16 lanes of a DPP row (the lanes that hold one output row of a 16 x 16 MFMA tile), result in every lane: two
+// quad permutes, row_half_mirror, row_mirror on the two halves of the double -- VALU moves instead of the eight LDS-crossbar
+// ds_bpermute_b32 a __shfl_xor butterfly costs (256 of them per lane in the 64 x 64 wave tile's epilogue: 0.9 ms of the product)
+template <int CTRL> __device__ __forceinline__ double dpp_mov_f64(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row16_sum(double x) {
+    x += dpp_mov_f64<0xB1>(x);                                  // quad_perm [1,0,3,2]
+    x += dpp_mov_f64<0x4E>(x);                                  // quad_perm [2,3,0,1]
+    x += dpp_mov_f64<0x141>(x);                                 // row_half_mirror
+    x += dpp_mov_f64<0x140>(x);                                 // row_mirror
+    return x;
+}
+// fp64 epilogue of the LDS-DMA tiles (64 x 32 wave tiles of two 16-column MFMA tiles): the B operand's rows were staged in the
+// order that makes MFMA tile tn, lane column i output column 2 i + tn of the wave tile -- a lane holds two ADJACENT columns of
+// each of its rows and moves V, Phi and Phibar 16 bytes at a time.  Same quantities as apply_epilogue below, all in fp64.
+template <class Cfg, int EPI, bool MU>
+__device__ __forceinline__ void apply_epilogue_vec2(
+    const typename Cfg::MTr::acc_t (&acc)[Cfg::TM][Cfg::TN], const double* __restrict__ Phi, double* V,
+    double* __restrict__ vpart, const double* __restrict__ p, const double* __restrict__ q, const double* __restrict__ y,
+    const double* __restrict__ alpha, const double* __restrict__ ut, int K, int Kp, int64_t Np, int64_t rb, int cbase, int jtg,
+    double* __restrict__ bpart, char* smem_raw, double* __restrict__ mupart) {
+    static_assert(Cfg::TN == 2 && Cfg::MS == 16 && sizeof(typename Cfg::T) == 8 && (EPI == 0 || EPI == 1 || EPI == 3 || EPI == 4), "VEC2 layout");
+    AccCoord<Cfg> co;
+    const int jg = cbase + co.wn0 + 2 * (co.lane & 15);         // first of this lane's two adjacent columns
+    if constexpr (EPI == 4) {
+#pragma unroll
+        for (int tm = 0; tm < Cfg::TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                *reinterpret_cast<v2d*>(V + (rb * Cfg::BM + co.row(tm, r)) * Kp + jg) = v2d{acc[tm][0][r], acc[tm][1][r]};
+    } else if constexpr (EPI == 0 || EPI == 3) {
+        double* red = reinterpret_cast<double*>(smem_raw);
+        double* red2 = red + Cfg::WGN * Cfg::BM;
+        const int wn = (threadIdx.x >> 6) % Cfg::WGN;
+        double al[2], live[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) { live[k] = jg + k < K ? 1.0 : 0.0; al[k] = MU && jg + k < K ? alpha[jg + k] : 0.0; }
+#pragma unroll
+        for (int tm = 0; tm < Cfg::TM; ++tm) {
+            v2d ph[4];
+            int64_t off[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {                       // the four re-reads of Phi at once, not one dependent round trip per row
+                off[r] = (rb * Cfg::BM + co.row(tm, r)) * Kp + jg;
+                if (EPI == 0 || MU) ph[r] = *reinterpret_cast<const v2d*>(Phi + off[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = co.row(tm, r);
+                const double c0 = acc[tm][0][r], c1 = acc[tm][1][r];
+                *reinterpret_cast<v2d*>(V + off[r]) = v2d{c0, c1};
+                double part, mup = 0;
+                if (EPI == 3) part = fma(c0, c0, c1 * c1);
+                else part = fma(ph[r][0] * live[0], c0, ph[r][1] * live[1] * c1);
+                if (MU) mup = fma(ph[r][0], al[0], ph[r][1] * al[1]);
+                part = row16_sum(part);
+                if ((co.lane & 15) == 0) red[wn * Cfg::BM + row] = part;
+                if (MU) {
+                    mup = row16_sum(mup);
+                    if ((co.lane & 15) == 0) red2[wn * Cfg::BM + row] = mup;
+                }
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < Cfg::BM) {
+            double s = 0, s2 = 0;
+#pragma unroll
+            for (int k = 0; k < Cfg::WGN; ++k) { s += red[k * Cfg::BM + threadIdx.x]; if (MU) s2 += red2[k * Cfg::BM + threadIdx.x]; }
+            vpart[(int64_t)jtg * Np + rb * Cfg::BM + threadIdx.x] = s;
+            if (MU && mupart) mupart[(int64_t)jtg * Np + rb * Cfg::BM + threadIdx.x] = s2;
+        }
+    } else {                                                    // EPI 1
+        double bb = 0;
+        double al[2], u2[2], live[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) { al[k] = alpha[jg + k]; u2[k] = ut[jg + k]; live[k] = jg + k < K ? 1.0 : 0.0; }
+        double* rowsc = reinterpret_cast<double*>(smem_raw);      // [BM][3]: 2 q, p, y of the tile's rows (LDS is free after the loop)
+        for (int i = threadIdx.x; i < Cfg::BM; i += Cfg::THREADS) {
+            const int64_t n = rb * Cfg::BM + i;
+            rowsc[3 * i] = 2.0 * q[n]; rowsc[3 * i + 1] = p[n]; rowsc[3 * i + 2] = y[n];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tm = 0; tm < Cfg::TM; ++tm) {
+            v2d vv[4], ph[4];
+            int64_t off[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                off[r] = (rb * Cfg::BM + co.row(tm, r)) * Kp + jg;
+                vv[r] = *reinterpret_cast<const v2d*>(V + off[r]);
+                ph[r] = *reinterpret_cast<const v2d*>(Phi + off[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = co.row(tm, r);
+                const double qn = rowsc[3 * row], pn = rowsc[3 * row + 1], yn = rowsc[3 * row + 2];
+                v2d o;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    o[k] = 2.0 * acc[tm][k][r] + qn * vv[r][k] + pn * al[k] + yn * u2[k];
+                    bb = fma(o[k], ph[r][k] * live[k], bb);
+                }
+                *reinterpret_cast<v2d*>(V + off[r]) = o;
+            }
+        }
+        double* red = rowsc + 3 * Cfg::BM;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) bb += __shfl_xor(bb, m);
+        if (co.lane == 0) red[threadIdx.x >> 6] = bb;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double s = 0;
+            for (int k = 0; k < Cfg::THREADS / 64; ++k) s += red[k];
+            bpart[blockIdx.x] = s;
+        }
+    }
+}
+template <class Cfg, int EPI, bool MU = false, bool VEC4 = false>
+__device__ __forceinline__ void apply_epilogue(
+    const typename Cfg::MTr::acc_t (&acc)[Cfg::TM][Cfg::TN], const typename Cfg::T* __restrict__ Phi, typename Cfg::T* V,
+    double* __restrict__ vpart, const double* __restrict__ p, const double* __restrict__ q, const double* __restrict__ y,
+    const double* __restrict__ alpha, const double* __restrict__ ut, int K, int Kp, int64_t Np, int64_t rb, int cbase, int jtg,
+    double* __restrict__ bpart, char* smem_raw, double* __restrict__ mupart = nullptr) {
+    typedef typename Cfg::T T;
+    if constexpr (VEC4 && sizeof(T) == 8) {                        // the LDS-DMA tiles in fp64
+        apply_epilogue_vec2<Cfg, EPI, MU>(acc, Phi, V, vpart, p, q, y, alpha, ut, K, Kp, Np, rb, cbase, jtg, bpart, smem_raw, mupart);
+        return;
+    }
+    AccCoord<Cfg> co;
+    if constexpr (VEC4 && sizeof(T) == 4) {
+        static_assert(Cfg::TN == 4 && Cfg::MS == 16 && sizeof(T) == 4 && (EPI == 0 || EPI == 1 || EPI == 3 || EPI == 4), "VEC4 layout");
+        const int c4 = co.wn0 + 4 * (co.lane & 15);               // first of this lane's four adjacent columns
+        const int jg = cbase + c4;
+        if constexpr (EPI == 4) {
+#pragma unroll
+            for (int tm = 0; tm < Cfg::TM; ++tm)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    *reinterpret_cast<v4f*>(V + (rb * Cfg::BM + co.row(tm, r)) * Kp + jg) = v4f{acc[tm][0][r], acc[tm][1][r], acc[tm][2][r], acc[tm][3][r]};
+        } else if constexpr (EPI == 0 || EPI == 3) {
+            double* red = reinterpret_cast<double*>(smem_raw);
+            double* red2 = red + Cfg::WGN * Cfg::BM;
+            const int wn = (threadIdx.x >> 6) % Cfg::WGN;
+            double al[4], live[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { live[k] = jg + k < K ? 1.0 : 0.0; al[k] = MU && jg + k < K ? alpha[jg + k] : 0.0; }
+            // the re-read of Phi is issued for the four rows of an accumulator row group at once: written row by row, every row's
+            // load waited for the row before it (16 dependent round trips per tile; profiles/r03_tuning.md)
+#pragma unroll
+            for (int tm = 0; tm < Cfg::TM; ++tm) {
+                v4f ph[4];
+                int64_t off[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    off[r] = (rb * Cfg::BM + co.row(tm, r)) * Kp + jg;
+                    if (EPI == 0 || MU) ph[r] = *reinterpret_cast<const v4f*>(Phi + off[r]);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = co.row(tm, r);
+                    const v4f c = v4f{acc[tm][0][r], acc[tm][1][r], acc[tm][2][r], acc[tm][3][r]};
+                    *reinterpret_cast<v4f*>(V + off[r]) = c;
+                    double part = 0, mup = 0;
+                    if (EPI == 3) {
+                        part = (double)(c[0] * c[0]) + (double)(c[1] * c[1]) + (double)(c[2] * c[2]) + (double)(c[3] * c[3]);
+                        if (MU) mup = (double)ph[r][0] * al[0] + (double)ph[r][1] * al[1] + (double)ph[r][2] * al[2] + (double)ph[r][3] * al[3];
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { part += (double)ph[r][k] * (double)c[k] * live[k]; if (MU) mup += (double)ph[r][k] * al[k]; }
+                    }
+                    part = row16_sum(part);
+                    if ((co.lane & 15) == 0) red[wn * Cfg::BM + row] = part;
+                    if (MU) {
+                        mup = row16_sum(mup);
+                        if ((co.lane & 15) == 0) red2[wn * Cfg::BM + row] = mup;
+                    }
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x < Cfg::BM) {
+                double s = 0, s2 = 0;
+#pragma unroll
+                for (int k = 0; k < Cfg::WGN; ++k) { s += red[k * Cfg::BM + threadIdx.x]; if (MU) s2 += red2[k * Cfg::BM + threadIdx.x]; }
+                vpart[(int64_t)jtg * Np + rb * Cfg::BM + threadIdx.x] = s;
+                if (MU && mupart) mupart[(int64_t)jtg * Np + rb * Cfg::BM + threadIdx.x] = s2;
+            }
+        } else {                                                    // EPI 1
+            double bb = 0;
+            double al[4], u4[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { al[k] = alpha[jg + k]; u4[k] = ut[jg + k]; }
+            float alf[4], u4f[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { alf[k] = (float)al[k]; u4f[k] = (float)u4[k]; }
+            // per-row scalars (2 q, p, y) of the tile's rows through LDS (free after the loop's last barrier), and the re-reads of V
+            // and Phi issued for the four rows of an accumulator row group at once: written row by row, the in-place store of a row
+            // stood between the loads of the next one and its own (16 dependent round trips per tile; profiles/r03_tuning.md)
+            float* rowsc = reinterpret_cast<float*>(smem_raw);        // [BM][3]
+            for (int i = threadIdx.x; i < Cfg::BM; i += Cfg::THREADS) {
+                const int64_t n = rb * Cfg::BM + i;
+                rowsc[3 * i] = (float)(2.0 * q[n]); rowsc[3 * i + 1] = (float)p[n]; rowsc[3 * i + 2] = (float)y[n];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int tm = 0; tm < Cfg::TM; ++tm) {
+                v4f vv[4], ph[4];
+                int64_t off[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    off[r] = (rb * Cfg::BM + co.row(tm, r)) * Kp + jg;
+                    vv[r] = *reinterpret_cast<const v4f*>(V + off[r]);
+                    ph[r] = *reinterpret_cast<const v4f*>(Phi + off[r]);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = co.row(tm, r);
+                    // Phibar is stored in fp32: its four terms are combined in fp32 FMAs (one rounding per term instead of one at
+                    // the end; the accumulator itself carries ~1e-7 of the product), and the b-bar dot takes the four products of a
+                    // lane in fp32 and everything above them in fp64 -- the fp64 conversions and FMAs of the all-fp64 form were
+                    // ~1 ms of the launch (profiles/r03_tuning.md)
+                    const float qn = rowsc[3 * row], pn = rowsc[3 * row + 1], yn = rowsc[3 * row + 2];
+                    v4f o;
+                    float dot = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        o[k] = fmaf(qn, vv[r][k], fmaf(pn, alf[k], fmaf(yn, u4f[k], 2.0f * acc[tm][k][r])));
+                        dot = fmaf(o[k], jg + k < K ? ph[r][k] : 0.f, dot);
+                    }
+                    bb += (double)dot;
+                    *reinterpret_cast<v4f*>(V + off[r]) = o;
+                }
+            }
+            double* red = reinterpret_cast<double*>(rowsc + 4 * Cfg::BM);
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) bb += __shfl_xor(bb, m);
+            if (co.lane == 0) red[threadIdx.x >> 6] = bb;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                double s = 0;
+                for (int k = 0; k < Cfg::THREADS / 64; ++k) s += red[k];
+                bpart[blockIdx.x] = s;
+            }
+        }
+        return;
+    }
+    if (EPI == 4) {
+#pragma unroll
+        for (int tm = 0; tm < Cfg::TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < Cfg::MTr::NACC; ++r) {
+                const int64_t off = (rb * Cfg::BM + co.row(tm, r)) * Kp + cbase;
+#pragma unroll
+                for (int tn = 0; tn < Cfg::TN; ++tn) V[off + co.col(tn)] = acc[tm][tn][r];
+            }
+    } else if (EPI == 0 || EPI == 2 || EPI == 3) {
+        double* red = reinterpret_cast<double*>(smem_raw);          // [WGN][BM] (MU: twice); main loop ended with a barrier
+        double* red2 = red + Cfg::WGN * Cfg::BM;
+        const int wn = (threadIdx.x >> 6) % Cfg::WGN;
+        double al[Cfg::TN];
+        if (MU) {
+#pragma unroll
+            for (int tn = 0; tn < Cfg::TN; ++tn) al[tn] = cbase + co.col(tn) < K ? alpha[cbase + co.col(tn)] : 0.0;
+        }
+#pragma unroll
+        for (int tm = 0; tm < Cfg::TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < Cfg::MTr::NACC; ++r) {
+                const int row = co.row(tm, r);
+                const int64_t off = (rb * Cfg::BM + row) * Kp + cbase;
+                double part = 0, mup = 0;
+#pragma unroll
+                for (int tn = 0; tn < Cfg::TN; ++tn) {
+                    const T c = acc[tm][tn][r];
+                    if (EPI != 2) V[off + co.col(tn)] = c;
+                    if (EPI != 0) {                                   // v_n = || Li phi_n ||^2
+                        part += (double)c * (double)c;
+                        if (MU && cbase + co.col(tn) < K) mup += (double)Phi[off + co.col(tn)] * al[tn];
+                    } else if (cbase + co.col(tn) < K) {              // v_n = phi_n . (B phi_n)
+                        const double ph = (double)Phi[off + co.col(tn)];
+                        part += ph * (double)c;
+                        if (MU) mup += ph * al[tn];
+                    }
+                }
+                if constexpr (Cfg::MS == 16) part = row16_sum(part);                     // lanes of one MFMA row group
+                else {
+#pragma unroll
+                    for (int m = 1; m < Cfg::MS; m <<= 1) part += __shfl_xor(part, m);
+                }
+                if ((co.lane % Cfg::MS) == 0) red[wn * Cfg::BM + row] = part;
+                if (MU) {
+                    if constexpr (Cfg::MS == 16) mup = row16_sum(mup);
+                    else {
+#pragma unroll
+                        for (int m = 1; m < Cfg::MS; m <<= 1) mup += __shfl_xor(mup, m);
+                    }
+                    if ((co.lane % Cfg::MS) == 0) red2[wn * Cfg::BM + row] = mup;
+                }
+            }
+        __syncthreads();
+        if (threadIdx.x < Cfg::BM) {
+            double s = 0, s2 = 0;
+#pragma unroll
+            for (int k = 0; k < Cfg::WGN; ++k) { s += red[k * Cfg::BM + threadIdx.x]; if (MU) s2 += red2[k * Cfg::BM + threadIdx.x]; }
+            vpart[(int64_t)jtg * Np + rb * Cfg::BM + threadIdx.x] = s;
+            if (MU && mupart) mupart[(int64_t)jtg * Np + rb * Cfg::BM + threadIdx.x] = s2;
+        }
+    } else {
+        double bb = 0;                                                  // bbar = sum Phibar o Phi  (d cost / d b)
+        [[maybe_unused]] float alf[Cfg::TN], utf[Cfg::TN];
+        if constexpr (sizeof(T) == 4) {
+#pragma unroll
+            for (int tn = 0; tn < Cfg::TN; ++tn) { alf[tn] = (float)alpha[cbase + co.col(tn)]; utf[tn] = (float)ut[cbase + co.col(tn)]; }
+        }
+#pragma unroll
+        for (int tm = 0; tm < Cfg::TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < Cfg::MTr::NACC; ++r) {
+                const int64_t n = rb * Cfg::BM + co.row(tm, r);
+                const int64_t off = n * Kp + cbase;
+                const double qn = 2.0 * q[n], pn = p[n], yn = y[n];
+                if constexpr (sizeof(T) == 4) {                     // fp32 storage: fp32 FMAs, as in the VEC4 path above
+                    const float qf = (float)qn, pf = (float)pn, yf = (float)yn;
+                    float dot = 0.f;
+#pragma unroll
+                    for (int tn = 0; tn < Cfg::TN; ++tn) {
+                        const float o = fmaf(qf, V[off + co.col(tn)], fmaf(pf, alf[tn], fmaf(yf, utf[tn], 2.0f * acc[tm][tn][r])));
+                        V[off + co.col(tn)] = o;
+                        if (cbase + co.col(tn) < K) dot = fmaf(o, Phi[off + co.col(tn)], dot);
+                    }
+                    bb += (double)dot;
+                } else {
+#pragma unroll
+                    for (int tn = 0; tn < Cfg::TN; ++tn) {
+                        const int j = cbase + co.col(tn);
+                        const double v = 2.0 * (double)acc[tm][tn][r] + qn * (double)V[off + co.col(tn)] + pn * alpha[j] + yn * ut[j];
+                        V[off + co.col(tn)] = (T)v;
+                        if (j < K) bb += v * (double)Phi[off + co.col(tn)];
+                    }
+                }
+            }
+        double* red = reinterpret_cast<double*>(smem_raw);
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) bb += __shfl_xor(bb, m);
+        if (co.lane == 0) red[threadIdx.x >> 6] = bb;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double s = 0;
+            for (int k = 0; k < Cfg::THREADS / 64; ++k) s += red[k];
+            bpart[blockIdx.x] = s;
+        }
+    }
+}
+// one output tile (column tile jt of this launch, row block rb) of the apply product, operands staged through registers
+template <class Cfg, int EPI>
+__device__ __forceinline__ void apply_tile(
+    const typename Cfg::T* __restrict__ Phi, const typename Cfg::T* __restrict__ Bm, typename Cfg::T* V,
+    double* __restrict__ vpart, const double* __restrict__ p, const double* __restrict__ q, const double* __restrict__ y,
+    const double* __restrict__ alpha, const double* __restrict__ ut, int K, int Kp, int64_t Np, int njt,
+    double* __restrict__ bpart, int col0, int jt0, double* __restrict__ mu, int ntot, int jt, int64_t rb, char* smem_raw) {
+    typedef typename Cfg::T T;
+    T* smem = reinterpret_cast<T*>(smem_raw);
+    const int cbase = col0 + jt * Cfg::BN;
+    // EPI 0: column tile t of ntot also forms the slice kt % ntot == t of mu = Phi.alpha for its rows
+    const bool want_mu = (EPI == 0 || EPI == 2 || EPI == 3) && mu != nullptr;
+    // rows >= K of the operand matrix are zero padding, so the contraction stops at K rounded up to the k-tile;
+    // EPI 2: the operand is lower-triangular-transposed, column tile jt needs k < cbase + BN only, and forms the slice
+    // k in [cbase, cbase + BN) of mu (the k-tiles no earlier column tile visits)
+    const int nkt_all = (K + Cfg::BK - 1) / Cfg::BK;
+    const int nkt_tri = (cbase + Cfg::BN + Cfg::BK - 1) / Cfg::BK;
+    const int kt0 = EPI == 4 ? cbase / Cfg::BK : 0;                 // EPI 4: Bm[k][j] = 0 for k < j
+    const int nkt = ((EPI == 2 || EPI == 3) && nkt_tri < nkt_all ? nkt_tri : nkt_all) - kt0;
+    typename Cfg::MTr::acc_t acc[Cfg::TM][Cfg::TN];
+    acc_zero<Cfg>(acc);
+    TrLoader<T, T, Cfg::BM, Cfg::BK, Cfg::LDA, Cfg::THREADS, EPI != 1 && EPI != 4, Cfg::SWZA> la(
+        Phi + rb * Cfg::BM * Kp + kt0 * Cfg::BK, Kp, threadIdx.x, want_mu ? alpha : nullptr, jt0 + jt, ntot);
+    if (EPI == 2 || EPI == 3) la.dot_range(cbase / Cfg::BK, nkt);
+    else if (ntot == 0) {                                   // beside DMA-fed tiles: mu slices are the tiles' own column bands
+        const int hi = (cbase + Cfg::BN) / Cfg::BK;
+        la.dot_range(cbase / Cfg::BK, hi < nkt ? hi : nkt);
+    }
+    NatLoader<T, T, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS, false, false> lb(Bm + (int64_t)kt0 * Cfg::BK * Kp + cbase, Kp, threadIdx.x);
+    tile_mainloop<Cfg>(la, lb, nkt, acc, smem);
+    if constexpr (EPI != 1 && EPI != 4) { if (want_mu) la.dot_reduce(mu + (int64_t)(jt0 + jt) * Np + rb * Cfg::BM); }
+    apply_epilogue<Cfg, EPI>(acc, Phi, V, vpart, p, q, y, alpha, ut, K, Kp, Np, rb, cbase, jt0 + jt, bpart, smem_raw);
+}
+
+template <class Cfg, int EPI>
+__global__ __launch_bounds__(Cfg::THREADS) __attribute__((amdgpu_waves_per_eu(1, 8)))
+void apply_kernel(
+    const typename Cfg::T* __restrict__ Phi, const typename Cfg::T* __restrict__ Bm, typename Cfg::T* V,
+    double* __restrict__ vpart, const double* __restrict__ p, const double* __restrict__ q, const double* __restrict__ y,
+    const double* __restrict__ alpha, const double* __restrict__ ut, int K, int Kp, int64_t Np, int njt,
+    double* __restrict__ bpart, int col0, int jt0, double* __restrict__ mu, int ntot) {
+    // this launch covers columns [col0, col0 + njt*BN); jt0 = index of its first tile in vpart
+    SMEM_DECL;
+    const unsigned wid = xcd_remap(blockIdx.x, gridDim.x);
+    if constexpr (EPI == 3 || EPI == 4) {
+        // triangular operand: column tile jt contracts over (jt + 1) / njt (EPI 3) or (njt - jt) / njt (EPI 4) of the k range, so a
+        // workgroup takes tile t AND tile njt - 1 - t -- every workgroup of the launch then does the same amount of work
+        const int np = (njt + 1) / 2, t = (int)(wid % np), o = njt - 1 - t;
+        const int64_t rb = wid / np;
+        apply_tile<Cfg, EPI>(Phi, Bm, V, vpart, p, q, y, alpha, ut, K, Kp, Np, njt, bpart, col0, jt0, mu, ntot, t, rb, smem_raw);
+        if (o != t) {
+            __syncthreads();                                     // the first tile's epilogue is done with the LDS
+            apply_tile<Cfg, EPI>(Phi, Bm, V, vpart, p, q, y, alpha, ut, K, Kp, Np, njt, bpart, col0, jt0, mu, ntot, o, rb, smem_raw);
+        }
+    } else
+        apply_tile<Cfg, EPI>(Phi, Bm, V, vpart, p, q, y, alpha, ut, K, Kp, Np, njt, bpart, col0, jt0, mu, ntot, (int)(wid % njt), wid / njt, smem_raw);
+}
+
+// Apply product with LDS-DMA staging: both operands go global -> LDS by global_load_lds_dwordx4 into a ring of three stages of
+// 16 k each, counted vmcnt, one raw barrier per stage: no staging registers, no ds_write, and the fetch of stage s+2 is in flight
+// while stage s is multiplied.  Bm must hold the k-contiguous COLUMNS of the operand as its rows: the matrix itself when it is
+// symmetric (B and Abar are), else its transpose (factor form: Li for C = Phi Li^T, Li^T for V = C Li).
+//   LDS image of an operand: row x at x * ROWB bytes (ROWB = 16 k: 64 B in fp32, 128 B in fp64) = its 16 k as CPR 16-byte
+//   chunks, chunk c stored at position c ^ swz(x) (source-side swizzle: the DMA itself writes linearly, 1 KiB per wave
+//   instruction).  Lane group q of the 16x16x4 shape takes the 4 k numbered 4q .. 4q+3 -- chunk q in fp32, chunks 2q and 2q+1
+//   in fp64 -- and feeds component e to k-step e: both operands use the same permutation of the 16 k, so the sum is unchanged
+//   and a fragment is ONE ds_read_b128 (fp32) or two (fp64) per stage.  swz makes the four 16-lane groups ds_read_b128 is
+//   served in ({0-3,12-15,20-27}, {4-11,16-19,28-31} and the same + 32: MI355X_MICROARCH.md, LDS) touch 16 distinct
+//   16-byte slots of the 256-byte bank row each.
+//   B rows are staged in the order that leaves an MFMA lane TN ADJACENT output columns (LDS row tn*16 + i of a wave tile holds
+//   operand row TN i + tn), so the epilogue moves V, Phi and Phibar 16 bytes per lane.
+//   EPI 3 / 4 (factor form): the stages run over k < cbase + BN (EPI 3) or k >= cbase (EPI 4) only.
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+template <typename T, int BN_>
+struct ApplyDma {
+    static constexpr int ES = (int)sizeof(T), BM = 256, BN = BN_, ROWB = 16 * ES, CPR = ROWB / 16;
+    static constexpr int WN = ES == 4 ? 64 : 32;               // wave tile 64 x 64 (fp32) / 64 x 32 (fp64): 64 accumulator registers
+    static constexpr int WAVES = 4 * (BN / WN), STAGE = (BM + BN) * ROWB, STAGES = 3, LDS_BYTES = STAGES * STAGE,
+                         DMA_PER_WAVE = STAGE / 1024 / WAVES, ROWS_PER_DMA = 1024 / ROWB;
+    typedef TileCfg<T, BM, BN, 16, 4, BN / WN, 16, true> Cfg;      // wave grid / accumulator map of the epilogue
+    static_assert(STAGE / 1024 % WAVES == 0 && LDS_BYTES <= 160 * 1024, "whole DMA instructions per wave; the ring fits the LDS");
+    // position swizzle of row x (see above): fp32 f[(x >> 2) & 3], f = (0, 2, 3, 1); fp64 f[(x >> 1) & 7], f = (0, 1, 4, 5, 6, 7, 2, 3)
+    static __device__ __forceinline__ int swz(int x) {
+        if constexpr (ES == 4) return (0x78 >> (2 * ((x >> 2) & 3))) & 3;
+        else return (int)((0x6BEB08u >> (3 * ((x >> 1) & 7))) & 7);
+    }
+};
+static_assert(((0x6BEB08u >> 0) & 7) == 0 && ((0x6BEB08u >> 3) & 7) == 1 && ((0x6BEB08u >> 6) & 7) == 4 && ((0x6BEB08u >> 9) & 7) == 5 &&
+              ((0x6BEB08u >> 12) & 7) == 6 && ((0x6BEB08u >> 15) & 7) == 7 && ((0x6BEB08u >> 18) & 7) == 2 && ((0x6BEB08u >> 21) & 7) == 3,
+              "fp64 swizzle table");
+
+// fp32 BN = 256: 16 waves, one workgroup per CU, 32 operand bytes per MFMA; BN = 128: 8 waves, two workgroups per CU, 48 bytes;
+// fp64 BN = 128: 16 waves of 64 x 32, one workgroup per CU (3 x 48 KB of LDS), 96 bytes per MFMA of twice the duration
+template <typename T, int EPI, int BN>
+__global__ __launch_bounds__((64 * ApplyDma<T, BN>::WAVES)) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void apply_dma_kernel(const T* __restrict__ Phi, const T* __restrict__ Bm, T* V,
+                      double* __restrict__ vpart, const double* __restrict__ p, const double* __restrict__ q,
+                      const double* __restrict__ y, const double* __restrict__ alpha, const double* __restrict__ ut,
+                      int K, int Kp, int64_t Np, int njt, double* __restrict__ bpart, double* __restrict__ mu, int col0, int slot0) {
+    typedef ApplyDma<T, BN> D;
+    typedef typename D::Cfg Cfg;
+    typedef T frag_t __attribute__((ext_vector_type(16 / sizeof(T))));      // one 16-byte LDS read
+    constexpr int NR = 4 * (int)sizeof(T) / 16;                              // reads per fragment: its 4 k are NR chunks
+    SMEM_DECL;
+    char* smem = smem_raw;
+    const unsigned wid = xcd_remap(blockIdx.x, gridDim.x);
+    const int jt = wid % njt;
+    const int64_t rb = wid / njt;
+    const int cbase = col0 + jt * D::BN;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // DMA instruction t = DMA_PER_WAVE wave + u of a stage: rows ROWS_PER_DMA t .. of the stacked (A: 256, then B: BN) operand
+    // rows; lane l carries row + l / CPR, position l % CPR <- chunk (l % CPR) ^ swz(row)
+    const char* src[D::DMA_PER_WAVE]; int dst[D::DMA_PER_WAVE];
+#pragma unroll
+    for (int u = 0; u < D::DMA_PER_WAVE; ++u) {
+        const int t = wave * D::DMA_PER_WAVE + u, x = D::ROWS_PER_DMA * t + lane / D::CPR, c = (lane % D::CPR) ^ D::swz(x);
+        const int xb = x - D::BM, xcol = (xb & ~(D::WN - 1)) + Cfg::TN * (xb & 15) + ((xb >> 4) & (Cfg::TN - 1));
+        const T* rowp = x < D::BM ? Phi + (rb * D::BM + x) * Kp : Bm + (int64_t)(cbase + xcol) * Kp;
+        src[u] = reinterpret_cast<const char*>(rowp) + c * 16 + (EPI == 4 ? (cbase / 16) * D::ROWB : 0);
+        dst[u] = t * 1024;
+    }
+    const auto issue = [&](int slot) {
+#pragma unroll
+        for (int u = 0; u < D::DMA_PER_WAVE; ++u) {
+            __builtin_amdgcn_global_load_lds((gbl_void*)src[u], (lds_void*)(smem + slot * D::STAGE + dst[u]), 16, 0, 0);
+            src[u] += D::ROWB;                                  // 16 k further
+        }
+    };
+    const int i = lane & 15, qg = lane >> 4;
+    const int wm0 = (wave / Cfg::WGN) * Cfg::WM, wn0 = (wave % Cfg::WGN) * Cfg::WN;
+    // byte offsets of this lane's NR chunks inside a fragment row (the wave tile bases are multiples of 16 rows: swz(row) = swz(i))
+    int sw[NR];
+#pragma unroll
+    for (int h = 0; h < NR; ++h) sw[h] = ((NR * qg + h) ^ D::swz(i)) << 4;
+    const int aoff = (wm0 + i) * D::ROWB, boff = D::BM * D::ROWB + (wn0 + i) * D::ROWB;
+    typename Cfg::MTr::acc_t acc[Cfg::TM][Cfg::TN];
+    acc_zero<Cfg>(acc);
+    const int nst_all = (K + 15) / 16, nst_tri = (cbase + D::BN + 15) / 16;
+    const int nst = (EPI == 3 && nst_tri < nst_all ? nst_tri : nst_all) - (EPI == 4 ? cbase / 16 : 0);
+    issue(0);
+    if (nst > 1) issue(1);
+    int slot = 0, fill = 2;
+    for (int s = 0; s < nst; ++s) {
+        // this wave's share of stage s has landed when only the DMAs of stage s+1 are outstanding
+        if (s + 1 < nst) {
+            if (D::DMA_PER_WAVE == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (D::DMA_PER_WAVE == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                          // everybody's has; nobody reads the slot of stage s-1 any more
+        asm volatile("" ::: "memory");
+        if (s + 2 < nst) issue(fill);
+        const char* base = smem + slot * D::STAGE;
+        frag_t a[Cfg::TM][NR], b[Cfg::TN][NR];
+#pragma unroll
+        for (int tm = 0; tm < Cfg::TM; ++tm)
+#pragma unroll
+            for (int h = 0; h < NR; ++h) a[tm][h] = *reinterpret_cast<const frag_t*>(base + aoff + tm * 16 * D::ROWB + sw[h]);
+#pragma unroll
+        for (int tn = 0; tn < Cfg::TN; ++tn)
+#pragma unroll
+            for (int h = 0; h < NR; ++h) b[tn][h] = *reinterpret_cast<const frag_t*>(base + boff + tn * 16 * D::ROWB + sw[h]);
+        constexpr int EPC = 16 / (int)sizeof(T);                // k per chunk
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int tm = 0; tm < Cfg::TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < Cfg::TN; ++tn) Cfg::MTr::mfma(acc[tm][tn], a[tm][e / EPC][e % EPC], b[tn][e / EPC][e % EPC]);
+        slot = slot == 2 ? 0 : slot + 1;
+        fill = fill == 2 ? 0 : fill + 1;
+    }
+    __syncthreads();
+    constexpr int SLOTS = BN / 128;                            // vpart / mupart slots are 128 columns wide
+    const int vslot = slot0 + SLOTS * jt;
+    apply_epilogue<Cfg, EPI, EPI == 0 || EPI == 3, true>(acc, Phi, V, vpart, p, q, y, alpha, ut, K, Kp, Np, rb, cbase, vslot, bpart, smem_raw, mu);
+    if (SLOTS == 2 && (EPI == 0 || EPI == 3) && threadIdx.x < D::BM) {
+        vpart[(int64_t)(vslot + 1) * Np + rb * D::BM + threadIdx.x] = 0.0;
+        if (mu) mu[(int64_t)(vslot + 1) * Np + rb * D::BM + threadIdx.x] = 0.0;
+    }
+}
+
+// Columns [0, K) of the output are covered by a cascade of launches of decreasing tile width
+// (128-wide tiles, then 64-wide tiles for the ragged remainder; K = 2112: 16 x 128 + 1 x 64), so no workgroup multiplies a
+// half-empty tile; columns >= K of the output buffer are never written and stay zero.
+template <typename T> struct ApplyPlan {
+    static constexpr int NW = 2;
+    int width[NW], count[NW], col0[NW], jt0[NW], total;
+    explicit ApplyPlan(int K) {
+        const int w[NW] = {128, 64};
+        int col = 0, jt = 0;
+        // K <= 256: a handful of workgroups whatever the tiling, so ONE launch of 64-wide tiles (a launch costs more
+        // than the half-empty tile there: Boston shape, K = 144, 80 -> 45 us per product)
+        const bool small = K <= 256;
+        for (int i = 0; i < NW; ++i) {
+            width[i] = w[i];
+            const bool last = i == NW - 1;
+            count[i] = small && !last ? 0 : (last ? (K - col + w[i] - 1) / w[i] : (K - col) / w[i]);
+            col0[i] = col; jt0[i] = jt;
+            col += count[i] * w[i]; jt += count[i];
+        }
+        total = jt;
+    }
+};
+template <class Cfg, int EPI, typename T>
+static int apply_launch_cfg(const Geom& g, int njt, int col0, int jt0, int boff, const T* Phi, const T* Bm, T* V, double* vpart,
+                            const double* p, const double* q, const double* y, const double* alpha, const double* ut,
+                            double* bpart, double* mu, int ntot, hipStream_t st) {
+    if (njt <= 0) return 0;
+    const int64_t nrb = g.Np / Cfg::BM;
+    const int wgs_per_rb = EPI == 3 || EPI == 4 ? (njt + 1) / 2 : njt;          // triangular products pair their column tiles
+    allow_big_lds(apply_kernel<Cfg, EPI>, Cfg::LDS_BYTES);
+    hipLaunchKernelGGL((apply_kernel<Cfg, EPI>), dim3((unsigned)(wgs_per_rb * nrb)), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st,
+                       Phi, Bm, V, vpart, p, q, y, alpha, ut, g.K, g.Kp, g.Np, njt, bpart ? bpart + boff : nullptr, col0, jt0, mu, ntot);
+    return (int)(njt * nrb);
+}
+template <typename T, int EPI, int BN>
+static int apply_dma_launch(const Geom& g, int njt, int col0, int slot0, int boff, const T* Phi, const T* Bm, T* V, double* vpart,
+                            const double* p, const double* q, const double* y, const double* alpha, const double* ut,
+                            double* bpart, double* mu, hipStream_t st) {
+    if (njt <= 0) return 0;
+    typedef ApplyDma<T, BN> D;
+    const int64_t nrb = g.Np / D::BM;
+    allow_big_lds(apply_dma_kernel<T, EPI, BN>, D::LDS_BYTES);
+    hipLaunchKernelGGL((apply_dma_kernel<T, EPI, BN>), dim3((unsigned)(njt * nrb)), dim3(64 * D::WAVES), D::LDS_BYTES, st,
+                       Phi, Bm, V, vpart, p, q, y, alpha, ut, g.K, g.Kp, g.Np, njt, bpart ? bpart + boff : nullptr, mu, col0, slot0);
+    return (int)(njt * nrb);
+}
+// dma: 0 = every tile by the register-staged kernel; 1 / 2 = the full 128-column tiles by LDS-DMA, 128 wide / 256 wide (fp32
+//      only; an odd 128-column tile and fp64 stay 128 wide), the ragged 64-wide remainder by the register-staged kernel
+// BmT: the operand with its k-contiguous columns as rows (what the DMA-fed tiles read); NULL: Bm is symmetric
+template <typename T, int EPI>
+static int apply_launch(const Geom& g, const T* Phi, const T* Bm, T* V, double* vpart, const double* p, const double* q,
+                        const double* y, const double* alpha, const double* ut, double* bpart, double* mu, hipStream_t st,
+                        int dma = 0, const T* BmT = nullptr) {
+    if (!BmT) BmT = Bm;
+    const ApplyPlan<T> pl(g.K);
+    int nb = 0;
+    if constexpr (EPI != 2) {
+        if (dma && pl.count[0] > 0) {
+            int n256 = 0;
+            if constexpr (sizeof(T) == 4) {
+                n256 = dma == 2 ? pl.count[0] / 2 : 0;
+                nb += apply_dma_launch<T, EPI, 256>(g, n256, 0, 0, nb, Phi, BmT, V, vpart, p, q, y, alpha, ut, bpart, mu, st);
+            }
+            nb += apply_dma_launch<T, EPI, 128>(g, pl.count[0] - 2 * n256, 256 * n256, 2 * n256, nb, Phi, BmT, V, vpart, p, q, y, alpha, ut, bpart, mu, st);
+            // beside DMA-fed tiles the mu slices of the remainder are its own column bands (ntot = 0)
+            nb += apply_launch_cfg<typename ApplyCfg<T, 64>::type, EPI, T>(g, pl.count[1], pl.col0[1], pl.jt0[1], nb, Phi, Bm, V, vpart, p, q, y, alpha, ut,
+                                                                          bpart, mu, 0, st);
+            return nb;
+        }
+    }
+    nb += apply_launch_cfg<typename ApplyCfg<T, 128>::type, EPI, T>(g, pl.count[0], pl.col0[0], pl.jt0[0], nb, Phi, Bm, V, vpart, p, q, y, alpha, ut, bpart, mu, pl.total, st);
+    nb += apply_launch_cfg<typename ApplyCfg<T, 64>::type, EPI, T>(g, pl.count[1], pl.col0[1], pl.jt0[1], nb, Phi, Bm, V, vpart, p, q, y, alpha, ut, bpart, mu, pl.total, st);
+    return nb;
+}
+
+template <typename T>
+void ApplyKernels<T>::apply_v(const Geom& g, const T* Phi, const T* Bm, T* V, double* vpart, const double* alpha, double* mu,
+                              hipStream_t st, int dma) {
+    apply_launch<T, 0>(g, Phi, Bm, V, vpart, nullptr, nullptr, nullptr, alpha, nullptr, nullptr, mu, st, dma);
+}
+template <typename T>
+void ApplyKernels<T>::apply_predict(const Geom& g, const T* Phi, const T* LiT, double* vpart, const double* alpha, double* mu,
+                                    hipStream_t st) {
+    apply_launch<T, 2>(g, Phi, LiT, (T*)nullptr, vpart, nullptr, nullptr, nullptr, alpha, nullptr, nullptr, mu, st);
+}
+// Out[n][c] = sum_{k < Kc} A[n][k] Bm[k][c] for c < ncols (rounded up to 64-wide tiles), everything with leading dimension Kp;
+// Bm[k][c] = 0 for k < c is assumed (the contraction of a column tile starts at its first column)
+template <typename T>
+void ApplyKernels<T>::apply_plain(const Geom& g, const T* A, const T* Bm, T* Out, int Kc, int ncols, hipStream_t st) {
+    Geom gk = g; gk.K = Kc;
+    apply_launch_cfg<typename ApplyCfg<T, 64>::type, 4, T>(gk, (ncols + 63) / 64, 0, 0, 0, A, Bm, Out, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                                           nullptr, nullptr, nullptr, ApplyPlan<T>(Kc).total, st);
+}
+
+template <typename T>
+void ApplyKernels<T>::apply_c(const Geom& g, const T* Phi, const T* LiT, const T* Li, T* C, double* vpart, const double* alpha,
+                              double* mu, hipStream_t st, int dma) {
+    apply_launch<T, 3>(g, Phi, LiT, C, vpart, nullptr, nullptr, nullptr, alpha, nullptr, nullptr, mu, st, dma, Li);
+}
+template <typename T>
+void ApplyKernels<T>::apply_vc(const Geom& g, const T* C, const T* Li, const T* LiT, T* V, hipStream_t st, int dma) {
+    apply_launch<T, 4>(g, C, Li, V, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, st, dma, LiT);
+}
+template <typename T>
+int ApplyKernels<T>::apply_phibar(const Geom& g, const T* Phi, const T* Abar, T* V, const double* p, const double* q,
+                                  const double* y, const double* alpha, const double* ut, double* bpart, hipStream_t st, int dma) {
+    return apply_launch<T, 1>(g, Phi, Abar, V, nullptr, p, q, y, alpha, ut, bpart, nullptr, st, dma);
+}
+
+// number of column tiles of the apply kernel (vpart leading count)
+template <typename T> static int apply_njt(const Geom& g) { return ApplyPlan<T>(g.K).total; }
+template <typename T>
+int ApplyKernels<T>::apply_blocks(const Geom& g) {
+    return (int)(apply_njt<T>(g) * (g.Np / Tune<T>::APPLY_BM));
+}
+
+
+// --------------------------------------------------------------------------
+// per-row statistics from apply_v's per-tile by-products: one thread per row.
+//   mu = sum_jt mupart, v = sum_jt vpart, d = kappa (v+1), r = mu - y
+//   MODE 0 (train): p = 2r/d, e = 1/d - (r^2+v)/d^2, q = 1/d + kappa e; block partials of
+//                   T2 = (r^2+v)/d + log(2 pi d) and kbar = e (v+1)
+//   MODE 1 (predict): mu, sd = sqrt(kappa (1+v))
+// --------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void rowstats_kernel(const double* __restrict__ mupart, const double* __restrict__ vpart, int njt,
+                                                       const double* __restrict__ y, const Scal* __restrict__ sc,
+                                                       double* __restrict__ o1, double* __restrict__ o2,
+                                                       double* __restrict__ partial, int64_t N, int64_t Np) {
+    __shared__ double red[2][256];
+    const double kappa = sc->kappa;
+    double t2 = 0, kb = 0;
+    for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < Np; n += (int64_t)gridDim.x * 256) {
+        double v = 0, mu = 0;
+        for (int t = 0; t < njt; ++t) { v += vpart[(int64_t)t * Np + n]; mu += mupart[(int64_t)t * Np + n]; }
+        const double d = kappa * (v + 1.0);
+        if (MODE == 0) {
+            double pn = 0, qn = 0;
+            if (n < N) {
+                const double r = mu - y[n];
+                const double rv = r * r + v;
+                const double e = 1.0 / d - rv / (d * d);
+                pn = 2.0 * r / d;
+                qn = 1.0 / d + kappa * e;
+                t2 += rv / d + log(2.0 * M_PI * d);
+                kb += e * (v + 1.0);
+            }
+            o1[n] = pn; o2[n] = qn;
+        } else if (n < N) {
+            o1[n] = mu; o2[n] = sqrt(d);
+        }
+    }
+    if (MODE == 0) {
+        red[0][threadIdx.x] = t2; red[1][threadIdx.x] = kb;
+        __syncthreads();
+        for (int w = 128; w >= 1; w >>= 1) {
+            if ((int)threadIdx.x < w) { red[0][threadIdx.x] += red[0][threadIdx.x + w]; red[1][threadIdx.x] += red[1][threadIdx.x + w]; }
+            __syncthreads();
+        }
+        if (threadIdx.x < 2) partial[blockIdx.x * 2 + threadIdx.x] = red[threadIdx.x][0];
+    }
+}
+
+template <typename T>
+void ApplyKernels<T>::rowstats(const Geom& g, const double* mupart, const double* vpart, const double* y,
+                               const Scal* sc, double* p, double* q, double* partial, int nblocks, hipStream_t st) {
+    hipLaunchKernelGGL((rowstats_kernel<0>), dim3(nblocks), dim3(256), 0, st, mupart, vpart, apply_njt<T>(g), y, sc, p, q,
+                       partial, g.N, g.Np);
+}
+
+template <typename T>
+void ApplyKernels<T>::rowpredict(const Geom& g, const double* mupart, const double* vpart, const Scal* sc, double* mu, double* sd,
+                                 hipStream_t st) {
+    const int nblocks = (int)((g.Np + 255) / 256 < 1024 ? (g.Np + 255) / 256 : 1024);
+    hipLaunchKernelGGL((rowstats_kernel<1>), dim3(nblocks), dim3(256), 0, st, mupart, vpart, apply_njt<T>(g),
+                       (const double*)nullptr, sc, mu, sd, (double*)nullptr, g.N, g.Np);
+}
+template struct ApplyKernels<double>;
+template struct ApplyKernels<float>;
+
+// single workgroup: fixed-order tree over block partials
+__global__ __launch_bounds__(256) void reduce_scalars_kernel(const double* __restrict__ partial, int nblocks, int width,
+                                                             double* __restrict__ scalars, int slot0) {
+    __shared__ double red[256];
+    for (int k = 0; k < width; ++k) {
+        double s = 0;
+        for (int b = threadIdx.x; b < nblocks; b += 256) s += partial[(int64_t)b * width + k];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        for (int m = 128; m >= 1; m >>= 1) {
+            if (threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) scalars[slot0 + k] = red[0];
+        __syncthreads();
+    }
+}
+// many partials of one scalar (one per workgroup of the apply product: 6.6e4 at the headline shape, 108 us for the single
+// workgroup above): 128 workgroups first sum a contiguous chunk each, in a fixed order, into the chunk's first slot
+__global__ __launch_bounds__(256) void reduce_chunks_kernel(double* __restrict__ partial, int n, int chunk) {
+    __shared__ double red[256];
+    const int64_t b0 = (int64_t)blockIdx.x * chunk;
+    const int len = b0 + chunk <= n ? chunk : (int)(n - b0);
+    double s = 0;
+    for (int b = threadIdx.x; b < len; b += 256) s += partial[b0 + b];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int m = 128; m >= 1; m >>= 1) {
+        if (threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && len > 0) partial[b0] = red[0];
+}
+__global__ __launch_bounds__(128) void reduce_strided_kernel(const double* __restrict__ partial, int nchunks, int chunk,
+                                                             double* __restrict__ scalars, int slot0) {
+    __shared__ double red[128];
+    red[threadIdx.x] = (int)threadIdx.x < nchunks ? partial[(int64_t)threadIdx.x * chunk] : 0.0;
+    __syncthreads();
+    for (int m = 64; m >= 1; m >>= 1) {
+        if ((int)threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) scalars[slot0] = red[0];
+}
+void reduce_scalars(double* partial, int nblocks, int width, double* scalars, int slot0, hipStream_t st) {
+    if (width == 1 && nblocks > 8192) {                        // the partials are scratch: the first stage works in place
+        const int chunk = (nblocks + 127) / 128, nchunks = (nblocks + chunk - 1) / chunk;
+        hipLaunchKernelGGL(reduce_chunks_kernel, dim3(nchunks), dim3(256), 0, st, partial, nblocks, chunk);
+        hipLaunchKernelGGL(reduce_strided_kernel, dim3(1), dim3(128), 0, st, partial, nchunks, chunk, scalars, slot0);
+        return;
+    }
+    hipLaunchKernelGGL(reduce_scalars_kernel, dim3(1), dim3(256), 0, st, partial, nblocks, width, scalars, slot0);
+}
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const double* __restrict__ y, int64_t n, double* __restrict__ partial) {
+    __shared__ double red[256];
+    double s = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += y[i] * y[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int m = 128; m >= 1; m >>= 1) {
+        if (threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+void sum_squares(const double* y, int64_t n, double* scalars, int slot, double* scratch, hipStream_t st) {
+    const int nb = 256;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(256), 0, st, y, n, scratch);
+    reduce_scalars(scratch, nb, 1, scalars, slot, st);
+}

@@ -1,0 +1,453 @@
+// TN products of the SCFGP objective (contraction over the rows):  Phi^T diag(w) Phi with its side vector Phi^T s
+// (SCFGP/SCFGP.py:104,108 and the backward of :111-113) and X~^T Zbar (the reverse sweep of :98-102), plus the
+// reductions of their per-split fp64 slabs.  Built on tile_engine.h; templated on the compute type T (double | float).
+#include "kernels.h"
+#include "tile_cfgs.h"
+
+#include <algorithm>
+
+// Diagnostic build (-DSCFGP_TRACE, library variant "_trace"): every workgroup of the Gram kernel records
+// [start, end] on the 100 MHz constant clock, its XCC id and its job kind, so the tail and the spread of job lengths
+// can be read off (tests/gpu_gram_trace.py).  No stamp reaches any output; the product build contains none of this.
+#ifdef SCFGP_TRACE
+constexpr int TRACE_CAP = 1 << 16;
+__device__ unsigned long long g_trace[TRACE_CAP][4];
+#define TRACE_BEGIN() const unsigned long long tr_t0 = __builtin_amdgcn_s_memrealtime()
+#define TRACE_END(kind)                                                                                     \
+    do {                                                                                                    \
+        __syncthreads();                                                                                    \
+        if (threadIdx.x == 0 && blockIdx.x < TRACE_CAP) {                                                   \
+            g_trace[blockIdx.x][0] = tr_t0; g_trace[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();      \
+            g_trace[blockIdx.x][2] = (unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) |    \
+                                     ((unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) << 8); \
+            g_trace[blockIdx.x][3] = (unsigned long long)(kind);                                            \
+        }                                                                                                   \
+    } while (0)
+int64_t trace_read(void* host, int64_t max_bytes) {
+    const int64_t n = max_bytes < (int64_t)sizeof(g_trace) ? max_bytes : (int64_t)sizeof(g_trace);
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_trace), n) == hipSuccess ? n : -2;
+}
+#else
+#define TRACE_BEGIN()
+#define TRACE_END(kind)
+int64_t trace_read(void*, int64_t) { return -1; }
+#endif
+
+// Gram tiles: 256 x 128 (fp32 only) and 128 x 128 output tiles plus a 64 x 128 strip (tile_cfgs.h)
+template <typename T, int TILE> struct GramCfg {
+    typedef TileCfg<T, TILE, TILE, Tune<T>::GRAM_BK, Tune<T>::GRAM_WGM, Tune<T>::GRAM_WGN, Tune<T>::MS> type;
+};
+// the 64-high strip below the square tiles: same workgroup size (one launch), 32 x 32 wave tiles
+template <typename T> struct GramStripCfg {
+    typedef TileCfg<T, 64, 128, Tune<T>::GRAM_BK, Tune<T>::GRAM_WGM / 2, Tune<T>::GRAM_WGN * 2, Tune<T>::MS> type;
+};
+// fp32 only: the tall Gram tile (64 x 64 wave tiles); fp64 would need 16 waves for the same tile
+template <typename T> struct GramBigCfg {
+    typedef TileCfg<T, 256, 128, SCFGP_BK, Tune<T>::GRAM_WGM, Tune<T>::GRAM_WGN, Tune<T>::MS> type;
+};
+// fp32 only: four strip tiles side by side as one 64 x 512 tile (eight 64 x 64 wave tiles: the MFMA-per-barrier ratio of
+// the tall tile; the 64 x 128 strip tiles ran at half its rate and were 6 % of the launch)
+template <typename T> struct GramWideCfg {
+    typedef TileCfg<T, 64, 512, SCFGP_BK, 1, 8, Tune<T>::MS> type;
+};
+template <typename T> struct XtzCfg { typedef TileCfg<T, 128, 128, 16, 4, 2, Tune<T>::MS> type; };
+// row tiles of X~^T Zbar that hold at most 96 / 64 live rows of X~^T (D + 1 = 65 at the headline shape): same 128-wide
+// slabs, fewer MFMA rows
+template <typename T> struct Xtz96Cfg { typedef TileCfg<T, 96, 128, 16, 2, 4, 16> type; };     // 48-row wave tiles: 16 x 16 MFMA shape only
+template <typename T> struct Xtz64Cfg { typedef TileCfg<T, 64, 128, 16, 2, 4, Tune<T>::MS> type; };
+
+// --------------------------------------------------------------------------
+// TN products (contraction over rows), one workgroup per (output tile, row split):
+//   gram_kernel  lower tiles of  Phi^T diag(w) Phi; its diagonal tiles also form Phi^T y / Phi^T p in
+//                fp64 from the rows they stage anyway
+//   xtz_kernel   X~^T Zbar with Zbar formed on the fly (ZbarLoader)
+// fp32 accumulators are flushed into the workgroup's private fp64 slab every `chunk` rows
+// (one fp32 chain stays ~sqrt(chunk)*2^-24); fp64 runs one chunk.
+// --------------------------------------------------------------------------
+// slab_hi: for 256-row tiles, the slab of rows 128..255 (the two 128 x 128 slabs of a tall tile are not adjacent)
+template <class Cfg>
+__device__ __forceinline__ void slab_flush(const typename Cfg::MTr::acc_t (&acc)[Cfg::TM][Cfg::TN], double* slab, bool first,
+                                           double* slab_hi = nullptr) {
+    AccCoord<Cfg> co;
+    if (Cfg::BM > 128 && co.wm0 >= 128) slab = slab_hi - 128 * Cfg::BN;          // a wave's rows lie in one half
+    // wide tiles (BN > 128): consecutive 128 x 128 slabs, one per 128 output columns; a wave's columns lie in one of them
+    constexpr int LDS_ = Cfg::BN > 128 ? 128 : Cfg::BN;
+    if (Cfg::BN > 128) slab += (co.wn0 / 128) * (128 * 128) - (co.wn0 / 128) * 128;
+#pragma unroll
+    for (int tm = 0; tm < Cfg::TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < Cfg::MTr::NACC; ++r) {
+            double* d = slab + co.row(tm, r) * LDS_;
+#pragma unroll
+            for (int tn = 0; tn < Cfg::TN; ++tn) {
+                const double v = (double)acc[tm][tn][r];
+                d[co.col(tn)] = first ? v : d[co.col(tn)] + v;
+            }
+        }
+}
+
+// Tile grid of the Gram products: `nfull` rows of square tiles (lower triangle) and, when the 64-column blocks of K
+// do not pair up, one 64-high STRIP of nfull+1 tiles (64 x 128) below them whose results occupy the upper halves of
+// the slabs of tile row nfull.  Diagonal tiles also produce the side vector sum_n s_n Phi[n][col] (s = y: Phi^T y,
+// s = p: Phi^T p) for their columns from the rows they stream anyway: sidepart[split][col].
+// One launch covers everything; the job order is described at the decode in gram_kernel.
+// DIAG is a compile-time property of the instantiation (the side sums cost a dozen registers that only the diagonal jobs need:
+// with them in every job the 64 x 64 wave tiles spilled inside the k-loop); gram_body dispatches on the job's flag
+template <class Cfg, bool WEIGHT, bool STRIP, bool DIAG>
+__device__ __forceinline__ void gram_body_impl(
+    const typename Cfg::T* __restrict__ Phi, int64_t ld, const double* __restrict__ w, const double* __restrict__ side,
+    int64_t r0, int64_t r1, int64_t chunk, int acol, int bcol, double* __restrict__ sideout,
+    double* __restrict__ slab, double* __restrict__ slab_hi, char* smem_raw) {
+    typedef typename Cfg::T T;
+    T* smem = reinterpret_cast<T*>(smem_raw);
+    typename Cfg::MTr::acc_t acc[Cfg::TM][Cfg::TN];
+    // consecutive chunks are consecutive k-tiles, so one pair of loaders walks the whole row range
+    NatLoader<T, T, Cfg::BM, Cfg::BK, Cfg::LDA, Cfg::THREADS, WEIGHT, false, DIAG> la(
+        Phi + r0 * ld + acol, ld, threadIdx.x, WEIGHT ? w + r0 : nullptr, 0, DIAG ? side + r0 : nullptr);
+    NatLoader<T, T, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS, false, false> lb(Phi + r0 * ld + bcol, ld, threadIdx.x);
+    bool first = true;
+    for (int64_t c0 = r0; c0 < r1 || first; c0 += chunk) {
+        const int64_t c1 = c0 + chunk < r1 ? c0 + chunk : r1;
+        acc_zero<Cfg>(acc);
+        if (c0 < r1) tile_mainloop<Cfg>(la, lb, (int)((c1 - c0) / Cfg::BK), acc, smem);
+        slab_flush<Cfg>(acc, slab, first, slab_hi);
+        if constexpr (DIAG) la.side_flush();
+        first = false;
+    }
+    if constexpr (STRIP) {                                     // lower half of the 128 x 128 slab(s): rows the strip does not have
+        constexpr int NB = Cfg::BN / 128, REST = (128 - Cfg::BM) * 128;
+        for (int e = threadIdx.x; e < NB * REST; e += Cfg::THREADS) slab[(e / REST) * (128 * 128) + Cfg::BM * 128 + e % REST] = 0.0;
+    }
+    if constexpr (DIAG) la.side_reduce(reinterpret_cast<double*>(smem_raw), sideout);
+}
+template <class Cfg, bool WEIGHT, bool STRIP>
+__device__ __forceinline__ void gram_body(
+    const typename Cfg::T* __restrict__ Phi, int64_t ld, const double* __restrict__ w, const double* __restrict__ side,
+    int64_t r0, int64_t r1, int64_t chunk, int acol, int bcol, bool diag, double* __restrict__ sideout,
+    double* __restrict__ slab, double* __restrict__ slab_hi, char* smem_raw) {
+    if (diag) gram_body_impl<Cfg, WEIGHT, STRIP, true>(Phi, ld, w, side, r0, r1, chunk, acol, bcol, sideout, slab, slab_hi, smem_raw);
+    else gram_body_impl<Cfg, WEIGHT, STRIP, false>(Phi, ld, w, side, r0, r1, chunk, acol, bcol, sideout, slab, slab_hi, smem_raw);
+}
+
+// Job list of one row split (all kernels of the launch have 8 waves):
+//   !BIG  diagonal 128 x 128 tiles, strictly lower tiles row by row, strip tiles
+//    BIG  (fp32) pairs of 128-row blocks are covered by 256 x 128 tiles (64 x 64 wave tiles, the shape of the apply
+//         product): tile (a, b), b <= 2a, is blocks (2a, b) and (2a+1, b); the diagonal blocks (2a+1, 2a+1), an
+//         unpaired last block row and the strip stay 128- / 64-row tiles.  Tall tiles with b == 2a hold the diagonal
+//         block of both of their column blocks' rows and carry the side vector for all 256 columns.
+// Jobs are split-major and the XCD map hands each XCD a contiguous range of them (whole splits), so the workgroups
+// running together on one L2 work on the same rows and share operand panels; inside a split the longest jobs come
+// first and the short strip jobs last.
+template <bool BIG> __host__ __device__ inline int gram_jobs_per_split(int nfull, int nstrip) {
+    if (!BIG) return nfull * (nfull + 1) / 2 + nstrip * (nfull + 1);
+    const int R = nfull / 2, odd = nfull & 1, nsb = nstrip * (nfull + 1);
+    return R * R + nsb / 4 + R + odd * nfull + nsb % 4;          // tall, wide (4 strip tiles each), small, single strips
+}
+template <class Cfg, class SCfg, class BCfg, class WCfg, bool WEIGHT, bool BIG>
+__global__ __launch_bounds__(Cfg::THREADS)
+__attribute__((amdgpu_waves_per_eu(4, 4)))       // two 8-wave workgroups per CU: the compiler would take up to 256 VGPRs
+void gram_kernel(
+    const typename Cfg::T* __restrict__ Phi, int64_t ld, const double* __restrict__ w, const double* __restrict__ side,
+    RowSplits rs, int64_t chunk, int nfull, int nstrip, double* __restrict__ sidepart, double* __restrict__ slabs) {
+    static_assert(Cfg::THREADS == SCfg::THREADS && Cfg::THREADS == BCfg::THREADS && Cfg::THREADS == WCfg::THREADS &&
+                  Cfg::BN == SCfg::BN && Cfg::BN == BCfg::BN && Cfg::BM == Cfg::BN && WCfg::BM == SCfg::BM && WCfg::BN == 4 * Cfg::BN,
+                  "one launch, four tile shapes");
+    SMEM_DECL;
+    TRACE_BEGIN();
+    constexpr int B = Cfg::BN;
+    const int nall = nfull + nstrip, ntile_all = nall * (nall + 1) / 2;
+    const int per_split = gram_jobs_per_split<BIG>(nfull, nstrip);
+    const int j = (int)xcd_remap(blockIdx.x, gridDim.x);
+    const int split = j / per_split;
+    int u = j % per_split, acol, bcol, slab_t, slab_t2 = 0, kind = 0;     // kind 0: 128-row tile, 1: strip, 2: 256-row tile, 3: wide strip
+    bool diag = false;
+    const auto tri = [](int ti, int tj) { return ti * (ti + 1) / 2 + tj; };
+    if (BIG) {
+        const int R = nfull / 2, nbig = R * R, nsmall = R + (nfull & 1) * nfull, nwide = nstrip * (nfull + 1) / 4;
+        if (u < nbig) {                                        // tall tile (a, b), u = a^2 + b
+            int a = (int)sqrtf((float)u);
+            while ((a + 1) * (a + 1) <= u) ++a;
+            while (a * a > u) --a;
+            const int b = u - a * a;
+            acol = 2 * a * B; bcol = b * B; slab_t = tri(2 * a, b); slab_t2 = tri(2 * a + 1, b); kind = 2;
+            diag = side != nullptr && b == 2 * a;
+        } else if (u < nbig + nwide) {                         // wide strip tile: strip tiles 4q .. 4q+3
+            const int q = u - nbig;
+            acol = nfull * B; bcol = 4 * q * B; slab_t = tri(nfull, 4 * q); kind = 3;
+            diag = side != nullptr && nfull >= 4 * q && nfull < 4 * q + 4;
+        } else if (u < nbig + nwide + R) {                     // diagonal block of the second row of a pair
+            const int i = 2 * (u - nbig - nwide) + 1;
+            acol = bcol = i * B; slab_t = tri(i, i);
+        } else if (u < nbig + nwide + nsmall) {                // unpaired last block row
+            const int i = nfull - 1, b = u - nbig - nwide - R;
+            acol = i * B; bcol = b * B; slab_t = tri(i, b); diag = side != nullptr && b == i;
+        } else {                                               // the strip tiles that do not fill a wide one
+            const int tj = 4 * nwide + u - nbig - nwide - nsmall;
+            acol = nfull * B; bcol = tj * B; slab_t = tri(nfull, tj); kind = 1; diag = side != nullptr && tj == nfull;
+        }
+    } else {
+        const int noff = nfull * (nfull - 1) / 2;
+        if (u < nfull) {                                       // diagonal tiles (they also carry the side vector)
+            acol = bcol = u * B; slab_t = tri(u, u); diag = side != nullptr;
+        } else if (u < nfull + noff) {                         // strictly lower tiles: u = (ti-1) ti / 2 + tj
+            u -= nfull;
+            int tq = (int)((sqrtf(8.0f * u + 1.0f) - 1.0f) * 0.5f);
+            while ((tq + 1) * (tq + 2) / 2 <= u) ++tq;
+            while (tq * (tq + 1) / 2 > u) --tq;
+            const int ti = tq + 1, tj = u - tq * (tq + 1) / 2;
+            acol = ti * B; bcol = tj * B; slab_t = tri(ti, tj);
+        } else {                                               // strip tiles
+            const int tj = u - nfull - noff;
+            acol = nfull * B; bcol = tj * B; slab_t = tri(nfull, tj); kind = 1; diag = side != nullptr && tj == nfull;
+        }
+    }
+    int64_t r0, r1;
+    rs.range(split, r0, r1);
+    double* slab = slabs + ((int64_t)split * ntile_all + slab_t) * (B * B);
+    double* slab2 = slabs + ((int64_t)split * ntile_all + slab_t2) * (B * B);
+    double* sideout = sidepart + (int64_t)split * ld + acol;
+    if (kind == 1) { gram_body<SCfg, WEIGHT, true>(Phi, ld, w, side, r0, r1, chunk, acol, bcol, diag, sideout, slab, nullptr, smem_raw); TRACE_END(kind); return; }
+    if constexpr (BIG) {
+        if (kind == 2) { gram_body<BCfg, WEIGHT, false>(Phi, ld, w, side, r0, r1, chunk, acol, bcol, diag, sideout, slab, slab2, smem_raw); TRACE_END(kind); return; }
+        if (kind == 3) { gram_body<WCfg, WEIGHT, true>(Phi, ld, w, side, r0, r1, chunk, acol, bcol, diag, sideout, slab, nullptr, smem_raw); TRACE_END(kind); return; }
+    }
+    gram_body<Cfg, WEIGHT, false>(Phi, ld, w, side, r0, r1, chunk, acol, bcol, diag, sideout, slab, nullptr, smem_raw);
+    TRACE_END(kind);
+}
+
+// Row tile ti0 + (t / ntn) of the output (tiles are 128 rows apart whatever Cfg::BM is: a narrower Cfg multiplies only the
+// first BM rows of its tile and zeroes the rest of the 128 x 128 slab)
+//   PLAIN: the B operand is a stored matrix (Phi[n][j], j < J; Pb unused) instead of Zbar formed from Phi and Phibar
+template <class Cfg, typename S, bool PLAIN = false>
+__global__ __launch_bounds__(Cfg::THREADS) void xtz_kernel(
+    const double* __restrict__ Xt, int Dp, const S* __restrict__ Phi, const S* __restrict__ Pb, int64_t ld, int J, int64_t Np,
+    int64_t rows_per_split, int64_t chunk, int ntn, int ntile, int ntile_all, int ti0, double* __restrict__ slabs) {
+    typedef typename Cfg::T T;
+    static_assert(Cfg::BN == 128 && Cfg::BM <= 128, "slabs are 128 x 128");
+    SMEM_DECL;
+    T* smem = reinterpret_cast<T*>(smem_raw);
+    const unsigned wid = xcd_remap(blockIdx.x, gridDim.x);
+    const int t = (int)(wid % ntile), split = (int)(wid / ntile);
+    const int ti = ti0 + t / ntn, tj = t % ntn;
+    const int64_t r0 = (int64_t)split * rows_per_split;
+    const int64_t r1 = r0 + rows_per_split < Np ? r0 + rows_per_split : Np;
+    double* slab = slabs + ((int64_t)split * ntile_all + ti * ntn + tj) * (128 * 128);
+    typename Cfg::MTr::acc_t acc[Cfg::TM][Cfg::TN];
+    bool first = true;
+    for (int64_t c0 = r0; c0 < r1 || first; c0 += chunk) {
+        const int64_t c1 = c0 + chunk < r1 ? c0 + chunk : r1;
+        acc_zero<Cfg>(acc);
+        if (c0 < r1) {
+            NatLoader<double, T, Cfg::BM, Cfg::BK, Cfg::LDA, Cfg::THREADS, false, true> la(
+                Xt + c0 * Dp + (int64_t)ti * 128, Dp, threadIdx.x, nullptr, Dp - ti * 128);
+            if constexpr (PLAIN) {
+                NatLoader<S, T, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS, false, true> lb(Phi + c0 * ld + tj * Cfg::BN, ld, threadIdx.x, nullptr,
+                                                                                         J - tj * Cfg::BN);
+                tile_mainloop<Cfg>(la, lb, (int)((c1 - c0) / Cfg::BK), acc, smem);
+            } else {
+                ZbarLoader<S, T, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS> lb(Phi + c0 * ld, Pb + c0 * ld, ld, J, tj * Cfg::BN, threadIdx.x);
+                tile_mainloop<Cfg>(la, lb, (int)((c1 - c0) / Cfg::BK), acc, smem);
+            }
+        }
+        slab_flush<Cfg>(acc, slab, first);
+        first = false;
+    }
+    if (Cfg::BM < 128)
+        for (int e = threadIdx.x; e < (128 - Cfg::BM) * 128; e += Cfg::THREADS) slab[Cfg::BM * 128 + e] = 0.0;
+}
+
+template <typename T>
+int GramKernels<T>::gram_jobs(const Geom& g) { return gram_jobs_per_split<sizeof(T) == 4>(g.gfull, g.gstrip); }
+
+// Row splits: enough workgroups (>> 512 resident) that faster CUs can take more of them, but long jobs -- at least 5120
+// rows per unit (fp32) -- so that the slab traffic (nsplit x K^2/2 x 8 B written and re-read by the reduction) and the
+// per-job prologue stay small.  Measured (profiles/r01_tuning.md): the fp32 job list (tall tiles, 89 jobs per split at
+// K = 2112) is fastest at 48 units for N = 2.5e5..1e6 and at Np/5120 below that.  From 16 units on they are dealt to the
+// 8 XCD groups and the last unit of each group is tapered (kernels.h: RowSplits).
+RowSplits gram_row_splits(int jobs, int64_t Np, bool f32, int nsplit_override, int taper) {
+    int64_t s = ((f32 ? 4224 : 6144) + jobs - 1) / jobs;
+    const int64_t smax = std::max<int64_t>(Np / (f32 ? 5120 : 2048), 1);
+    if (s > smax) s = smax;
+    // small problems (the job list would leave most of the 512 workgroup slots empty): 64-row granules, as many
+    // splits as fill the slots -- each workgroup's k-loop is a chain of dependent fetches, so fewer rows per job
+    // is what shortens the launch (Boston shape, 512 rows: 80 -> 25 us)
+    int gran = 256;
+    if (jobs * s < 256 && Np / 64 > s) { gran = 64; s = std::min<int64_t>(Np / 64, (512 + jobs - 1) / jobs); }
+    if (nsplit_override > 0) s = std::min<int64_t>(nsplit_override, Np / gran);
+    if (s < 1) s = 1;
+    RowSplits rs;
+    rs.gran = gran; rs.nrb = Np / gran;
+    // the taper pays once a group has at least 5 units; below that its extra slabs cost more in the reduction than the tail
+    // option value 1 (default): 1/2, 1/4, 1/8, 1/8; values t >= 2: t + 2 halvings
+    if (s >= 16) { rs.groups = 8; rs.units = (int)((s + 4) / 8); rs.taper = taper && rs.units >= 5 ? (taper == 1 ? 3 : taper + 2) : 0; }
+    else { rs.groups = 1; rs.units = (int)s; rs.taper = 0; }
+    rs.nsplit = rs.groups * rs.per_group();
+    return rs;
+}
+
+template <typename T>
+void GramKernels<T>::gram(const Geom& g, const T* Phi, const double* w, const double* side, const RowSplits& rs, int64_t chunk,
+                          double* slabs, double* sidepart, hipStream_t st) {
+    typedef typename GramCfg<T, 128>::type Cfg;
+    typedef typename GramStripCfg<T>::type SCfg;
+    typedef typename GramBigCfg<T>::type BCfg;
+    typedef typename GramWideCfg<T>::type WCfg;
+    constexpr bool BIG = sizeof(T) == 4;
+    const int njobs = gram_jobs(g) * rs.nsplit;
+    if (chunk <= 0 || chunk > g.Np) chunk = g.Np;
+    chunk = round_up(chunk, 256);                              // splits start and end on 64- or 256-row granules
+    constexpr int L1 = Cfg::LDS_BYTES > SCfg::LDS_BYTES ? Cfg::LDS_BYTES : SCfg::LDS_BYTES;
+    constexpr int L2 = BIG && BCfg::LDS_BYTES > L1 ? BCfg::LDS_BYTES : L1;
+    constexpr int LDS = BIG && WCfg::LDS_BYTES > L2 ? WCfg::LDS_BYTES : L2;
+    static_assert(2 * LDS <= 160 * 1024, "two workgroups per CU");
+    const auto launch = [&](auto kernel) {
+        allow_big_lds(kernel, LDS);
+        hipLaunchKernelGGL(kernel, dim3(njobs), dim3(Cfg::THREADS), LDS, st, Phi, (int64_t)g.Kp, w, side, rs, chunk, g.gfull, g.gstrip,
+                           sidepart, slabs);
+    };
+    if (w) launch(gram_kernel<Cfg, SCfg, BCfg, WCfg, true, BIG>);
+    else launch(gram_kernel<Cfg, SCfg, BCfg, WCfg, false, BIG>);
+}
+
+// A^T B over the rows, A (Np x Dp, fp64) and B either Zbar formed in the loader (PLAIN false: Bsrc = Phi, Bsrc2 = Phibar) or the
+// stored matrix Bsrc (Np x J live columns, leading dimension ldb); slabs: nsplit x (ceil(Dp/128) x ceil(J/128)) tiles
+template <typename T, bool PLAIN>
+static void tn_product(const double* A, int Dp, const T* Bsrc, const T* Bsrc2, int64_t ldb, int J, int64_t Np, int nsplit, int64_t chunk,
+                       double* slabs, hipStream_t st) {
+    const int ntm = (Dp + 127) / 128, ntn = (J + 127) / 128;
+    const int64_t rps = round_up((Np + nsplit - 1) / nsplit, 64);
+    if (chunk <= 0 || chunk > rps) chunk = rps;
+    chunk = round_up(chunk, 16);
+    const auto launch = [&](auto cfg, int ti0, int nti) {
+        typedef typename decltype(cfg)::type Cfg;
+        if (nti <= 0) return;
+        allow_big_lds(xtz_kernel<Cfg, T, PLAIN>, Cfg::LDS_BYTES);
+        hipLaunchKernelGGL((xtz_kernel<Cfg, T, PLAIN>), dim3(nti * ntn * nsplit), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st,
+                           A, Dp, Bsrc, Bsrc2, ldb, J, Np, rps, chunk, ntn, nti * ntn, ntm * ntn, ti0, slabs);
+    };
+    const int last = Dp - 128 * (ntm - 1);
+    const int nfull = last > 96 ? ntm : ntm - 1;
+    launch(XtzCfg<T>{}, 0, nfull);
+    if (nfull < ntm) {
+        if (last <= 64) launch(Xtz64Cfg<T>{}, nfull, 1);
+        else launch(Xtz96Cfg<T>{}, nfull, 1);
+    }
+}
+template <typename T>
+void GramKernels<T>::tn_plain(const double* A, int Dp, const T* Bm, int64_t ldb, int J, int64_t Np, int nsplit, int64_t chunk, double* slabs,
+                               hipStream_t st) {
+    tn_product<T, true>(A, Dp, Bm, nullptr, ldb, J, Np, nsplit, chunk, slabs, st);
+}
+
+// Zbar[n][j] = Phi[n][j] Phibar[n][J+j] - Phi[n][J+j] Phibar[n][j], j < J, written over Phibar[n][j] (the cosine half of Phibar
+// is dead afterwards; its sine half stays until the caller overwrites it)
+template <typename T>
+__global__ __launch_bounds__(256) void zbar_kernel(const T* __restrict__ Phi, T* Pb, int64_t ld, int J, int64_t Np) {
+    const int jv = (J + 3) / 4;                                        // four columns per thread where J allows vector access
+    const int64_t total = Np * jv;
+    const bool vec = (J % 4 == 0) && sizeof(T) == 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t n = i / jv; const int j0 = (int)(i - n * jv) * 4;
+        const T* f = Phi + n * ld; T* b = Pb + n * ld;
+        if (vec) {
+            typedef T t4 __attribute__((ext_vector_type(4)));
+            const t4 fc = *reinterpret_cast<const t4*>(f + j0), fs = *reinterpret_cast<const t4*>(f + J + j0);
+            const t4 bc = *reinterpret_cast<const t4*>(b + j0), bs = *reinterpret_cast<const t4*>(b + J + j0);
+            *reinterpret_cast<t4*>(b + j0) = fc * bs - fs * bc;
+        } else {
+            for (int e = 0; e < 4 && j0 + e < J; ++e) { const int j = j0 + e; b[j] = f[j] * b[J + j] - f[J + j] * b[j]; }
+        }
+    }
+}
+template <typename T>
+void GramKernels<T>::zbar_inplace(const Geom& g, const T* Phi, T* Phibar, hipStream_t st) {
+    hipLaunchKernelGGL(zbar_kernel<T>, dim3(8192), dim3(256), 0, st, Phi, Phibar, (int64_t)g.Kp, g.J, g.Np);
+}
+// Rsel (typed, leading dimension Kp, Kp rows): rows j < S the identity, rows S + m the row m of r_F, zero elsewhere -- the operand of
+// U = Zbar . Rsel = Zbar_L + Zbar_M r_F
+template <typename T>
+__global__ void rsel_kernel(const double* __restrict__ params, int D, int S, int M, T* __restrict__ out, int Kp, int ncol) {
+    const int64_t total = (int64_t)Kp * ncol;
+    const double* rF = params + 3 + (int64_t)D * S;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int k = (int)(i / ncol), c = (int)(i % ncol);
+        T v = 0;
+        if (c < S) { if (k < S) v = k == c ? (T)1 : (T)0; else if (k < S + M) v = (T)rF[(int64_t)(k - S) * S + c]; }
+        out[(int64_t)k * Kp + c] = v;
+    }
+}
+template <typename T>
+void GramKernels<T>::rsel(const Geom& g, const double* params, T* out, hipStream_t st) {
+    hipLaunchKernelGGL(rsel_kernel<T>, dim3(1024), dim3(256), 0, st, params, g.D, g.S, g.M, out, g.Kp, (int)round_up(g.S, 64));
+}
+template <typename T>
+void GramKernels<T>::xtz(const Geom& g, const double* Xt, const T* Phi, const T* Phibar, int nsplit, int64_t chunk, double* slabs,
+                          hipStream_t st) {
+    tn_product<T, false>(Xt, g.Dp, Phi, Phibar, (int64_t)g.Kp, g.J, g.Np, nsplit, chunk, slabs, st);
+}
+template struct GramKernels<double>;
+template struct GramKernels<float>;
+
+// --------------------------------------------------------------------------
+// reductions (deterministic: fixed order over splits)
+// --------------------------------------------------------------------------
+// packed lower-tile layout of a symmetric Kp x Kp matrix: tile (ti >= tj) number t = ti(ti+1)/2 + tj holds
+// its B x B elements row-major at [t*B*B, (t+1)*B*B) -- what the all-reduce of a sharded run moves
+// (K^2/2 instead of K^2 doubles).
+__global__ __launch_bounds__(256) void reduce_tri_kernel(const double* __restrict__ slabs, int nsplit, int ntiles, int B,
+                                                         double* __restrict__ packed) {
+    const int t = blockIdx.x;
+    for (int e = blockIdx.y * 256 + threadIdx.x; e < B * B; e += gridDim.y * 256) {
+        double s = 0;
+        for (int sp = 0; sp < nsplit; ++sp) s += slabs[((int64_t)sp * ntiles + t) * (B * B) + e];
+        packed[(int64_t)t * B * B + e] = s;
+    }
+}
+void reduce_tri_tiles(const double* slabs, int nsplit, int nts, int tile, double* packed, hipStream_t st) {
+    const int ntiles = nts * (nts + 1) / 2;
+    hipLaunchKernelGGL(reduce_tri_kernel, dim3(ntiles, 16), dim3(256), 0, st, slabs, nsplit, ntiles, tile, packed);
+}
+// vec[j] = sum over splits of the Gram's side partials for j < ncov (columns covered by diagonal tiles), 0 beyond
+__global__ void reduce_side_kernel(const double* __restrict__ sidepart, int nsplit, int Kp, int ncov, double* __restrict__ vec) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= Kp) return;
+    double s = 0;
+    if (j < ncov)
+        for (int sp = 0; sp < nsplit; ++sp) s += sidepart[(int64_t)sp * Kp + j];
+    vec[j] = s;
+}
+void reduce_side(const double* sidepart, int nsplit, int Kp, int ncov, double* vec, hipStream_t st) {
+    hipLaunchKernelGGL(reduce_side_kernel, dim3((Kp + 255) / 256), dim3(256), 0, st, sidepart, nsplit, Kp, ncov, vec);
+}
+// full symmetric matrix (ld = Kp) from the packed lower tiles; diagonal tiles carry both triangles
+__global__ __launch_bounds__(256) void unpack_tri_kernel(const double* __restrict__ packed, int B, double* __restrict__ full, int64_t ld) {
+    const int t = blockIdx.x;
+    int ti = (int)((sqrtf(8.0f * t + 1.0f) - 1.0f) * 0.5f);
+    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    while (ti * (ti + 1) / 2 > t) --ti;
+    const int tj = t - ti * (ti + 1) / 2;
+    for (int e = blockIdx.y * 256 + threadIdx.x; e < B * B; e += gridDim.y * 256) {
+        const double v = packed[(int64_t)t * B * B + e];
+        const int i = ti * B + e / B, j = tj * B + e % B;
+        full[(int64_t)i * ld + j] = v;
+        if (ti != tj) full[(int64_t)j * ld + i] = v;
+    }
+}
+void unpack_tri_tiles(const double* packed, int nts, int tile, double* full, int64_t ld, hipStream_t st) {
+    hipLaunchKernelGGL(unpack_tri_kernel, dim3(nts * (nts + 1) / 2, 16), dim3(256), 0, st, packed, tile, full, ld);
+}
+
+__global__ __launch_bounds__(256) void reduce_full_kernel(const double* __restrict__ slabs, int nsplit, int ntiles, int ntn,
+                                                          double* __restrict__ out, int64_t ldo) {
+    constexpr int B = 128;
+    const int t = blockIdx.x, ti = t / ntn, tj = t % ntn;
+    for (int e = blockIdx.y * 256 + threadIdx.x; e < B * B; e += gridDim.y * 256) {
+        double s = 0;
+        for (int sp = 0; sp < nsplit; ++sp) s += slabs[((int64_t)sp * ntiles + t) * (B * B) + e];
+        out[(int64_t)(ti * B + e / B) * ldo + tj * B + e % B] = s;
+    }
+}
+void reduce_full_tiles(const double* slabs, int nsplit, int ntm, int ntn, double* out, int64_t ldo, hipStream_t st) {
+    // few tiles, many splits: 64 workgroups per tile keep the 150 MB of slabs streaming (16: 210 us at the headline shape)
+    hipLaunchKernelGGL(reduce_full_kernel, dim3(ntm * ntn, 64), dim3(256), 0, st, slabs, nsplit, ntm * ntn, ntn, out, ldo);
+}

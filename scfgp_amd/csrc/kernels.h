@@ -52,87 +52,29 @@ struct RowSplits {
 };
 RowSplits gram_row_splits(int jobs_per_split, int64_t Np, bool f32, int nsplit_override, int taper);
 
-// Table-driven schedule of the fp32 Gram products ("lock-step plan", option gram_plan).  The split plan above lets every
-// workgroup stream its own rows: its re-reads of Phi miss the 4 MB L2 of its XCD (98 GB of fabric traffic per launch against
-// 8.45 GB of Phi at the headline shape, profiles/r03_pmc_gram_jobs.json).  Here every XCD owns 1/8 of the rows and its 64
-// resident workgroups sweep those rows TOGETHER, one tall tile each from the first row to the last, so a row fetched by the
-// leading workgroup is an L2 hit for the 63 behind it (a workgroup that runs ahead pays the misses and falls back: the pack
-// holds itself together).  Tiles beyond the 64 x (number of full waves) tall ones are cut into row slices and follow,
-// slice-major.  A job is one entry; entries are XCD-major in launch order (xcd_remap hands XCD x the x-th contiguous share).
-struct GramJob {
-    int acol, bcol;        // first column of the A panel (tile rows) and of the B panel (tile columns)
-    int kind;              // 0: 128 x 128, 1: 64 x 128 strip, 2: 256 x 128 tall, 3: 64 x 512 wide strip
-    int diag;              // carries the side vector for its A columns
-    int64_t r0, r1;        // rows
-    int part;              // partial index: slabs[part][tile], sidepart[part][.]
-    int tile, tile2;       // output tile(s) in packed lower-triangle numbering (tile2: second row block of a tall tile)
-    int pad;
-};
-struct GramPlan { const GramJob* jobs = nullptr; int njobs = 0, nparts = 0; const int* cnt = nullptr; };     // device pointers
-// host side: the plan for the fp32 job list; cnt[t] = partials of output tile t.  False when the problem is too small for it.
-bool gram_lockstep_plan(const Geom& g, int64_t Np, std::vector<GramJob>& jobs, std::vector<int>& cnt, int& nparts);
-
 // operands of the phase projection: Fall (Dp x Jp); Lall (Dp x round_up(Sp,64)) = [l_F | e_D], Rall (Sp x Jp) =
 // [[I_S | r_F^T]; phase offsets], Tt (Np x Sp) scratch for T~
 struct Projection { const double* Fall; const double* Lall; const double* Rall; double* Tt; };
 
-// bf16-plane copies of the operands of one apply product (SCFGP_BF16X3 mode)
-struct Bf3Planes {
-    const void* rows = nullptr;       // Phi:  bf3_split_rows
-    const void* matrix16 = nullptr;   // B^T / Abar^T: bf3_presplit16
-    int dma = 0;                      // fp32 mode: apply tiles by LDS-DMA (1 = 128 wide, 2 = 256 wide, 3 = 256 for Phi.B and 128 for Phibar); needs no planes
-};
-
+// ---- fmap.hip: feature map and operand staging ---------------------------------------------------------------------
 template <typename T>
-struct SweepKernels {
+struct FmapKernels {
     // Phi = s*[cos Z, sin Z], Z = X~ . Fall  or, F = l_F r_F^T being rank S (SCFGP.py:83), Z = (X~ . Lall) . Rall
     //                                                            (SCFGP.py:98-102 / :139-142)
-    //   Zout (experiment, else NULL): also the phases Z (Np x Jp; fp32: reduced to [-pi, pi]) for gram()'s Zsrc
-    static void featuremap(const Geom& g, const double* Xt, const Projection& pr, const Scal* sc, T* Phi, hipStream_t st, T* Zout = nullptr);
+    static void featuremap(const Geom& g, const double* Xt, const Projection& pr, const Scal* sc, T* Phi, hipStream_t st);
+    // fp64 Kp x Kp matrix -> sweep operand (type T, rows/cols >= K zeroed)
+    static void convert(const double* src, T* dst, int K, int Kp, hipStream_t st);
+    static void convert_transposed(const double* src, T* dst, int K, int Kp, hipStream_t st);      // dst = src^T on the K x K block
+};
+
+// ---- gram.hip: TN products (contraction over the rows) ---------------------------------------------------------------
+template <typename T>
+struct GramKernels {
     // lower tiles of  Phi^T diag(w) Phi  into per-split fp64 slabs (SCFGP.py:104; weighted: backward of :111-113)
     // and, from the diagonal tiles, sidepart[split][Kp] = partials of Phi^T side (side = y: SCFGP.py:108)
-    //   Zsrc (experiment, unweighted product only): read the phases instead of Phi and form s cos / s sin in the loaders
     static void gram(const Geom& g, const T* Phi, const double* w, const double* side, const RowSplits& rs, int64_t chunk,
-                     double* slabs, double* sidepart, hipStream_t st, const T* Zsrc = nullptr, double zscale = 0.0);
+                     double* slabs, double* sidepart, hipStream_t st);
     static int gram_jobs(const Geom& g);        // workgroups per row split of gram() (sizes the row split)
-    // the same products scheduled by a job table (fp32 list only); slabs[part][tile], sidepart[part][Kp] (zeroed here)
-    static void gram_planned(const Geom& g, const T* Phi, const double* w, const double* side, const GramPlan& plan, int64_t chunk,
-                             double* slabs, double* sidepart, hipStream_t st);
-    // V = Phi . Bm, vpart[jt][n] = sum_{j in tile} Phi[n][j] V[n][j]    (SCFGP.py:112); column tile jt also forms
-    // mupart[jt][n] = its slice of mu = Phi . alpha (SCFGP.py:111 / :143) from the rows it stages
-    //   bf3 (fp32 only): split-precision MFMA tiles (tile_bf16x3.h), compute mode SCFGP_BF16X3; Bm / Abar then point to
-    //   the matrix pre-split by bf3_presplit()
-    //   planes (bf3 only): row planes of Phi and 16-deep matrix planes of Bm for the DMA-fed 256-wide tiles (tile_bf16x3_dma.h)
-    static void apply_v(const Geom& g, const T* Phi, const T* Bm, T* V, double* vpart, const double* alpha, double* mupart,
-                        hipStream_t st, bool bf3 = false, const Bf3Planes* planes = nullptr);
-    // predict: vpart[jt][n] = slices of v_n = || Li phi_n ||^2 (the reference's rowsum((Phi Li^T)^2), SCFGP.py:144) from the
-    // triangular product Phi . LiT, LiT[k][j] = Li[j][k] (convert_transposed); mupart as apply_v.  Half the flops of apply_v.
-    static void apply_predict(const Geom& g, const T* Phi, const T* LiT, double* vpart, const double* alpha, double* mupart,
-                              hipStream_t st, bool bf3 = false);
-    // Factor form of pass 2 (the reference's own products, SCFGP/SCFGP.py:112: v = rowsum((Phi Li^T)^2)): C = Phi . LiT
-    // (triangular: half the flops), vpart = slices of rowsum(C^2), mupart as apply_v; then V = C . Li = Phi B (triangular).
-    // Li / LiT: the typed K x K copies of L^-1 and its transpose (padding zeroed).  Rounding errors of C are amplified by
-    // cond(L) = sqrt(cond(A)) where those of V = Phi . B computed directly are amplified by cond(A)
-    // (profiles/r03_c3_owner.md); planes: only `dma` is used.
-    static void apply_c(const Geom& g, const T* Phi, const T* LiT, const T* Li, T* C, double* vpart, const double* alpha,
-                        double* mupart, hipStream_t st, const Bf3Planes* planes = nullptr);
-    static void apply_vc(const Geom& g, const T* C, const T* Li, const T* LiT, T* V, hipStream_t st, const Bf3Planes* planes = nullptr);
-    // Phibar = 2 Phi.Abar + 2 q V + p alpha^T + y ut^T  (in place over V); bpart[block] = partial of
-    // bbar = sum Phibar o Phi.  Returns the number of blocks (= partials written).
-    static int apply_phibar(const Geom& g, const T* Phi, const T* Abar, T* V, const double* p, const double* q,
-                            const double* y, const double* alpha, const double* ut, double* bpart, hipStream_t st, bool bf3 = false,
-                            const Bf3Planes* planes = nullptr);
-    // the same product with the Zbar epilogue (Zbar over V's cosine half, Phibar never stored): -1 when it does not apply
-    static int apply_zbar(const Geom& g, const T* Phi, const T* Abar, T* V, const double* p, const double* q,
-                          const double* y, const double* alpha, const double* ut, double* bpart, hipStream_t st,
-                          const Bf3Planes* planes);
-    static int apply_blocks(const Geom& g);
-    // per-row moments and adjoint scalars; block partials of (T2, kbar)  (SCFGP.py:111-113,121-124)
-    static void rowstats(const Geom& g, const double* mupart, const double* vpart, const double* y,
-                         const Scal* sc, double* p, double* q, double* partial, int nblocks, hipStream_t st);
-    // predictive mean / std                                          (SCFGP.py:143-144)
-    static void rowpredict(const Geom& g, const double* mupart, const double* vpart, const Scal* sc, double* mu, double* sd,
-                           hipStream_t st);
     // X~^T Zbar into per-split fp64 slabs, Zbar[n][j] = Phi[n][j] Phibar[n][J+j] - Phi[n][J+j] Phibar[n][j]
     // formed inside the operand loader
     static void xtz(const Geom& g, const double* Xt, const T* Phi, const T* Phibar, int nsplit, int64_t chunk, double* slabs,
@@ -143,40 +85,62 @@ struct SweepKernels {
     static void zbar_inplace(const Geom& g, const T* Phi, T* Phibar, hipStream_t st);
     // Rsel = [I_S ; r_F] as a typed Kp x Kp-strided operand (round_up(S,64) columns written)
     static void rsel(const Geom& g, const double* params, T* out, hipStream_t st);
-    // Out = A . Bm over k < Kc for ncols columns (64-wide tiles, leading dimension Kp everywhere; Bm[k][c] = 0 for k < c)
-    static void apply_plain(const Geom& g, const T* A, const T* Bm, T* Out, int Kc, int ncols, hipStream_t st);
     // A^T Bm over the rows into per-split slabs: A (Np x Dp fp64), Bm (Np x J live columns, leading dimension ldb)
     static void tn_plain(const double* A, int Dp, const T* Bm, int64_t ldb, int J, int64_t Np, int nsplit, int64_t chunk, double* slabs,
                          hipStream_t st);
-    // fp64 Kp x Kp matrix -> sweep operand (type T, rows/cols >= K zeroed)
-    static void convert(const double* src, T* dst, int K, int Kp, hipStream_t st);
-    static void convert_transposed(const double* src, T* dst, int K, int Kp, hipStream_t st);      // dst = src^T on the K x K block
 };
+
+// ---- apply.hip: NT products (contraction over the feature columns) and the per-row statistics ------------------------
+//   dma: 0 = operands staged through registers; 1 / 2 = the full 128-column tiles by LDS-DMA, 128 / 256 wide (256: fp32 only)
+template <typename T>
+struct ApplyKernels {
+    // V = Phi . Bm, vpart[jt][n] = sum_{j in tile} Phi[n][j] V[n][j]    (SCFGP.py:112); column tile jt also forms
+    // mupart[jt][n] = its slice of mu = Phi . alpha (SCFGP.py:111 / :143) from the rows it stages
+    static void apply_v(const Geom& g, const T* Phi, const T* Bm, T* V, double* vpart, const double* alpha, double* mupart,
+                        hipStream_t st, int dma = 0);
+    // predict: vpart[jt][n] = slices of v_n = || Li phi_n ||^2 (the reference's rowsum((Phi Li^T)^2), SCFGP.py:144) from the
+    // triangular product Phi . LiT, LiT[k][j] = Li[j][k] (convert_transposed); mupart as apply_v.  Half the flops of apply_v.
+    static void apply_predict(const Geom& g, const T* Phi, const T* LiT, double* vpart, const double* alpha, double* mupart,
+                              hipStream_t st);
+    // Factor form of pass 2 (the reference's own products, SCFGP/SCFGP.py:112: v = rowsum((Phi Li^T)^2)): C = Phi . LiT
+    // (triangular: half the flops), vpart = slices of rowsum(C^2), mupart as apply_v; then V = C . Li = Phi B (triangular).
+    // Li / LiT: the typed K x K copies of L^-1 and its transpose (padding zeroed).  Rounding errors of C are amplified by
+    // cond(L) = sqrt(cond(A)) where those of V = Phi . B computed directly are amplified by cond(A)
+    // (profiles/r03_c3_owner.md).
+    static void apply_c(const Geom& g, const T* Phi, const T* LiT, const T* Li, T* C, double* vpart, const double* alpha,
+                        double* mupart, hipStream_t st, int dma = 0);
+    static void apply_vc(const Geom& g, const T* C, const T* Li, const T* LiT, T* V, hipStream_t st, int dma = 0);
+    // Phibar = 2 Phi.Abar + 2 q V + p alpha^T + y ut^T  (in place over V); bpart[block] = partial of
+    // bbar = sum Phibar o Phi.  Returns the number of blocks (= partials written).
+    static int apply_phibar(const Geom& g, const T* Phi, const T* Abar, T* V, const double* p, const double* q,
+                            const double* y, const double* alpha, const double* ut, double* bpart, hipStream_t st, int dma = 0);
+    static int apply_blocks(const Geom& g);
+    // Out = A . Bm over k < Kc for ncols columns (64-wide tiles, leading dimension Kp everywhere; Bm[k][c] = 0 for k < c)
+    static void apply_plain(const Geom& g, const T* A, const T* Bm, T* Out, int Kc, int ncols, hipStream_t st);
+    // per-row moments and adjoint scalars; block partials of (T2, kbar)  (SCFGP.py:111-113,121-124)
+    static void rowstats(const Geom& g, const double* mupart, const double* vpart, const double* y,
+                         const Scal* sc, double* p, double* q, double* partial, int nblocks, hipStream_t st);
+    // predictive mean / std                                          (SCFGP.py:143-144)
+    static void rowpredict(const Geom& g, const double* mupart, const double* vpart, const Scal* sc, double* mu, double* sd,
+                           hipStream_t st);
+};
+
+// everything that sweeps the rows, under one name
+template <typename T> struct SweepKernels : FmapKernels<T>, GramKernels<T>, ApplyKernels<T> {};
 
 // diagnostic builds only (-DSCFGP_TRACE): per-workgroup [start, end, xcc, kind] of the last Gram launch; -1 otherwise
 int64_t trace_read(void* host, int64_t max_bytes);
 int64_t chol_trace_read(void* host, int64_t max_bytes);     // per Cholesky step: 12 phase stamps of workgroup 0
 
-// fp32 Kp x Kp sweep operand -> bf16 plane layout of the split-precision apply product (Kp*Kp*6 bytes)
-void bf3_presplit(const float* M, void* out, int Kp, hipStream_t st);
-// the same matrix as 16-deep planes [k16][plane][Kp][16] (Kp*Kp*6 bytes), and a row-major fp32 matrix S (Np x Kp, leading
-// dimension ld) as row planes [k16][plane][Np][16] (Np*Kp*6 bytes): the operands of the DMA-fed tiles
-void bf3_presplit16(const float* M, void* out, int Kp, hipStream_t st);
-void bf3_split_rows(const float* S, int64_t ld, void* out, int64_t Np, int Kp, hipStream_t st);
-
 // ---- reductions ------------------------------------------------------------
 // packed lower tiles = sum over splits of the per-split lower-tile slabs (tile t = ti(ti+1)/2+tj, row-major)
 void reduce_tri_tiles(const double* slabs, int nsplit, int nts, int tile, double* packed, hipStream_t st);
-// the same with cnt[t] partials for output tile t (slabs[part][tile], parts 0 .. cnt[t]-1)
-void reduce_tri_tiles_cnt(const double* slabs, const int* cnt, int nts, int tile, double* packed, hipStream_t st);
 // packed lower tiles -> full symmetric Kp x Kp matrix
 void unpack_tri_tiles(const double* packed, int nts, int tile, double* full, int64_t ld, hipStream_t st);
 // out (ldo) = sum over splits of a full ntm x ntn tile grid of slabs
 void reduce_full_tiles(const double* slabs, int nsplit, int ntm, int ntn, double* out, int64_t ldo, hipStream_t st);
 // vec[j < ncov] = sum over splits of sidepart[split][j] (ld Kp), vec[ncov..Kp) = 0
 void reduce_side(const double* sidepart, int nsplit, int Kp, int ncov, double* vec, hipStream_t st);
-// out[i] = sum_s partial[s][i], i < n
-void reduce_rows(const double* partial, int nsplit, int64_t n, double* out, hipStream_t st);
 // scalars[slot0 + k] = sum_b partial[b*width + k], k < width (the partials are scratch: a large single-scalar sum is staged in place)
 void reduce_scalars(double* partial, int nblocks, int width, double* scalars, int slot0, hipStream_t st);
 // scalars[slot] = sum y^2

@@ -45,16 +45,16 @@ __device__ __forceinline__ void gemm64_body(const GemmArgs& a, int tm, int tn, d
             TrLoader<double, double, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS, false, false, 3> lb(a.B + (int64_t)tn * Cfg::BN * a.ldb + k0, a.ldb, threadIdx.x);
             tile_mainloop_deep3<Cfg>(la, lb, nkt, acc, smem);
         } else {
-            NatLoader<double, double, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS, false, false, false, false, 3> lb(a.B + (int64_t)k0 * a.ldb + tn * Cfg::BN, a.ldb, threadIdx.x);
+            NatLoader<double, double, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS, false, false, false, 3> lb(a.B + (int64_t)k0 * a.ldb + tn * Cfg::BN, a.ldb, threadIdx.x);
             tile_mainloop_deep3<Cfg>(la, lb, nkt, acc, smem);
         }
     } else {
-        NatLoader<double, double, Cfg::BM, Cfg::BK, Cfg::LDA, Cfg::THREADS, false, false, false, false, 3> la(a.A + (int64_t)k0 * a.lda + tm * Cfg::BM, a.lda, threadIdx.x);
+        NatLoader<double, double, Cfg::BM, Cfg::BK, Cfg::LDA, Cfg::THREADS, false, false, false, 3> la(a.A + (int64_t)k0 * a.lda + tm * Cfg::BM, a.lda, threadIdx.x);
         if (TRB) {
             TrLoader<double, double, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS, false, false, 3> lb(a.B + (int64_t)tn * Cfg::BN * a.ldb + k0, a.ldb, threadIdx.x);
             tile_mainloop_deep3<Cfg>(la, lb, nkt, acc, smem);
         } else {
-            NatLoader<double, double, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS, false, false, false, false, 3> lb(a.B + (int64_t)k0 * a.ldb + tn * Cfg::BN, a.ldb, threadIdx.x);
+            NatLoader<double, double, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS, false, false, false, 3> lb(a.B + (int64_t)k0 * a.ldb + tn * Cfg::BN, a.ldb, threadIdx.x);
             tile_mainloop_deep3<Cfg>(la, lb, nkt, acc, smem);
         }
     }

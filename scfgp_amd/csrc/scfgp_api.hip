@@ -28,12 +28,6 @@ static constexpr int64_t PRED_ROWS = 32768; // predict processes test rows in ch
 // gradient blocks, against fp64 mode is about SCFGP_ERR_PER_COND times the condition estimate (measured 7e-8 .. 2e-6 times
 // the estimate at estimates 4 .. 6.4e3: the estimate is a lower bound of cond_2 of varying tightness).  Level 1 keeps the predicted alpha error under 3e-6 (north star: 1e-5), level 2
 // the predicted gradient error under 3e-4 (SURVEY App. E acceptance: 1e-3 per block).
-#ifndef SCFGP_PASS3_PARTS
-#define SCFGP_PASS3_PARTS 1        // default number of row parts of pass 3 from 262144 rows up (1: off)
-#endif
-#ifndef SCFGP_GRAM_PLAN_DEFAULT
-#define SCFGP_GRAM_PLAN_DEFAULT 0
-#endif
 #ifndef SCFGP_COND_THRESHOLD
 #define SCFGP_COND_THRESHOLD 10.0
 #endif
@@ -70,13 +64,8 @@ struct scfgp_ctx {
     int dtype = 0, device = 0;
     hipStream_t st = nullptr; bool own_stream = false;
     hipStream_t copy_st = nullptr; hipEvent_t ev_factor = nullptr;          // alpha/Li D2H beside pass 2/3 ...
-    hipStream_t aux_st = nullptr; std::vector<hipEvent_t> ev_p3; int pass3_parts = -1;      // pass 3 in row parts (pass3_pipelined)
     // rank-S form of the backward projection: exchange 3 = [T~^T Zbar (Spp x Jp) ... | 8 scalars at Dpp*Jp | X~^T U (Dpp x Sq)]
     int lowrank_bwd = -1; int Spp = 0, Sq = 0; bool last_lrb = false;
-    // pass 3 without the Phibar round trip: the Phibar product's epilogue writes Zbar (SweepKernels::apply_zbar) where it applies
-    // (fp32 LDS-DMA tiles, J % 4 == 0).  Option zbar_fused: 0 off (default: measured 0.6 ms SLOWER at the headline shape -- the
-    // epilogue gains 1.7 ms, X~^T Zbar loses 1.1; profiles/r03_tuning.md), 1 on
-    int zbar_fused = 0; bool last_zfused = false;
     bool want_lrb() const {
         // T~ = [X l_F | 1] exists only when the forward projection goes through the S columns (g.lowrank), and U needs room in
         // Phibar's dead sine half
@@ -106,8 +95,8 @@ struct scfgp_ctx {
     double *d_xp1 = nullptr, *d_xp2 = nullptr; int64_t n_xp = 0, n_pk = 0;
     double *d_x1 = nullptr, *d_x2 = nullptr, *d_x3 = nullptr; int64_t n_x1 = 0, n_x2 = 0, n_x3 = 0; int Dpp = 0;
     double *d_Li = nullptr, *d_B = nullptr, *d_T1 = nullptr, *d_T2 = nullptr, *d_Abar = nullptr;
-    void *d_BT = nullptr, *d_AbarT = nullptr, *d_M3 = nullptr;     // d_M3: B / Abar split into bf16 planes (SCFGP_BF16X3)
-    void *d_M16 = nullptr, *d_P3 = nullptr; int64_t p3_cap = 0; int bf3_dma = 0, apply_dma = -1;   // apply_dma: -1 = by problem size   // 16-deep planes of B / Abar; row planes of Phi (DMA-fed tiles)
+    void *d_BT = nullptr, *d_AbarT = nullptr;                      // sweep operands: typed copies of B (or Li) and Abar (or Li^T)
+    int apply_dma = -1;                                            // option: -1 = by problem size, 0 off, 1 = 128-wide tiles, 2 = 256-wide (fp32)
     double *d_vecs = nullptr;            // beta, alpha, u, ut, alpha_pred (Kp each)
     double *d_scalars = nullptr, *d_yy = nullptr; int* d_flag = nullptr;
     double *d_slabs = nullptr; size_t slabs_bytes = 0;
@@ -123,11 +112,8 @@ struct scfgp_ctx {
     int use_graph = 1;
     // options
     int gram_nsplit = 0, gram_taper = 1, xtz_nsplit = 0; int64_t gram_chunk = 4096;
-    int fuse_fmap = 0; void* d_Z = nullptr; int64_t z_cap = 0;         // experiment: Gram of pass 1 fed from the phases
     RowSplits splits{};
-    // lock-step schedule of the fp32 Gram products (kernels.h: GramPlan); option gram_plan: 0 split plan, 1 lock-step plan
-    int gram_plan = SCFGP_GRAM_PLAN_DEFAULT; GramPlan plan{}; GramJob* d_gjobs = nullptr; int* d_gcnt = nullptr; int64_t plan_Np = -1;
-    // Precision escalation (fp32 / bf16x3 modes; profiles/r03_c3_owner.md).  The fp32 Gram products carry a relative error
+    // Precision escalation (fp32 mode; profiles/r03_c3_owner.md).  The fp32 Gram products carry a relative error
     // of ~6e-8 that reaches alpha / Li (pass 1) and the gradient (pass 2's V^T diag(q) V) multiplied by the condition of A,
     // so the K x K stage's free condition estimate decides how the two TN products are formed:
     //   level 0  both in fp32 MFMA (fp64 across 4096-row chunks)
@@ -161,21 +147,16 @@ struct scfgp_ctx {
 
     double* beta() { return d_vecs; }
     double* alpha() { return d_vecs + g.Kp; }
-    Bf3Planes planes() const {                                  // valid after pass 1 of the current working set
-        Bf3Planes pl;
-        if (bf3 && bf3_dma && g.K > 256 && d_P3 && p3_cap >= g.Np) { pl.rows = d_P3; pl.matrix16 = d_M16; }
-        // fp32 apply products by LDS-DMA (kernels_sweep.hip: apply_dma_kernel).  Auto: large problems only, 256-wide tiles for both
-        // products (round 2 shipped 128-wide tiles for Phibar, whose epilogue then wanted a second resident workgroup to hide
-        // behind; with the 16-byte epilogue of round 3 the 256-wide tile wins there too: profiles/r03_tuning.md); the small ones
-        // keep the loader-staged tiles, whose single 64-wide launch per product matters more there
-        const int auto_dma = g.K >= 1024 && g.Np >= 65536 ? 2 : 0;
-        pl.dma = !bf3 && dtype == SCFGP_F32 ? (apply_dma < 0 ? auto_dma : apply_dma) : 0;
-        return pl;
+    // the apply products by LDS-DMA (apply.hip: apply_dma_kernel).  Auto: large problems only (fp32: 256-wide tiles for both
+    // products, profiles/r03_tuning.md; fp64: 128-wide); the small ones keep the loader-staged tiles, whose single 64-wide
+    // launch per product matters more there
+    int dma() const {
+        const int auto_dma = g.K >= 1024 && g.Np >= 65536 ? (dtype == SCFGP_F32 ? 2 : 1) : 0;
+        return apply_dma < 0 ? auto_dma : apply_dma;
     }
     double* u() { return d_vecs + 2 * g.Kp; }
     double* ut() { return d_vecs + 3 * g.Kp; }
     double* alpha_pred() { return d_vecs + 4 * g.Kp; }
-    bool bf3 = false;                                                       // SCFGP_BF16X3: dtype is SCFGP_F32 plus split-precision products
     size_t tsize() const { return dtype == SCFGP_F32 ? 4 : 8; }
     double h_scale() const { return std::exp(h_params[1]) * std::sqrt(2.0 / g.M); }      // s = e^b sqrt(2/M) from the host copy
     KStage kstage() {
@@ -233,7 +214,7 @@ static void free_rows(scfgp_ctx* c) {
     c->Ncap = 0; c->slabs_bytes = 0;
 }
 
-// optional row buffers (fp64 features of an escalated pass 1, the experiments' phase matrix and bf16 row planes): sized
+// optional row buffers (fp64 features of an escalated pass 1, C of the factor form): sized
 // for the current working set, allocated HERE and never inside a pass -- a pass may be running under graph capture
 static int ensure_aux_rows(scfgp_ctx* c) {
     const Geom& g = c->g;
@@ -248,16 +229,6 @@ static int ensure_aux_rows(scfgp_ctx* c) {
         if (int rc = dmalloc(c, &c->d_C, c->tsize() * g.Np * g.Kp)) return rc;
         HIPCHK(c, hipMemsetAsync(c->d_C, 0, c->tsize() * g.Np * g.Kp, c->st));
         c->c_cap = g.Np;
-    }
-    if (c->fuse_fmap && c->z_cap < g.Np) {
-        dfree(c->d_Z); c->z_cap = 0;
-        if (int rc = dmalloc(c, &c->d_Z, c->tsize() * g.Np * g.Jp)) return rc;
-        c->z_cap = g.Np;
-    }
-    if (c->bf3 && c->bf3_dma && g.K > 256 && c->p3_cap < g.Np) {
-        dfree(c->d_P3); c->p3_cap = 0;
-        if (int rc = dmalloc(c, &c->d_P3, (size_t)6 * g.Np * g.Kp)) return rc;
-        c->p3_cap = g.Np;
     }
     return SCFGP_OK;
 }
@@ -278,23 +249,6 @@ static int ensure_rows(scfgp_ctx* c, int64_t N) {
         c->splits64 = gram_row_splits(SweepKernels<double>::gram_jobs(g), Np, false, c->gram_nsplit, c->gram_taper);
         gs = std::max(gs, c->splits64.nsplit);
     }
-    // lock-step plan of the fp32 Gram products: (re)built when the row count changes
-    if (c->dtype == SCFGP_F32 && c->gram_plan == 1) {
-        if (c->plan_Np != Np) {
-            std::vector<GramJob> jobs; std::vector<int> cnt; int nparts = 0;
-            c->plan = GramPlan{}; c->plan_Np = Np;
-            if (gram_lockstep_plan(g, Np, jobs, cnt, nparts)) {
-                HIPCHK(c, hipStreamSynchronize(c->st));
-                dfree(c->d_gjobs); dfree(c->d_gcnt);
-                if (int rc = dmalloc(c, &c->d_gjobs, sizeof(GramJob) * jobs.size())) return rc;
-                if (int rc = dmalloc(c, &c->d_gcnt, sizeof(int) * cnt.size())) return rc;
-                HIPCHK(c, hipMemcpy(c->d_gjobs, jobs.data(), sizeof(GramJob) * jobs.size(), hipMemcpyHostToDevice));
-                HIPCHK(c, hipMemcpy(c->d_gcnt, cnt.data(), sizeof(int) * cnt.size(), hipMemcpyHostToDevice));
-                c->plan.jobs = c->d_gjobs; c->plan.njobs = (int)jobs.size(); c->plan.nparts = nparts; c->plan.cnt = c->d_gcnt;
-            }
-        }
-        if (c->plan.jobs) gs = std::max(gs, c->plan.nparts);
-    } else { c->plan = GramPlan{}; c->plan_Np = -1; }
     const int xs = c->xtz_nsplit > 0 ? (int)std::min<int64_t>(c->xtz_nsplit, Np / 64) : xtz_split(ntx, Np);
     // Gram slabs are followed by the per-split side-vector partials (gs x Kp)
     // the two row-contracted products of the rank-S backward projection (pass3): (Spp x Jp) and (Dpp x Sq) tile grids
@@ -331,11 +285,10 @@ static int ensure_rows(scfgp_ctx* c, int64_t N) {
 }
 
 extern "C" int scfgp_create(scfgp_ctx** out, int D, int S, int M, int dtype, int device, void* stream) {
-    if (!out || D < 1 || S < 1 || M < 1 || (dtype != SCFGP_F64 && dtype != SCFGP_F32 && dtype != SCFGP_BF16X3)) return SCFGP_EARG;
+    if (!out || D < 1 || S < 1 || M < 1 || (dtype != SCFGP_F64 && dtype != SCFGP_F32)) return SCFGP_EARG;
     scfgp_ctx* c = new scfgp_ctx();
     *out = c;
-    c->bf3 = dtype == SCFGP_BF16X3;
-    c->dtype = c->bf3 ? SCFGP_F32 : dtype; c->device = device;
+    c->dtype = dtype; c->device = device;
     Geom& g = c->g;
     derive_geom(g, D, S, M);
     if (const char* e = getenv("SCFGP_LOWRANK")) g.lowrank = atoi(e) != 0;                       // tuning override
@@ -372,8 +325,6 @@ extern "C" int scfgp_create(scfgp_ctx** out, int D, int S, int M, int dtype, int
     if ((rc = dmalloc(c, &c->d_Abar, sizeof(double) * K2))) return rc;
     if ((rc = dmalloc(c, &c->d_BT, c->tsize() * K2))) return rc;        // sweep operands: typed, padding zeroed
     if ((rc = dmalloc(c, &c->d_AbarT, c->tsize() * K2))) return rc;
-    if (c->bf3 && (rc = dmalloc(c, &c->d_M3, 6 * K2))) return rc;
-    if (c->bf3 && (rc = dmalloc(c, &c->d_M16, 6 * K2))) return rc;
     if ((rc = dmalloc(c, &c->d_vecs, sizeof(double) * 5 * Kp))) return rc;
     if ((rc = dmalloc(c, &c->d_scalars, sizeof(double) * 32))) return rc;
     if ((rc = dmalloc(c, &c->d_yy, sizeof(double) * 8))) return rc;
@@ -396,10 +347,10 @@ extern "C" void scfgp_destroy(scfgp_ctx* c) {
     hipSetDevice(c->device);
     if (c->st) hipStreamSynchronize(c->st);
     free_rows(c);
-    dfree(c->d_Z); dfree(c->d_Phi64); dfree(c->d_C); dfree(c->d_gjobs); dfree(c->d_gcnt); dfree(c->d_Xraw); dfree(c->d_yraw); dfree(c->d_idx); dfree(c->d_xscale); dfree(c->d_yscale);
+    dfree(c->d_Phi64); dfree(c->d_C); dfree(c->d_Xraw); dfree(c->d_yraw); dfree(c->d_idx); dfree(c->d_xscale); dfree(c->d_yscale);
     dfree(c->d_params); dfree(c->d_F); dfree(c->d_Fall); dfree(c->d_Lall); dfree(c->d_Rall); dfree(c->d_sc); dfree(c->p_Tt);
     dfree(c->d_xp1); dfree(c->d_xp2); dfree(c->d_x1); dfree(c->d_x2); dfree(c->d_x3); dfree(c->d_Li); dfree(c->d_B); dfree(c->d_T1); dfree(c->d_T2);
-    dfree(c->d_Abar); dfree(c->d_BT); dfree(c->d_AbarT); dfree(c->d_M3); dfree(c->d_M16); dfree(c->d_P3); dfree(c->d_vecs); dfree(c->d_scalars); dfree(c->d_yy);
+    dfree(c->d_Abar); dfree(c->d_BT); dfree(c->d_AbarT); dfree(c->d_vecs); dfree(c->d_scalars); dfree(c->d_yy);
     dfree(c->d_flag); dfree(c->d_partial); dfree(c->d_work); dfree(c->d_grad);
     dfree(c->p_Xt); dfree(c->p_vpart); dfree(c->p_mupart); dfree(c->p_Phi);
     if (c->gexec) hipGraphExecDestroy(c->gexec);
@@ -407,8 +358,6 @@ extern "C" void scfgp_destroy(scfgp_ctx* c) {
     dfree(c->d_opt); dfree(c->d_tctr); dfree(c->d_hist);
     for (hipEvent_t e : c->pool) hipEventDestroy(e);
     if (c->copy_st) { hipStreamSynchronize(c->copy_st); hipStreamDestroy(c->copy_st); }
-    if (c->aux_st) { hipStreamSynchronize(c->aux_st); hipStreamDestroy(c->aux_st); }
-    for (hipEvent_t e : c->ev_p3) hipEventDestroy(e);
     if (c->ev_factor) hipEventDestroy(c->ev_factor);
     if (c->ev_fence) hipEventDestroy(c->ev_fence);
     if (c->h_pin) hipHostFree(c->h_pin);
@@ -477,40 +426,14 @@ static void unpack_exchange(scfgp_ctx* c, const double* xp, double* x) {
 
 template <typename T> struct Impl {
     typedef SweepKernels<T> SK;
-    // sweep operand of the apply products: the typed matrix, or in SCFGP_BF16X3 mode its bf16-plane split (made here)
-    static const T* operand(scfgp_ctx* c, const void* typed) {
-        if constexpr (sizeof(T) == 4) {
-            if (c->bf3) {
-                bf3_presplit((const float*)typed, c->d_M3, c->g.Kp, c->st);
-                if (c->planes().rows) bf3_presplit16((const float*)typed, c->d_M16, c->g.Kp, c->st);
-                return (const T*)c->d_M3;
-            }
-        }
-        return (const T*)typed;
-    }
-    static const T* BT(scfgp_ctx* c) { return operand(c, c->d_BT); }
-    static const T* AbarT(scfgp_ctx* c) { return operand(c, c->d_AbarT); }
-
     // out = [packed lower tiles of M^T diag(w) M | M^T side (Kp)],  M = Phi (pass 1) or V = Phi B (pass 2)
-    static void gram_to(scfgp_ctx* c, const T* Mx, const double* w, const double* side, double* out, const char* name,
-                        const T* Zsrc = nullptr) {
+    static void gram_to(scfgp_ctx* c, const T* Mx, const double* w, const double* side, double* out, const char* name) {
         const Geom& g = c->g;
         const int nts = g.Kp / g.tile, ntiles = nts * (nts + 1) / 2;
-        if constexpr (sizeof(T) == 4) {
-            if (c->plan.jobs && !Zsrc) {                           // lock-step plan (kernels.h)
-                const int np = c->plan.nparts;
-                double* sidepart = c->d_slabs + (size_t)np * ntiles * g.tile * g.tile;
-                { ProfScope ps(c, name); SK::gram_planned(g, Mx, w, side, c->plan, c->gram_chunk, c->d_slabs, sidepart, c->st); }
-                { ProfScope ps(c, "reduce_tiles"); reduce_tri_tiles_cnt(c->d_slabs, c->plan.cnt, nts, g.tile, out, c->st);
-                  reduce_side(sidepart, np, g.Kp, g.gfull * g.tile + g.gstrip * 64, out + c->n_pk, c->st); }
-                return;
-            }
-        }
         const int gs = c->splits.nsplit;
         double* sidepart = c->d_slabs + (size_t)gs * ntiles * g.tile * g.tile;
         { ProfScope ps(c, name);
-          SK::gram(g, Mx, w, side, c->splits, c->dtype == SCFGP_F32 ? c->gram_chunk : 0, c->d_slabs, sidepart, c->st, Zsrc,
-                   Zsrc ? c->h_scale() : 0.0); }
+          SK::gram(g, Mx, w, side, c->splits, c->dtype == SCFGP_F32 ? c->gram_chunk : 0, c->d_slabs, sidepart, c->st); }
         { ProfScope ps(c, "reduce_tiles"); reduce_tri_tiles(c->d_slabs, gs, nts, g.tile, out, c->st);
           reduce_side(sidepart, gs, g.Kp, g.gfull * g.tile + g.gstrip * 64, out + c->n_pk, c->st); }
     }
@@ -518,9 +441,8 @@ template <typename T> struct Impl {
         const Geom& g = c->g;
         if (!c->in_train) HIPCHK(c, hipMemsetAsync(c->d_flag, 0, sizeof(int) * 4, c->st));
         const bool use64 = sizeof(T) == 4 && c->use64();
-        const bool fuse = !use64 && c->fuse_fmap && g.J % (16 / (int)sizeof(T)) == 0;
         c->last_cform = c->want_cform();
-        if ((fuse && c->z_cap < g.Np) || (use64 && c->phi64_cap < g.Np) || (c->last_cform && c->c_cap < g.Np)) {
+        if ((use64 && c->phi64_cap < g.Np) || (c->last_cform && c->c_cap < g.Np)) {
             c->err = "pass1: auxiliary row buffer missing"; return SCFGP_EARG;
         }
         const Projection proj{c->d_Fall, c->d_Lall, c->d_Rall, c->d_Tt};
@@ -536,15 +458,8 @@ template <typename T> struct Impl {
                   reduce_side(sidepart, gs, g.Kp, g.gfull * g.tile + g.gstrip * 64, c->d_xp1 + c->n_pk, c->st); }
             }
         }
-        { ProfScope ps(c, "featuremap"); SK::featuremap(g, c->d_Xt, proj, c->d_sc, (T*)c->d_Phi, c->st, fuse ? (T*)c->d_Z : nullptr); }
-        if constexpr (sizeof(T) == 4) {
-            if (c->bf3 && c->bf3_dma && g.K > 256 && c->p3_cap >= g.Np) {           // row planes of Phi for the DMA-fed apply tiles
-                ProfScope ps(c, "split_rows");
-                bf3_split_rows((const float*)c->d_Phi, g.Kp, c->d_P3, g.Np, g.Kp, c->st);
-            }
-        }
-        if (!use64)
-            gram_to(c, (const T*)c->d_Phi, nullptr, c->d_y, c->d_xp1, fuse ? "gram_fused" : "gram", fuse ? (const T*)c->d_Z : nullptr);
+        { ProfScope ps(c, "featuremap"); SK::featuremap(g, c->d_Xt, proj, c->d_sc, (T*)c->d_Phi, c->st); }
+        if (!use64) gram_to(c, (const T*)c->d_Phi, nullptr, c->d_y, c->d_xp1, "gram");
         c->last_used64 = use64 || sizeof(T) == 8; c->last_level = sizeof(T) == 8 ? 0 : c->level();
         HIPCHK(c, hipMemcpyAsync(c->d_xp1 + c->n_pk + g.Kp, c->d_yy, sizeof(double), hipMemcpyDeviceToDevice, c->st));
         HIPCHK(c, hipGetLastError());
@@ -566,14 +481,14 @@ template <typename T> struct Impl {
         if (c->last_cform) {
             // triangular products: the loader-staged 256 x 128 tiles (two workgroups per CU) ride out the unequal k ranges best
             // (C3: 41.7 / 40.1 ms against 43.9 / 41.6 by LDS-DMA 128 wide and 49.8 / 46.9 by 256-wide tiles); LDS-DMA on request only
-            Bf3Planes pl; pl.dma = c->apply_dma > 0 ? c->planes().dma : 0;
+            const int dma = c->apply_dma > 0 ? c->apply_dma : 0;
             { ProfScope ps(c, "apply_c");
-              SK::apply_c(g, (const T*)c->d_Phi, (const T*)c->d_AbarT, (const T*)c->d_BT, (T*)c->d_C, c->d_vpart, c->alpha(), c->d_mu, c->st, &pl); }
+              SK::apply_c(g, (const T*)c->d_Phi, (const T*)c->d_AbarT, (const T*)c->d_BT, (T*)c->d_C, c->d_vpart, c->alpha(), c->d_mu, c->st, dma); }
             { ProfScope ps(c, "apply_vc");
-              SK::apply_vc(g, (const T*)c->d_C, (const T*)c->d_BT, (const T*)c->d_AbarT, (T*)c->d_V, c->st, &pl); }
+              SK::apply_vc(g, (const T*)c->d_C, (const T*)c->d_BT, (const T*)c->d_AbarT, (T*)c->d_V, c->st, dma); }
         } else {
-            ProfScope ps(c, "apply_v"); const Bf3Planes pl = c->planes();
-            SK::apply_v(g, (const T*)c->d_Phi, BT(c), (T*)c->d_V, c->d_vpart, c->alpha(), c->d_mu, c->st, c->bf3, &pl);
+            ProfScope ps(c, "apply_v");
+            SK::apply_v(g, (const T*)c->d_Phi, (const T*)c->d_BT, (T*)c->d_V, c->d_vpart, c->alpha(), c->d_mu, c->st, c->dma());
         }
         const int nb = (int)std::min<int64_t>(g.Np / 4, 2048);
         { ProfScope ps(c, "rowstats");
@@ -595,59 +510,11 @@ template <typename T> struct Impl {
         HIPCHK(c, hipGetLastError());
         return SCFGP_OK;
     }
-    // Pass 3 in row parts: X~^T Zbar of part i (HBM-bound: it streams Phi and Phibar once) runs on a second stream while the
-    // MFMA-bound Phibar product of part i+1 runs on the first (option pass3_parts; off in bf16x3 mode, whose row planes of Phi
-    // are not addressed by row offsets)
-    static int pass3_pipelined(scfgp_ctx* c, int Q) {
-        const Geom& g = c->g;
-        const int ntm = c->Dpp / XT, ntn = g.Jp / XT;
-        const int xs_all = c->xtz_nsplit > 0 ? (int)std::min<int64_t>(c->xtz_nsplit, g.Np / 64) : xtz_split(ntm * ntn, g.Np);
-        const int xs_q = std::max(1, xs_all / Q);
-        const int64_t nrb = g.Np / 256;
-        if (!c->aux_st) HIPCHK(c, hipStreamCreateWithFlags(&c->aux_st, hipStreamNonBlocking));
-        while ((int)c->ev_p3.size() < Q + 1) { hipEvent_t e; HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->ev_p3.push_back(e); }
-        const T* Ab = AbarT(c);
-        const Bf3Planes pl = c->planes();
-        int nb = 0;
-        {
-            ProfScope ps(c, "apply_phibar");
-            for (int i = 0; i < Q; ++i) {
-                const int64_t r0 = nrb * i / Q * 256, r1 = nrb * (i + 1) / Q * 256;
-                Geom gq = g; gq.Np = r1 - r0; gq.N = std::max<int64_t>(0, std::min<int64_t>(g.N, r1) - r0);
-                nb += SK::apply_phibar(gq, (const T*)c->d_Phi + r0 * g.Kp, Ab, (T*)c->d_V + r0 * g.Kp, c->d_p + r0, c->d_q + r0, c->d_y + r0,
-                                       c->alpha(), c->ut(), c->d_bpart + nb, c->st, false, &pl);
-                HIPCHK(c, hipEventRecord(c->ev_p3[i], c->st));
-                HIPCHK(c, hipStreamWaitEvent(c->aux_st, c->ev_p3[i], 0));
-                SK::xtz(gq, c->d_Xt + r0 * g.Dp, (const T*)c->d_Phi + r0 * g.Kp, (const T*)c->d_V + r0 * g.Kp, xs_q,
-                        c->dtype == SCFGP_F32 ? c->gram_chunk : 0, c->d_slabs + (size_t)i * xs_q * ntm * ntn * XT * XT, c->aux_st);
-            }
-            reduce_scalars(c->d_bpart, nb, 1, c->x3_scalars(), 0, c->st);
-        }
-        {
-            ProfScope ps(c, "xtz");                             // what is left of it after the last product: its last part and the slab sum
-            HIPCHK(c, hipEventRecord(c->ev_p3[Q], c->aux_st));
-            HIPCHK(c, hipStreamWaitEvent(c->st, c->ev_p3[Q], 0));
-            reduce_full_tiles(c->d_slabs, xs_q * Q, ntm, ntn, c->d_x3, g.Jp, c->st);
-        }
-        HIPCHK(c, hipGetLastError());
-        return SCFGP_OK;
-    }
     static int pass3(scfgp_ctx* c) {
         const Geom& g = c->g;
-        {
-            const int Q = c->pass3_parts >= 0 ? c->pass3_parts : (g.Np >= 262144 ? SCFGP_PASS3_PARTS : 1);
-            // not inside scfgp_train: a captured two-stream iteration crashed the graph runtime once in a dozen runs (ROCm 7.2)
-            if (Q > 1 && !c->bf3 && !c->in_train && !c->want_lrb() && g.Np / 256 >= 4 * Q) { c->last_lrb = false; c->last_zfused = false; return pass3_pipelined(c, Q); }
-        }
-        { ProfScope ps(c, "apply_phibar"); const Bf3Planes pl = c->planes();
-          int nb = -1;
-          if (c->zbar_fused > 0 && !c->bf3)
-              nb = SK::apply_zbar(g, (const T*)c->d_Phi, (const T*)c->d_AbarT, (T*)c->d_V, c->d_p, c->d_q, c->d_y, c->alpha(), c->ut(),
-                                  c->d_bpart, c->st, &pl);
-          c->last_zfused = nb >= 0;
-          if (nb < 0)
-              nb = SK::apply_phibar(g, (const T*)c->d_Phi, AbarT(c), (T*)c->d_V, c->d_p, c->d_q, c->d_y, c->alpha(), c->ut(),
-                                    c->d_bpart, c->st, c->bf3, &pl);
+        { ProfScope ps(c, "apply_phibar");
+          const int nb = SK::apply_phibar(g, (const T*)c->d_Phi, (const T*)c->d_AbarT, (T*)c->d_V, c->d_p, c->d_q, c->d_y, c->alpha(), c->ut(),
+                                          c->d_bpart, c->st, c->dma());
           reduce_scalars(c->d_bpart, nb, 1, c->x3_scalars(), 0, c->st); }
         const int ntm = c->Dpp / XT, ntn = g.Jp / XT;
         const int64_t chunk = c->dtype == SCFGP_F32 ? c->gram_chunk : 0;
@@ -658,7 +525,7 @@ template <typename T> struct Impl {
             // sine half; X~^T U.  2 N (S+1) J + 2 N J S + 2 N (D+1) S flops instead of 2 N (D+1) J.
             ProfScope ps(c, "xtz");
             T* Zb = (T*)c->d_V; T* U = (T*)c->d_V + g.Jp;
-            if (!c->last_zfused) SK::zbar_inplace(g, (const T*)c->d_Phi, Zb, c->st);
+            SK::zbar_inplace(g, (const T*)c->d_Phi, Zb, c->st);
             SK::rsel(g, c->d_params, (T*)c->d_AbarT, c->st);                       // Abar's typed copy is dead after the product above
             SK::apply_plain(g, Zb, (const T*)c->d_AbarT, U, g.J, g.S, c->st);
             const int nt1 = (c->Spp / XT) * ntn, xs1 = xtz_split(nt1, g.Np);
@@ -672,15 +539,14 @@ template <typename T> struct Impl {
         }
         const int xs = c->xtz_nsplit > 0 ? (int)std::min<int64_t>(c->xtz_nsplit, g.Np / 64) : xtz_split(ntm * ntn, g.Np);
         { ProfScope ps(c, "xtz");
-          if (c->last_zfused) SK::tn_plain(c->d_Xt, g.Dp, (const T*)c->d_V, g.Kp, g.J, g.Np, xs, chunk, c->d_slabs, c->st);    // Zbar is there already
-          else SK::xtz(g, c->d_Xt, (const T*)c->d_Phi, (const T*)c->d_V, xs, chunk, c->d_slabs, c->st);
+          SK::xtz(g, c->d_Xt, (const T*)c->d_Phi, (const T*)c->d_V, xs, chunk, c->d_slabs, c->st);
           reduce_full_tiles(c->d_slabs, xs, ntm, ntn, c->d_x3, g.Jp, c->st); }
         HIPCHK(c, hipGetLastError());
         return SCFGP_OK;
     }
     static int predict_chunk(scfgp_ctx* c, const Geom& g, const T* Bt, double* mu, double* sd) {
         SK::featuremap(g, c->p_Xt, Projection{c->d_Fall, c->d_Lall, c->d_Rall, c->p_Tt}, c->d_sc, (T*)c->p_Phi, c->st);
-        SK::apply_predict(g, (const T*)c->p_Phi, Bt, c->p_vpart, c->alpha_pred(), c->p_mupart, c->st, c->bf3);   // Bt = Li^T (split already in bf16x3 mode)
+        SK::apply_predict(g, (const T*)c->p_Phi, Bt, c->p_vpart, c->alpha_pred(), c->p_mupart, c->st);           // Bt = Li^T
         SK::rowpredict(g, c->p_mupart, c->p_vpart, c->d_sc, mu, sd, c->st);
         HIPCHK(c, hipGetLastError());
         return SCFGP_OK;
@@ -942,7 +808,6 @@ static int predict_impl(scfgp_ctx* c, const double* Xs, int64_t T, const double*
     const void* Bt = c->d_AbarT;                                  // AbarT is scratch outside adjoint..pass3
     if (c->dtype == SCFGP_F32) SweepKernels<float>::convert_transposed(c->d_T1, (float*)c->d_AbarT, g0.K, g0.Kp, c->st);
     else SweepKernels<double>::convert_transposed(c->d_T1, (double*)c->d_AbarT, g0.K, g0.Kp, c->st);
-    if (c->bf3) { bf3_presplit((const float*)c->d_AbarT, c->d_M3, g0.Kp, c->st); Bt = c->d_M3; }
     HIPCHK(c, hipStreamSynchronize(c->st));                     // raw is reused below
     const int nchunks = (int)((T + PRED_ROWS - 1) / PRED_ROWS);
     if (post && ys) {
@@ -1197,7 +1062,7 @@ extern "C" int scfgp_get_timings(scfgp_ctx* c, double* ms, const char** names, i
     return k;
 }
 
-// host-only: geometry as scfgp_create derives it, then the Gram plan's invariants (tests run this without a GPU)
+// host-only: geometry as scfgp_create derives it (the row-split self-test below runs without a GPU)
 static void derive_geom(Geom& g, int D, int S, int M) {
     g.D = D; g.S = S; g.M = M; g.J = S + M; g.K = 2 * g.J; g.P = 3 + D * S + M * S + S + M;
     g.Dp = (int)round_up(D + 1, 16); g.Jp = (int)round_up(g.J, XT);
@@ -1225,51 +1090,15 @@ extern "C" int scfgp_selftest_row_splits(int D, int S, int M, int64_t N, int dty
     return at == g.Np ? 0 : 3;
 }
 
-// host-only: the lock-step plan of the fp32 Gram products (kernels.h) for this shape and its invariants: the jobs fill the
-// 8 XCD shares evenly, and for every output tile the jobs that write it use the partial slots 0 .. cnt-1 exactly once with
-// row ranges that tile [0, Np).  1: the problem is too small for the plan (the split plan is used), 0: ok.
-extern "C" int scfgp_selftest_gram_plan(int D, int S, int M, int64_t N) {
-    if (D < 1 || S < 1 || M < 1 || N < 1) return SCFGP_EARG;
-    Geom g{};
-    derive_geom(g, D, S, M);
-    g.N = N; g.Np = round_up(N, 256);
-    std::vector<GramJob> jobs; std::vector<int> cnt; int nparts = 0;
-    if (!gram_lockstep_plan(g, g.Np, jobs, cnt, nparts)) return 1;
-    if (jobs.empty() || jobs.size() % 8 != 0) return 2;
-    const int ntile = (int)cnt.size();
-    std::vector<std::vector<std::pair<int, std::pair<int64_t, int64_t>>>> cover(ntile);
-    for (const GramJob& j : jobs) {
-        if (j.r0 % 256 || j.r1 % 256 || j.r1 < j.r0 || j.part < 0 || j.part >= nparts) return 3;
-        const int n = j.kind == 3 ? 4 : 1;
-        for (int k = 0; k < n; ++k) { if (j.tile + k >= ntile) return 4; cover[j.tile + k].push_back({j.part, {j.r0, j.r1}}); }
-        if (j.kind == 2) { if (j.tile2 >= ntile) return 4; cover[j.tile2].push_back({j.part, {j.r0, j.r1}}); }
-    }
-    for (int t = 0; t < ntile; ++t) {
-        auto& v = cover[t];
-        if ((int)v.size() != cnt[t] || cnt[t] < 1) return 5;
-        std::sort(v.begin(), v.end());
-        for (int i = 0; i < (int)v.size(); ++i) if (v[i].first != i) return 6;          // partial slots 0 .. cnt-1, once each
-        std::sort(v.begin(), v.end(), [](const auto& a, const auto& b) { return a.second < b.second; });
-        int64_t at = 0;
-        for (const auto& e : v) { if (e.second.first != at) return 7; at = e.second.second; }
-        if (at != g.Np) return 8;
-    }
-    return 0;
-}
-
 extern "C" int scfgp_set_option(scfgp_ctx* c, const char* name, int64_t value) {
     if (!c || !name) return SCFGP_EARG;
     const std::string s(name);
     if (s == "gram_nsplit") c->gram_nsplit = (int)value;
     else if (s == "gram_taper") c->gram_taper = (int)value;
-    else if (s == "fuse_fmap") c->fuse_fmap = (int)value;
-    else if (s == "bf3_dma") c->bf3_dma = (int)value;
-    else if (s == "apply_dma") c->apply_dma = (int)value;
+    else if (s == "apply_dma") { if (value < -1 || value > 2) { c->err = "apply_dma: -1 auto, 0 off, 1 = 128-wide tiles, 2 = 256-wide (fp32)"; return SCFGP_EARG; }
+                                 c->apply_dma = (int)value; }
     else if (s == "gram_chunk") c->gram_chunk = value;
-    else if (s == "gram_plan") { c->gram_plan = (int)value; c->plan_Np = -1; }
-    else if (s == "pass3_parts") c->pass3_parts = (int)value;
     else if (s == "lowrank_bwd") c->lowrank_bwd = (int)value;
-    else if (s == "zbar_fused") c->zbar_fused = (int)value;
     else if (s == "xtz_nsplit") c->xtz_nsplit = (int)value;
     else if (s == "use_graph") c->use_graph = (int)value;
     else if (s == "gram64") { if (value < 0 || value > 3) { c->err = "gram64: 0 never, 1 always level 1, 2 auto, 3 always level 2"; return SCFGP_EARG; }

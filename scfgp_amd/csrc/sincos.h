@@ -49,19 +49,3 @@ __device__ __forceinline__ void fast_sincos(double z, float& sn, float& cs) {
     sn = (q & 2) ? -ss : ss;
     cs = ((q + 1) & 2) ? -cc : cc;
 }
-
-// stored phases (fused-feature-map experiment): fp64 phases are unreduced, fp32 phases lie in [-pi, pi]
-__device__ __forceinline__ void phase_sincos(double x, double& sn, double& cs) { fast_sincos(x, sn, cs); }
-__device__ __forceinline__ void phase_sincos(float x, float& sn, float& cs) {
-    const float fn = rintf(x * 6.366197723675814e-01f);                       // |fn| <= 2
-    const float r = fmaf(-fn, -4.371139000186241e-08f, fmaf(-fn, 1.5707963705062866f, x));    // pi/2 = hi + lo in fp32
-    const float z2 = r * r;
-    const float s = fmaf(r * z2, fmaf(z2, fmaf(z2, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f), r);
-    const float c = fmaf(z2 * z2, fmaf(z2, fmaf(z2, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f),
-                         fmaf(-0.5f, z2, 1.0f));
-    const int q = (int)fn & 3;
-    const float ss = (q & 1) ? c : s, cc = (q & 1) ? s : c;
-    sn = (q & 2) ? -ss : ss;
-    cs = ((q + 1) & 2) ? -cc : cc;
-}
-

@@ -17,13 +17,6 @@
 #include "common.h"
 #include "sincos.h"
 
-#ifndef SCFGP_DRY_LOOP
-#define SCFGP_DRY_LOOP 0
-#endif
-#ifndef SCFGP_PERM_AHEAD
-#define SCFGP_PERM_AHEAD 0               // PERM tiles: fragment reads this many k-steps ahead of their MFMAs (0 or 1)
-#endif
-
 // MFMA traits: element type T and instruction shape MS (16: 16x16x4, 32: 32x32x2, f32 only).
 //   lane l supplies A[i = l % MS][k = l / MS] and B[k = l / MS][j = l % MS]
 template <typename T, int MS> struct MT;
@@ -55,17 +48,12 @@ template <> struct MT<float, 32> {
 };
 
 // SWZA: the A image is written by a TrLoader<..., SWZ = true> (column index XOR-swizzled, see there)
-// PERM (k-major images from NatLoaders, 16x16x4 shapes): MFMA tile tm, tile row rho of a wave IS output row TM rho + tm of the
-//   wave tile (columns likewise with TN), so a lane's TM fragment elements of one k row are TM CONSECUTIVE elements of the image:
-//   one 8- or 16-byte LDS read per k row and operand instead of TM (TN) 4-byte ones -- 8 ds_read_b128 per 64 MFMAs of a
-//   64 x 64 fp32 wave tile instead of 32 ds_read_b32 -- and a lane ends up with TN ADJACENT output columns (AccCoord).
-template <typename T_, int BM_, int BN_, int BK_, int WGM_, int WGN_, int MS_ = 16, bool SWZA_ = false, bool PERM_ = false>
+template <typename T_, int BM_, int BN_, int BK_, int WGM_, int WGN_, int MS_ = 16, bool SWZA_ = false>
 struct TileCfg {
     typedef T_ T;
     typedef MT<T_, MS_> MTr;
     static constexpr int BM = BM_, BN = BN_, BK = BK_, WGM = WGM_, WGN = WGN_, MS = MS_;
-    static constexpr bool SWZA = SWZA_, PERM = PERM_;
-    static_assert(!PERM_ || (MS_ == 16 && !SWZA_), "permuted tile rows: 16x16x4 shapes, unswizzled images");
+    static constexpr bool SWZA = SWZA_;
     static_assert(!SWZA_ || (BK_ == 16 && MS_ == 16), "swizzle is laid out for BK = 16 and the 16x16x4 shapes");
     static constexpr int THREADS = 64 * WGM * WGN;
     static constexpr int WM = BM / WGM, WN = BN / WGN;
@@ -89,11 +77,8 @@ template <> struct Vec16<float> { typedef v4f type; static constexpr int N = 4; 
 //   side[x] = sum_k s[k] * S[k][x] (Phi^T y, Phi^T p on the Gram's diagonal tiles): in the compute type
 //   per thread between side_flush() calls (one row in BK: a chain 1/BK as long as the MFMA's), fp64 across.
 // ---------------------------------------------------------------------------
-//   ZSRC (experiment: feature map fused into the consumer's loader): the source is the phase matrix Z (N x ldz, reduced
-//   to [-pi, pi] in fp32 mode) and the staged value of tile column c is s cos Z[k][c] (c < J), s sin Z[k][c - J]
-//   (J <= c < 2J) or 0; z_source() re-points the loader.  Needs J % VS == 0.
 //   NSETS: register sets for fetches more than one k-tile ahead (tile_mainloop_deep3); load<SET> / store<SET> name the set
-template <typename S, typename T, int BX, int BK, int LD, int THREADS, bool WEIGHT, bool GUARD, bool SIDE = false, bool ZSRC = false, int NSETS = 1>
+template <typename S, typename T, int BX, int BK, int LD, int THREADS, bool WEIGHT, bool GUARD, bool SIDE = false, int NSETS = 1>
 struct NatLoader {
     typedef typename Vec16<S>::type vec_t;
     static constexpr int VS = Vec16<S>::N;
@@ -108,17 +93,6 @@ struct NatLoader {
     static constexpr bool SAMEX = THREADS % VPR == 0;
     static constexpr int NS = SAMEX ? 1 : NV;
     const double* sptr[NV]; double sr[NV]; T sacc[NS][VS]; double stot[NS][VS]; bool side_on = false;
-    int zmode[NV]; T zscale;                                  // ZSRC: 0 cos, 1 sin, 2 zero column
-    __device__ __forceinline__ void z_source(const S* zrow0, int64_t ldz, int J, int col0, T scale) {
-        zscale = scale; step = (int64_t)BK * ldz;
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int v = tid + i * THREADS;
-            const int k = v / VPR, c = col0 + (v % VPR) * VS;
-            zmode[i] = c < J ? 0 : (c < 2 * J ? 1 : 2);
-            ptr[i] = zrow0 + (int64_t)k * ldz + (c < J ? c : (c < 2 * J ? c - J : 0));
-        }
-    }
     __device__ __forceinline__ NatLoader(const S* b, int64_t l, int t, const double* w_ = nullptr, int xl = 0,
                                          const double* s_ = nullptr)
         : step((int64_t)BK * l), xlim(xl), tid(t) {
@@ -137,22 +111,9 @@ struct NatLoader {
 #pragma unroll
             for (int e = 0; e < VS; ++e) { sacc[i][e] = 0; stot[i][e] = 0; }
     }
-    __device__ __forceinline__ void keep() const {               // diagnostic builds: the fetched registers stay live
-#pragma unroll
-        for (int i = 0; i < NV; ++i) asm volatile("" :: "v"(r[0][i]));
-    }
     __device__ __forceinline__ void advance(int64_t delta) {   // move the source window (segmented main loop)
 #pragma unroll
         for (int i = 0; i < NV; ++i) ptr[i] += delta;
-    }
-    // gathered columns: tile column x (a multiple of VS) comes from source column f(x) .. f(x) + VS - 1 of row-major b
-    template <class F>
-    __device__ __forceinline__ void remap_columns(const S* b, int64_t l, F f) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int v = tid + i * THREADS;
-            ptr[i] = b + (int64_t)(v / VPR) * l + f((v % VPR) * VS);
-        }
     }
     template <int SET = 0>
     __device__ __forceinline__ void load(int) {
@@ -184,13 +145,7 @@ struct NatLoader {
             const T wt = WEIGHT ? (T)wr[SET][i] : (T)1;
             T val[VS];
 #pragma unroll
-            for (int e = 0; e < VS; ++e) {
-                if constexpr (ZSRC) {
-                    T sn, cs;
-                    phase_sincos((T)r[SET][i][e], sn, cs);
-                    val[e] = zmode[i] == 2 ? (T)0 : zscale * (zmode[i] == 1 ? sn : cs);
-                } else val[e] = (T)r[SET][i][e];
-            }
+            for (int e = 0; e < VS; ++e) val[e] = (T)r[SET][i][e];
 #pragma unroll
             for (int e0 = 0; e0 < VS; e0 += TV) {
                 tv_t o;
@@ -270,10 +225,6 @@ struct TrLoader {
             ptr[i] = b + (int64_t)(v / VPR) * l + (v % VPR) * VS;
             dacc[i] = 0;
         }
-    }
-    __device__ __forceinline__ void keep() const {               // diagnostic builds: the fetched registers stay live
-#pragma unroll
-        for (int i = 0; i < NV; ++i) asm volatile("" :: "v"(r[0][i]));
     }
     __device__ __forceinline__ void advance(int64_t delta) {   // move the source window (segmented main loop)
 #pragma unroll
@@ -369,10 +320,6 @@ struct ZbarLoader {
         }
         ++kt;
     }
-    __device__ __forceinline__ void keep() const {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) asm volatile("" :: "v"(raw[i][0]), "v"(raw[i][1]), "v"(raw[i][2]), "v"(raw[i][3]));
-    }
     template <int SET = 0>
     __device__ __forceinline__ void store(T* s) const {
 #pragma unroll
@@ -395,33 +342,6 @@ __device__ __forceinline__ void tile_compute(const typename Cfg::T* sA, const ty
     constexpr int MS = Cfg::MS, KS = M::KS;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm0 = (wave / Cfg::WGN) * Cfg::WM, wn0 = (wave % Cfg::WGN) * Cfg::WN;
-    if constexpr (Cfg::PERM) {
-        typedef T va_t __attribute__((ext_vector_type(Cfg::TM)));
-        typedef T vb_t __attribute__((ext_vector_type(Cfg::TN)));
-        const T* a_p = sA + (lane / MS) * Cfg::LDA + wm0 + Cfg::TM * (lane % MS);
-        const T* b_p = sB + (lane / MS) * Cfg::LDB + wn0 + Cfg::TN * (lane % MS);
-#pragma unroll
-        for (int kk = 0; kk < Cfg::BK / KS; ++kk) {
-            const va_t a = *reinterpret_cast<const va_t*>(a_p + kk * KS * Cfg::LDA);
-            const vb_t b = *reinterpret_cast<const vb_t*>(b_p + kk * KS * Cfg::LDB);
-#pragma unroll
-            for (int tm = 0; tm < Cfg::TM; ++tm)
-#pragma unroll
-                for (int tn = 0; tn < Cfg::TN; ++tn) M::mfma(acc[tm][tn], a[tm], b[tn]);
-        }
-        // fragment reads one k-step ahead of their MFMAs and no further: hoisted to the top of the k-tile, the BK / 4 pairs of
-        // 16-byte fragments and the loaders' staging registers pushed the 64 x 64 wave tile over its 128 registers (spills in the loop)
-        constexpr int NS = Cfg::BK / KS, NM = Cfg::TM * Cfg::TN;
-#if SCFGP_PERM_AHEAD
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-#endif
-#pragma unroll
-        for (int kk = 0; kk < NS; ++kk) {
-            if (SCFGP_PERM_AHEAD == 0 || kk + 1 < NS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
-        }
-        return;
-    }
     const T* a_s = sA + (lane / MS) * Cfg::LDA + wm0 + (lane % MS);
     const T* b_s = sB + (lane / MS) * Cfg::LDB + wn0 + (lane % MS);
     // SWZA: lane (q = lane/16, i = lane%16) reads row k = 4 kk + q of k-step kk at column (..+i) ^ SZ*(k/VS):
@@ -466,26 +386,11 @@ __device__ __forceinline__ void tile_mainloop(LA& la, LB& lb, int nkt,
     // placed mid-tile, scheduler interleave hints, BK = 32, parity-unrolled body.
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
-#if SCFGP_DRY_LOOP == 1 || SCFGP_DRY_LOOP == 2     // diagnostic builds (results are wrong):
-        const bool stage = false;                    //   1: no staging, no barrier   2: no staging, barrier kept
-#else                                                //   3: staging kept, no barrier
         const bool stage = kt + 1 < nkt;
-#endif
-#if SCFGP_DRY_LOOP == 4                              //   4: LDS stores kept (of the first tile's registers), no fetches
-        tile_compute<Cfg>(sA + cur * Cfg::SA, sB + cur * Cfg::SB, acc);
-        if (stage) { la.template store<0>(sA + (cur ^ 1) * Cfg::SA); lb.template store<0>(sB + (cur ^ 1) * Cfg::SB); }
-#elif SCFGP_DRY_LOOP == 5                            //   5: fetches kept (and waited for), no LDS stores
-        if (stage) { la.template load<0>(kt + 1); lb.template load<0>(kt + 1); }
-        tile_compute<Cfg>(sA + cur * Cfg::SA, sB + cur * Cfg::SB, acc);
-        if (stage) { la.keep(); lb.keep(); }
-#else
         if (stage) { la.template load<0>(kt + 1); lb.template load<0>(kt + 1); }
         tile_compute<Cfg>(sA + cur * Cfg::SA, sB + cur * Cfg::SB, acc);
         if (stage) { la.template store<0>(sA + (cur ^ 1) * Cfg::SA); lb.template store<0>(sB + (cur ^ 1) * Cfg::SB); }
-#endif
-#if SCFGP_DRY_LOOP != 1 && SCFGP_DRY_LOOP != 3
         __syncthreads();
-#endif
     }
 }
 
@@ -571,10 +476,10 @@ struct AccCoord {
         wm0 = (wave / Cfg::WGN) * Cfg::WM; wn0 = (wave % Cfg::WGN) * Cfg::WN;
     }
     __device__ __forceinline__ int row(int tm, int r) const {
-        return Cfg::PERM ? wm0 + Cfg::TM * Cfg::MTr::crow(lane, r) + tm : wm0 + tm * Cfg::MS + Cfg::MTr::crow(lane, r);
+        return wm0 + tm * Cfg::MS + Cfg::MTr::crow(lane, r);
     }
     __device__ __forceinline__ int col(int tn) const {
-        return Cfg::PERM ? wn0 + Cfg::TN * (lane % Cfg::MS) + tn : wn0 + tn * Cfg::MS + (lane % Cfg::MS);
+        return wn0 + tn * Cfg::MS + (lane % Cfg::MS);
     }
 };
 

@@ -12,11 +12,10 @@ import sys
 import numpy as np
 
 from . import _lib
-from ._lib import SCFGP_BF16X3, SCFGP_F32, SCFGP_F64, dptr
+from ._lib import SCFGP_F32, SCFGP_F64, dptr
 
 _DTYPES = {'f64': SCFGP_F64, 'float64': SCFGP_F64, 'f32': SCFGP_F32, 'float32': SCFGP_F32,
-           'bf16x3': SCFGP_BF16X3,              # experimental split-precision products (include/scfgp_hip.h)
-           SCFGP_F64: SCFGP_F64, SCFGP_F32: SCFGP_F32, SCFGP_BF16X3: SCFGP_BF16X3}
+           SCFGP_F64: SCFGP_F64, SCFGP_F32: SCFGP_F32}
 
 
 def num_params(D, S, M):

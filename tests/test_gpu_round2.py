@@ -251,59 +251,7 @@ def test_gram_row_splits_uniform_and_tapered_give_the_same_gram(dtype, tol):
         eng.close()
 
 
-@pytest.mark.parametrize('dtype,tol', [('f64', 1e-10), ('f32', 5e-4)])
-def test_fused_feature_map_gram_experiment_matches(dtype, tol):
-    """Option fuse_fmap (profiles/r02_tuning.md): the Gram of pass 1 evaluates cos / sin of the stored phases inside
-    its operand loaders instead of reading Phi; same G and Phi^T y as the oracle."""
-    from scfgp_amd.engine import HipEngine
-    name = 'c2_small_n'                                        # S + M = 272: a multiple of the loaders' vector width
-    N, D, S, M, T, seed = CASES[name]
-    X, y, params, _ = case_inputs(name)
-    Phi = O.feature_map(X, params, D, S, M)
-    G0 = Phi.T @ Phi; g0 = Phi.T @ y.ravel()
-    K = 2 * (S + M)
-    eng = HipEngine(D, S, M, dtype=dtype); eng.set_params(params)
-    eng.set_option('fuse_fmap', 1)
-    eng.set_data(X, y)
-    eng.set_profiling(True)
-    eng.pass1()
-    assert 'gram_fused' in dict(eng.timings())
-    Kp = eng.dims()['Kp']
-    x1 = eng.debug_read('G', (Kp * Kp + Kp,))
-    G = x1[:Kp * Kp].reshape(Kp, Kp)[:K, :K]; g = x1[Kp * Kp:Kp * Kp + K]
-    assert rel(G, G0) < tol and rel(g, g0) < tol, (rel(G, G0), rel(g, g0))
-    eng.close()
-
-
-@pytest.mark.parametrize('K_case', [(700, 24, 20, 300), (1500, 40, 16, 560), (3000, 12, 8, 184)])
-def test_bf16x3_dma_fed_tiles_match_loader_split_tiles(K_case):
-    """Option bf3_dma (tile_bf16x3_dma.h, experiment): the 256-wide column tiles of the two apply products run from
-    pre-split bf16 planes through LDS-DMA, the remainder through the loader-split tiles; cost, gradient, alpha and the
-    per-row moments equal the default bf16x3 path (the six-term order differs, so fp32 rounding only) and the oracle
-    at the mode's usual bounds.  K = 640 (two wide tiles + one 128), 1152 (four + one 128), 384 (one + one 128)."""
-    from scfgp_amd.engine import HipEngine
-    from scfgp_amd import synth
-    N, D, S, M = K_case
-    seed = 0x5CF63000 + N
-    X = synth.make_X(seed, N, D)
-    y = synth.normal(seed + 9, 0, N).reshape(-1, 1)
-    params = synth.make_params(seed + 0x0202, D, S, M, abc=(-1.0, 0.0, -1.0))
-    c0, g0, a0, _ = O.value_and_grad(X, y, params, S, M)
-    out = {}
-    for dma in (0, 1):
-        eng = HipEngine(D, S, M, dtype='bf16x3'); eng.set_params(params); eng.set_option('bf3_dma', dma); eng.set_data(X, y)
-        eng.set_profiling(True)
-        cost, grad, alpha, Li = eng.eval(want_grad=True)
-        assert ('split_rows' in dict(eng.timings())) == bool(dma)
-        out[dma] = (float(cost), grad.copy(), alpha.copy(), eng.debug_read('p', (N,)).copy(), eng.debug_read('q', (N,)).copy())
-        eng.close()
-    assert abs(out[1][0] - out[0][0]) < 1e-7 * abs(out[0][0])
-    for k in (1, 2, 3, 4):
-        assert rel(out[1][k], out[0][k]) < 2e-5, (k, rel(out[1][k], out[0][k]))
-    assert abs(out[1][0] - c0) < 2e-5 * abs(c0) and rel(out[1][1], g0) < 3e-3 and rel(out[1][2], a0) < 1e-3
-
-
-@pytest.mark.parametrize('dtype,tol', [('f64', 1e-10), ('f32', 3e-6), ('bf16x3', 3e-6)])
+@pytest.mark.parametrize('dtype,tol', [('f64', 1e-10), ('f32', 3e-6)])
 @pytest.mark.parametrize('D,S,M,T', [(12, 9, 291, 5000), (30, 20, 44, 777), (20, 16, 1040, 40000)])
 def test_predict_triangular_product_against_the_oracle(D, S, M, T, dtype, tol):
     """scfgp_predict forms sigma* from the triangular product Phi* Li^T (contraction of a column tile cut at its last
@@ -328,12 +276,14 @@ def test_predict_triangular_product_against_the_oracle(D, S, M, T, dtype, tol):
     eng.close()
 
 
+@pytest.mark.parametrize('dtype,ptol,ctol,gtol', [('f32', 2e-5, 2e-5, 3e-3), ('f64', 1e-11, 1e-10, 1e-8)])
 @pytest.mark.parametrize('N,D,S,M', [(1500, 40, 16, 560), (3000, 12, 8, 184), (700, 24, 20, 300)])
-def test_fp32_apply_tiles_fed_by_lds_dma_match(N, D, S, M):
-    """Option apply_dma (fp32 mode, experiment): the 128-wide tiles of the two apply products take both operands through
-    LDS-DMA into a three-stage ring (no register staging), the 64-wide remainder and the mu slices as column bands;
-    cost, gradient, alpha and the per-row adjoint scalars equal the default path (same products, the 16 k of a stage
-    summed in a permuted order) and the oracle at the mode's usual bounds.  K = 1152 (9 tiles), 384 (3), 640 (5)."""
+def test_apply_tiles_fed_by_lds_dma_match(N, D, S, M, dtype, ptol, ctol, gtol):
+    """Option apply_dma: the 128-wide tiles of the two apply products take both operands through LDS-DMA into a three-stage
+    ring (no register staging), the 64-wide remainder and the mu slices as column bands; cost, gradient, alpha and the
+    per-row adjoint scalars equal the register-staged path (same products, the 16 k of a stage summed in a permuted order)
+    and the oracle at the mode's usual bounds.  K = 1152 (9 tiles), 384 (3), 640 (5).  fp32: 128- and 256-wide tiles;
+    fp64: 128-wide tiles of 64 x 32 wave tiles (option value 2 means the same there)."""
     from scfgp_amd.engine import HipEngine
     from scfgp_amd import synth
     seed = 0x5CF66000 + N
@@ -342,16 +292,16 @@ def test_fp32_apply_tiles_fed_by_lds_dma_match(N, D, S, M):
     params = synth.make_params(seed + 0x0202, D, S, M, abc=(-1.0, 0.0, -1.0))
     c0, g0, a0, _ = O.value_and_grad(X, y, params, S, M)
     out = {}
-    for dma in (0, 1, 2, 4, 5):                                # 2: 256-wide tiles (16 waves), a 128-wide one for an odd count; 4: 256-wide on 8 waves of 128 x 64; 5: as 2, fragment reads pipelined by half stages
-        eng = HipEngine(D, S, M, dtype='f32'); eng.set_params(params); eng.set_option('apply_dma', dma); eng.set_data(X, y)
+    for dma in (0, 1, 2):                                      # 2: 256-wide tiles (16 waves), a 128-wide one for an odd count
+        eng = HipEngine(D, S, M, dtype=dtype); eng.set_params(params); eng.set_option('apply_dma', dma); eng.set_data(X, y)
         cost, grad, alpha, Li = eng.eval(want_grad=True)
         out[dma] = (float(cost), grad.copy(), alpha.copy(), eng.debug_read('p', (N,)).copy(), eng.debug_read('q', (N,)).copy())
         eng.close()
-    for dma in (1, 2, 4, 5):
-        assert abs(out[dma][0] - out[0][0]) < 1e-7 * abs(out[0][0])
+    for dma in (1, 2):
+        assert abs(out[dma][0] - out[0][0]) < ptol * 1e-2 * abs(out[0][0])
         for k in (1, 2, 3, 4):
-            assert rel(out[dma][k], out[0][k]) < 2e-5, (dma, k, rel(out[dma][k], out[0][k]))
-        assert abs(out[dma][0] - c0) < 2e-5 * abs(c0) and rel(out[dma][1], g0) < 3e-3 and rel(out[dma][2], a0) < 1e-3
+            assert rel(out[dma][k], out[0][k]) < ptol, (dma, k, rel(out[dma][k], out[0][k]))
+        assert abs(out[dma][0] - c0) < ctol * abs(c0) and rel(out[dma][1], g0) < gtol and rel(out[dma][2], a0) < max(gtol / 3, 1e-9)
 
 
 def _random_shapes(n, seed):
@@ -362,7 +312,7 @@ def _random_shapes(n, seed):
     return out
 
 
-@pytest.mark.parametrize('dtype,ctol,gtol', [('f64', 1e-10, 1e-8), ('f32', 2e-5, 3e-3), ('bf16x3', 2e-5, 3e-3)])
+@pytest.mark.parametrize('dtype,ctol,gtol', [('f64', 1e-10, 1e-8), ('f32', 2e-5, 3e-3)])
 def test_random_shapes_against_oracle(dtype, ctol, gtol):
     """24 seeded random (N, D, S, M): every tile-edge combination of the Gram job list (tall / wide / square / strip tiles,
     64- and 256-row granules), the apply column plans (128 + 64, 64 only) and the Cholesky step counts against the

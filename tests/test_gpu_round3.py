@@ -224,7 +224,7 @@ def test_fp32_mode_against_fp64_mode_at_full_size(cfg):
     e32.close(); e64.close()
 
 
-@pytest.mark.parametrize('dtype,dma,ctol,gtol', [('f64', -1, 1e-10, 1e-8), ('f32', 0, 2e-5, 2e-3), ('f32', 3, 2e-5, 2e-3), ('f32', 1, 2e-5, 2e-3), ('f32', 5, 2e-5, 2e-3)])
+@pytest.mark.parametrize('dtype,dma,ctol,gtol', [('f64', -1, 1e-10, 1e-8), ('f64', 1, 1e-10, 1e-8), ('f32', 0, 2e-5, 2e-3), ('f32', 2, 2e-5, 2e-3), ('f32', 1, 2e-5, 2e-3)])
 def test_factor_form_of_pass2_matches_oracle(dtype, dma, ctol, gtol):
     """Option factor_form = 1: pass 2 as the reference writes it (SCFGP/SCFGP.py:112) -- C = Phi Li^T (triangular), v = rowsum(C^2),
     V = C Li (triangular), B W B = Li^T (C^T diag(q) C) Li, u = Li^T C^T p -- against the oracle: loader-staged tiles (f64, f32)
@@ -296,76 +296,6 @@ def test_checkpoint_keeps_a_non_default_momentum_and_numpy_scalar_kwargs(tmp_pat
     assert not np.array_equal(default.params.get_value(), full.params.get_value())     # the momentum does matter
 
 
-@pytest.mark.parametrize('N,D,S,M', [(70000, 64, 32, 1024),      # headline tile list: 64 tall tiles = one full lock-step wave + sliced leftovers
-                                     (66000, 6, 3, 285),        # K = 576: nfull 4, strip: no full wave, everything sliced
-                                     (67000, 9, 20, 428)])      # K = 896: nfull 7 (odd: unpaired last block row), no strip
-def test_lockstep_gram_plan_equals_the_split_plan(N, D, S, M):
-    """Option gram_plan = 1 (kernels.h: GramPlan, job table + counted slab reduction): same G, Phi^T y, weighted Gram and
-    gradient as the split plan and as fp64 mode; deterministic."""
-    from scfgp_amd.engine import HipEngine
-    seed = 0x5CF63800 + M
-    X = synth.make_X(seed, N, D)
-    y = synth.normal(seed + 9, 0, N).reshape(-1, 1)
-    params = synth.make_params(seed + 0x0202, D, S, M, abc=(1.5, 0.0, -1.0))      # lam = e^3: well conditioned, so that the second
-    K = 2 * (S + M)                                                                 # Gram (on V = Phi B) sees the same B in every run
-    res = {}
-    for tag, dtype, plan in (('f64', 'f64', 0), ('split', 'f32', 0), ('lock', 'f32', 1)):
-        eng = HipEngine(D, S, M, dtype); eng.set_option('gram64', 0); eng.set_option('gram_plan', plan)
-        eng.set_params(params); eng.set_data(X, y)
-        eng.pass1()
-        Kp = eng.dims()['Kp']
-        x1 = eng.debug_read('G', (Kp * Kp + Kp,))
-        G = x1[:Kp * Kp].reshape(Kp, Kp)[:K, :K].copy(); g = x1[Kp * Kp:Kp * Kp + K].copy()
-        eng.factor(); eng.pass2(True)
-        x2 = eng.debug_read('W', (Kp * Kp + Kp,))
-        W = x2[:Kp * Kp].reshape(Kp, Kp)[:K, :K].copy(); u = x2[Kp * Kp:Kp * Kp + K].copy()
-        eng.adjoint(); eng.pass3()
-        out = eng.finish(True)
-        out2 = eng.eval()
-        assert float(out2[0]) == float(out[0]) and np.array_equal(out2[1], out[1])
-        res[tag] = (G, g, W, u, out)
-        eng.close()
-    for tag in ('split', 'lock'):
-        G, g, W, u, out = res[tag]; G0, g0, W0, u0, out0 = res['f64']
-        assert np.array_equal(G, G.T)
-        # W and u are formed from the fp32 V = Phi B: their distance from fp64 mode is V's (the D = 6 case is ill-conditioned)
-        assert rel(G, G0) < 5e-7 and rel(g, g0) < 5e-6 and rel(W, W0) < 2e-3 and rel(u, u0) < 2e-3, (tag, rel(G, G0), rel(g, g0), rel(W, W0), rel(u, u0))
-        assert abs(float(out[0]) - float(out0[0])) < 1e-6 * max(1.0, abs(float(out0[0])))
-        for a, b in zip(grad_blocks(out[1], D, S, M), grad_blocks(out0[1], D, S, M)):
-            assert rel(a, b) < 1e-3
-    for k, tol in enumerate((5e-7, 5e-6, 5e-4, 1e-3)):          # W = V^T diag(q) V: q has both signs, its sum cancels          # the two schedules differ by the fp32 chains' row partition only
-        assert rel(res['lock'][k], res['split'][k]) < tol, (k, rel(res['lock'][k], res['split'][k]))
-
-
-@pytest.mark.parametrize('dtype,tol', [('f64', 1e-12), ('f32', 2e-6)])
-def test_pass3_in_row_parts_overlapping_xtz(dtype, tol):
-    """Option pass3_parts: the Phibar product and X~^T Zbar run part by part on two streams (scfgp_api.hip: pass3_pipelined);
-    same cost and gradient as the one-piece pass; scfgp_train ignores the option (its iteration is one captured stream)."""
-    from scfgp_amd.engine import HipEngine
-    N, D, S, M = 9000, 12, 6, 90
-    seed = 0x5CF63900
-    X = synth.make_X(seed, N, D)
-    y = synth.normal(seed + 9, 0, N).reshape(-1, 1)
-    params = synth.make_params(seed + 0x0202, D, S, M, abc=(-0.5, 0.0, -1.0))
-    ref = None
-    for parts in (1, 2, 4, 7):
-        eng = HipEngine(D, S, M, dtype); eng.set_option('gram64', 0); eng.set_option('pass3_parts', parts)
-        eng.set_params(params); eng.set_data(X, y)
-        c, g, a, L = eng.eval()
-        c2, g2, _, _ = eng.eval()
-        assert float(c2) == float(c) and np.array_equal(g2, g)
-        eng.opt_init('adam', learning_rate=0.01)
-        hist, _, _ = eng.train(4)                                  # eager first iteration, then the captured graph
-        if ref is None:
-            ref = (float(c), g, hist)
-            c0, g0, _, _ = O.value_and_grad(X, y, params, S, M)
-            assert abs(float(c) - c0) < max(tol, 1e-10) * 10 * abs(c0) and rel(g, g0) < (1e-8 if dtype == 'f64' else 1e-3)
-        else:
-            assert abs(float(c) - ref[0]) < tol * abs(ref[0]) and rel(g, ref[1]) < tol * 10, (parts, rel(g, ref[1]))
-            assert np.allclose(hist, ref[2], rtol=tol * 100, atol=0)
-        eng.close()
-
-
 @pytest.mark.parametrize('dtype,gtol', [('f64', 1e-9), ('f32', 1e-3)])
 def test_rank_s_backward_projection_matches_the_dense_one(dtype, gtol):
     """Option lowrank_bwd (automatic when D >> S): the reverse sweep of F = l_F r_F^T (SCFGP/SCFGP.py:83,100) through
@@ -397,13 +327,6 @@ def test_rank_s_backward_projection_matches_the_dense_one(dtype, gtol):
             eng.close()
         assert outs[0][0] == outs[1][0]
         assert rel(outs[1][1], outs[0][1]) < (1e-11 if dtype == 'f64' else 1e-4)
-        if dtype == 'f32':                                         # ... and with Zbar written by the Phibar product itself (J % 4 == 0 only)
-            eng = HipEngine(D, S, M, dtype); eng.set_option('gram64', 0); eng.set_option('lowrank_bwd', 1)
-            eng.set_option('apply_dma', 2); eng.set_option('zbar_fused', 1)
-            eng.set_params(params); eng.set_data(X, y)
-            c, g, _, _ = eng.eval()
-            assert rel(g, outs[1][1]) < 1e-4, (D, rel(g, outs[1][1]))
-            eng.close()
         assert np.allclose(outs[1][2], outs[0][2], rtol=1e-10 if dtype == 'f64' else 1e-5, atol=0)
 
 
@@ -540,7 +463,7 @@ def test_non_finite_cost_comes_back_as_a_value_through_the_triple():
     eng.close()
 
 
-@pytest.mark.parametrize('dtype,ctol,gtol,ptol', [('f64', 1e-10, 1e-8, 1e-9), ('f32', 2e-5, 3e-3, 2e-4), ('bf16x3', 2e-5, 3e-3, 2e-4)])
+@pytest.mark.parametrize('dtype,ctol,gtol,ptol', [('f64', 1e-10, 1e-8, 1e-9), ('f32', 2e-5, 3e-3, 2e-4)])
 @pytest.mark.parametrize('D,S,M', [(7, 3, 40), (40, 6, 150), (5, 12, 200)])
 def test_one_context_through_a_random_sequence_of_calls(D, S, M, dtype, ctol, gtol, ptol):
     """Stale-state check: ONE context lives through 40 seeded random calls -- new rows (1 .. 3000, growing and shrinking), new
@@ -566,11 +489,8 @@ def test_one_context_through_a_random_sequence_of_calls(D, S, M, dtype, ctol, gt
     params = new_params(); X, y = new_data()
     eng.set_params(params); eng.set_data(X, y)
     alpha = Li = None
-    options = [('gram64', (0, 2, 3)), ('factor_form', (-1, 1)), ('lowrank_bwd', (-1, 0, 1)), ('gram_nsplit', (0, 3)), ('gram_taper', (0, 1))]
-    if dtype == 'f32':
-        options.append(('apply_dma', (-1, 0, 1, 2)))
-    if dtype == 'bf16x3':
-        options.append(('bf3_dma', (0, 1)))
+    options = [('gram64', (0, 2, 3)), ('factor_form', (-1, 1)), ('lowrank_bwd', (-1, 0, 1)), ('gram_nsplit', (0, 3)), ('gram_taper', (0, 1)),
+               ('apply_dma', (-1, 0, 1, 2))]
     log = []
     for step in range(40):
         op = rng.choice(['data', 'params', 'eval', 'eval', 'rows', 'predict', 'option', 'train'])
@@ -618,11 +538,11 @@ def test_one_context_through_a_random_sequence_of_calls(D, S, M, dtype, ctol, gt
     eng.close()
 
 
-@pytest.mark.parametrize('dma', [1, 2, 3])
-def test_lds_dma_apply_tiles_on_random_widths(dma):
-    """The LDS-DMA apply kernels (128- and 256-wide tiles, the narrower remainder on the loader-staged kernel) forced on 12
-    seeded random shapes with K from ~130 to ~1500 -- ragged K, odd and even tile counts, row counts that are no multiple of
-    256 -- against the oracle, with and without the factor form (triangular k ranges)."""
+@pytest.mark.parametrize('dtype,dma,ctol,gtol', [('f32', 1, 2e-5, 3e-3), ('f32', 2, 2e-5, 3e-3), ('f64', 1, 1e-10, 1e-8)])
+def test_lds_dma_apply_tiles_on_random_widths(dtype, dma, ctol, gtol):
+    """The LDS-DMA apply kernels (fp32: 128- and 256-wide tiles, fp64: 128-wide; the narrower remainder on the loader-staged
+    kernel) forced on 12 seeded random shapes with K from ~130 to ~1500 -- ragged K, odd and even tile counts, row counts that
+    are no multiple of 256 -- against the oracle, with and without the factor form (triangular k ranges)."""
     from scfgp_amd.engine import HipEngine
     rng0 = np.random.default_rng(20261006 + dma)
     for it in range(12):
@@ -632,16 +552,10 @@ def test_lds_dma_apply_tiles_on_random_widths(dma):
         params = O.init_params(D, S, M, rng)
         params[0] = -0.4; params[1] = 0.1; params[2] = -0.6; params[3:3 + D * S] *= 0.6
         c0, g0, a0, L0 = O.value_and_grad(X, y, params, S, M)
-        eng = HipEngine(D, S, M, 'f32')
+        eng = HipEngine(D, S, M, dtype)
         eng.set_option('apply_dma', dma); eng.set_option('factor_form', it % 2)
         eng.set_params(params); eng.set_data(X, y)
         cost, grad, alpha, Li = eng.eval(want_grad=True)
-        assert abs(float(cost) - c0) < 2e-5 * max(1.0, abs(c0)), (N, D, S, M, float(cost), c0)
-        assert rel(grad, g0) < 3e-3, (N, D, S, M, rel(grad, g0))
-        # option zbar_fused: the Phibar product writes Zbar (cosine and sine columns of a j gathered into one tile; applies when
-        # J % 4 == 0, otherwise the call is the unfused path again): same gradient, phases included
-        eng.set_option('zbar_fused', 1)
-        cost2, grad2, _, _ = eng.eval(want_grad=True)
-        assert float(cost2) == float(cost) and rel(grad2, grad) < 1e-5, (N, D, S, M, rel(grad2, grad))
-        assert rel(grad2, g0) < 3e-3
+        assert abs(float(cost) - c0) < ctol * max(1.0, abs(c0)), (N, D, S, M, float(cost), c0)
+        assert rel(grad, g0) < gtol, (N, D, S, M, rel(grad, g0))
         eng.close()

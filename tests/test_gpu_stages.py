@@ -17,7 +17,7 @@ def rel(a, b):
 
 
 @pytest.mark.parametrize('name', ['tiny_257x5', 'kin8nm_like', 'c1_boston_shape'])
-@pytest.mark.parametrize('dtype,tol', [('f64', 1e-9), ('f32', 2e-4), ('bf16x3', 2e-4)])
+@pytest.mark.parametrize('dtype,tol', [('f64', 1e-9), ('f32', 2e-4)])
 def test_stages_match_oracle(name, dtype, tol):
     from scfgp_amd.engine import HipEngine
     N, D, S, M, T, seed = CASES[name]

@@ -187,18 +187,6 @@ def test_gram_row_splits_tile_the_rows(D, S, M):
     assert lib.scfgp_selftest_row_splits(0, 1, 1, 5, 0, 0, 0) == -1
 
 
-def test_lockstep_gram_plan_invariants_without_a_gpu():
-    """scfgp_selftest_gram_plan (host only): for every output tile of the fp32 Gram's job table the jobs that write it use
-    the tile's partial slots once each and their row ranges tile [0, Np); small problems decline the plan."""
-    from scfgp_amd import _lib
-    lib = _lib.load()
-    for (D, S, M) in [(64, 32, 1024), (512, 64, 2048), (8, 32, 1024), (6, 3, 285), (9, 20, 428), (13, 8, 64), (3, 2, 3), (40, 17, 130)]:
-        for N in (65536, 66000, 70001, 250000, 1000000, 4000000):
-            assert lib.scfgp_selftest_gram_plan(D, S, M, N) == 0, (D, S, M, N)
-        assert lib.scfgp_selftest_gram_plan(D, S, M, 60000) == 1
-    assert lib.scfgp_selftest_gram_plan(0, 1, 1, 100000) == -1
-
-
 def test_output_arrays_are_reused_only_after_the_caller_let_go():
     """HipEngine hands out alpha / Li arrays from a small pool (a fresh 35.7 MB array per call costs ~1.4 ms of page faults at
     the headline shape); an array is handed out again only when nobody but the pool references it -- a view counts."""

@@ -15,11 +15,6 @@ for (D, S, M) in [(13, 8, 64), (64, 32, 1024), (512, 64, 2048), (3, 2, 3), (8, 2
                 for tp in (0, 1):
                     assert lib.scfgp_selftest_row_splits(D, S, M, N, dt, ns, tp) == 0
                     n += 1
-for (D, S, M) in [(64, 32, 1024), (512, 64, 2048), (8, 32, 1024), (6, 3, 285), (9, 20, 428), (13, 8, 64), (3, 2, 3)]:
-    for N in (65536, 66000, 100000, 1000000, 4000000):
-        assert lib.scfgp_selftest_gram_plan(D, S, M, N) == 0, (D, S, M, N)
-        n += 1
-    assert lib.scfgp_selftest_gram_plan(D, S, M, 60000) == 1
 # a context on a GPU-less box: create fails cleanly inside hipSetDevice / hipMalloc, the error text is readable, destroy is safe
 rc = lib.scfgp_create(C.byref(ctx), 4, 2, 3, 0, 0, None)
 print('create on a GPU-less box ->', rc, lib.scfgp_last_error(ctx) if ctx else None)

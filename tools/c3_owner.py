@@ -34,6 +34,7 @@ def run(cfg, rows=None, chunk=None):
     N = rows or N
     J = S + M; K = 2 * J
     e32 = HipEngine(D, S, M, 'f32')
+    e32.set_option('gram64', 0)                                # the plain fp32 products are the subject: no precision escalation, no REDO from finish()
     X, y, params = bench.build_problem(e32, N, D, S, M, 0, N, None)
     e64 = HipEngine(D, S, M, 'f64')
     for e in (e32, e64):

@@ -15,7 +15,7 @@ alpha = rng.standard_normal(K) / np.sqrt(K)
 Li = np.tril(rng.standard_normal((K, K))) / np.sqrt(K)
 out = {}
 ref = None
-for dt in ('f64', 'f32', 'bf16x3'):
+for dt in ('f64', 'f32'):
     eng = HipEngine(D, S, M, dtype=dt)
     eng.set_params(params)
     eng.predict(Xs[:4096], alpha, Li)
