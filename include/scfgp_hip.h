@@ -171,6 +171,9 @@ int scfgp_stream_fence(scfgp_ctx* ctx, void* peer_stream, int direction);
  * two state vectors, 2 = Nesterov velocity (P doubles each), 3 = step counter (1 double). */
 int scfgp_opt_init(scfgp_ctx* ctx, int algo, const double* hyper, int nhyper, double momentum);
 int scfgp_opt_state(scfgp_ctx* ctx, int set, int which, double* buf);
+/* one step of the device rule with a caller-supplied gradient (P doubles, host): parameters and state advance as inside
+ * scfgp_train, no evaluation (for gradients formed elsewhere; the rule's known-answer tests drive it) */
+int scfgp_opt_step(scfgp_ctx* ctx, const double* grad, int P);
 int scfgp_train(scfgp_ctx* ctx, int n_iters, double* cost_hist, double* alpha, double* Li);
 
 /* ---- conditioning and precision level (no reference counterpart) -----------------------------------

@@ -47,6 +47,7 @@ SIGNATURES = {
     'scfgp_stream_fence': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     'scfgp_opt_init': (C.c_int, [C.c_void_p, C.c_int, _c_double_p, C.c_int, C.c_double]),
     'scfgp_opt_state': (C.c_int, [C.c_void_p, C.c_int, C.c_int, _c_double_p]),
+    'scfgp_opt_step': (C.c_int, [C.c_void_p, _c_double_p, C.c_int]),
     'scfgp_train': (C.c_int, [C.c_void_p, C.c_int, _c_double_p, _c_double_p, _c_double_p]),
     'scfgp_get_condition': (C.c_int, [C.c_void_p, _c_double_p, C.c_int]),
     'scfgp_get_dims': (C.c_int, [C.c_void_p, _c_i64_p, C.c_int]),

@@ -941,6 +941,23 @@ extern "C" int scfgp_opt_state(scfgp_ctx* c, int set, int which, double* buf) {
     return SCFGP_OK;
 }
 
+// One step of the device rule with a caller-supplied gradient (P doubles on the host): the parameter vector and the rule's
+// state advance exactly as inside scfgp_train, without an evaluation -- for callers that form the gradient elsewhere and for
+// known-answer tests of the rule itself (tests/golden/optimizer_kats.npz).
+extern "C" int scfgp_opt_step(scfgp_ctx* c, const double* grad, int P) {
+    if (!c || !grad || P != c->g.P) { if (c) c->err = "opt_step: wrong gradient length"; return SCFGP_EARG; }
+    if (c->opt_algo < 0 || !c->have_params) { c->err = "opt_step: call scfgp_set_params and scfgp_opt_init first"; return SCFGP_EARG; }
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(c->d_grad, grad, sizeof(double) * P, hipMemcpyHostToDevice, c->st));
+    opt_update(c->opt_algo, c->opt_h, P, c->d_params, c->d_grad, c->d_opt, c->d_tctr, c->d_scalars, nullptr, 0, c->st);
+    unpack_params(c->g, c->d_params, c->d_F, c->d_Fall, c->d_Lall, c->d_Rall, c->d_sc, c->st);
+    HIPCHK(c, hipMemcpyAsync(c->h_params.data(), c->d_params, sizeof(double) * P, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    HIPCHK(c, hipGetLastError());
+    c->cond_valid = false;
+    return SCFGP_OK;
+}
+
 static int enqueue_train_iter(scfgp_ctx* c) {
     int rc;
     if ((rc = DISPATCH(c, pass1, c))) return rc;

@@ -300,6 +300,12 @@ class HipEngine(object):
         self._check(self.lib.scfgp_opt_state(self.ctx, 0 if value is None else 1, int(which), dptr(buf)), 'opt_state')
         return buf
 
+    def opt_step(self, grad):
+        """One step of the device rule with the given gradient (no evaluation); returns the updated parameter vector."""
+        g = np.ascontiguousarray(grad, dtype=np.float64).ravel()
+        self._check(self.lib.scfgp_opt_step(self.ctx, dptr(g), g.size), 'opt_step')
+        return self.get_params()
+
     def train(self, n_iters, want_factors=True):
         """n_iters x (NLML+grad evaluation + update) on the resident rows without host round trips.
         Returns (cost history (n,), alpha, Li of the last evaluation)."""

@@ -69,8 +69,8 @@ def _content_key(a, trusted):
     Default, at EVERY size: a 64-bit hash of every byte (threaded xxh3: 2.6 ms for config C2, tens of ms for the 512 MB of
     the headline X against its 220 ms evaluation) -- any in-place edit is seen; the reference re-reads its arguments on
     every call too (SCFGP/SCFGP.py:237).
-    `trusted` (the array is read-only, or the caller maintains a version token with set_data_version): contents cannot change
-    unnoticed, so 4096 evenly spaced 512-byte blocks identify the array."""
+    `trusted` (the caller maintains a version token with set_data_version): contents cannot change unnoticed, so 4096
+    evenly spaced 512-byte blocks identify the array."""
     flat = a.reshape(-1)
     if not trusted or flat.size <= (1 << 16):
         return ('full', _hash64(np.ascontiguousarray(flat)))
@@ -81,19 +81,21 @@ def _content_key(a, trusted):
 
 
 def _fingerprint(X, y, version=None):
-    """Identity of a data set for the residency check: shapes, buffer addresses, the caller's version token and
-    the content keys of both arrays (see _content_key)."""
-    tx = version is not None or not X.flags.writeable
-    ty = version is not None or not y.flags.writeable
-    return (X.shape, X.ctypes.data, y.ctypes.data, version, _content_key(X, tx), _content_key(y, ty))
+    """Identity of a data set for the residency check: shapes, the caller's version token and the content keys of both
+    arrays (see _content_key).  Addresses are NOT part of it: a freed array's address is handed out again."""
+    trusted = version is not None
+    return (X.shape, y.shape, version, _content_key(X, trusted), _content_key(y, trusted))
 
 
-def _frozen_identity(X, y, version):
-    """(addresses, shapes, token) when BOTH arrays are read-only: then this alone proves the resident copy current and
-    no byte is hashed; None otherwise."""
-    if X.flags.writeable or y.flags.writeable:
-        return None
-    return (X.ctypes.data, X.shape, X.strides, y.ctypes.data, y.shape, y.strides, version)
+def _nobody_can_write(a):
+    """True when no ndarray through which `a`'s memory could be edited exists on its ownership chain: `a` and every array
+    in its .base chain are read-only, and the chain ends in memory numpy allocated itself (or an immutable bytes object).
+    A read-only VIEW of a writeable array is not frozen -- the base still writes through."""
+    while isinstance(a, np.ndarray):
+        if a.flags.writeable:
+            return False
+        a = a.base
+    return a is None or isinstance(a, bytes)
 
 
 class CompiledFuncs(object):
@@ -144,12 +146,20 @@ class CompiledFuncs(object):
         self.data_version = version
 
     def _sync_data(self, X, y):
+        """Upload X, y unless the resident copy is provably current.
+          * the SAME array objects as last time, both frozen (_nobody_can_write): nothing is hashed -- their contents cannot have
+            changed, and holding a reference to them means their memory cannot have been handed to another array either.  This is
+            the steady state of SCFGP.optimize, whose model freezes the arrays it creates in set_data (SCFGP/SCFGP.py:161-162,237);
+          * anything else -- writeable arrays, read-only views of writeable arrays, new objects: every byte of both arrays is
+            hashed on every call (sampled only under a caller-maintained version token)."""
         version = getattr(self, 'data_version', None)
-        frozen = _frozen_identity(X, y, version)
-        if frozen is not None and frozen == getattr(self, '_resident_frozen', None) and self._resident is not None:
-            return                                             # read-only arrays at the same addresses: nothing to hash
+        held = getattr(self, '_resident_frozen', None)
+        if (held is not None and self._resident is not None and held[0] is X and held[1] is y and held[2] == version
+                and _nobody_can_write(X) and _nobody_can_write(y)):
+            return
         fp = _fingerprint(X, y, version)
-        self._resident_frozen = frozen
+        # strong references, kept only for frozen arrays (a writeable array is re-hashed anyway)
+        self._resident_frozen = (X, y, version) if _nobody_can_write(X) and _nobody_can_write(y) else None
         if fp != self._resident:
             n_global = self.n_global
             if self.allreduce is not None and n_global is None:

@@ -104,8 +104,11 @@ class SCFGP(object):
         self.message("-" * 60, "\nNormalizing SCFGP training data...")
         self.X_scaler.fit(X)
         self.y_scaler.fit(y)
-        self.X = np.ascontiguousarray(self.X_scaler.forward_transform(X), dtype=np.float64)
-        self.y = np.ascontiguousarray(self.y_scaler.forward_transform(y), dtype=np.float64)
+        # the model's own copies, frozen: the triple's residency check then never hashes them again (funcs.py: _sync_data)
+        self.X = np.array(self.X_scaler.forward_transform(X), dtype=np.float64, order='C')
+        self.y = np.array(self.y_scaler.forward_transform(y), dtype=np.float64, order='C')
+        self.X.flags.writeable = False
+        self.y.flags.writeable = False
         self.message("done.")
         self.N, self.D = self.X.shape
         if 'train_func' not in self.__dict__.keys():

@@ -444,6 +444,34 @@ def test_device_optimizer_matches_host_rules(algo, kw):
     assert np.array_equal(hist_e, hist)
 
 
+@pytest.mark.parametrize('wrapper', ['nesterov', 'plain'])
+@pytest.mark.parametrize('rule', ['sgd', 'adagrad', 'rmsprop', 'adadelta', 'adam', 'adamax'])
+def test_device_update_rule_follows_the_known_answer_vectors(rule, wrapper):
+    """opt_update_kernel against tests/golden/optimizer_kats.npz (literal recurrences of SCFGP/Optimizer.py, generated by
+    tests/golden/make_optimizer_kats.py -- NOT against scfgp_amd/optimizer.py): the fixed gradient sequence goes in through
+    scfgp_opt_step, the parameter vector, both state vectors and the Nesterov velocity come back after every step."""
+    from scfgp_amd.engine import HipEngine
+    z = np.load(os.path.join(GOLD, 'optimizer_kats.npz'))
+    lr, r1, b2, eps = [float(v) for v in z[rule + '/kwargs']]
+    D, S, M = 1, 1, 1                                            # P = 3 + 1 + 1 + 1 + 1 = 7 = the vectors' length
+    eng = HipEngine(D, S, M, 'f64')
+    assert eng.P == z['theta0'].size
+    eng.set_params(z['theta0'])
+    eng.opt_init(rule, learning_rate=lr, beta1=r1, beta2=b2, epsilon=eps, momentum=float(z['momentum']) if wrapper == 'nesterov' else -1.0)
+    pre = '%s/%s/' % (rule, wrapper)
+    for t, g in enumerate(z['grads']):
+        theta = eng.opt_step(g)
+        assert np.allclose(theta, z[pre + 'theta'][t + 1], rtol=1e-13, atol=0), (rule, wrapper, t)
+        assert np.array_equal(theta, eng.get_params())
+        if rule != 'sgd':
+            assert np.allclose(eng.opt_state(0), z[pre + 's1'][t + 1], rtol=1e-13, atol=0)
+            assert np.allclose(eng.opt_state(1), z[pre + 's2'][t + 1], rtol=1e-13, atol=0)
+        if wrapper == 'nesterov':
+            assert np.allclose(eng.opt_state(2), z[pre + 'vel'][t + 1], rtol=1e-13, atol=1e-300)
+        assert eng.opt_state(3)[0] == t + 1
+    eng.close()
+
+
 def test_index_list_minibatches_on_resident_rows():
     """scfgp_eval_rows: a batch gathered on the device equals the same rows uploaded from the host, and
     the full set is back for the next plain evaluation; the facade's minibatch loop uses it."""

@@ -60,6 +60,61 @@ def test_sgd_nesterov_three_steps():
         assert np.allclose(got[k], x, rtol=1e-13, atol=0)
 
 
+def _kat_kwargs(rule, kw):
+    lr, r1, b2, eps = [float(v) for v in kw]
+    return {'sgd': dict(learning_rate=lr), 'adagrad': dict(learning_rate=lr, epsilon=eps),
+            'rmsprop': dict(learning_rate=lr, rho=r1, epsilon=eps), 'adadelta': dict(learning_rate=lr, rho=r1, epsilon=eps),
+            'adam': dict(learning_rate=lr, beta1=r1, beta2=b2, epsilon=eps),
+            'adamax': dict(learning_rate=lr, beta1=r1, beta2=b2, epsilon=eps)}[rule]
+
+
+@pytest.mark.parametrize('wrapper', ['nesterov', 'plain', 'momentum'])
+@pytest.mark.parametrize('rule', ['sgd', 'adagrad', 'rmsprop', 'adadelta', 'adam', 'adamax'])
+def test_every_rule_follows_its_known_answer_vectors(rule, wrapper):
+    """tests/golden/optimizer_kats.npz (tests/golden/make_optimizer_kats.py: the literal recurrences of SCFGP/Optimizer.py
+    :27-382 on explicit state, independent of scfgp_amd/optimizer.py): three steps of every rule under
+    apply_nesterov_momentum (what SCFGP.py:131 uses), without a wrapper and under apply_momentum -- parameter vector, the
+    rule's state variables and the velocity after every step."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'optimizer_kats.npz'))
+    p = Shared(z['theta0']); g = _G()
+    up = getattr(OPT, rule)(p, g, **_kat_kwargs(rule, z[rule + '/kwargs']))
+    plain_keys = list(up.keys())
+    if wrapper == 'nesterov':
+        up = OPT.apply_nesterov_momentum(up, momentum=float(z['momentum']))
+    elif wrapper == 'momentum':
+        up = OPT.apply_momentum(up, momentum=float(z['momentum']))
+    vel = [k for k in up.keys() if k not in plain_keys]
+    state = [k for k in plain_keys if k is not p and np.ndim(k.get_value(borrow=True)) == 1]      # accu | m, then delta_accu | v | u
+    pre = '%s/%s/' % (rule, wrapper)
+    for t, gi in enumerate(z['grads']):
+        g.g = gi
+        apply_updates(up)
+        assert np.allclose(p.get_value(), z[pre + 'theta'][t + 1], rtol=1e-14, atol=0), (rule, wrapper, t)
+        if state:
+            assert np.allclose(state[0].get_value(), z[pre + 's1'][t + 1], rtol=1e-14, atol=0)
+        if len(state) > 1:
+            assert np.allclose(state[1].get_value(), z[pre + 's2'][t + 1], rtol=1e-14, atol=0)
+        if vel:
+            assert np.allclose(vel[0].get_value(), z[pre + 'vel'][t + 1], rtol=1e-14, atol=1e-300)
+
+
+def test_optimizer_kats_file_is_what_its_generator_writes():
+    import os
+    from tests.golden import make_optimizer_kats as G
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'optimizer_kats.npz'))
+    fresh = G.build()
+    assert sorted(z.files) == sorted(fresh)
+    for k in z.files:
+        assert np.array_equal(z[k], fresh[k]), k
+    # the vectors are not degenerate: every rule moves every coordinate with a non-zero gradient, wrappers differ
+    for rule in G.RULES:
+        th = z[rule + '/nesterov/theta']
+        assert np.all(th[1][[0, 1, 3, 4, 6]] != th[0][[0, 1, 3, 4, 6]])
+        assert not np.array_equal(z[rule + '/nesterov/theta'][3], z[rule + '/plain/theta'][3]) or rule != 'sgd'
+        assert not np.array_equal(z[rule + '/nesterov/s1'][3], z[rule + '/plain/s1'][3]) or rule == 'sgd'
+
+
 @pytest.mark.parametrize('algo,kw', [('sgd', {}), ('adagrad', {}), ('rmsprop', {}), ('adadelta', {}),
                                       ('adamax', {}), ('adam', {})])
 def test_rules_run_and_descend(algo, kw):
@@ -152,14 +207,85 @@ def test_residency_fingerprint_sees_every_element():
     s0 = funcs._content_key(big, True)                         # trusted: sampled
     assert s0[0] == 'sampled'
     Xb = rng.random((70000, 3)); yb = rng.random((70000, 1))
-    assert funcs._fingerprint(Xb, yb)[4][0] == 'full'
-    assert funcs._fingerprint(Xb, yb, version=1)[4][0] == 'sampled'
+    assert funcs._fingerprint(Xb, yb)[3][0] == 'full'
+    assert funcs._fingerprint(Xb, yb, version=1)[3][0] == 'sampled'
     assert funcs._fingerprint(Xb, yb, version=1) != funcs._fingerprint(Xb, yb, version=2)
-    assert funcs._frozen_identity(Xb, yb, None) is None
     Xb.flags.writeable = False; yb.flags.writeable = False
-    assert funcs._fingerprint(Xb, yb)[4][0] == 'sampled'
-    fid = funcs._frozen_identity(Xb, yb, None)
-    assert fid is not None and fid == funcs._frozen_identity(Xb, yb, None) and fid != funcs._frozen_identity(Xb[1:], yb[1:], None)
+    assert funcs._fingerprint(Xb, yb)[3][0] == 'full'             # read-only alone buys no sampling: only a version token does
+
+
+class _FakeEngine(object):
+    def __init__(self):
+        self.uploads = []
+
+    def set_data(self, X, y, n_global=None):
+        self.uploads.append((X.copy(), y.copy()))
+
+
+def _funcs_without_a_gpu():
+    """A CompiledFuncs whose engine records uploads: the residency logic of _sync_data runs without the library."""
+    from scfgp_amd import funcs
+    cf = funcs.CompiledFuncs.__new__(funcs.CompiledFuncs)
+    cf.engine = _FakeEngine(); cf.allreduce = None; cf.n_global = None
+    cf._resident = None; cf._resident_frozen = None
+    return cf
+
+
+def test_resident_rows_follow_what_the_caller_passes(monkeypatch):
+    """ADVICE r03 (funcs.py _sync_data): (a) read-only arrays freed and re-created with the same shape land at the same
+    address -- different contents must be uploaded; (b) a read-only VIEW of a writeable array hides nothing: an edit through
+    the base is seen; (c) the same frozen objects are never hashed again; (d) writeable arrays are hashed on every call and
+    an in-place edit is uploaded."""
+    from scfgp_amd import funcs
+    calls = []
+    real = funcs._hash64
+    monkeypatch.setattr(funcs, '_hash64', lambda buf: (calls.append(1), real(buf))[1])
+    rng = np.random.default_rng(5)
+    # (a) fresh frozen arrays per "fold", same shape: the allocator hands the freed block out again
+    cf = _funcs_without_a_gpu()
+    seen = set()
+    for fold in range(6):
+        X = rng.random((4096, 5)); y = rng.random((4096, 1))
+        X.flags.writeable = False; y.flags.writeable = False
+        seen.add(X.ctypes.data)
+        cf._sync_data(X, y)
+        assert len(cf.engine.uploads) == fold + 1 and np.array_equal(cf.engine.uploads[-1][0], X), fold
+        # while the triple holds the fold's arrays their memory cannot be reused; once the caller drops its own references the
+        # next fold's arrays are new objects and are hashed whatever address they get
+        del X, y
+    # (b) read-only view of a writeable base
+    cf = _funcs_without_a_gpu()
+    base = rng.random((3000, 4)); yb = rng.random((3000, 1))
+    Xv = base.view(); Xv.flags.writeable = False
+    yv = yb.view(); yv.flags.writeable = False
+    assert not funcs._nobody_can_write(Xv)
+    cf._sync_data(Xv, yv); cf._sync_data(Xv, yv)
+    assert len(cf.engine.uploads) == 1
+    base[1234, 2] += 1e-12                                      # through the base
+    cf._sync_data(Xv, yv)
+    assert len(cf.engine.uploads) == 2 and cf.engine.uploads[-1][0][1234, 2] == base[1234, 2]
+    # (c) frozen owners: hashed once, then never
+    cf = _funcs_without_a_gpu()
+    X = np.array(rng.random((3000, 4))); y = np.array(rng.random((3000, 1)))
+    X.flags.writeable = False; y.flags.writeable = False
+    assert funcs._nobody_can_write(X) and funcs._nobody_can_write(np.frombuffer(b'12345678', dtype=np.float64))
+    cf._sync_data(X, y)
+    n0 = len(calls)
+    for _ in range(5):
+        cf._sync_data(X, y)
+    assert len(calls) == n0 and len(cf.engine.uploads) == 1
+    cf.set_data_version(7)                                      # a new token invalidates the shortcut
+    cf._sync_data(X, y)
+    assert len(calls) > n0
+    # (d) writeable arrays: hashed every call; an edit is uploaded
+    cf = _funcs_without_a_gpu()
+    X = rng.random((3000, 4)); y = rng.random((3000, 1))
+    cf._sync_data(X, y); n0 = len(calls)
+    cf._sync_data(X, y)
+    assert len(calls) == n0 + 2 and len(cf.engine.uploads) == 1
+    y[2999, 0] = -y[2999, 0]
+    cf._sync_data(X, y)
+    assert len(cf.engine.uploads) == 2
 
 
 def test_scaler_key_follows_contents_not_identity():
