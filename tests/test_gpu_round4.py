@@ -1,0 +1,177 @@
+"""
+Round-4 GPU tests: the BASELINE configs that are DEFINED by their sharding, at full size on one card.
+
+C4 (N = 4e6, D = 64, S = 32, M = 1024, fp32, "row-sharded across 2/4/8 GPUs") and C5 (N = 1e6, D = 512, S = 64, M = 2048,
+fp32, "8 x MI355X") split the row sums of SCFGP/SCFGP.py:104 (Phi^T Phi), :108 (Phi^T y) and :126 (y^T y, the expected-NLL
+sum) -- and of the reverse sweep of :129 -- over ranks.  Here the 8 ranks are 8 contexts on ONE GPU with 1/8 of the rows
+each and `n_global` = N, their exchange buffers summed the way the all-reduce would; the result must be the single-context
+one.  C4 is also checked against fp64 mode (the reference's arithmetic, SCFGP/SCFGP.py:95-96) at its full 4e6 rows:
+Phi there has 8.7e9 elements, more than 2^32.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return float(np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(np.asarray(b)), 1e-300))
+
+
+def grad_blocks(g, D, S, M):
+    o = 3 + D * S
+    return dict(grad_abc=g[:3], grad_lF=g[3:o], grad_rF=g[o:o + M * S])
+
+
+def _single(dtype, D, S, M, params, X, y, Xs):
+    """One context on all rows: (cost, grad, alpha, Li), predictions on Xs, condition record, ms of the second evaluation."""
+    import time
+    from scfgp_amd.engine import HipEngine
+    e = HipEngine(D, S, M, dtype)
+    e.set_params(params); e.set_data(X, y)
+    e.eval()
+    t0 = time.perf_counter()
+    out = e.eval()
+    ms = (time.perf_counter() - t0) * 1e3
+    mu, sd = e.predict(Xs, out[2], out[3])
+    cd = e.condition()
+    e.close()
+    return out, (mu, sd), cd, ms
+
+
+def _sharded(R, D, S, M, params, X, y, want_grad=True):
+    """R fp32 contexts on one card, rows [lo_r, hi_r) each, n_global = N; exchange buffers summed in rank order."""
+    import torch
+    from scfgp_amd.engine import HipEngine
+    from scfgp_amd.sharded import shard_rows
+    N = X.shape[0]
+    stream = torch.cuda.current_stream().cuda_stream
+    engs = []
+    for r in range(R):
+        lo, hi = shard_rows(N, r, R)
+        e = HipEngine(D, S, M, 'f32', stream=stream)
+        e.set_params(params); e.set_data(X[lo:hi], y[lo:hi], n_global=N)
+        engs.append(e)
+    sizes = {}
+
+    def allsum(stage):
+        bufs = [e.exchange(stage) for e in engs]
+        sizes[stage] = bufs[0].numel() * 8
+        tot = bufs[0].clone()
+        for b in bufs[1:]:
+            tot += b
+        for b in bufs:
+            b.copy_(tot)
+
+    outs = None
+    for _ in range(3):                                          # at most two precision escalations; all ranks decide alike
+        for e in engs: e.pass1()
+        allsum(1)
+        for e in engs: e.factor()
+        for e in engs: e.pass2(want_grad)
+        allsum(2)
+        if want_grad:
+            for e in engs: e.adjoint()
+            for e in engs: e.pass3()
+            allsum(3)
+        outs = [e.finish(want_grad) for e in engs]
+        assert all(o is None for o in outs) or all(o is not None for o in outs)
+        if outs[0] is not None:
+            break
+    levels = [e.condition()['level'] for e in engs]
+    for e in engs:
+        e.close()
+    return outs, sizes, levels
+
+
+@pytest.mark.parametrize('cfg', ['C4', 'C5'])
+def test_eight_row_shards_on_one_card_equal_the_single_context_at_full_size(cfg):
+    """C4 and C5 as their 8 ranks would run them: 500 000- / 125 000-row shards, n_global != N, 20 MB / 71 MB exchange buffers.
+    fp32 mode flushes its fp32 accumulators to fp64 every 4096 rows OF A ROW SPLIT, so another row partition rounds the Gram
+    differently at the 6e-8 level: the bound on alpha / Li / the gradient is the fp32-vs-fp64 one, not bit equality (cost is
+    insensitive: 1e-9).  Every rank must come back with the same numbers bit for bit (replicated K x K stage on equal sums).
+    C4 additionally: fp32 mode against fp64 mode at 4e6 rows, the north star's outputs within 1e-5."""
+    import bench
+    from scfgp_amd import synth
+    from scfgp_amd.engine import HipEngine
+    N, D, S, M = bench.CONFIGS[cfg][:4]
+    e0 = HipEngine(D, S, M, 'f32')
+    X, y, params = bench.build_problem(e0, N, D, S, M, 0, N, None)
+    e0.close()
+    Xs = synth.make_X(bench.SEED + 0x0909, 4096, D)
+    out32, pred32, cd32, ms32 = _single('f32', D, S, M, params, X, y, Xs)
+    assert cd32['level'] == 0 and cd32['cond_est'] < 10
+    if cfg == 'C4':
+        out64, pred64, _, ms64 = _single('f64', D, S, M, params, X, y, Xs)
+        par = dict(cost=abs(float(out32[0]) - float(out64[0])) / abs(float(out64[0])), alpha=rel(out32[2], out64[2]),
+                   Li=rel(out32[3], out64[3]), mu=rel(pred32[0], pred64[0]), std=rel(pred32[1], pred64[1]))
+        par.update({k: rel(v, w) for (k, v), w in zip(grad_blocks(out32[1], D, S, M).items(), grad_blocks(out64[1], D, S, M).values())})
+        print('\nC4 fp32 (%.0f ms) vs fp64 (%.0f ms) at %d rows: ' % (ms32, ms64, N) + ' '.join('%s %.2e' % kv for kv in par.items()))
+        bounds = dict(cost=5e-10, grad_abc=1e-9, grad_lF=3e-5, grad_rF=3e-5, alpha=5e-6, Li=1e-6, mu=5e-6, std=1e-10)   # the H / C5 bounds
+        for k, b in bounds.items():
+            assert par[k] < b, (k, par[k], b)
+        assert all(par[k] < 1e-5 for k in ('cost', 'alpha', 'Li', 'mu', 'std'))
+    outs, sizes, levels = _sharded(8, D, S, M, params, X, y)
+    assert levels == [0] * 8
+    K = 2 * (S + M)
+    assert sizes[1] == sizes[2] and sizes[1] > 8 * K * (K + 1) // 2          # packed lower tiles + vector + scalars
+    c0, g0, a0, L0 = out32
+    c, g, a, L = outs[0]
+    for o in outs[1:]:                                          # replicated K x K stage on the same sums: ranks agree bit for bit
+        assert float(o[0]) == float(c) and np.array_equal(o[1], g) and np.array_equal(o[2], a) and np.array_equal(o[3], L)
+    sh = dict(cost=abs(float(c) - float(c0)) / abs(float(c0)), alpha=rel(a, a0), Li=rel(L, L0))
+    sh.update({k: rel(v, w) for (k, v), w in zip(grad_blocks(g, D, S, M).items(), grad_blocks(g0, D, S, M).values())})
+    print('\n%s as 8 shards of %d rows vs one context (exchange buffers %.1f / %.1f MB): ' % (cfg, N // 8, sizes[1] / 1e6, sizes[3] / 1e6)
+          + ' '.join('%s %.2e' % kv for kv in sh.items()))
+    assert sh['cost'] < 1e-9 and sh['alpha'] < 5e-6 and sh['Li'] < 1e-6
+    assert sh['grad_abc'] < 1e-8 and sh['grad_lF'] < 3e-5 and sh['grad_rF'] < 3e-5
+    # forward only (train_func): exchange 2 shrinks to the 8 scalars
+    outs_f, sizes_f, _ = _sharded(8, D, S, M, params, X, y, want_grad=False)
+    assert sizes_f[2] == 64 and abs(float(outs_f[0][0]) - float(c)) <= 1e-15 * abs(float(c))
+    assert np.array_equal(outs_f[0][2], a)
+
+
+def test_eight_fp64_row_shards_equal_the_single_context_at_c2_size_with_uneven_rows():
+    """The same exchange in the reference's arithmetic, where a row partition may not change anything above rounding of the
+    fp64 sums: N = 100 003 rows (C2's shape; shards of 12 500 / 12 501 rows), 8 contexts, cost 1e-13, alpha / Li / grad 1e-10."""
+    import torch
+    import bench
+    from scfgp_amd.engine import HipEngine
+    from scfgp_amd.sharded import shard_rows
+    N, D, S, M = bench.CONFIGS['C2'][:4]
+    N += 3
+    e0 = HipEngine(D, S, M, 'f64')
+    X, y, params = bench.build_problem(e0, N, D, S, M, 0, N, None)
+    e0.set_params(params); e0.set_data(X, y)
+    c0, g0, a0, L0 = e0.eval()
+    e0.close()
+    stream = torch.cuda.current_stream().cuda_stream
+    engs = []
+    for r in range(8):
+        lo, hi = shard_rows(N, r, 8)
+        e = HipEngine(D, S, M, 'f64', stream=stream)
+        e.set_params(params); e.set_data(X[lo:hi], y[lo:hi], n_global=N)
+        engs.append(e)
+    assert sorted(set(e.N for e in engs)) == [12500, 12501]
+
+    def allsum(stage):
+        bufs = [e.exchange(stage) for e in engs]
+        tot = bufs[0].clone()
+        for b in bufs[1:]:
+            tot += b
+        for b in bufs:
+            b.copy_(tot)
+
+    for e in engs: e.pass1()
+    allsum(1)
+    for e in engs: e.factor()
+    for e in engs: e.pass2(True)
+    allsum(2)
+    for e in engs: e.adjoint()
+    for e in engs: e.pass3()
+    allsum(3)
+    for e in engs:
+        c, g, a, L = e.finish(True)
+        assert abs(float(c) - float(c0)) < 1e-13 * abs(float(c0))
+        assert rel(a, a0) < 1e-10 and rel(L, L0) < 1e-10 and rel(g, g0) < 1e-10
+        e.close()
