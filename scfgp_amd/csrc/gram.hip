@@ -129,6 +129,121 @@ __device__ __forceinline__ void gram_body(
     else gram_body_impl<Cfg, WEIGHT, STRIP, false>(Phi, ld, w, side, r0, r1, chunk, acol, bcol, sideout, slab, slab_hi, smem_raw);
 }
 
+// fp32 tall tile (256 x 128, 8 waves of 64 x 64) with LDS-DMA staging: both operand panels go global -> LDS by
+// global_load_lds_dwordx4 into a ring of three stages of 16 rows, counted vmcnt, one raw barrier per stage -- no staging registers,
+// no ds_write, the fetch of stage s+2 in flight while stage s is multiplied (the structure of apply.hip's apply_dma_kernel).
+//   LDS image of a stage: the 16 rows of the A panel (256 floats = 1 KiB each: ONE DMA instruction per row), then the 16 rows of
+//   the B panel (128 floats: one instruction per two rows), k-major and unpadded: a lane of MFMA tile column i reads the FOUR
+//   adjacent floats 4 i .. 4 i + 3 of its k row with one ds_read_b128 -- MFMA tile tm, tile row rho IS output row 4 rho + tm of
+//   the wave tile (columns likewise), so a fragment of four tiles is one read, the 16 lanes of a k row cover one 256-byte bank
+//   row, and the four lane groups a ds_read_b128 is served in ({0-3,12-15 | 20-27}, ...: two k rows each) touch disjoint slots
+//   because every row starts on a bank-row boundary.  A lane ends up with a 4 x 4 block of the output: 32-byte slab updates.
+//   Row weights (WEIGHT: q_n) and the side vector's multipliers (DIAG: y_n or p_n) of the stage's 16 rows ride in the ring as
+//   one more 256-byte DMA (wave 0); the weight multiplies the A fragment after the LDS read, and the side sums
+//   sum_k s_k Phi[k][acol + m] are formed in fp64 from the same (unweighted) fragments.
+struct GramDma {
+    static constexpr int BM = 256, BN = 128, A_BYTES = 16 * BM * 4, B_BYTES = 16 * BN * 4, W_OFF = A_BYTES + B_BYTES, S_OFF = W_OFF + 128,
+                         STAGE = W_OFF + 256, STAGES = 3, LDS_BYTES = STAGES * STAGE, DMA_PER_WAVE = (A_BYTES + B_BYTES) / 1024 / 8;
+    static_assert(DMA_PER_WAVE == 3, "8 waves, 24 KiB of operands per stage");
+};
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+template <bool WEIGHT, bool DIAG>
+__device__ __forceinline__ void gram_tall_dma(
+    const float* __restrict__ Phi, int64_t ld, const double* __restrict__ w, const double* __restrict__ side,
+    int64_t r0, int64_t r1, int64_t chunk, int acol, int bcol, double* __restrict__ sideout,
+    double* __restrict__ slab, double* __restrict__ slab_hi, char* smem) {
+    typedef GramDma D;
+    constexpr bool WS = WEIGHT || DIAG;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, q = lane >> 4;
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+    // DMA instruction t = 3 wave + u of a stage: t < 16: row t of the A panel; else rows 2 (t - 16), 2 (t - 16) + 1 of the B panel
+    const char* src[D::DMA_PER_WAVE]; int dst[D::DMA_PER_WAVE];
+#pragma unroll
+    for (int u = 0; u < D::DMA_PER_WAVE; ++u) {
+        const int t = D::DMA_PER_WAVE * wave + u;
+        const float* g = t < 16 ? Phi + (r0 + t) * ld + acol + 4 * lane : Phi + (r0 + 2 * (t - 16) + (lane >> 5)) * ld + bcol + 4 * (lane & 31);
+        src[u] = reinterpret_cast<const char*>(g);
+        dst[u] = t * 1024;
+    }
+    const int64_t step = 16 * ld * (int64_t)sizeof(float);
+    // lanes 0..31: the 16 weights (as 32 dwords), lanes 32..63: the 16 side multipliers; an absent one is replaced by the other
+    const double* ws_lo = WEIGHT ? w : side; const double* ws_hi = DIAG ? side : w;
+    const char* wsrc = WS ? reinterpret_cast<const char*>((lane < 32 ? ws_lo : ws_hi) + r0) + 4 * (lane & 31) : nullptr;
+    const bool ws_wave = WS && wave == 0;
+    const auto issue = [&](int slot) {
+        char* base = smem + slot * D::STAGE;
+#pragma unroll
+        for (int u = 0; u < D::DMA_PER_WAVE; ++u) {
+            __builtin_amdgcn_global_load_lds((gbl_void*)src[u], (lds_void*)(base + dst[u]), 16, 0, 0);
+            src[u] += step;
+        }
+        if (ws_wave) {
+            __builtin_amdgcn_global_load_lds((gbl_void*)wsrc, (lds_void*)(base + D::W_OFF), 4, 0, 0);
+            wsrc += 128;
+        }
+    };
+    const int aoff = q * (D::BM * 4) + (wm0 + 4 * i) * 4, boff = D::A_BYTES + q * (D::BN * 4) + (wn0 + 4 * i) * 4;
+    v4f acc[4][4];
+    const int nst = (int)((r1 - r0) / 16);
+    issue(0);
+    if (nst > 1) issue(1);
+    int s = 0, slot = 0, fill = 2;
+    bool first = true;
+    for (int64_t c0 = r0; c0 < r1 || first; c0 += chunk) {
+        const int64_t c1 = c0 + chunk < r1 ? c0 + chunk : r1;
+        const int ns = c0 < r1 ? (int)((c1 - c0) / 16) : 0;
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = v4f{0.f, 0.f, 0.f, 0.f};
+        v4f sacc = v4f{0.f, 0.f, 0.f, 0.f};                     // side sums of this chunk: fp32 chains a quarter as long as the MFMAs'
+        for (int t = 0; t < ns; ++t, ++s) {
+            // this wave's share of stage s has landed when only the DMAs of stage s+1 are outstanding
+            if (s + 1 < nst) {
+                if (ws_wave) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                      // everybody's has; nobody reads the slot of stage s-1 any more
+            asm volatile("" ::: "memory");
+            if (s + 2 < nst) issue(fill);
+            const char* base = smem + slot * D::STAGE;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                v4f a = *reinterpret_cast<const v4f*>(base + aoff + kk * (4 * D::BM * 4));
+                const v4f b = *reinterpret_cast<const v4f*>(base + boff + kk * (4 * D::BN * 4));
+                if (DIAG) sacc += (float)*reinterpret_cast<const double*>(base + D::S_OFF + (4 * kk + q) * 8) * a;
+                if (WEIGHT) a *= (float)*reinterpret_cast<const double*>(base + D::W_OFF + (4 * kk + q) * 8);
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+            }
+            slot = slot == 2 ? 0 : slot + 1;
+            fill = fill == 2 ? 0 : fill + 1;
+        }
+        // accumulator (tm, tn, r) of lane (i, q) is output row wm0 + 16 q + 4 r + tm, column wn0 + 4 i + tn
+        double* sl = wm0 >= 128 ? slab_hi + (int64_t)(wm0 - 128) * D::BN : slab + (int64_t)wm0 * D::BN;
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v4d* d = reinterpret_cast<v4d*>(sl + (16 * q + 4 * r + tm) * D::BN + wn0 + 4 * i);
+                const v4d v = v4d{(double)acc[tm][0][r], (double)acc[tm][1][r], (double)acc[tm][2][r], (double)acc[tm][3][r]};
+                *d = first ? v : *d + v;
+            }
+        if constexpr (DIAG) {                                  // the 4 k rows of a k-step live in the 4 lane groups: sum over q, fp64 across chunks
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm) {
+                double x = (double)sacc[tm];
+                x += __shfl_xor(x, 16); x += __shfl_xor(x, 32);
+                if (q == 0 && wn0 == 0) { double* d = sideout + wm0 + 4 * i + tm; *d = first ? x : *d + x; }
+            }
+        }
+        first = false;
+    }
+}
+
 // Job list of one row split (all kernels of the launch have 8 waves):
 //   !BIG  diagonal 128 x 128 tiles, strictly lower tiles row by row, strip tiles
 //    BIG  (fp32) pairs of 128-row blocks are covered by 256 x 128 tiles (64 x 64 wave tiles, the shape of the apply
@@ -208,7 +323,11 @@ void gram_kernel(
     double* sideout = sidepart + (int64_t)split * ld + acol;
     if (kind == 1) { gram_body<SCfg, WEIGHT, true>(Phi, ld, w, side, r0, r1, chunk, acol, bcol, diag, sideout, slab, nullptr, smem_raw); TRACE_END(kind); return; }
     if constexpr (BIG) {
-        if (kind == 2) { gram_body<BCfg, WEIGHT, false>(Phi, ld, w, side, r0, r1, chunk, acol, bcol, diag, sideout, slab, slab2, smem_raw); TRACE_END(kind); return; }
+        if (kind == 2) {
+            if (diag) gram_tall_dma<WEIGHT, true>(Phi, ld, w, side, r0, r1, chunk, acol, bcol, sideout, slab, slab2, smem_raw);
+            else gram_tall_dma<WEIGHT, false>(Phi, ld, w, side, r0, r1, chunk, acol, bcol, sideout, slab, slab2, smem_raw);
+            TRACE_END(kind); return;
+        }
         if (kind == 3) { gram_body<WCfg, WEIGHT, true>(Phi, ld, w, side, r0, r1, chunk, acol, bcol, diag, sideout, slab, nullptr, smem_raw); TRACE_END(kind); return; }
     }
     gram_body<Cfg, WEIGHT, false>(Phi, ld, w, side, r0, r1, chunk, acol, bcol, diag, sideout, slab, nullptr, smem_raw);
@@ -297,7 +416,7 @@ void GramKernels<T>::gram(const Geom& g, const T* Phi, const double* w, const do
     if (chunk <= 0 || chunk > g.Np) chunk = g.Np;
     chunk = round_up(chunk, 256);                              // splits start and end on 64- or 256-row granules
     constexpr int L1 = Cfg::LDS_BYTES > SCfg::LDS_BYTES ? Cfg::LDS_BYTES : SCfg::LDS_BYTES;
-    constexpr int L2 = BIG && BCfg::LDS_BYTES > L1 ? BCfg::LDS_BYTES : L1;
+    constexpr int L2 = BIG && GramDma::LDS_BYTES > L1 ? GramDma::LDS_BYTES : L1;
     constexpr int LDS = BIG && WCfg::LDS_BYTES > L2 ? WCfg::LDS_BYTES : L2;
     static_assert(2 * LDS <= 160 * 1024, "two workgroups per CU");
     const auto launch = [&](auto kernel) {

@@ -49,9 +49,19 @@ def main():
         cu = xcc * 256 + ((hwid >> 8) & 0xFF)                      # (xcc, se/sh/cu bits of HW_ID)
         print('gram hipEvent %.2f ms; %d workgroups; span %.2f ms' % (tm.get('gram', -1), len(tr), en.max() / 1e3))
         names = {0: '128x128', 1: 'strip', 2: '256x128', 3: 'wide 64x512'}
+        area = {0: 128 * 128, 1: 64 * 128, 2: 256 * 128, 3: 64 * 512}
+        Kp = eng.dims()['Kp']; nfull = Kp // 128 - (1 if (2 * (S + M) + 63) // 64 % 2 else 0); nstrip = Kp // 128 - nfull
+        R = nfull // 2; nsb = nstrip * (nfull + 1)
+        per_split = {2: R * R, 3: nsb // 4, 0: R + (nfull & 1) * nfull, 1: nsb % 4} if dtype == 'f32' else \
+                    {0: nfull * (nfull + 1) // 2, 1: nsb}
         for k in sorted(set(kind.tolist())):
             d = (en - st)[kind == k]
-            print('  kind %-14s n=%5d  length us: min %.0f  median %.0f  max %.0f' % (names.get(int(k), k), len(d), d.min(), np.median(d), d.max()))
+            # all rows pass through every tile of the kind once: flops of the kind / its summed workgroup time = rate per resident
+            # workgroup; x 512 resident workgroups = what the chip would deliver on this kind alone
+            fl = 2.0 * eng.dims()['Np'] * area[int(k)] * per_split.get(int(k), 0)
+            print('  kind %-14s n=%5d  length us: min %.0f  median %.0f  max %.0f   summed %.1f ms   %.1f TFLOP/s at 512 resident workgroups (%.3f of 157.3)'
+                  % (names.get(int(k), k), len(d), d.min(), np.median(d), d.max(), d.sum() / 1e3, fl / (d.sum() * 1e-6 / 512) / 1e12,
+                     fl / (d.sum() * 1e-6 / 512) / 1e12 / (157.3 if dtype == 'f32' else 78.6)))
         # busy slots over time
         ev = np.concatenate([np.stack([st, np.ones_like(st)], 1), np.stack([en, -np.ones_like(en)], 1)])
         ev = ev[np.argsort(ev[:, 0], kind='stable')]
