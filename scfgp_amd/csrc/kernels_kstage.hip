@@ -1,4 +1,4 @@
-// K x K stage (fp64): A = G + lam I, blocked Cholesky, L^{-1} by recursive doubling,
+// K x K stage (fp64): A = G + lam I, blocked Cholesky with L^{-1} formed beside it (augmented factorisation),
 // B = Li^T Li, alpha, log det, and the K x K cotangent Abar of the backward pass.
 // Replaces Theano's Cholesky / MatrixInverse ops (SCFGP/SCFGP.py:105-110) and the
 // linear-algebra part of TT.grad (:129).  All matrices are Kp x Kp (Kp % 128 == 0)
@@ -84,26 +84,6 @@ static void gemm64(const GemmArgs& a, hipStream_t st) {
     if (a.M <= 0 || a.N <= 0) return;
     allow_big_lds(gemm64_kernel<TRA, TRB>, KCfg::LDS_BYTES);
     hipLaunchKernelGGL((gemm64_kernel<TRA, TRB>), dim3(a.N / KCfg::BN, a.M / KCfg::BM), dim3(KCfg::THREADS), KCfg::LDS_BYTES, st, a);
-}
-
-// one recursive-doubling level of the triangular inverse, batched over block pairs (blockIdx.z)
-//   STEP 0:  Tmp21 = L21 . Inv11          STEP 1:  Li21 = - Inv22 . Tmp21
-template <int STEP>
-__global__ __launch_bounds__(KCfg::THREADS) void trinv_level_kernel(const double* __restrict__ L, double* Li, double* Tmp,
-                                                                    int64_t ld, int Kp, int sz) {
-    SMEM_DECL;
-    const int o1 = 2 * blockIdx.z * sz, o2 = o1 + sz;
-    const int n2 = Kp - o2 < sz ? Kp - o2 : sz;
-    GemmArgs a;
-    a.lda = a.ldb = a.ldc = ld; a.tri = 0; a.beta = 0.0;
-    if (STEP == 0) {                                           // Inv11 is lower triangular: k >= n
-        a.A = L + (int64_t)o2 * ld + o1; a.B = Li + (int64_t)o1 * ld + o1; a.C = Tmp + (int64_t)o2 * ld + o1;
-        a.M = n2; a.N = sz; a.K = sz; a.alpha = 1.0; a.kskip = 2;
-    } else {                                                   // Inv22 is lower triangular: k <= m
-        a.A = Li + (int64_t)o2 * ld + o2; a.B = Tmp + (int64_t)o2 * ld + o1; a.C = Li + (int64_t)o2 * ld + o1;
-        a.M = n2; a.N = sz; a.K = n2; a.alpha = -1.0; a.kskip = 3;
-    }
-    gemm64_body<true, false>(a, blockIdx.y, blockIdx.x, reinterpret_cast<double*>(smem_raw));
 }
 
 // ---------------------------------------------------------------------------
@@ -192,17 +172,20 @@ int64_t chol_trace_read(void* host, int64_t max_bytes) {
 int64_t chol_trace_read(void*, int64_t) { return -1; }
 #endif
 
-// One launch per 64-column step p of the blocked Cholesky (nb = Kp / 64 steps, ONE dependent launch each):
+// One launch per 64-column step p of the blocked Cholesky (nb = Kp / 64 steps, ONE dependent launch each, plus a last one):
 //   workgroup 0      the diagonal block of step p.  It brings the block up to date itself -- D = A[p][p] - L_p L_p^T with
 //                    L_p = A[p][p-1] Inv(p-1)^T, the only part of step p-1's update it depends on -- then factors it,
 //                    D = L L^T, and inverts L:  Lm[p][p] = L, Li[p][p] = L^-1.
-//   workgroups 1..   the trailing update of step p-1, one 64 x 64 tile (i >= j >= p) each, with the panel solve folded
-//                    in: L_i = A[i][p-1] Inv(p-1)^T, L_j likewise, A[i][j] -= L_i L_j^T; the diagonal tiles also write
-//                    L_i to Lm[i][p-1].  The working matrix A keeps its unsolved panel columns (every tile re-derives
-//                    the L blocks it needs from them), the factor goes to the separate matrix Lm.
-// So the critical path of the factorisation is the chain of diagonal blocks alone -- one ~25 us workgroup per step --
-// with the O(K^3) update work of the previous step running beside it (the launch-per-operation version had three
-// dependent launches per step: diagonal block, panel solve, trailing update).
+//   workgroups 1..   the trailing update of step q = p-1, one 64 x 64 tile each, with the panel solve folded in:
+//                    L_i = A[i][q] Inv(q)^T, L_j likewise, A[i][j] -= L_i L_j^T.  The working matrix A keeps its unsolved panel
+//                    columns (every tile re-derives the L blocks it needs from them).
+//   The INVERSE rides along (no separate triangular-inverse launches): the factorisation of the augmented matrix [A; I]
+//   gives [L; L^-T], and the rows of the identity part are updated by the same tile code -- row e of it lives in the unused
+//   upper blocks A[e][j], e < j, zeroed beforehand (its own diagonal block I is implicit).  Per step q: tiles (e <= q, j > q)
+//   A[e][j] -= L_e L_j^T with L_e = A[e][q] Inv(q)^T (e = q: Inv(q)^T itself), and the finished blocks of the inverse
+//   Li[q][e] = L_e^T for e < q.  Nobody on the critical path waits for them: they fill the shadow of workgroup 0.
+// So the critical path of the whole K x K factor-and-invert is the chain of diagonal blocks alone -- one ~22 us workgroup per
+// step -- with the O(K^3) update work of the previous step running beside it.
 __global__ __launch_bounds__(256) void chol_step_kernel(double* A, double* Lm, double* Li, int64_t ld, int p, int nb, int* flag) {
     constexpr int NB = 64, LD = NB + 1, PB = 16;
     __shared__ double sL[NB * LD];                                     // 2 x 33 KB + 9 KB: two workgroups per CU
@@ -213,37 +196,60 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* A, double* Lm, d
     const int ci = lane & 15, cq = lane >> 4;                          // MFMA C/D map (fp64): column ci, rows cq + 4 r
     v4d acc[4];
     if (blockIdx.x > 0) {
-        // ---- trailing tile (i, j) of step q = p - 1
-        const int t = blockIdx.x - 1, q = p - 1;
-        int ti = (int)((sqrtf(8.0f * t + 1.0f) - 1.0f) * 0.5f);
-        while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-        while (ti * (ti + 1) / 2 > t) --ti;
-        const int i = p + ti, j = p + (t - ti * (ti + 1) / 2);
-        // every block this tile needs is requested before anything is waited for (the launch starts cold)
+        // ---- work item of step q = p - 1: trailing tile (i >= j >= p), identity-row tile (i <= q < j), or inverse block (j = q, i < q)
+        const int q = p - 1, n = nb - p, T = n * (n + 1) / 2, U = p * n;
+        int t = blockIdx.x - 1, i, j;
+        bool li_row = false;
+        if (t < T) {
+            int ti = (int)((sqrtf(8.0f * t + 1.0f) - 1.0f) * 0.5f);
+            while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+            while (ti * (ti + 1) / 2 > t) --ti;
+            i = p + ti; j = p + (t - ti * (ti + 1) / 2);
+            if (i == p && j == p) return;                              // workgroup 0 updates and factors this block itself
+        } else if (t < T + U) {
+            t -= T; i = t / n; j = p + t % n;
+        } else {
+            i = t - T - U; j = q; li_row = true;
+        }
+        // every block this item needs is requested before anything is waited for (the launch starts cold)
         const double* gw = Li + ((int64_t)q * ld + q) * NB;            // W = Inv(q)
         const double* gi = A + ((int64_t)i * ld + q) * NB;
         const double* gj = A + ((int64_t)j * ld + q) * NB;
         double* c = A + ((int64_t)i * ld + j) * NB;
-        const bool own = i == p && j == p;                             // workgroup 0 updates and factors this block itself
+        const bool unit_i = i == q;                                    // row q of the identity part: its block (q, q) is I, L_i = W^T
         v2d rw[8], ri[8], rj[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int e = (tid + u * 256) * 2;
             const int64_t o = (int64_t)(e / NB) * ld + e % NB;
             rw[u] = *reinterpret_cast<const v2d*>(gw + o);
-            ri[u] = *reinterpret_cast<const v2d*>(gi + o);
-            if (i != j) rj[u] = *reinterpret_cast<const v2d*>(gj + o);
+            if (!unit_i) ri[u] = *reinterpret_cast<const v2d*>(gi + o);
+            if (i != j && !li_row) rj[u] = *reinterpret_cast<const v2d*>(gj + o);
         }
         v4d accc[4];
-        if (!own) block_load(c, ld, accc);
+        if (!li_row) block_load(c, ld, accc);
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int e = (tid + u * 256) * 2, o = (e / NB) * LD + e % NB;
             sL[o] = rw[u][0]; sL[o + 1] = rw[u][1];
-            sI[o] = ri[u][0]; sI[o + 1] = ri[u][1];
+            if (!unit_i) { sI[o] = ri[u][0]; sI[o + 1] = ri[u][1]; }
         }
         __syncthreads();
-        block_xwt<LD>(sI, sL, acc);                                    // L_i (registers)
+        if (unit_i) {                                                  // L_i = W^T, straight into the accumulator layout
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[b][r] = sL[(16 * b + ci) * LD + 16 * wave + cq + 4 * r];
+        } else
+            block_xwt<LD>(sI, sL, acc);                                // L_i (registers)
+        if (li_row) {                                                  // Li[q][i] = L_i^T
+            double* d = Li + ((int64_t)q * ld + i) * NB;
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) d[(int64_t)(16 * b + ci) * ld + 16 * wave + cq + 4 * r] = acc[b][r];
+            return;
+        }
         v4d accj[4];
         if (i != j) {
             __syncthreads();
@@ -258,13 +264,12 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* A, double* Lm, d
         __syncthreads();
         block_store(sL, LD, acc);                                      // W is done with: L_i takes its place, L_j stays in sI's
         if (i != j) block_store(sI, LD, accj);
-        else block_store(Lm + ((int64_t)i * ld + q) * NB, ld, acc);    // the factor's block (i, q)
-        if (own) return;
         __syncthreads();
         block_sub_pqt<LD>(sL, i != j ? sI : sL, accc);
         block_store(c, ld, accc);
         return;
     }
+    if (p >= nb) return;                                               // the last launch carries only the inverse blocks of step nb - 1
     // ---- diagonal block of step p
     CSTAMP(0);
     double* a = A + ((int64_t)p * ld + p) * NB;
@@ -415,9 +420,16 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* A, double* Lm, d
 // ---------------------------------------------------------------------------
 // small vector / diagonal kernels
 // ---------------------------------------------------------------------------
-__global__ void add_diag_kernel(double* A, int64_t ld, int K, int Kp, const Scal* __restrict__ sc) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < Kp) A[(int64_t)i * ld + i] += i < K ? sc->lam : 1.0;
+// A += lam I on the K x K block (1 on the padding diagonal), and the strictly upper 64 x 64 blocks := 0: they hold the rows of the
+// identity half of the augmented factorisation (chol_step_kernel)
+__global__ __launch_bounds__(256) void kstage_prep_kernel(double* A, int64_t ld, int K, int Kp, const Scal* __restrict__ sc) {
+    const int64_t total = (int64_t)Kp * Kp;
+    const double lam = sc->lam;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int i = (int)(e / Kp), j = (int)(e % Kp);
+        if (j / 64 > i / 64) A[e] = 0.0;
+        else if (i == j) A[e] += i < K ? lam : 1.0;
+    }
 }
 
 // out[i] = sum_k M[i][k] v[k]      one wave per row
@@ -496,24 +508,14 @@ __global__ __launch_bounds__(256) void adjoint_vec_kernel(const double* __restri
 // ---------------------------------------------------------------------------
 // host drivers
 // ---------------------------------------------------------------------------
-// A (k.A, full symmetric) -> L in the lower blocks of k.T2, inverses of L's diagonal blocks in k.Li
-static void cholesky_blocked(const KStage& k, hipStream_t st) {
+// A (k.A: symmetric on entry, its upper blocks are scratch) -> the diagonal blocks of L in k.T2, L^-1 in k.Li
+static void cholesky_and_inverse(const KStage& k, hipStream_t st) {
     const int nb = k.Kp / 64;
-    for (int p = 0; p < nb; ++p) {
-        const int n = nb - p, tiles = p > 0 ? n * (n + 1) / 2 : 0;     // trailing update of step p-1: blocks i >= j >= p
-        hipLaunchKernelGGL(chol_step_kernel, dim3(1 + tiles), dim3(256), 0, st, k.A, k.T2, k.Li, (int64_t)k.Kp, p, nb, k.flag);
-    }
-}
-
-static void trinv(const KStage& k, hipStream_t st) {
-    const int Kp = k.Kp;
-    for (int sz = 64; sz < Kp; sz *= 2) {
-        const int npairs = (Kp - sz - 1) / (2 * sz) + 1;
-        dim3 grid(sz / 64, sz / 64, npairs);
-        allow_big_lds(trinv_level_kernel<0>, KCfg::LDS_BYTES);
-        allow_big_lds(trinv_level_kernel<1>, KCfg::LDS_BYTES);
-        hipLaunchKernelGGL((trinv_level_kernel<0>), grid, dim3(KCfg::THREADS), KCfg::LDS_BYTES, st, k.T2, k.Li, k.T1, (int64_t)Kp, Kp, sz);
-        hipLaunchKernelGGL((trinv_level_kernel<1>), grid, dim3(KCfg::THREADS), KCfg::LDS_BYTES, st, k.T2, k.Li, k.T1, (int64_t)Kp, Kp, sz);
+    for (int p = 0; p <= nb; ++p) {
+        // step p's diagonal block + the items of step p-1: trailing tiles (i >= j >= p), identity-row tiles (i < p <= j), inverse blocks
+        const int n = nb - p, items = p > 0 ? n * (n + 1) / 2 + p * n + (p - 1) : 0;
+        if (p == nb && items == 0) break;
+        hipLaunchKernelGGL(chol_step_kernel, dim3(1 + items), dim3(256), 0, st, k.A, k.T2, k.Li, (int64_t)k.Kp, p, nb, k.flag);
     }
 }
 
@@ -527,9 +529,8 @@ void kstage_factor(const KStage& k, const Scal* sc, hipStream_t st) {
     const int Kp = k.Kp;
     const int64_t ld = Kp;
     hipMemsetAsync(k.Li, 0, sizeof(double) * ld * Kp, st);
-    hipLaunchKernelGGL(add_diag_kernel, dim3((Kp + 255) / 256), dim3(256), 0, st, k.A, ld, k.K, Kp, sc);
-    cholesky_blocked(k, st);
-    trinv(k, st);
+    hipLaunchKernelGGL(kstage_prep_kernel, dim3(1024), dim3(256), 0, st, k.A, ld, k.K, Kp, sc);
+    cholesky_and_inverse(k, st);
     kstage_gram_li(k, st);
     // alpha = Li^T (Li g) = B g  (SCFGP.py:108-110); B is symmetric, so one coalesced row-dot GEMV
     hipLaunchKernelGGL(gemv_rows_kernel, dim3((Kp + 3) / 4), dim3(256), 0, st, k.B, ld, k.g, k.alpha, Kp);
