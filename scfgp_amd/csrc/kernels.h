@@ -190,7 +190,8 @@ struct KStage {
     double *g, *beta, *alpha, *h, *u, *ut;   // Kp vectors
     double *scalars; int* flag;
 };
-void kstage_factor(const KStage& k, const Scal* sc, hipStream_t st);          // SCFGP.py:105-110,125
+// SCFGP.py:105-110,125; packed: the summed packed lower 128 x 128 tiles of G (exchange buffer 1); the upper blocks of Li stay as
+// they are (zero from context creation: nothing ever writes them)
+void kstage_factor(const KStage& k, const double* packed, const Scal* sc, hipStream_t st);
 void kstage_adjoint(const KStage& k, const double* BWB, double* Abar, const Scal* sc, hipStream_t st);
 void kstage_adjoint_factor_form(const KStage& k, double* McBWB, double* Abar, const Scal* sc, hipStream_t st);
-void kstage_gram_li(const KStage& k, hipStream_t st);                         // B = Li^T Li only (predict)

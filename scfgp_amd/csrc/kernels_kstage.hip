@@ -155,6 +155,18 @@ __device__ __forceinline__ void block_sub_pqt(const double* sP, const double* sQ
             acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(x, sQ[(16 * b + i) * LD + 4 * s + q], acc[b], 0, 0, 0);
     }
 }
+// acc (tiles (w, b)) += P . Q^T
+template <int LD>
+__device__ __forceinline__ void block_add_pqt(const double* sP, const double* sQ, v4d (&acc)[4]) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const double x = sP[(16 * wave + i) * LD + 4 * s + q];
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+            acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(x, sQ[(16 * b + i) * LD + 4 * s + q], acc[b], 0, 0, 0);
+    }
+}
 __device__ __forceinline__ void block_to_lds(const double* src, int64_t pitch, double* dst, int LD) {
     for (int e = threadIdx.x; e < 64 * 64; e += 256) dst[(e / 64) * LD + e % 64] = src[(int64_t)(e / 64) * pitch + e % 64];
 }
@@ -179,14 +191,17 @@ int64_t chol_trace_read(void*, int64_t) { return -1; }
 //   workgroups 1..   the trailing update of step q = p-1, one 64 x 64 tile each, with the panel solve folded in:
 //                    L_i = A[i][q] Inv(q)^T, L_j likewise, A[i][j] -= L_i L_j^T.  The working matrix A keeps its unsolved panel
 //                    columns (every tile re-derives the L blocks it needs from them).
-//   The INVERSE rides along (no separate triangular-inverse launches): the factorisation of the augmented matrix [A; I]
-//   gives [L; L^-T], and the rows of the identity part are updated by the same tile code -- row e of it lives in the unused
-//   upper blocks A[e][j], e < j, zeroed beforehand (its own diagonal block I is implicit).  Per step q: tiles (e <= q, j > q)
-//   A[e][j] -= L_e L_j^T with L_e = A[e][q] Inv(q)^T (e = q: Inv(q)^T itself), and the finished blocks of the inverse
-//   Li[q][e] = L_e^T for e < q.  Nobody on the critical path waits for them: they fill the shadow of workgroup 0.
+//   The INVERSE and B = A^-1 ride along (no separate triangular-inverse or Li^T Li launches): the factorisation of the
+//   augmented matrix [[A, I], [I, 0]] gives [L; L^-T] and the Schur complement -A^-1, and its extra rows are updated by the same
+//   tile code -- row e of the identity part lives in the unused upper blocks A[e][j], e < j, zeroed beforehand (its own diagonal
+//   block I is implicit).  Per step q: identity-row tiles (e <= q, j > q) A[e][j] -= L_e L_j^T with L_e = A[e][q] Inv(q)^T
+//   (e = q: Inv(q)^T itself); the finished blocks of the inverse Li[q][e] = L_e^T for e < q; and the tiles (q >= e >= e') of
+//   B += L_e L_e'^T (first touched at step q = e; the mirror tile is rewritten with it).  Nobody on the critical path waits
+//   for them: they fill the shadow of workgroup 0.  Only the nbk = ceil(K / 64) live steps run: the padding blocks of A are
+//   the identity and factor to themselves (Li and B carry 1 on the padding diagonal).
 // So the critical path of the whole K x K factor-and-invert is the chain of diagonal blocks alone -- one ~22 us workgroup per
 // step -- with the O(K^3) update work of the previous step running beside it.
-__global__ __launch_bounds__(256) void chol_step_kernel(double* A, double* Lm, double* Li, int64_t ld, int p, int nb, int* flag) {
+__global__ __launch_bounds__(256) void chol_step_kernel(double* A, double* Lm, double* Li, double* Bm, int64_t ld, int p, int nb, int* flag) {
     constexpr int NB = 64, LD = NB + 1, PB = 16;
     __shared__ double sL[NB * LD];                                     // 2 x 33 KB + 9 KB: two workgroups per CU
     __shared__ double sI[NB * LD];
@@ -196,27 +211,35 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* A, double* Lm, d
     const int ci = lane & 15, cq = lane >> 4;                          // MFMA C/D map (fp64): column ci, rows cq + 4 r
     v4d acc[4];
     if (blockIdx.x > 0) {
-        // ---- work item of step q = p - 1: trailing tile (i >= j >= p), identity-row tile (i <= q < j), or inverse block (j = q, i < q)
-        const int q = p - 1, n = nb - p, T = n * (n + 1) / 2, U = p * n;
+        // ---- work item of step q = p - 1: trailing tile (i >= j >= p), identity-row tile (i <= q < j), inverse block (j = q, i < q)
+        //      or tile (q >= i >= j) of B
+        const int q = p - 1, n = nb - p, T = n * (n + 1) / 2, U = p * n, R = p - 1;
         int t = blockIdx.x - 1, i, j;
-        bool li_row = false;
-        if (t < T) {
-            int ti = (int)((sqrtf(8.0f * t + 1.0f) - 1.0f) * 0.5f);
+        bool li_row = false, b_tile = false;
+        const auto tri_decode = [](int t, int& ti, int& tj) {
+            ti = (int)((sqrtf(8.0f * t + 1.0f) - 1.0f) * 0.5f);
             while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
             while (ti * (ti + 1) / 2 > t) --ti;
-            i = p + ti; j = p + (t - ti * (ti + 1) / 2);
+            tj = t - ti * (ti + 1) / 2;
+        };
+        if (t < T) {
+            int ti, tj; tri_decode(t, ti, tj);
+            i = p + ti; j = p + tj;
             if (i == p && j == p) return;                              // workgroup 0 updates and factors this block itself
         } else if (t < T + U) {
             t -= T; i = t / n; j = p + t % n;
-        } else {
+        } else if (t < T + U + R) {
             i = t - T - U; j = q; li_row = true;
+        } else {
+            tri_decode(t - T - U - R, i, j); b_tile = true;            // q >= i >= j >= 0
         }
         // every block this item needs is requested before anything is waited for (the launch starts cold)
         const double* gw = Li + ((int64_t)q * ld + q) * NB;            // W = Inv(q)
         const double* gi = A + ((int64_t)i * ld + q) * NB;
         const double* gj = A + ((int64_t)j * ld + q) * NB;
-        double* c = A + ((int64_t)i * ld + j) * NB;
-        const bool unit_i = i == q;                                    // row q of the identity part: its block (q, q) is I, L_i = W^T
+        double* c = (b_tile ? Bm : A) + ((int64_t)i * ld + j) * NB;
+        const bool unit_i = i == q, unit_j = j == q;                   // row q of the identity part: its block (q, q) is I, L = W^T
+        const bool first_b = b_tile && i == q;                         // B[i][j] is first touched at step q = i
         v2d rw[8], ri[8], rj[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -224,10 +247,14 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* A, double* Lm, d
             const int64_t o = (int64_t)(e / NB) * ld + e % NB;
             rw[u] = *reinterpret_cast<const v2d*>(gw + o);
             if (!unit_i) ri[u] = *reinterpret_cast<const v2d*>(gi + o);
-            if (i != j && !li_row) rj[u] = *reinterpret_cast<const v2d*>(gj + o);
+            if (i != j && !li_row && !unit_j) rj[u] = *reinterpret_cast<const v2d*>(gj + o);
         }
         v4d accc[4];
-        if (!li_row) block_load(c, ld, accc);
+        if (!li_row && !first_b) block_load(c, ld, accc);
+        else {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) accc[b] = v4d{0, 0, 0, 0};
+        }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int e = (tid + u * 256) * 2, o = (e / NB) * LD + e % NB;
@@ -235,13 +262,14 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* A, double* Lm, d
             if (!unit_i) { sI[o] = ri[u][0]; sI[o + 1] = ri[u][1]; }
         }
         __syncthreads();
-        if (unit_i) {                                                  // L_i = W^T, straight into the accumulator layout
+        const auto w_transposed = [&](v4d (&a)[4]) {                   // W^T straight into the accumulator layout
 #pragma unroll
             for (int b = 0; b < 4; ++b)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[b][r] = sL[(16 * b + ci) * LD + 16 * wave + cq + 4 * r];
-        } else
-            block_xwt<LD>(sI, sL, acc);                                // L_i (registers)
+                for (int r = 0; r < 4; ++r) a[b][r] = sL[(16 * b + ci) * LD + 16 * wave + cq + 4 * r];
+        };
+        if (unit_i) w_transposed(acc);
+        else block_xwt<LD>(sI, sL, acc);                               // L_i (registers)
         if (li_row) {                                                  // Li[q][i] = L_i^T
             double* d = Li + ((int64_t)q * ld + i) * NB;
 #pragma unroll
@@ -252,19 +280,34 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* A, double* Lm, d
         }
         v4d accj[4];
         if (i != j) {
-            __syncthreads();
+            if (unit_j) w_transposed(accj);
+            else {
+                __syncthreads();
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = (tid + u * 256) * 2, o = (e / NB) * LD + e % NB;
-                sI[o] = rj[u][0]; sI[o + 1] = rj[u][1];
+                for (int u = 0; u < 8; ++u) {
+                    const int e = (tid + u * 256) * 2, o = (e / NB) * LD + e % NB;
+                    sI[o] = rj[u][0]; sI[o + 1] = rj[u][1];
+                }
+                __syncthreads();
+                block_xwt<LD>(sI, sL, accj);                           // L_j
             }
-            __syncthreads();
-            block_xwt<LD>(sI, sL, accj);                               // L_j
         }
         __syncthreads();
         block_store(sL, LD, acc);                                      // W is done with: L_i takes its place, L_j stays in sI's
         if (i != j) block_store(sI, LD, accj);
         __syncthreads();
+        if (b_tile) {
+            block_add_pqt<LD>(sL, i != j ? sI : sL, accc);
+            block_store(c, ld, accc);
+            if (i != j) {                                              // B is symmetric: the mirror tile
+                double* ct = Bm + ((int64_t)j * ld + i) * NB;
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ct[(int64_t)(16 * b + ci) * ld + 16 * wave + cq + 4 * r] = accc[b][r];
+            }
+            return;
+        }
         block_sub_pqt<LD>(sL, i != j ? sI : sL, accc);
         block_store(c, ld, accc);
         return;
@@ -336,7 +379,7 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* A, double* Lm, d
             if (pb > 0)
                 for (int ti = 0; ti < nt; ++ti) tile_update(pb + PB * ti, pb, pb - PB);
             const int row = pb + lane;                                 // lanes past the last row idle along
-            double v[PB];
+            double v[PB], invs[PB];
 #pragma unroll
             for (int c = 0; c < PB; ++c) v[c] = row < NB ? sL[row * LD + pb + c] : 0.0;
 #pragma unroll
@@ -348,14 +391,18 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* A, double* Lm, d
                 double inv = __builtin_amdgcn_rsq(d);
                 inv = fma(0.5 * inv, fma(-d * inv, inv, 1.0), inv);
                 inv = fma(0.5 * inv, fma(-d * inv, inv, 1.0), inv);
-                if (lane == j) sD[pb + j] = inv;
-                v[j] = lane == j ? d * inv : v[j] * inv;               // entries above the diagonal are never used
+                invs[j] = inv;                                         // d, and with it inv, is the same in every lane
+                v[j] *= inv;                                           // lane j: d * inv = L[j][j]; entries above the diagonal are never used
 #pragma unroll
                 for (int k = j + 1; k < PB; ++k) v[k] = fma(-v[j], lane_bcast(v[j], k), v[k]);    // L[pb+k][pb+j] lives in lane k
             }
 #pragma unroll
             for (int c = 0; c < PB; ++c)
                 if (row < NB) sL[row * LD + pb + c] = v[c];
+            if (lane == 0) {
+#pragma unroll
+                for (int c = 0; c < PB; ++c) sD[pb + c] = invs[c];
+            }
             CSTAMP(2 + pb / PB * 2);
             CSTAMP(3 + pb / PB * 2);
         } else if (pb > 0) {
@@ -420,15 +467,27 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* A, double* Lm, d
 // ---------------------------------------------------------------------------
 // small vector / diagonal kernels
 // ---------------------------------------------------------------------------
-// A += lam I on the K x K block (1 on the padding diagonal), and the strictly upper 64 x 64 blocks := 0: they hold the rows of the
-// identity half of the augmented factorisation (chol_step_kernel)
-__global__ __launch_bounds__(256) void kstage_prep_kernel(double* A, int64_t ld, int K, int Kp, const Scal* __restrict__ sc) {
-    const int64_t total = (int64_t)Kp * Kp;
+// summed exchange buffer 1 (packed lower 128 x 128 tiles of G) -> working matrix of the factorisation: lower 64 x 64 blocks of
+// G + lam I (1 on the padding diagonal); the strictly upper 64 x 64 blocks := 0 -- they hold the identity rows of the augmented
+// factorisation (chol_step_kernel).  Blocks of the padding rows / columns of Li and B: identity on the diagonal.
+__global__ __launch_bounds__(256) void kstage_unpack_kernel(const double* __restrict__ packed, int B, double* __restrict__ A, double* __restrict__ Li,
+                                                            double* __restrict__ Bm, int64_t ld, int K, int nbk, const Scal* __restrict__ sc) {
+    const int t = blockIdx.x;
+    int ti = (int)((sqrtf(8.0f * t + 1.0f) - 1.0f) * 0.5f);
+    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    while (ti * (ti + 1) / 2 > t) --ti;
+    const int tj = t - ti * (ti + 1) / 2;
     const double lam = sc->lam;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-        const int i = (int)(e / Kp), j = (int)(e % Kp);
-        if (j / 64 > i / 64) A[e] = 0.0;
-        else if (i == j) A[e] += i < K ? lam : 1.0;
+    for (int e = blockIdx.y * 256 + threadIdx.x; e < B * B; e += gridDim.y * 256) {
+        const double v = packed[(int64_t)t * B * B + e];
+        const int i = ti * B + e / B, j = tj * B + e % B;
+        A[(int64_t)i * ld + j] = j / 64 > i / 64 ? 0.0 : (i == j ? v + (i < K ? lam : 1.0) : v);
+        if (ti != tj) A[(int64_t)j * ld + i] = 0.0;
+        if (i / 64 >= nbk || j / 64 >= nbk) {                          // padding blocks: never touched by the step launches
+            const double id = i == j ? 1.0 : 0.0;
+            Li[(int64_t)i * ld + j] = id; Bm[(int64_t)i * ld + j] = id;
+            if (ti != tj) { Li[(int64_t)j * ld + i] = 0.0; Bm[(int64_t)j * ld + i] = 0.0; }
+        }
     }
 }
 
@@ -508,30 +567,23 @@ __global__ __launch_bounds__(256) void adjoint_vec_kernel(const double* __restri
 // ---------------------------------------------------------------------------
 // host drivers
 // ---------------------------------------------------------------------------
-// A (k.A: symmetric on entry, its upper blocks are scratch) -> the diagonal blocks of L in k.T2, L^-1 in k.Li
-static void cholesky_and_inverse(const KStage& k, hipStream_t st) {
-    const int nb = k.Kp / 64;
-    for (int p = 0; p <= nb; ++p) {
-        // step p's diagonal block + the items of step p-1: trailing tiles (i >= j >= p), identity-row tiles (i < p <= j), inverse blocks
-        const int n = nb - p, items = p > 0 ? n * (n + 1) / 2 + p * n + (p - 1) : 0;
-        if (p == nb && items == 0) break;
-        hipLaunchKernelGGL(chol_step_kernel, dim3(1 + items), dim3(256), 0, st, k.A, k.T2, k.Li, (int64_t)k.Kp, p, nb, k.flag);
+// A (k.A: lower blocks of G + lam I, upper blocks zero) -> the diagonal blocks of L in k.T2, L^-1 in k.Li, A^-1 in k.B
+static void cholesky_inverse_gram(const KStage& k, hipStream_t st) {
+    const int nbk = (k.K + 63) / 64;                                   // live steps: the padding blocks are the identity
+    for (int p = 0; p <= nbk; ++p) {
+        // step p's diagonal block + the items of step p-1: trailing tiles (i >= j >= p), identity-row tiles (i < p <= j), inverse
+        // blocks (p - 1), tiles of B (p (p + 1) / 2)
+        const int n = nbk - p, items = p > 0 ? n * (n + 1) / 2 + p * n + (p - 1) + p * (p + 1) / 2 : 0;
+        hipLaunchKernelGGL(chol_step_kernel, dim3(1 + items), dim3(256), 0, st, k.A, k.T2, k.Li, k.B, (int64_t)k.Kp, p, nbk, k.flag);
     }
 }
 
-void kstage_gram_li(const KStage& k, hipStream_t st) {
-    const int64_t ld = k.Kp;
-    GemmArgs a = {k.Li, k.Li, k.B, ld, ld, ld, k.Kp, k.Kp, k.Kp, 1.0, 0.0, 2, 1};
-    gemm64<false, false>(a, st);                                      // B = Li^T Li: lower tiles, mirrored on the store
-}
-
-void kstage_factor(const KStage& k, const Scal* sc, hipStream_t st) {
-    const int Kp = k.Kp;
+// packed: the summed exchange buffer 1 (lower 128 x 128 tiles of G, then Phi^T y and the scalars, which the caller copies)
+void kstage_factor(const KStage& k, const double* packed, const Scal* sc, hipStream_t st) {
+    const int Kp = k.Kp, nts = Kp / 128, nbk = (k.K + 63) / 64;
     const int64_t ld = Kp;
-    hipMemsetAsync(k.Li, 0, sizeof(double) * ld * Kp, st);
-    hipLaunchKernelGGL(kstage_prep_kernel, dim3(1024), dim3(256), 0, st, k.A, ld, k.K, Kp, sc);
-    cholesky_and_inverse(k, st);
-    kstage_gram_li(k, st);
+    hipLaunchKernelGGL(kstage_unpack_kernel, dim3(nts * (nts + 1) / 2, 16), dim3(256), 0, st, packed, 128, k.A, k.Li, k.B, ld, k.K, nbk, sc);
+    cholesky_inverse_gram(k, st);
     // alpha = Li^T (Li g) = B g  (SCFGP.py:108-110); B is symmetric, so one coalesced row-dot GEMV
     hipLaunchKernelGGL(gemv_rows_kernel, dim3((Kp + 3) / 4), dim3(256), 0, st, k.B, ld, k.g, k.alpha, Kp);
     hipLaunchKernelGGL(factor_scalars_kernel, dim3(1), dim3(256), 0, st, k.T2, k.B, ld, k.K, k.g, k.alpha, k.scalars);

@@ -336,6 +336,7 @@ extern "C" int scfgp_create(scfgp_ctx** out, int D, int S, int M, int dtype, int
     HIPCHK(c, hipMemsetAsync(c->d_x1, 0, sizeof(double) * c->n_x1, c->st));
     HIPCHK(c, hipMemsetAsync(c->d_x2, 0, sizeof(double) * c->n_x2, c->st));
     HIPCHK(c, hipMemsetAsync(c->d_x3, 0, sizeof(double) * c->n_x3, c->st));
+    HIPCHK(c, hipMemsetAsync(c->d_Li, 0, sizeof(double) * K2, c->st));          // its upper blocks stay zero for good (kstage_factor)
     HIPCHK(c, hipMemsetAsync(c->d_vecs, 0, sizeof(double) * 5 * Kp, c->st));
     HIPCHK(c, hipMemsetAsync(c->d_scalars, 0, sizeof(double) * 32, c->st));
     HIPCHK(c, hipStreamSynchronize(c->st));
@@ -467,7 +468,9 @@ template <typename T> struct Impl {
     }
     static int factor(scfgp_ctx* c) {
         const Geom& g = c->g;
-        { ProfScope ps(c, "kstage_factor"); unpack_exchange(c, c->d_xp1, c->d_x1); kstage_factor(c->kstage(), c->d_sc, c->st); }
+        { ProfScope ps(c, "kstage_factor");
+          hipMemcpyAsync(c->d_x1 + (int64_t)g.Kp * g.Kp, c->d_xp1 + c->n_pk, sizeof(double) * (g.Kp + 8), hipMemcpyDeviceToDevice, c->st);
+          kstage_factor(c->kstage(), c->d_xp1, c->d_sc, c->st); }
         if (c->last_cform) {                                   // factor form: the typed operands are Li (in B's place) and Li^T (scratch)
             SK::convert(c->d_Li, (T*)c->d_BT, g.K, g.Kp, c->st);
             SK::convert_transposed(c->d_Li, (T*)c->d_AbarT, g.K, g.Kp, c->st);
