@@ -125,31 +125,70 @@ def _blas_threads():
         return int(os.cpu_count())
 
 
+def _host_topology():
+    """(sockets, physical cores per socket, logical CPUs) of this host from /proc/cpuinfo; (1, cpu_count, cpu_count) when unreadable."""
+    try:
+        phys, cores = set(), set()
+        pid = cid = None
+        for ln in open('/proc/cpuinfo'):
+            if ln.startswith('physical id'):
+                pid = ln.split(':')[1].strip()
+            elif ln.startswith('core id'):
+                cid = ln.split(':')[1].strip()
+            elif not ln.strip() and pid is not None:
+                phys.add(pid); cores.add((pid, cid)); pid = cid = None
+        ns = max(len(phys), 1)
+        return ns, max(len(cores) // ns, 1), int(os.cpu_count())
+    except Exception:
+        n = int(os.cpu_count())
+        return 1, n, n
+
+
 def cpu_baseline(X, y, params, S, M, N_full, budget_rows):
     """The reference's CPU path cannot run (Theano is absent), so its stand-ins are timed on the host cores of
-    this box on a bounded sample of the same workload (first `budget_rows` rows), scaled linearly in rows:
-      primary  torch-CPU float64 autograd of the LITERAL graph of SCFGP/SCFGP.py:92-129 (oracle/autograd_ref.py:
-               forward + reverse sweep as TT.grad would execute it, GH-30 tensor included), all torch threads
-      also     the numpy 3-sweep oracle (oracle/scfgp_oracle.py::value_and_grad), BLAS-threaded GEMMs"""
+    this box on bounded samples of the same workload (the first rows), scaled linearly in rows:
+      primary    torch-CPU float64 autograd of the LITERAL graph of SCFGP/SCFGP.py:92-129 (oracle/autograd_ref.py: forward +
+                 reverse sweep as TT.grad would execute it, GH-30 tensor included) on ALL torch threads of the box
+      one_socket the same on the physical cores of one socket, threads_8 on 8 threads (this container's core count)
+      also       the numpy 3-sweep oracle (oracle/scfgp_oracle.py::value_and_grad), BLAS-threaded GEMMs
+    The linear scaling of the sample is checked once per round at the full 1e6 rows (tools/cpu_full.py ->
+    profiles/r04_cpu_full.json)."""
     import torch
     from oracle import autograd_ref as AR
     from oracle import scfgp_oracle as O
+    all_threads = int(torch.get_num_threads())
+    sockets, per_socket, logical = _host_topology()
+
+    def timed(threads, rows):
+        n = min(rows, X.shape[0])
+        Xs, ys = np.ascontiguousarray(X[:n]), np.ascontiguousarray(y[:n])
+        torch.set_num_threads(threads)
+        t0 = time.time()
+        AR.value_and_grad(Xs, ys, params, S, M)
+        dt = time.time() - t0
+        torch.set_num_threads(all_threads)
+        return {"value": n / float(N_full) / dt, "unit": "evals/s", "cores": int(threads), "kind": "port",
+                "sample": "first %d of %d rows: %.1f s, scaled linearly in rows (the K^3 stage is not scaled down)" % (n, N_full, dt)}
+
+    out = timed(all_threads, budget_rows)
+    out["sample"] = ("torch-CPU float64 autograd of the literal reference graph (oracle/autograd_ref.py, stand-in for Theano's compiled "
+                     "TT.grad, SCFGP/SCFGP.py:129) on the " + out["sample"])
+    out["host"] = {"sockets": sockets, "physical_cores_per_socket": per_socket, "logical_cpus": logical}
+    # smaller samples for the smaller thread counts, so that each stays ~10-20 s
+    s1 = min(per_socket, all_threads)
+    out["one_socket"] = timed(s1, max(budget_rows * s1 // max(all_threads, 1), budget_rows // 4))
+    out["threads_8"] = timed(min(8, all_threads), max(budget_rows // 5, 1000))
     n = min(budget_rows, X.shape[0])
-    Xs, ys = np.ascontiguousarray(X[:n]), np.ascontiguousarray(y[:n])
     t0 = time.time()
-    AR.value_and_grad(Xs, ys, params, S, M)
-    dt_ag = time.time() - t0
-    t0 = time.time()
-    O.value_and_grad(Xs, ys, params, S, M, chunk=n)             # one chunk: the oracle's fastest setting
+    O.value_and_grad(np.ascontiguousarray(X[:n]), np.ascontiguousarray(y[:n]), params, S, M, chunk=n)   # one chunk: the oracle's fastest setting
     dt_np = time.time() - t0
-    scale = n / float(N_full)
-    return {"value": scale / dt_ag, "unit": "evals/s", "cores": int(torch.get_num_threads()), "kind": "port",
-            "sample": "torch-CPU float64 autograd of the literal reference graph (oracle/autograd_ref.py, stand-in for Theano's "
-                      "compiled TT.grad, SCFGP/SCFGP.py:129) on the first %d of %d rows: %.1f s, scaled linearly in rows "
-                      "(the K^3 stage is not scaled down)" % (n, N_full, dt_ag),
-            "also": {"value": scale / dt_np, "unit": "evals/s", "cores": _blas_threads(), "kind": "port",
-                     "sample": "numpy 3-sweep oracle (oracle/scfgp_oracle.py value_and_grad; GEMMs on the BLAS threads in `cores`, "
-                               "element-wise numpy on one) on the same %d rows: %.1f s" % (n, dt_np)}}
+    out["also"] = {"value": n / float(N_full) / dt_np, "unit": "evals/s", "cores": _blas_threads(), "kind": "port",
+                   "sample": "numpy 3-sweep oracle (oracle/scfgp_oracle.py value_and_grad; GEMMs on the BLAS threads in `cores`, "
+                             "element-wise numpy on one) on the first %d rows: %.1f s" % (n, dt_np)}
+    full = os.path.join(ROOT, 'profiles', 'r04_cpu_full.json')
+    if os.path.exists(full):
+        out["full_size_check"] = json.load(open(full))
+    return out
 
 
 def box_probe(device):
@@ -163,7 +202,7 @@ def box_probe(device):
     return {"mfma_f32_TFLOPs": out[0], "mfma_f32_frac_of_peak": out[0] / PEAK_TFLOPS['f32'], "mfma_clock_GHz": out[1],
             "mfma_f32_TFLOPs_at_1_2_8_waves_per_simd": [out[3], out[4], out[5]],
             "copy_GBs": out[2], "copy_frac_of_8TBs": out[2] / HBM_PEAK_GBS,
-            "what": "scfgp_box_probe before the timed loop: register-only v_mfma_f32_16x16x4_f32 loop on random operands "
+            "what": "scfgp_box_probe before the engine is created: register-only v_mfma_f32_16x16x4_f32 loop on random operands "
                     "(no memory traffic), shader clock held during it, 1 GiB -> 1 GiB streaming copy (read + write)"}
 
 
@@ -285,12 +324,14 @@ def main(a):
     N, D, S, M = a.rows, a.D, a.S, a.M
     J = S + M; K = 2 * J
     lo, hi = shard_rows(N, rank, world)
+    # the probe runs before the engine exists (its own stream, its 2 GiB freed again); building the problem below takes seconds
+    # of host work, so the chip's clock and thermal state have settled again when the warm-up starts
+    box = box_probe(local) if rank == 0 else None
     eng = HipEngine(D, S, M, dtype=a.dtype, device=local, stream=torch.cuda.current_stream().cuda_stream)
     X, y, params = build_problem(eng, N, D, S, M, lo, hi, allreduce)
     eng.set_params(params)
     eng.set_data(X, y, n_global=N)
     ev = ShardedEvaluator(eng, allreduce, time_exchanges=use_dist)
-    box = box_probe(local) if rank == 0 else None
 
     def barrier():
         torch.cuda.synchronize()

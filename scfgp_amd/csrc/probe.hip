@@ -52,22 +52,24 @@ extern "C" int scfgp_box_probe(int device, double* out, int n) {
     const int ncu = prop.multiProcessorCount, nwg = ncu * 8;
     float* sink = nullptr; unsigned long long* stamps = nullptr; char* buf = nullptr;
     const size_t half = (size_t)1 << 30;                          // 1 GiB in, 1 GiB out
-    hipEvent_t e0, e1;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipStream_t ps = nullptr;                                     // the probe's own non-blocking stream: no implicit ordering against anybody's work
     int rc = SCFGP_OK;
-    if (hipMalloc((void**)&sink, 64) != hipSuccess || hipMalloc((void**)&stamps, sizeof(unsigned long long) * 2 * nwg) != hipSuccess ||
+    if (hipStreamCreateWithFlags(&ps, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc((void**)&sink, 64) != hipSuccess || hipMalloc((void**)&stamps, sizeof(unsigned long long) * 2 * nwg) != hipSuccess ||
         hipMalloc((void**)&buf, 2 * half) != hipSuccess || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
         rc = SCFGP_EHIP;
     } else {
         float ms = 0;
-        (void)hipMemset(buf, 1, 2 * half);
-        hipLaunchKernelGGL(probe_mfma_kernel, dim3(nwg), dim3(256), 0, 0, sink, stamps, 2000);      // warm-up
+        (void)hipMemsetAsync(buf, 1, 2 * half, ps);
+        hipLaunchKernelGGL(probe_mfma_kernel, dim3(nwg), dim3(256), 0, ps, sink, stamps, 2000);      // warm-up
         out[0] = 0; out[1] = 0;
         const int wps[3] = {1, 2, 8};                                 // waves per SIMD = 4-wave workgroups per CU
         for (int v = 0; v < 3; ++v) {
             const int g = ncu * wps[v], iters = 240000 / wps[v];       // ~25-30 ms each
-            (void)hipEventRecord(e0, 0);
-            hipLaunchKernelGGL(probe_mfma_kernel, dim3(g), dim3(256), 0, 0, sink, stamps, iters);
-            (void)hipEventRecord(e1, 0);
+            (void)hipEventRecord(e0, ps);
+            hipLaunchKernelGGL(probe_mfma_kernel, dim3(g), dim3(256), 0, ps, sink, stamps, iters);
+            (void)hipEventRecord(e1, ps);
             (void)hipEventSynchronize(e1);
             (void)hipEventElapsedTime(&ms, e0, e1);
             const double tf = (double)g * 4 * iters * 8 * 2048.0 / (ms * 1e-3) / 1e12;
@@ -84,9 +86,9 @@ extern "C" int scfgp_box_probe(int device, double* out, int n) {
         }
         double best = 0;
         for (int rep = 0; rep < 4; ++rep) {
-            (void)hipEventRecord(e0, 0);
-            hipLaunchKernelGGL(probe_copy_kernel, dim3(ncu * 16), dim3(256), 0, 0, (const v4f*)buf, (v4f*)(buf + half), (int64_t)(half / 16));
-            (void)hipEventRecord(e1, 0);
+            (void)hipEventRecord(e0, ps);
+            hipLaunchKernelGGL(probe_copy_kernel, dim3(ncu * 16), dim3(256), 0, ps, (const v4f*)buf, (v4f*)(buf + half), (int64_t)(half / 16));
+            (void)hipEventRecord(e1, ps);
             (void)hipEventSynchronize(e1);
             (void)hipEventElapsedTime(&ms, e0, e1);
             if (rep > 0) best = std::max(best, 2.0 * half / (ms * 1e-3) / 1e9);
@@ -94,6 +96,10 @@ extern "C" int scfgp_box_probe(int device, double* out, int n) {
         out[2] = best;
         if (hipGetLastError() != hipSuccess) rc = SCFGP_EHIP;
     }
+    if (ps) (void)hipStreamSynchronize(ps);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (ps) (void)hipStreamDestroy(ps);
     if (sink) (void)hipFree(sink);
     if (stamps) (void)hipFree(stamps);
     if (buf) (void)hipFree(buf);

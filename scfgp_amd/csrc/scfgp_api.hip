@@ -125,7 +125,7 @@ struct scfgp_ctx {
     // finished evaluation asks for a higher level that evaluation is repeated (scfgp_finish returns SCFGP_REDO; scfgp_eval
     // does so itself) and the following ones start at that level; the level drops when the estimate falls below a quarter
     // of the threshold.  Inside one scfgp_train call the level is fixed (the iteration may be a captured graph).
-    int gram64 = 2, esc_level = 0; double esc_thr = SCFGP_COND_THRESHOLD, escw_thr = SCFGP_COND_THRESHOLD_W; bool last_used64 = false;
+    int gram64 = 2, esc_level = 0, esc_denied = 0; double esc_thr = SCFGP_COND_THRESHOLD, escw_thr = SCFGP_COND_THRESHOLD_W; bool last_used64 = false;
     int last_level = 0; bool cond_valid = false;               // cond_valid: cond[] describes the current parameters and rows
     double cond[3] = {0, 0, 0};                                         // min L_ii^2, max L_ii^2, max_j (A^-1)_jj of the last factorisation
     void* d_Phi64 = nullptr; int64_t phi64_cap = 0; RowSplits splits64{};
@@ -393,7 +393,7 @@ static int load_working_set(scfgp_ctx* c, const int64_t* d_idx, int64_t n, int64
     sum_squares(c->d_y, c->g.Np, c->d_yy, 0, c->d_partial, c->st);
     HIPCHK(c, hipGetLastError());
     c->work_full = d_idx == nullptr;
-    c->have_data = true; c->stage = 0; c->cond_valid = false;
+    c->have_data = true; c->stage = 0; c->cond_valid = false; c->esc_denied = 0;
     return SCFGP_OK;
 }
 
@@ -671,8 +671,24 @@ static void enqueue_epilogue(scfgp_ctx* c, int want_grad) {
 static int update_level(scfgp_ctx* c, bool notpd, bool want_grad, bool may_redo = true) {
     if (c->dtype != SCFGP_F32 || c->gram64 != 2) return SCFGP_OK;
     const double est = c->cond_est();
-    const int want = notpd || !std::isfinite(est) ? 2 : c->want_level(est, 1.0);
-    if (want > c->esc_level) c->esc_level = want;
+    int want = notpd || !std::isfinite(est) ? 2 : c->want_level(est, 1.0);
+    const int top = c->esc_denied > 0 ? std::min(want, c->esc_denied - 1) : want;     // levels refused before are not tried again
+    if (top > c->esc_level) {
+        // the buffers of the higher level first; the level is committed only when they exist.  If they cannot be allocated
+        // (~17 GB at the headline shape for level 1, N Kp 4 bytes more for level 2) the context stays usable at the level below:
+        // scfgp_get_condition keeps reporting the estimate and the predicted error, last_error says what was refused.  A
+        // row-sharded caller must treat that message as fatal: the ranks would no longer agree on the level.
+        const int old = c->esc_level;
+        for (int lvl = top; lvl > old; --lvl) {                  // level 2 refused: level 1 may still fit
+            c->esc_level = lvl;
+            if (ensure_aux_rows(c) == SCFGP_OK) break;
+            (void)hipGetLastError();
+            c->esc_level = lvl - 1; c->esc_denied = lvl;
+            c->err = "precision level " + std::to_string(lvl) + " refused (auxiliary row buffers could not be allocated); staying at level " +
+                     std::to_string(lvl - 1) + ": " + c->err;
+        }
+    }
+    want = std::min(want, std::max(c->esc_level, 0));
     // level 2 only serves the gradient: a forward-only evaluation at level 1 is final
     if (may_redo && (want_grad ? want : std::min(want, 1)) > c->last_level) {
         if (c->gexec) { hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
@@ -1122,7 +1138,7 @@ extern "C" int scfgp_set_option(scfgp_ctx* c, const char* name, int64_t value) {
     else if (s == "xtz_nsplit") c->xtz_nsplit = (int)value;
     else if (s == "use_graph") c->use_graph = (int)value;
     else if (s == "gram64") { if (value < 0 || value > 3) { c->err = "gram64: 0 never, 1 always level 1, 2 auto, 3 always level 2"; return SCFGP_EARG; }
-                              c->gram64 = (int)value; c->esc_level = 0; }
+                              c->gram64 = (int)value; c->esc_level = 0; c->esc_denied = 0; }
     else if (s == "factor_form") { if (value < -1 || value > 1) { c->err = "factor_form: -1 auto, 0 never, 1 always"; return SCFGP_EARG; } c->factor_form = (int)value; }
     else if (s == "cond_threshold") c->esc_thr = (double)value;
     else if (s == "cond_threshold_w") c->escw_thr = (double)value;

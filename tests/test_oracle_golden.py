@@ -117,3 +117,17 @@ def test_host_scaler_is_pinned_by_the_artifacts_fitted_dictionaries():
         assert f.data['cols'] == ref.data['cols']
         assert np.array_equal(f.data['min'], ref.data['min']) and np.array_equal(f.data['max'], ref.data['max'])
         assert np.allclose(f.data['boxcox'], ref.data['boxcox'], rtol=2e-2), (tag, f.data['boxcox'], ref.data['boxcox'])
+
+
+def test_row_chunked_literal_graph_equals_the_unchunked_one():
+    """oracle/autograd_ref.py value_and_grad_chunked (what tools/cpu_full.py times at the full 1e6 rows) is the same function:
+    cost, gradient, alpha and Li of the literal graph, the row tensors formed 700 rows at a time."""
+    from oracle import autograd_ref as AR
+    rng = np.random.default_rng(3)
+    N, D, S, M = 3000, 7, 4, 30
+    X = rng.random((N, D)); y = rng.standard_normal((N, 1))
+    p = O.init_params(D, S, M, rng); p[:3] = [-0.5, 0.1, -0.7]
+    c0, g0, a0, L0 = AR.value_and_grad(X, y, p, S, M)
+    c1, g1, a1, L1 = AR.value_and_grad_chunked(X, y, p, S, M, chunk=700)
+    assert abs(c1 - c0) < 1e-13 * abs(c0) and np.linalg.norm(g1 - g0) < 1e-12 * np.linalg.norm(g0)
+    assert np.linalg.norm(a1 - a0) < 1e-10 * np.linalg.norm(a0) and np.linalg.norm(L1 - L0) < 1e-10 * np.linalg.norm(L0)

@@ -1,7 +1,7 @@
 """Phase breakdown of workgroup 0 of the Cholesky steps (diagnostic _trace build): SCFGP_LIB_VARIANT=_trace python tools/chol_trace.py"""
-import sys
+import os, sys
 import numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from scfgp_amd.engine import HipEngine
 from scfgp_amd import synth
 N, D, S, M = 65536, 64, 32, 1024
@@ -11,7 +11,7 @@ params = synth.make_params(seed + 0x0202, D, S, M, abc=(-1.0, 0.0, -1.0))
 eng = HipEngine(D, S, M, dtype='f32'); eng.set_params(params); eng.set_data(X, y)
 eng.eval(want_grad=True); eng.eval(want_grad=True)
 t = eng.debug_read('chol_trace', (64, 16), dtype=np.uint64).astype(np.int64)
-nb = eng.dims()['Kp'] // 64
+nb = (eng.K + 63) // 64                         # live steps (the padding blocks are skipped)
 t = t[1:nb]                                      # steps p >= 1 (the first has no diagonal update)
 names = ['diag update (2 MFMA products)', 'panel 0', 'rank-16 upd 0', 'panel 1', 'rank-16 upd 1', 'panel 2', 'rank-16 upd 2',
          'panel 3', 'rank-16 upd 3', 'inverse level 0', 'inverse doubling + store']
