@@ -195,8 +195,8 @@ int64_t chol_trace_read(void*, int64_t) { return -1; }
 //   augmented matrix [[A, I], [I, 0]] gives [L; L^-T] and the Schur complement -A^-1, and its extra rows are updated by the same
 //   tile code -- row e of the identity part lives in the unused upper blocks A[e][j], e < j, zeroed beforehand (its own diagonal
 //   block I is implicit).  Per step q: identity-row tiles (e <= q, j > q) A[e][j] -= L_e L_j^T with L_e = A[e][q] Inv(q)^T
-//   (e = q: Inv(q)^T itself); the finished blocks of the inverse Li[q][e] = L_e^T for e < q; and the tiles (q >= e >= e') of
-//   B += L_e L_e'^T (first touched at step q = e; the mirror tile is rewritten with it).  Nobody on the critical path waits
+//   (e = q: Inv(q)^T itself); and the tiles (q >= e >= e') of B += L_e L_e'^T (first touched at step q = e; the mirror tile is
+//   rewritten with it), of which the tiles (q, e < q) also store the finished block Li[q][e] = L_e^T of the inverse.  Nobody on the critical path waits
 //   for them: they fill the shadow of workgroup 0.  Only the nbk = ceil(K / 64) live steps run: the padding blocks of A are
 //   the identity and factor to themselves (Li and B carry 1 on the padding diagonal).
 // So the critical path of the whole K x K factor-and-invert is the chain of diagonal blocks alone -- one ~22 us workgroup per
@@ -211,11 +211,11 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* A, double* Lm, d
     const int ci = lane & 15, cq = lane >> 4;                          // MFMA C/D map (fp64): column ci, rows cq + 4 r
     v4d acc[4];
     if (blockIdx.x > 0) {
-        // ---- work item of step q = p - 1: trailing tile (i >= j >= p), identity-row tile (i <= q < j), inverse block (j = q, i < q)
-        //      or tile (q >= i >= j) of B
-        const int q = p - 1, n = nb - p, T = n * (n + 1) / 2, U = p * n, R = p - 1;
+        // ---- work item of step q = p - 1: trailing tile (i >= j >= p), identity-row tile (i <= q < j) or tile (q >= i >= j) of B
+        //      (the tiles (q, j < q) of B hold L_j = the finished block Li[q][j]^T of the inverse and store it too)
+        const int q = p - 1, n = nb - p, T = n * (n + 1) / 2, U = p * n;
         int t = blockIdx.x - 1, i, j;
-        bool li_row = false, b_tile = false;
+        bool b_tile = false;
         const auto tri_decode = [](int t, int& ti, int& tj) {
             ti = (int)((sqrtf(8.0f * t + 1.0f) - 1.0f) * 0.5f);
             while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
@@ -228,10 +228,8 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* A, double* Lm, d
             if (i == p && j == p) return;                              // workgroup 0 updates and factors this block itself
         } else if (t < T + U) {
             t -= T; i = t / n; j = p + t % n;
-        } else if (t < T + U + R) {
-            i = t - T - U; j = q; li_row = true;
         } else {
-            tri_decode(t - T - U - R, i, j); b_tile = true;            // q >= i >= j >= 0
+            tri_decode(t - T - U, i, j); b_tile = true;                // q >= i >= j >= 0
         }
         // every block this item needs is requested before anything is waited for (the launch starts cold)
         const double* gw = Li + ((int64_t)q * ld + q) * NB;            // W = Inv(q)
@@ -247,10 +245,10 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* A, double* Lm, d
             const int64_t o = (int64_t)(e / NB) * ld + e % NB;
             rw[u] = *reinterpret_cast<const v2d*>(gw + o);
             if (!unit_i) ri[u] = *reinterpret_cast<const v2d*>(gi + o);
-            if (i != j && !li_row && !unit_j) rj[u] = *reinterpret_cast<const v2d*>(gj + o);
+            if (i != j && !unit_j) rj[u] = *reinterpret_cast<const v2d*>(gj + o);
         }
         v4d accc[4];
-        if (!li_row && !first_b) block_load(c, ld, accc);
+        if (!first_b) block_load(c, ld, accc);
         else {
 #pragma unroll
             for (int b = 0; b < 4; ++b) accc[b] = v4d{0, 0, 0, 0};
@@ -270,14 +268,6 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* A, double* Lm, d
         };
         if (unit_i) w_transposed(acc);
         else block_xwt<LD>(sI, sL, acc);                               // L_i (registers)
-        if (li_row) {                                                  // Li[q][i] = L_i^T
-            double* d = Li + ((int64_t)q * ld + i) * NB;
-#pragma unroll
-            for (int b = 0; b < 4; ++b)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) d[(int64_t)(16 * b + ci) * ld + 16 * wave + cq + 4 * r] = acc[b][r];
-            return;
-        }
         v4d accj[4];
         if (i != j) {
             if (unit_j) w_transposed(accj);
@@ -290,6 +280,13 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* A, double* Lm, d
                 }
                 __syncthreads();
                 block_xwt<LD>(sI, sL, accj);                           // L_j
+            }
+            if (b_tile && unit_i) {                                    // Li[q][j] = L_j^T, j < q
+                double* d = Li + ((int64_t)q * ld + j) * NB;
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) d[(int64_t)(16 * b + ci) * ld + 16 * wave + cq + 4 * r] = accj[b][r];
             }
         }
         __syncthreads();
@@ -571,9 +568,9 @@ __global__ __launch_bounds__(256) void adjoint_vec_kernel(const double* __restri
 static void cholesky_inverse_gram(const KStage& k, hipStream_t st) {
     const int nbk = (k.K + 63) / 64;                                   // live steps: the padding blocks are the identity
     for (int p = 0; p <= nbk; ++p) {
-        // step p's diagonal block + the items of step p-1: trailing tiles (i >= j >= p), identity-row tiles (i < p <= j), inverse
-        // blocks (p - 1), tiles of B (p (p + 1) / 2)
-        const int n = nbk - p, items = p > 0 ? n * (n + 1) / 2 + p * n + (p - 1) + p * (p + 1) / 2 : 0;
+        // step p's diagonal block + the items of step p-1: trailing tiles (i >= j >= p), identity-row tiles (i < p <= j), tiles of B
+        // (p (p + 1) / 2): nbk (nbk + 1) / 2 items whatever p
+        const int n = nbk - p, items = p > 0 ? n * (n + 1) / 2 + p * n + p * (p + 1) / 2 : 0;
         hipLaunchKernelGGL(chol_step_kernel, dim3(1 + items), dim3(256), 0, st, k.A, k.T2, k.Li, k.B, (int64_t)k.Kp, p, nbk, k.flag);
     }
 }
