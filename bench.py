@@ -244,14 +244,15 @@ def _parity(out, ref, eng, eng_ref, D, S, M, what):
 def through_triple(X, y, params, D, S, M, local, n=3):
     """One train_iter_func call of the reference-shaped triple (scfgp_amd/funcs.py: residency check of X and y, evaluation,
     host update rule, parameter upload) -- what a user of SCFGP.optimize pays per iteration on top of `value`'s bare
-    evaluation.  Writeable arrays are hashed completely on every call; read-only ones are not hashed at all."""
+    evaluation.  `read_only_arrays`: frozen arrays that own their memory, which is what SCFGP.set_data hands to the triple
+    (model.py freezes its copies): checked by identity, nothing hashed.  `writeable_arrays`: a caller's own arrays passed to the
+    triple directly: every byte hashed on every call (the reference re-reads its arguments on every call, SCFGP/SCFGP.py:237)."""
     from scfgp_amd.funcs import CompiledFuncs
     cf = CompiledFuncs(D, S, M, params.copy(), 'adam', {'learning_rate': 1e-3}, dtype='f32', device=local)
     res = {}
-    for tag, frozen in (('writeable_arrays', False), ('read_only_arrays', True)):
-        Xc, yc = X, y
-        if frozen:
-            Xc = X.view(); yc = y.view(); Xc.flags.writeable = False; yc.flags.writeable = False
+    Xf = np.array(X); yf = np.array(y)                          # the model's own copies (SCFGP.set_data)
+    Xf.flags.writeable = False; yf.flags.writeable = False
+    for tag, (Xc, yc) in (('writeable_arrays', (X, y)), ('read_only_arrays', (Xf, yf))):
         cf.train_iter_func(Xc, yc)                                  # upload + first touch
         ts = []
         for _ in range(n):
@@ -260,7 +261,8 @@ def through_triple(X, y, params, D, S, M, local, n=3):
             ts.append(time.perf_counter() - t0)
         res[tag] = {"ms_per_call": float(np.median(ts)) * 1e3}
     cf.engine.close()
-    res["note"] = "CompiledFuncs.train_iter_func (host adam + Nesterov), median of %d calls; never `value`" % n
+    res["note"] = ("CompiledFuncs.train_iter_func (host adam + Nesterov), median of %d calls; never `value`.  read_only_arrays is the "
+                   "drop-in path (SCFGP.optimize on the arrays SCFGP.set_data froze); writeable_arrays pays a full hash per call" % n)
     return res
 
 

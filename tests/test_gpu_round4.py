@@ -175,3 +175,33 @@ def test_eight_fp64_row_shards_equal_the_single_context_at_c2_size_with_uneven_r
         assert abs(float(c) - float(c0)) < 1e-13 * abs(float(c0))
         assert rel(a, a0) < 1e-10 and rel(L, L0) < 1e-10 and rel(g, g0) < 1e-10
         e.close()
+
+
+def test_model_optimize_hashes_its_own_arrays_once(monkeypatch):
+    """SCFGP.set_data freezes the arrays it creates (SCFGP/SCFGP.py:161-162 stores self.X / self.y; :237 passes them to
+    train_iter_func on every iteration), so the triple's residency check hashes them on the FIRST call only: every later
+    iteration of optimize goes straight to the evaluation.  An array the caller edits in place is still re-uploaded when it is
+    passed to the triple directly (writeable arrays are hashed on every call)."""
+    from scfgp_amd import SCFGP, funcs
+    calls = []
+    real = funcs._hash64
+    monkeypatch.setattr(funcs, '_hash64', lambda buf: (calls.append(memoryview(buf).nbytes), real(buf))[1])
+    rng = np.random.default_rng(11)
+    np.random.seed(11)
+    X = rng.uniform(-2, 2, (20000, 5))                          # 800 KB: above the 64K-element threshold of the sampled path
+    y = np.sin(X[:, :1]) + 0.3 * X[:, 1:2] + 0.05 * rng.standard_normal((20000, 1))
+    model = SCFGP(sparsity=4, nfeats=20)
+    model.set_data(X, y)
+    assert not model.X.flags.writeable and not model.y.flags.writeable and model.X.base is None
+    model.optimize(max_iter=12, max_cvrg=100)
+    big = [n for n in calls if n >= model.y.nbytes]             # hashes of X or y (everything smaller is scaler keys etc.)
+    assert len(model.evals['COST'][1]) == 12
+    assert len(big) == 2, big                                   # X and y, once, on the first train_iter_func call
+    # the reference's own pattern of a caller-owned writeable array handed to the triple: edits are seen
+    cf = model._compiled
+    Xw = np.array(model.X); yw = np.array(model.y)
+    c1 = float(cf.train_func(Xw, yw)[0])
+    n0 = len(calls)
+    assert float(cf.train_func(Xw, yw)[0]) == c1 and len(calls) == n0 + 2
+    yw[123, 0] += 0.5
+    assert float(cf.train_func(Xw, yw)[0]) != c1
