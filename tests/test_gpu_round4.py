@@ -195,7 +195,7 @@ def test_model_optimize_hashes_its_own_arrays_once(monkeypatch):
     assert not model.X.flags.writeable and not model.y.flags.writeable and model.X.base is None
     model.optimize(max_iter=12, max_cvrg=100)
     big = [n for n in calls if n >= model.y.nbytes]             # hashes of X or y (everything smaller is scaler keys etc.)
-    assert len(model.evals['COST'][1]) == 12
+    assert len(model.evals['COST'][1]) == 13                    # 12 iterations + the closing refit (SCFGP/SCFGP.py:265)
     assert len(big) == 2, big                                   # X and y, once, on the first train_iter_func call
     # the reference's own pattern of a caller-owned writeable array handed to the triple: edits are seen
     cf = model._compiled
