@@ -66,6 +66,8 @@ def parse_args(argv=None):
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-secondary', action='store_true', help='skip the fp64 leg and the parity block')
     ap.add_argument('--backend', default='nccl', help="'gloo' rehearses the multi-rank flow on one GPU")
+    ap.add_argument('--native-rccl', action='store_true',
+                    help='the three sums by the library itself (scfgp_comm_init: ncclAllReduce on its own stream) instead of torch.distributed')
     a = ap.parse_args(argv)
     N, D, S, M, dt, label = CONFIGS[a.config]
     a.custom = any(v is not None for v in (a.rows, a.D, a.S, a.M))
@@ -305,7 +307,7 @@ def f64_leg_and_parity(X, y, params, D, S, M, local, f32_out, f32_eng, steps=5, 
 def main(a):
     import torch
     from scfgp_amd.engine import HipEngine
-    from scfgp_amd.sharded import ShardedEvaluator, shard_rows, torch_allreduce
+    from scfgp_amd.sharded import ShardedEvaluator, attach_native_comm, shard_rows, torch_allreduce
     # stdout carries exactly ONE line, rank 0's JSON: anything libraries print to fd 1 meanwhile (RCCL's version banner
     # at communicator creation, for one) goes to stderr
     sys.stdout.flush()
@@ -333,7 +335,10 @@ def main(a):
     X, y, params = build_problem(eng, N, D, S, M, lo, hi, allreduce)
     eng.set_params(params)
     eng.set_data(X, y, n_global=N)
-    ev = ShardedEvaluator(eng, allreduce, time_exchanges=use_dist)
+    native = bool(a.native_rccl or os.environ.get('SCFGP_NATIVE_RCCL') == '1') and use_dist and a.backend == 'nccl'
+    if native:
+        attach_native_comm(eng)                                # from here on the stage calls sum over the ranks themselves
+    ev = ShardedEvaluator(eng, None if native else allreduce, time_exchanges=use_dist and not native)
 
     def barrier():
         torch.cuda.synchronize()
@@ -399,7 +404,8 @@ def main(a):
             "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": "%s: %s -- N=%d D=%d S=%d M=%d (K=%d), resident rows, cost+grad+alpha+Li to host"
                                    % (a.config, a.label, N, D, S, M, K),
-                       "rows_per_gpu": hi - lo, "parallelism": "row-sharded dp%d, 3 all-reduces/eval" % world,
+                       "rows_per_gpu": hi - lo, "parallelism": "row-sharded dp%d, 3 all-reduces/eval%s" % (
+                           world, " (ncclAllReduce issued by the library, scfgp_comm_init)" if native else " (torch.distributed)"),
                        "F_alg_per_eval": falg, "F_alg_TFLOPs": falg / (dt / a.steps) / 1e12},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                          "traffic": traffic, "traffic_source": traffic_src,

@@ -156,6 +156,20 @@ int scfgp_exchange(scfgp_ctx* ctx, int stage, void** dev_ptr, int64_t* count);
  * a no-op when peer is the library's own stream.  No reference counterpart (the reference is single-device). */
 int scfgp_stream_fence(scfgp_ctx* ctx, void* peer_stream, int direction);
 
+/* ---- the sums inside the library: RCCL all-reduce over xGMI (no reference counterpart: the reference is single-device) ----
+ * One process per GPU.  Rank 0 calls scfgp_comm_unique_id and hands the 128 bytes to the other ranks by any means (MPI, a file,
+ * torch.distributed.broadcast_object_list); every rank then calls scfgp_comm_init on its context (collective: ncclCommInitRank).
+ * From then on the three sums of the row sums of SCFGP/SCFGP.py:104,108,126 and of the reverse sweep -- exchange buffers 1..3
+ * above -- are ncclAllReduce(fp64, sum) calls the library enqueues itself on the context's stream at the end of scfgp_pass1 /
+ * scfgp_pass2 / scfgp_pass3, so scfgp_eval and scfgp_eval_rows are complete sharded evaluations (set the rows of the rank with
+ * scfgp_set_data(..., n_global = sum of the ranks' N)); the precision level is decided from the summed matrix, alike on every
+ * rank.  scfgp_train stays single-GPU.  librccl.so is looked up at run time (a copy the process already carries is reused):
+ * the library has no link-time dependency on it and single-GPU users never load it.  A caller that prefers to run the sums in
+ * its own framework leaves the communicator out and uses scfgp_exchange + scfgp_stream_fence as before. */
+int scfgp_comm_unique_id(void* id128);
+int scfgp_comm_init(scfgp_ctx* ctx, int nranks, int rank, const void* id128);
+int scfgp_comm_destroy(scfgp_ctx* ctx);
+
 /* ---- on-device update rule and multi-iteration residency -------------
  * The arithmetic of SCFGP/Optimizer.py as a device kernel behind the evaluation, so a training
  * iteration (SCFGP/SCFGP.py:237: train_iter_func) needs no host round trip; from the second

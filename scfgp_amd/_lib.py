@@ -45,6 +45,9 @@ SIGNATURES = {
     'scfgp_fetch_factors': (C.c_int, [C.c_void_p, _c_double_p, _c_double_p]),
     'scfgp_exchange': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), _c_i64_p]),
     'scfgp_stream_fence': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    'scfgp_comm_unique_id': (C.c_int, [C.c_void_p]),
+    'scfgp_comm_init': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    'scfgp_comm_destroy': (C.c_int, [C.c_void_p]),
     'scfgp_opt_init': (C.c_int, [C.c_void_p, C.c_int, _c_double_p, C.c_int, C.c_double]),
     'scfgp_opt_state': (C.c_int, [C.c_void_p, C.c_int, C.c_int, _c_double_p]),
     'scfgp_opt_step': (C.c_int, [C.c_void_p, _c_double_p, C.c_int]),

@@ -4,6 +4,7 @@
 #include "kernels.h"
 
 #include <dlfcn.h>
+#include <rccl/rccl.h>          // types only: the library is looked up at run time (scfgp_comm_init), no link-time dependency
 
 #include <algorithm>
 #include <cmath>
@@ -57,6 +58,27 @@ struct Roctx {
 };
 static Roctx& roctx() { static Roctx r; return r; }
 
+// RCCL, resolved at run time the first time a communicator is asked for: a process that already carries a copy (the host
+// framework's, e.g. torch's librccl.so) is served by that copy, otherwise ROCm's is loaded.  Single-GPU users never load it.
+struct Rccl {
+    void* h = nullptr;
+    decltype(&ncclGetUniqueId) get_id = nullptr; decltype(&ncclCommInitRank) init_rank = nullptr;
+    decltype(&ncclAllReduce) all_reduce = nullptr; decltype(&ncclCommDestroy) destroy = nullptr;
+    decltype(&ncclGetErrorString) err_string = nullptr;
+    Rccl() {
+        const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names) if (!h) h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);     // a copy the process already has
+        for (const char* n : names) if (!h) h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (!h) return;
+        get_id = (decltype(get_id))dlsym(h, "ncclGetUniqueId"); init_rank = (decltype(init_rank))dlsym(h, "ncclCommInitRank");
+        all_reduce = (decltype(all_reduce))dlsym(h, "ncclAllReduce"); destroy = (decltype(destroy))dlsym(h, "ncclCommDestroy");
+        err_string = (decltype(err_string))dlsym(h, "ncclGetErrorString");
+        if (!get_id || !init_rank || !all_reduce || !destroy || !err_string) h = nullptr;
+    }
+    bool ok() const { return h != nullptr; }
+};
+static Rccl& rccl() { static Rccl r; return r; }
+
 struct ProfRec { std::string name; hipEvent_t e0, e1; };
 
 struct scfgp_ctx {
@@ -75,6 +97,7 @@ struct scfgp_ctx {
     double* x3_scalars() { return d_x3 + (int64_t)Dpp * g.Jp; }
     double* x3_xu() { return d_x3 + (int64_t)Dpp * g.Jp + 8; }
     hipEvent_t ev_fence = nullptr;                                          // scfgp_stream_fence
+    ncclComm_t comm = nullptr; int comm_ranks = 0, comm_rank = 0;           // scfgp_comm_init: the three sums run inside the library
     double* h_pin = nullptr;                                                // ... through pinned staging (K*K + K doubles)
     int64_t Ncap = 0, Nglobal = 0, Nglobal_full = 0;        // Nglobal_full: n_global given to scfgp_set_data
     bool have_params = false, have_data = false;
@@ -359,6 +382,7 @@ extern "C" void scfgp_destroy(scfgp_ctx* c) {
     dfree(c->d_opt); dfree(c->d_tctr); dfree(c->d_hist);
     for (hipEvent_t e : c->pool) hipEventDestroy(e);
     if (c->copy_st) { hipStreamSynchronize(c->copy_st); hipStreamDestroy(c->copy_st); }
+    if (c->comm && rccl().ok()) rccl().destroy(c->comm);
     if (c->ev_factor) hipEventDestroy(c->ev_factor);
     if (c->ev_fence) hipEventDestroy(c->ev_fence);
     if (c->h_pin) hipHostFree(c->h_pin);
@@ -573,12 +597,25 @@ static int restore_full_set(scfgp_ctx* c) {
     return load_working_set(c, nullptr, c->Nstore, c->Nglobal_full);
 }
 
+// with a communicator attached (scfgp_comm_init) every sweep ends in its sum over the ranks, enqueued on the context's own
+// stream right behind the sweep: no fences, no host in between
+static int comm_sum(scfgp_ctx* c, int stage, const char* name) {
+    if (!c->comm) return SCFGP_OK;
+    void* p = nullptr; int64_t n = 0;
+    if (int rc = scfgp_exchange(c, stage, &p, &n)) return rc;
+    ProfScope ps(c, name);
+    const ncclResult_t r = rccl().all_reduce(p, p, (size_t)n, ncclFloat64, ncclSum, c->comm, c->st);
+    if (r != ncclSuccess) { c->err = std::string("ncclAllReduce: ") + rccl().err_string(r); return SCFGP_EHIP; }
+    return SCFGP_OK;
+}
+
 extern "C" int scfgp_pass1(scfgp_ctx* c) {
     if (int rc = ready(c)) return rc;
     if (int rc = restore_full_set(c)) return rc;
     if (c->prof) { c->recs.clear(); c->pool_used = 0; }
     if (int rc = DISPATCH(c, pass1, c)) return rc;
-    c->stage = 1; return SCFGP_OK;
+    c->stage = 1;
+    return comm_sum(c, 1, "exchange1");
 }
 extern "C" int scfgp_factor(scfgp_ctx* c) {
     if (int rc = ready(c)) return rc;
@@ -591,7 +628,8 @@ extern "C" int scfgp_pass2(scfgp_ctx* c, int want_grad) {
     if (int rc = ready(c)) return rc;
     if (c->stage != 2) { c->err = "pass2: call factor first"; return SCFGP_EARG; }
     if (int rc = DISPATCH(c, pass2, c, want_grad)) return rc;
-    c->last_want_grad = want_grad; c->stage = 3; return SCFGP_OK;
+    c->last_want_grad = want_grad; c->stage = 3;
+    return comm_sum(c, 2, "exchange2");
 }
 extern "C" int scfgp_adjoint(scfgp_ctx* c) {
     if (int rc = ready(c)) return rc;
@@ -603,7 +641,8 @@ extern "C" int scfgp_pass3(scfgp_ctx* c) {
     if (int rc = ready(c)) return rc;
     if (c->stage != 4) { c->err = "pass3: call adjoint first"; return SCFGP_EARG; }
     if (int rc = DISPATCH(c, pass3, c)) return rc;
-    c->stage = 5; return SCFGP_OK;
+    c->stage = 5;
+    return comm_sum(c, 3, "exchange3");
 }
 
 extern "C" int scfgp_exchange(scfgp_ctx* c, int stage, void** dev_ptr, int64_t* count) {
@@ -747,7 +786,8 @@ static int pass1_current(scfgp_ctx* c) {                  // pass 1 on the worki
     if (int rc = ready(c)) return rc;
     if (c->prof) { c->recs.clear(); c->pool_used = 0; }
     if (int rc = DISPATCH(c, pass1, c)) return rc;
-    c->stage = 1; return SCFGP_OK;
+    c->stage = 1;
+    return comm_sum(c, 1, "exchange1");
 }
 static int run_eval(scfgp_ctx* c, int want_grad, double* cost, double* grad, double* alpha, double* Li, bool subset = false) {
     int rc = SCFGP_OK;
@@ -994,6 +1034,7 @@ static int enqueue_train_iter(scfgp_ctx* c) {
 extern "C" int scfgp_train(scfgp_ctx* c, int n_iters, double* cost_hist, double* alpha, double* Li) {
     if (int rc = ready(c)) return rc;
     if (c->opt_algo < 0 || n_iters < 1) { c->err = "train: call scfgp_opt_init first"; return SCFGP_EARG; }
+    if (c->comm) { c->err = "train: the on-device training loop is single-GPU; with a communicator use scfgp_eval + scfgp_opt_step"; return SCFGP_EARG; }
     if (int rc = restore_full_set(c)) return rc;
     const Geom& g = c->g;
     if (n_iters > c->hist_cap) {
@@ -1067,6 +1108,38 @@ extern "C" int scfgp_train(scfgp_ctx* c, int n_iters, double* cost_hist, double*
     c->cond_valid = true;
     if (h_flag[0]) { c->err = "Phi^T Phi + (e^{2a}+1e-6) I is not positive definite"; return SCFGP_ENOTPD; }
     if (cost_hist) for (int i = 0; i < n_iters; ++i) if (!std::isfinite(cost_hist[i])) { c->err = "non-finite cost"; return SCFGP_ENONFINITE; }
+    return SCFGP_OK;
+}
+
+// ----------------------------------------------------------------------------------------------
+// row-sharded evaluation with the sums inside the library (RCCL all-reduce over xGMI)
+// ----------------------------------------------------------------------------------------------
+extern "C" int scfgp_comm_unique_id(void* id128) {
+    if (!id128) return SCFGP_EARG;
+    if (!rccl().ok()) return SCFGP_EHIP;
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    return rccl().get_id((ncclUniqueId*)id128) == ncclSuccess ? SCFGP_OK : SCFGP_EHIP;
+}
+extern "C" int scfgp_comm_init(scfgp_ctx* c, int nranks, int rank, const void* id128) {
+    if (!c || !id128 || nranks < 1 || rank < 0 || rank >= nranks) { if (c) c->err = "comm_init: bad arguments"; return SCFGP_EARG; }
+    if (c->comm) { c->err = "comm_init: this context already has a communicator"; return SCFGP_EARG; }
+    if (!rccl().ok()) { c->err = "comm_init: librccl.so could not be loaded"; return SCFGP_EHIP; }
+    HIPCHK(c, hipSetDevice(c->device));
+    ncclUniqueId id; memcpy(&id, id128, sizeof(id));
+    const ncclResult_t r = rccl().init_rank(&c->comm, nranks, id, rank);
+    if (r != ncclSuccess) { c->comm = nullptr; c->err = std::string("ncclCommInitRank: ") + rccl().err_string(r); return SCFGP_EHIP; }
+    c->comm_ranks = nranks; c->comm_rank = rank;
+    if (c->gexec) { hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
+    if (c->graph) { hipGraphDestroy(c->graph); c->graph = nullptr; }
+    return SCFGP_OK;
+}
+extern "C" int scfgp_comm_destroy(scfgp_ctx* c) {
+    if (!c) return SCFGP_EARG;
+    if (c->comm) {
+        HIPCHK(c, hipSetDevice(c->device));
+        HIPCHK(c, hipStreamSynchronize(c->st));
+        rccl().destroy(c->comm); c->comm = nullptr; c->comm_ranks = 0;
+    }
     return SCFGP_OK;
 }
 

@@ -287,6 +287,25 @@ class HipEngine(object):
         # name the engine's own GPU: a bare 'cuda' is torch's CURRENT device and as_tensor would silently copy
         return torch.as_tensor(_Alias(), device=torch.device('cuda', self.device))
 
+    # -- the sums inside the library (RCCL) -----------------------------------------------------------
+    def comm_unique_id(self):
+        """128 bytes identifying a new communicator (rank 0 creates them and hands them to the other ranks)."""
+        buf = C.create_string_buffer(128)
+        rc = self.lib.scfgp_comm_unique_id(buf)
+        if rc != 0:
+            raise RuntimeError('scfgp_comm_unique_id failed (%d): is librccl.so loadable?' % rc)
+        return buf.raw
+
+    def comm_init(self, nranks, rank, unique_id):
+        """Join the communicator (collective over the ranks): from now on pass1 / pass2 / pass3 -- and with them eval() and
+        eval_rows() -- end in their ncclAllReduce on the library's stream; no ShardedEvaluator, no fences."""
+        if len(unique_id) != 128:
+            raise ValueError('the unique id is 128 bytes')
+        self._check(self.lib.scfgp_comm_init(self.ctx, int(nranks), int(rank), C.c_char_p(bytes(unique_id))), 'comm_init')
+
+    def comm_destroy(self):
+        self._check(self.lib.scfgp_comm_destroy(self.ctx), 'comm_destroy')
+
     # -- on-device optimiser ------------------------------------------------------------------------
     ALGOS = {'sgd': 0, 'adagrad': 1, 'rmsprop': 2, 'adadelta': 3, 'adam': 4, 'adamax': 5}
 

@@ -40,6 +40,17 @@ def torch_allreduce(group=None):
     return _ar
 
 
+def attach_native_comm(engine, group=None):
+    """The sums inside the library instead (include/scfgp_hip.h: scfgp_comm_init): rank 0's 128-byte RCCL id travels over the
+    process group that is there anyway (any transport would do), every rank joins, and from then on the engine's pass1 / pass2 /
+    pass3 end in their own ncclAllReduce on the library's stream.  Use the engine with ShardedEvaluator(engine, None) or call
+    engine.eval() directly."""
+    import torch.distributed as dist
+    box = [engine.comm_unique_id() if dist.get_rank(group) == 0 else None]
+    dist.broadcast_object_list(box, src=0, group=group)
+    engine.comm_init(dist.get_world_size(group), dist.get_rank(group), box[0])
+
+
 def shard_rows(N, rank, world):
     """Contiguous block [lo, hi) of rank `rank` out of `world` (sizes differ by at most 1)."""
     base, rem = divmod(N, world)

@@ -205,3 +205,73 @@ def test_model_optimize_hashes_its_own_arrays_once(monkeypatch):
     assert float(cf.train_func(Xw, yw)[0]) == c1 and len(calls) == n0 + 2
     yw[123, 0] += 0.5
     assert float(cf.train_func(Xw, yw)[0]) != c1
+
+
+@pytest.mark.parametrize('dtype', ['f64', 'f32'])
+def test_sums_inside_the_library_with_a_one_rank_communicator(dtype):
+    """scfgp_comm_unique_id / scfgp_comm_init (include/scfgp_hip.h): with a communicator attached the staged calls end in their
+    own ncclAllReduce on the library's stream.  One rank is all a one-GPU box can supply (RCCL refuses two ranks on one device):
+    the sum over one rank changes nothing, so eval(), the staged calls, eval_rows() and predict() return the plain context's
+    numbers bit for bit, the profile shows the three exchanges, scfgp_train is refused, and the communicator can be dropped."""
+    from scfgp_amd.engine import HipEngine
+    from tests.golden.make_oracle_kats import CASES, case_inputs
+    name = 'kin8nm_like'
+    N, D, S, M, T, seed = CASES[name]
+    X, y, params, Xs = case_inputs(name)
+    plain = HipEngine(D, S, M, dtype); plain.set_params(params); plain.set_data(X, y)
+    c0, g0, a0, L0 = plain.eval()
+    eng = HipEngine(D, S, M, dtype); eng.set_params(params); eng.set_data(X, y, n_global=N)
+    uid = eng.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    eng.comm_init(1, 0, uid)
+    with pytest.raises(ValueError):
+        eng.comm_init(1, 0, uid)                                # one communicator per context
+    eng.set_profiling(True)
+    c, g, a, L = eng.eval()
+    names = [n for n, _ in eng.timings()]
+    assert [n for n in names if n.startswith('exchange')] == ['exchange1', 'exchange2', 'exchange3']
+    assert float(c) == float(c0) and np.array_equal(g, g0) and np.array_equal(a, a0) and np.array_equal(L, L0)
+    eng.pass1(); eng.factor(); eng.pass2(False)
+    cf, _, af, _ = eng.finish(False)
+    assert float(cf) == float(plain.eval(want_grad=False)[0]) and np.array_equal(af, a0)
+    idx = np.arange(0, N, 3)
+    cr, gr, _, _ = eng.eval_rows(idx)
+    cr0, gr0, _, _ = plain.eval_rows(idx)
+    assert float(cr) == float(cr0) and np.array_equal(gr, gr0)
+    eng.opt_init('adam')
+    with pytest.raises(ValueError):
+        eng.train(2)
+    eng.comm_destroy()
+    eng.set_profiling(True)
+    c2, _, _, _ = eng.eval()
+    assert float(c2) == float(c0) and not [n for n, _ in eng.timings() if n.startswith('exchange')]
+    eng.close(); plain.close()
+
+
+def test_one_rank_under_the_launcher_with_the_sums_inside_the_library():
+    """bench.py --native-rccl under the driver's launcher line with one rank: the 128-byte id travels over torch.distributed,
+    the library joins the communicator and issues the three ncclAllReduce calls itself; same cost as the plain run, bit for bit,
+    and the line says which path summed."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'TORCHELASTIC_RUN_ID')}
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    args = ['--config', 'C2', '--rows', '20000', '--steps', '2', '--warmup', '1', '--no-cpu', '--no-secondary']
+    one = subprocess.run([sys.executable, os.path.join(root, 'bench.py')] + args, env=env, stdout=subprocess.PIPE,
+                         universal_newlines=True, timeout=600)
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '1', '--native-rccl'] + args
+    nat = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, universal_newlines=True, timeout=600)
+    assert one.returncode == 0 and nat.returncode == 0
+    o1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith('{')][-1])
+    o2 = json.loads([ln for ln in nat.stdout.splitlines() if ln.startswith('{')][-1])
+    assert o2['n_gpus'] == 1 and o2['cost'] == o1['cost']
+    assert 'issued by the library' in o2['config']['parallelism']
+    st = o2['stages_ms']
+    assert all(('exchange%d' % k) in st and st['exchange%d' % k] >= 0 for k in (1, 2, 3))
