@@ -7,6 +7,18 @@
 #include <algorithm>
 
 // apply tiles: 256 rows x {256, 128, 64} columns (tile_cfgs.h)
+// Diagnostic build (-DSCFGP_TRACE): every workgroup of the LDS-DMA apply kernel records [start, end] on the 100 MHz constant
+// clock and its XCC id (tools/apply_trace.py); the product build contains none of this
+#ifdef SCFGP_TRACE
+constexpr int ATRACE_CAP = 1 << 16;
+__device__ unsigned long long g_atrace[ATRACE_CAP][3];
+int64_t apply_trace_read(void* host, int64_t max_bytes) {
+    const int64_t n = max_bytes < (int64_t)sizeof(g_atrace) ? max_bytes : (int64_t)sizeof(g_atrace);
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_atrace), n) == hipSuccess ? n : -2;
+}
+#else
+int64_t apply_trace_read(void*, int64_t) { return -1; }
+#endif
 template <typename T, int TILE> struct ApplyCfg {
     typedef TileCfg<T, Tune<T>::APPLY_BM, TILE, SCFGP_BK, Tune<T>::APPLY_WGM, Tune<T>::apply_wgn(TILE), Tune<T>::MS,
                     SCFGP_BK == 16 && Tune<T>::MS == 16> type;                 // swizzled Phi image (TrLoader)
@@ -492,6 +504,9 @@ void apply_dma_kernel(const T* __restrict__ Phi, const T* __restrict__ Bm, T* V,
     constexpr int NR = 4 * (int)sizeof(T) / 16;                              // reads per fragment: its 4 k are NR chunks
     SMEM_DECL;
     char* smem = smem_raw;
+#ifdef SCFGP_TRACE
+    const unsigned long long tr_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const unsigned wid = xcd_remap(blockIdx.x, gridDim.x);
     const int jt = wid % njt;
     const int64_t rb = wid / njt;
@@ -568,6 +583,13 @@ void apply_dma_kernel(const T* __restrict__ Phi, const T* __restrict__ Bm, T* V,
         vpart[(int64_t)(vslot + 1) * Np + rb * D::BM + threadIdx.x] = 0.0;
         if (mu) mu[(int64_t)(vslot + 1) * Np + rb * D::BM + threadIdx.x] = 0.0;
     }
+#ifdef SCFGP_TRACE
+    __syncthreads();
+    if (threadIdx.x == 0 && blockIdx.x < ATRACE_CAP) {
+        g_atrace[blockIdx.x][0] = tr_t0; g_atrace[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
+        g_atrace[blockIdx.x][2] = (unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));
+    }
+#endif
 }
 
 // Columns [0, K) of the output are covered by a cascade of launches of decreasing tile width

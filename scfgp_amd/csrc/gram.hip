@@ -12,15 +12,15 @@
 #ifdef SCFGP_TRACE
 constexpr int TRACE_CAP = 1 << 16;
 __device__ unsigned long long g_trace[TRACE_CAP][4];
-#define TRACE_BEGIN() const unsigned long long tr_t0 = __builtin_amdgcn_s_memrealtime()
+#define TRACE_BEGIN() const unsigned long long tr_t0 = __builtin_amdgcn_s_memrealtime()   /* TRACE_END reads the job id `j` */
 #define TRACE_END(kind)                                                                                     \
     do {                                                                                                    \
         __syncthreads();                                                                                    \
-        if (threadIdx.x == 0 && blockIdx.x < TRACE_CAP) {                                                   \
-            g_trace[blockIdx.x][0] = tr_t0; g_trace[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();      \
-            g_trace[blockIdx.x][2] = (unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) |    \
-                                     ((unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) << 8); \
-            g_trace[blockIdx.x][3] = (unsigned long long)(kind);                                            \
+        if (threadIdx.x == 0 && j < TRACE_CAP) {                                                            \
+            g_trace[j][0] = tr_t0; g_trace[j][1] = __builtin_amdgcn_s_memrealtime();                        \
+            g_trace[j][2] = (unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) |             \
+                            ((unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) << 8);       \
+            g_trace[j][3] = (unsigned long long)(kind);                                                     \
         }                                                                                                   \
     } while (0)
 int64_t trace_read(void* host, int64_t max_bytes) {
@@ -67,8 +67,8 @@ template <typename T> struct Xtz64Cfg { typedef TileCfg<T, 64, 128, 16, 2, 4, Tu
 // slab_hi: for 256-row tiles, the slab of rows 128..255 (the two 128 x 128 slabs of a tall tile are not adjacent)
 template <class Cfg>
 __device__ __forceinline__ void slab_flush(const typename Cfg::MTr::acc_t (&acc)[Cfg::TM][Cfg::TN], double* slab, bool first,
-                                           double* slab_hi = nullptr) {
-    AccCoord<Cfg> co;
+                                           double* slab_hi = nullptr, int tid = (int)threadIdx.x) {
+    AccCoord<Cfg> co(tid);
     if (Cfg::BM > 128 && co.wm0 >= 128) slab = slab_hi - 128 * Cfg::BN;          // a wave's rows lie in one half
     // wide tiles (BN > 128): consecutive 128 x 128 slabs, one per 128 output columns; a wave's columns lie in one of them
     constexpr int LDS_ = Cfg::BN > 128 ? 128 : Cfg::BN;
@@ -101,16 +101,20 @@ __device__ __forceinline__ void gram_body_impl(
     typedef typename Cfg::T T;
     T* smem = reinterpret_cast<T*>(smem_raw);
     typename Cfg::MTr::acc_t acc[Cfg::TM][Cfg::TN];
+    // the thread id behind an opaque move: inside the persistent launch the compiler would otherwise hoist every lane-dependent
+    // address of every tile shape out of the job loop and keep them all in registers (spills in the k-loops)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
     // consecutive chunks are consecutive k-tiles, so one pair of loaders walks the whole row range
     NatLoader<T, T, Cfg::BM, Cfg::BK, Cfg::LDA, Cfg::THREADS, WEIGHT, false, DIAG> la(
-        Phi + r0 * ld + acol, ld, threadIdx.x, WEIGHT ? w + r0 : nullptr, 0, DIAG ? side + r0 : nullptr);
-    NatLoader<T, T, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS, false, false> lb(Phi + r0 * ld + bcol, ld, threadIdx.x);
+        Phi + r0 * ld + acol, ld, tid, WEIGHT ? w + r0 : nullptr, 0, DIAG ? side + r0 : nullptr);
+    NatLoader<T, T, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS, false, false> lb(Phi + r0 * ld + bcol, ld, tid);
     bool first = true;
     for (int64_t c0 = r0; c0 < r1 || first; c0 += chunk) {
         const int64_t c1 = c0 + chunk < r1 ? c0 + chunk : r1;
         acc_zero<Cfg>(acc);
-        if (c0 < r1) tile_mainloop<Cfg>(la, lb, (int)((c1 - c0) / Cfg::BK), acc, smem);
-        slab_flush<Cfg>(acc, slab, first, slab_hi);
+        if (c0 < r1) tile_mainloop<Cfg>(la, lb, (int)((c1 - c0) / Cfg::BK), acc, smem, tid);
+        slab_flush<Cfg>(acc, slab, first, slab_hi, tid);
         if constexpr (DIAG) la.side_flush();
         first = false;
     }
@@ -155,7 +159,10 @@ __device__ __forceinline__ void gram_tall_dma(
     double* __restrict__ slab, double* __restrict__ slab_hi, char* smem) {
     typedef GramDma D;
     constexpr bool WS = WEIGHT || DIAG;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, q = lane >> 4;
+    // the thread id behind an opaque move (see gram_body_impl)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), i = lane & 15, q = lane >> 4;
     const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
     // DMA instruction t = 3 wave + u of a stage: t < 16: row t of the A panel; else rows 2 (t - 16), 2 (t - 16) + 1 of the B panel
     const char* src[D::DMA_PER_WAVE]; int dst[D::DMA_PER_WAVE];
@@ -258,21 +265,18 @@ template <bool BIG> __host__ __device__ inline int gram_jobs_per_split(int nfull
     const int R = nfull / 2, odd = nfull & 1, nsb = nstrip * (nfull + 1);
     return R * R + nsb / 4 + R + odd * nfull + nsb % 4;          // tall, wide (4 strip tiles each), small, single strips
 }
+// one job (row split, output tile) of the list
 template <class Cfg, class SCfg, class BCfg, class WCfg, bool WEIGHT, bool BIG>
-__global__ __launch_bounds__(Cfg::THREADS)
-__attribute__((amdgpu_waves_per_eu(4, 4)))       // two 8-wave workgroups per CU: the compiler would take up to 256 VGPRs
-void gram_kernel(
-    const typename Cfg::T* __restrict__ Phi, int64_t ld, const double* __restrict__ w, const double* __restrict__ side,
-    RowSplits rs, int64_t chunk, int nfull, int nstrip, double* __restrict__ sidepart, double* __restrict__ slabs) {
+__device__ __forceinline__ void gram_job(
+    const int j, const typename Cfg::T* __restrict__ Phi, int64_t ld, const double* __restrict__ w, const double* __restrict__ side,
+    const RowSplits& rs, int64_t chunk, int nfull, int nstrip, double* __restrict__ sidepart, double* __restrict__ slabs, char* smem_raw) {
     static_assert(Cfg::THREADS == SCfg::THREADS && Cfg::THREADS == BCfg::THREADS && Cfg::THREADS == WCfg::THREADS &&
                   Cfg::BN == SCfg::BN && Cfg::BN == BCfg::BN && Cfg::BM == Cfg::BN && WCfg::BM == SCfg::BM && WCfg::BN == 4 * Cfg::BN,
                   "one launch, four tile shapes");
-    SMEM_DECL;
     TRACE_BEGIN();
     constexpr int B = Cfg::BN;
     const int nall = nfull + nstrip, ntile_all = nall * (nall + 1) / 2;
     const int per_split = gram_jobs_per_split<BIG>(nfull, nstrip);
-    const int j = (int)xcd_remap(blockIdx.x, gridDim.x);
     const int split = j / per_split;
     int u = j % per_split, acol, bcol, slab_t, slab_t2 = 0, kind = 0;     // kind 0: 128-row tile, 1: strip, 2: 256-row tile, 3: wide strip
     bool diag = false;
@@ -334,6 +338,49 @@ void gram_kernel(
     TRACE_END(kind);
 }
 
+// Persistent launch (long job lists): as many workgroups as the chip holds (two per CU), each pulling jobs until the list is empty.  The list is
+// cut into 8 contiguous queues, one per XCD (split-major: the workgroups of an XCD work on the same rows and share operand
+// panels in its L2, as the static XCD map did); a workgroup serves the queue of the XCD it runs on (XCC_ID) and, once that is
+// empty, steals from the others -- the hardware deals workgroups to XCDs statically, so with one job per workgroup an XCD that
+// ran 2 % faster idled while the others finished (0.8 ms spread of the last job starts in a 37 ms launch,
+// profiles/r04_gram_trace_H.txt).  head[x] counts the jobs handed out from queue x (zeroed by the host before the launch).
+// Every workgroup leaves when all eight queues are empty: nobody waits for anybody.
+template <class Cfg, class SCfg, class BCfg, class WCfg, bool WEIGHT, bool BIG>
+__global__ __launch_bounds__(Cfg::THREADS)
+__attribute__((amdgpu_waves_per_eu(4, 4)))       // two 8-wave workgroups per CU: the compiler would take up to 256 VGPRs
+void gram_kernel(
+    const typename Cfg::T* __restrict__ Phi, int64_t ld, const double* __restrict__ w, const double* __restrict__ side,
+    RowSplits rs, int64_t chunk, int nfull, int nstrip, double* __restrict__ sidepart, double* __restrict__ slabs,
+    int njobs, int* __restrict__ head) {
+    SMEM_DECL;
+    if ((int)gridDim.x >= njobs) {                             // short job lists: one job per workgroup, static XCD map
+        gram_job<Cfg, SCfg, BCfg, WCfg, WEIGHT, BIG>((int)xcd_remap(blockIdx.x, gridDim.x), Phi, ld, w, side, rs, chunk, nfull, nstrip, sidepart, slabs, smem_raw);
+        return;
+    }
+    __shared__ int s_job;
+    const int q8 = njobs / 8, r8 = njobs % 8;
+    const int xcd = (int)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 7;      // HW_REG_XCC_ID
+    for (;;) {
+        if (threadIdx.x == 0) {
+            int job = -1;
+            for (int a = 0; a < 8 && job < 0; ++a) {
+                const int x = (xcd + a) & 7, len = q8 + (x < r8 ? 1 : 0);
+                if (len <= 0) continue;
+                // the unlocked read spares the atomics on queues known to be empty; the count itself decides
+                if (__atomic_load_n(&head[x], __ATOMIC_RELAXED) >= len) continue;
+                const int t = atomicAdd(&head[x], 1);
+                if (t < len) job = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + t;
+            }
+            s_job = job;
+        }
+        __syncthreads();                                       // also: every wave is done with the previous job's LDS
+        const int j = s_job;
+        __syncthreads();                                       // s_job may be rewritten
+        if (j < 0) return;
+        gram_job<Cfg, SCfg, BCfg, WCfg, WEIGHT, BIG>(j, Phi, ld, w, side, rs, chunk, nfull, nstrip, sidepart, slabs, smem_raw);
+    }
+}
+
 // Row tile ti0 + (t / ntn) of the output (tiles are 128 rows apart whatever Cfg::BM is: a narrower Cfg multiplies only the
 // first BM rows of its tile and zeroes the rest of the 128 x 128 slab)
 //   PLAIN: the B operand is a stored matrix (Phi[n][j], j < J; Pb unused) instead of Zbar formed from Phi and Phibar
@@ -375,6 +422,15 @@ __global__ __launch_bounds__(Cfg::THREADS) void xtz_kernel(
         for (int e = threadIdx.x; e < (128 - Cfg::BM) * 128; e += Cfg::THREADS) slab[Cfg::BM * 128 + e] = 0.0;
 }
 
+static int num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
 template <typename T>
 int GramKernels<T>::gram_jobs(const Geom& g) { return gram_jobs_per_split<sizeof(T) == 4>(g.gfull, g.gstrip); }
 
@@ -406,7 +462,7 @@ RowSplits gram_row_splits(int jobs, int64_t Np, bool f32, int nsplit_override, i
 
 template <typename T>
 void GramKernels<T>::gram(const Geom& g, const T* Phi, const double* w, const double* side, const RowSplits& rs, int64_t chunk,
-                          double* slabs, double* sidepart, hipStream_t st) {
+                          double* slabs, double* sidepart, int* qhead, hipStream_t st) {
     typedef typename GramCfg<T, 128>::type Cfg;
     typedef typename GramStripCfg<T>::type SCfg;
     typedef typename GramBigCfg<T>::type BCfg;
@@ -419,10 +475,16 @@ void GramKernels<T>::gram(const Geom& g, const T* Phi, const double* w, const do
     constexpr int L2 = BIG && GramDma::LDS_BYTES > L1 ? GramDma::LDS_BYTES : L1;
     constexpr int LDS = BIG && WCfg::LDS_BYTES > L2 ? WCfg::LDS_BYTES : L2;
     static_assert(2 * LDS <= 160 * 1024, "two workgroups per CU");
+    // Persistent launch with per-XCD queues from 6 rounds of jobs up; below that one job per workgroup.  Measured on one box
+    // (profiles/r04_tuning.md): H (12 rounds) gram + gram_w 72.9-73.1 against 73.0-73.5 ms, C5 293.3 against 297.0, but a
+    // 125 000-row shard (3.6 rounds) 10.2 against 9.9 ms
+    const int resident = 2 * num_cus();                        // two workgroups per CU
+    const bool persistent = njobs >= 6 * resident;
+    if (persistent) (void)hipMemsetAsync(qhead, 0, sizeof(int) * 8, st);       // the eight queue heads
     const auto launch = [&](auto kernel) {
         allow_big_lds(kernel, LDS);
-        hipLaunchKernelGGL(kernel, dim3(njobs), dim3(Cfg::THREADS), LDS, st, Phi, (int64_t)g.Kp, w, side, rs, chunk, g.gfull, g.gstrip,
-                           sidepart, slabs);
+        hipLaunchKernelGGL(kernel, dim3(persistent ? resident : njobs), dim3(Cfg::THREADS), LDS, st, Phi, (int64_t)g.Kp, w, side, rs, chunk,
+                           g.gfull, g.gstrip, sidepart, slabs, njobs, qhead);
     };
     if (w) launch(gram_kernel<Cfg, SCfg, BCfg, WCfg, true, BIG>);
     else launch(gram_kernel<Cfg, SCfg, BCfg, WCfg, false, BIG>);

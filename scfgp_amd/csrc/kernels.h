@@ -72,8 +72,9 @@ template <typename T>
 struct GramKernels {
     // lower tiles of  Phi^T diag(w) Phi  into per-split fp64 slabs (SCFGP.py:104; weighted: backward of :111-113)
     // and, from the diagonal tiles, sidepart[split][Kp] = partials of Phi^T side (side = y: SCFGP.py:108)
+    //   qhead: 8 ints of device scratch (the heads of the per-XCD job queues of the persistent launch)
     static void gram(const Geom& g, const T* Phi, const double* w, const double* side, const RowSplits& rs, int64_t chunk,
-                     double* slabs, double* sidepart, hipStream_t st);
+                     double* slabs, double* sidepart, int* qhead, hipStream_t st);
     static int gram_jobs(const Geom& g);        // workgroups per row split of gram() (sizes the row split)
     // X~^T Zbar into per-split fp64 slabs, Zbar[n][j] = Phi[n][j] Phibar[n][J+j] - Phi[n][J+j] Phibar[n][j]
     // formed inside the operand loader
@@ -130,6 +131,7 @@ template <typename T> struct SweepKernels : FmapKernels<T>, GramKernels<T>, Appl
 
 // diagnostic builds only (-DSCFGP_TRACE): per-workgroup [start, end, xcc, kind] of the last Gram launch; -1 otherwise
 int64_t trace_read(void* host, int64_t max_bytes);
+int64_t apply_trace_read(void* host, int64_t max_bytes);    // per workgroup of the last LDS-DMA apply launch: [start, end, xcc]
 int64_t chol_trace_read(void* host, int64_t max_bytes);     // per Cholesky step: 12 phase stamps of workgroup 0
 
 // ---- reductions ------------------------------------------------------------

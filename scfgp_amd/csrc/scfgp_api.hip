@@ -351,7 +351,7 @@ extern "C" int scfgp_create(scfgp_ctx** out, int D, int S, int M, int dtype, int
     if ((rc = dmalloc(c, &c->d_vecs, sizeof(double) * 5 * Kp))) return rc;
     if ((rc = dmalloc(c, &c->d_scalars, sizeof(double) * 32))) return rc;
     if ((rc = dmalloc(c, &c->d_yy, sizeof(double) * 8))) return rc;
-    if ((rc = dmalloc(c, &c->d_flag, sizeof(int) * 4))) return rc;
+    if ((rc = dmalloc(c, &c->d_flag, sizeof(int) * 16))) return rc;         // [0..3] not-positive-definite flag, [8..15] the Gram's queue heads
     c->n_partial = 16384;                                             // block partials of the scalar reductions
     if ((rc = dmalloc(c, &c->d_partial, sizeof(double) * c->n_partial))) return rc;
     if ((rc = dmalloc(c, &c->d_work, sizeof(double) * (4 * D + 4 + (int64_t)D * M)))) return rc;
@@ -458,7 +458,7 @@ template <typename T> struct Impl {
         const int gs = c->splits.nsplit;
         double* sidepart = c->d_slabs + (size_t)gs * ntiles * g.tile * g.tile;
         { ProfScope ps(c, name);
-          SK::gram(g, Mx, w, side, c->splits, c->dtype == SCFGP_F32 ? c->gram_chunk : 0, c->d_slabs, sidepart, c->st); }
+          SK::gram(g, Mx, w, side, c->splits, c->dtype == SCFGP_F32 ? c->gram_chunk : 0, c->d_slabs, sidepart, c->d_flag + 8, c->st); }
         { ProfScope ps(c, "reduce_tiles"); reduce_tri_tiles(c->d_slabs, gs, nts, g.tile, out, c->st);
           reduce_side(sidepart, gs, g.Kp, g.gfull * g.tile + g.gstrip * 64, out + c->n_pk, c->st); }
     }
@@ -478,7 +478,7 @@ template <typename T> struct Impl {
                 double* sidepart = c->d_slabs + (size_t)gs * ntiles * g.tile * g.tile;
                 { ProfScope ps(c, "featuremap64"); SK64::featuremap(g, c->d_Xt, proj, c->d_sc, (double*)c->d_Phi64, c->st); }
                 { ProfScope ps(c, "gram64");
-                  SK64::gram(g, (const double*)c->d_Phi64, nullptr, c->d_y, c->splits64, 0, c->d_slabs, sidepart, c->st); }
+                  SK64::gram(g, (const double*)c->d_Phi64, nullptr, c->d_y, c->splits64, 0, c->d_slabs, sidepart, c->d_flag + 8, c->st); }
                 { ProfScope ps(c, "reduce_tiles"); reduce_tri_tiles(c->d_slabs, gs, nts, g.tile, c->d_xp1, c->st);
                   reduce_side(sidepart, gs, g.Kp, g.gfull * g.tile + g.gstrip * 64, c->d_xp1 + c->n_pk, c->st); }
             }
@@ -1245,6 +1245,7 @@ extern "C" int64_t scfgp_debug_read(scfgp_ctx* c, const char* name, void* host, 
     const Geom& g = c->g;
     const std::string s(name);
     if (s == "chol_trace") { if (hipStreamSynchronize(c->st) != hipSuccess) return SCFGP_EHIP; return chol_trace_read(host, max_bytes); }
+    if (s == "apply_trace") { if (hipStreamSynchronize(c->st) != hipSuccess) return SCFGP_EHIP; return apply_trace_read(host, max_bytes); }
     if (s == "trace") { if (hipStreamSynchronize(c->st) != hipSuccess) return SCFGP_EHIP; return trace_read(host, max_bytes); }
     const int64_t K2 = (int64_t)g.Kp * g.Kp;
     const size_t ts = c->tsize();

@@ -334,13 +334,15 @@ struct ZbarLoader {
 };
 
 // MFMAs of one k-tile out of LDS buffer `cur`
+//   tid: the thread's id; a caller that runs many tiles in one launch passes its own (opaque) copy so that the addresses derived
+//   from it are not hoisted out of its job loop (gram.hip)
 template <class Cfg>
 __device__ __forceinline__ void tile_compute(const typename Cfg::T* sA, const typename Cfg::T* sB,
-                                             typename Cfg::MTr::acc_t (&acc)[Cfg::TM][Cfg::TN]) {
+                                             typename Cfg::MTr::acc_t (&acc)[Cfg::TM][Cfg::TN], int tid) {
     typedef typename Cfg::T T;
     typedef typename Cfg::MTr M;
     constexpr int MS = Cfg::MS, KS = M::KS;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = tid & 63, wave = tid >> 6;
     const int wm0 = (wave / Cfg::WGN) * Cfg::WM, wn0 = (wave % Cfg::WGN) * Cfg::WN;
     const T* a_s = sA + (lane / MS) * Cfg::LDA + wm0 + (lane % MS);
     const T* b_s = sB + (lane / MS) * Cfg::LDB + wn0 + (lane % MS);
@@ -374,7 +376,7 @@ __device__ __forceinline__ void tile_compute(const typename Cfg::T* sA, const ty
 template <class Cfg, class LA, class LB>
 __device__ __forceinline__ void tile_mainloop(LA& la, LB& lb, int nkt,
                                               typename Cfg::MTr::acc_t (&acc)[Cfg::TM][Cfg::TN],
-                                              typename Cfg::T* smem) {
+                                              typename Cfg::T* smem, int tid) {
     typedef typename Cfg::T T;
     T* sA = smem;
     T* sB = smem + 2 * Cfg::SA;
@@ -388,10 +390,15 @@ __device__ __forceinline__ void tile_mainloop(LA& la, LB& lb, int nkt,
         const int cur = kt & 1;
         const bool stage = kt + 1 < nkt;
         if (stage) { la.template load<0>(kt + 1); lb.template load<0>(kt + 1); }
-        tile_compute<Cfg>(sA + cur * Cfg::SA, sB + cur * Cfg::SB, acc);
+        tile_compute<Cfg>(sA + cur * Cfg::SA, sB + cur * Cfg::SB, acc, tid);
         if (stage) { la.template store<0>(sA + (cur ^ 1) * Cfg::SA); lb.template store<0>(sB + (cur ^ 1) * Cfg::SB); }
         __syncthreads();
     }
+}
+template <class Cfg, class LA, class LB>
+__device__ __forceinline__ void tile_mainloop(LA& la, LB& lb, int nkt, typename Cfg::MTr::acc_t (&acc)[Cfg::TM][Cfg::TN],
+                                              typename Cfg::T* smem) {
+    tile_mainloop<Cfg>(la, lb, nkt, acc, smem, (int)threadIdx.x);
 }
 
 // Main loop for products that run ONE workgroup per CU (the K x K stage): the operand fetch of k-tile t+3 is issued while
@@ -401,7 +408,7 @@ template <class Cfg, int S, class LA, class LB>
 __device__ __forceinline__ void tile_deep3_step(LA& la, LB& lb, int t, int nkt, typename Cfg::MTr::acc_t (&acc)[Cfg::TM][Cfg::TN],
                                                 typename Cfg::T* sA, typename Cfg::T* sB) {
     const int cur = t & 1;
-    tile_compute<Cfg>(sA + cur * Cfg::SA, sB + cur * Cfg::SB, acc);
+    tile_compute<Cfg>(sA + cur * Cfg::SA, sB + cur * Cfg::SB, acc, (int)threadIdx.x);
     if (t + 1 < nkt) { la.template store<(S + 1) % 3>(sA + (cur ^ 1) * Cfg::SA); lb.template store<(S + 1) % 3>(sB + (cur ^ 1) * Cfg::SB); }
     if (t + 3 < nkt) { la.template load<S>(t + 3); lb.template load<S>(t + 3); }     // set S: tile t's, stored an iteration ago
     __syncthreads();
@@ -459,7 +466,7 @@ __device__ __forceinline__ void tile_mainloop_segments(LA& la, LB& lb, int nkt, 
             if (last) { la.advance(dA); lb.advance(dB); }
             la.template load<0>(t + 1); lb.template load<0>(t + 1);
         }
-        tile_compute<Cfg>(sA + cur * Cfg::SA, sB + cur * Cfg::SB, acc);
+        tile_compute<Cfg>(sA + cur * Cfg::SA, sB + cur * Cfg::SB, acc, (int)threadIdx.x);
         if (last) { flush(seg, acc); acc_zero<Cfg>(acc); ++seg; kin = 0; } else ++kin;
         if (stage) { la.template store<0>(sA + (cur ^ 1) * Cfg::SA); lb.template store<0>(sB + (cur ^ 1) * Cfg::SB); }
         __syncthreads();
@@ -470,9 +477,9 @@ __device__ __forceinline__ void tile_mainloop_segments(LA& la, LB& lb, int nkt, 
 template <class Cfg>
 struct AccCoord {
     int lane, wm0, wn0;
-    __device__ __forceinline__ AccCoord() {
-        lane = threadIdx.x & 63;
-        const int wave = threadIdx.x >> 6;
+    __device__ __forceinline__ explicit AccCoord(int tid = (int)threadIdx.x) {
+        lane = tid & 63;
+        const int wave = tid >> 6;
         wm0 = (wave / Cfg::WGN) * Cfg::WM; wn0 = (wave % Cfg::WGN) * Cfg::WN;
     }
     __device__ __forceinline__ int row(int tm, int r) const {

@@ -1,0 +1,29 @@
+"""Per-XCD timeline of the LDS-DMA apply launch (diagnostic _trace build): do the eight XCDs finish their static shares of the
+tile list together?   SCFGP_LIB_VARIANT=_trace python tools/apply_trace.py [config]"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault('SCFGP_LIB_VARIANT', '_trace')
+import bench
+from scfgp_amd import synth
+from scfgp_amd.engine import HipEngine
+cfg = sys.argv[1] if len(sys.argv) > 1 else 'H'
+N, D, S, M, dtype = bench.CONFIGS[cfg][:5]
+X = synth.make_X(bench.SEED, N, D); y = synth.normal(bench.SEED + 9, 0, N).reshape(-1, 1)
+params = synth.make_params(bench.SEED + 0x0202, D, S, M, abc=(-1.0, 0.0, -1.0))
+eng = HipEngine(D, S, M, dtype=dtype); eng.set_params(params); eng.set_data(X, y)
+eng.eval(); eng.set_profiling(True)
+eng.pass1(); eng.factor(); eng.pass2(False)                      # the last LDS-DMA launch traced: the 128- or 256-wide tiles of Phi.B
+tm = dict(eng.timings())
+tr = eng.debug_read('apply_trace', (1 << 16, 3), dtype=np.uint64)
+tr = tr[tr[:, 1] > 0].astype(np.int64)
+tr = tr[tr[:, 0] >= tr[:, 1].max() - int(100e6 * 1.2e-3 * tm['apply_v'])]
+t0 = tr[:, 0].min(); st, en, xcc = (tr[:, 0] - t0) / 100.0, (tr[:, 1] - t0) / 100.0, tr[:, 2] & 0xF
+print('apply_v hipEvent %.2f ms; %d workgroups traced; span %.2f ms' % (tm['apply_v'], len(tr), en.max() / 1e3))
+for x in sorted(set(xcc.tolist())):
+    m = xcc == x
+    print('  xcc %d: %5d workgroups, mean length %.1f us, last start %.2f ms, last end %.2f ms' % (x, m.sum(), (en - st)[m].mean(), st[m].max() / 1e3, en[m].max() / 1e3))
+ev = np.concatenate([np.stack([st, np.ones_like(st)], 1), np.stack([en, -np.ones_like(en)], 1)]); ev = ev[np.argsort(ev[:, 0], kind='stable')]
+busy = np.cumsum(ev[:, 1]); area = np.sum(busy[:-1] * np.diff(ev[:, 0]))
+print('  peak resident workgroups %d, mean occupancy of the slots %.3f' % (busy.max(), area / (busy.max() * en.max())))
+eng.close()
