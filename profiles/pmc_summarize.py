@@ -93,7 +93,7 @@ def main():
     for k, v in kernels.items():
         if 'GB_corrected' not in v:
             continue
-        m = re.match(r'apply_dma_kernel_(\d)_', k) or re.match(r'apply_kernel_.*_(\d)$', k)
+        m = re.match(r'apply_dma_kernel_(?:float_|double_)?(\d)_', k) or re.match(r'apply_kernel_.*_(\d)$', k)
         if m:
             prod[m.group(1)] = prod.get(m.group(1), 0.0) + v['GB_corrected']      # each of a product's kernels runs once per evaluation
     if prod:

@@ -152,6 +152,9 @@ struct GramDma {
 };
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
+// generic address of an LDS byte -> LDS pointer: the low 32 bits are the LDS offset (the address-space cast proper carries a null
+// check that this compiler mis-selects in one of the kernels below: "V_CMP_NE_U32 0, $src_shared_base")
+__device__ __forceinline__ lds_void* lds_ptr(const char* p) { return (lds_void*)(uintptr_t)((unsigned)(uintptr_t)p); }
 template <bool WEIGHT, bool DIAG>
 __device__ __forceinline__ void gram_tall_dma(
     const float* __restrict__ Phi, int64_t ld, const double* __restrict__ w, const double* __restrict__ side,
@@ -182,11 +185,11 @@ __device__ __forceinline__ void gram_tall_dma(
         char* base = smem + slot * D::STAGE;
 #pragma unroll
         for (int u = 0; u < D::DMA_PER_WAVE; ++u) {
-            __builtin_amdgcn_global_load_lds((gbl_void*)src[u], (lds_void*)(base + dst[u]), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void*)src[u], lds_ptr(base + dst[u]), 16, 0, 0);
             src[u] += step;
         }
         if (ws_wave) {
-            __builtin_amdgcn_global_load_lds((gbl_void*)wsrc, (lds_void*)(base + D::W_OFF), 4, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void*)wsrc, lds_ptr(base + D::W_OFF), 4, 0, 0);
             wsrc += 128;
         }
     };
@@ -248,6 +251,103 @@ __device__ __forceinline__ void gram_tall_dma(
             }
         }
         first = false;
+    }
+}
+
+// fp64 square tile (128 x 128, 8 waves of 32 x 64) with LDS-DMA staging: the same structure as the fp32 tall tile with 16-row
+// stages of 32 KiB (A panel 16 x 128 doubles, B panel likewise, one DMA instruction per row) in a ring of TWO (two workgroups per
+// CU share the 160 KiB): the fetch of stage s+1 is issued behind the barrier of stage s and lands while stage s is multiplied.
+//   A fragment: the two adjacent doubles 2 i, 2 i + 1 of the k row (MFMA tile tm, tile row rho = output row 2 rho + tm);
+//   B fragment: doubles 2 i, 2 i + 1 and 32 + 2 i, 32 + 2 i + 1 (MFMA tile tn, tile column i = output column
+//   32 (tn >> 1) + 2 i + (tn & 1)): every read is one ds_read_b128 whose 16 lanes cover one 256-byte bank row.
+struct GramDma64 {
+    static constexpr int B = 128, ROWB = B * 8, A_BYTES = 16 * ROWB, W_OFF = 2 * A_BYTES, S_OFF = W_OFF + 128, STAGE = W_OFF + 256,
+                         STAGES = 2, LDS_BYTES = STAGES * STAGE, DMA_PER_WAVE = 2 * A_BYTES / 1024 / 8;
+    static_assert(DMA_PER_WAVE == 4, "8 waves, 32 KiB of operands per stage");
+};
+template <bool WEIGHT, bool DIAG>
+__device__ __forceinline__ void gram_sq_dma64(
+    const double* __restrict__ Phi, int64_t ld, const double* __restrict__ w, const double* __restrict__ side,
+    int64_t r0, int64_t r1, int acol, int bcol, double* __restrict__ sideout, double* __restrict__ slab, char* smem) {
+    typedef GramDma64 D;
+    constexpr bool WS = WEIGHT || DIAG;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));                              // opaque thread id (see gram_body_impl)
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), i = lane & 15, q = lane >> 4;
+    const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 64;
+    // DMA instruction t = 4 wave + u of a stage: t < 16: row t of the A panel, else row t - 16 of the B panel; a lane carries 16 bytes
+    const char* src[D::DMA_PER_WAVE]; int dst[D::DMA_PER_WAVE];
+#pragma unroll
+    for (int u = 0; u < D::DMA_PER_WAVE; ++u) {
+        const int t = D::DMA_PER_WAVE * wave + u;
+        const double* g = Phi + (r0 + (t & 15)) * ld + (t < 16 ? acol : bcol) + 2 * lane;
+        src[u] = reinterpret_cast<const char*>(g);
+        dst[u] = t * 1024;
+    }
+    const int64_t step = 16 * ld * (int64_t)sizeof(double);
+    const double* ws_lo = WEIGHT ? w : side; const double* ws_hi = DIAG ? side : w;
+    const char* wsrc = WS ? reinterpret_cast<const char*>((lane < 32 ? ws_lo : ws_hi) + r0) + 4 * (lane & 31) : nullptr;
+    const bool ws_wave = WS && wave == 0;
+    const auto issue = [&](int slot) {
+        char* base = smem + slot * D::STAGE;
+#pragma unroll
+        for (int u = 0; u < D::DMA_PER_WAVE; ++u) {
+            __builtin_amdgcn_global_load_lds((gbl_void*)src[u], lds_ptr(base + dst[u]), 16, 0, 0);
+            src[u] += step;
+        }
+        if (ws_wave) {
+            __builtin_amdgcn_global_load_lds((gbl_void*)wsrc, lds_ptr(base + D::W_OFF), 4, 0, 0);
+            wsrc += 128;
+        }
+    };
+    const int aoff = q * D::ROWB + (wm0 + 2 * i) * 8, boff = D::A_BYTES + q * D::ROWB + (wn0 + 2 * i) * 8;
+    v4d acc[2][4];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = v4d{0, 0, 0, 0};
+    v2d sacc = v2d{0, 0};
+    const int nst = (int)((r1 - r0) / 16);
+    if (nst > 0) issue(0);
+    int slot = 0;
+    for (int s = 0; s < nst; ++s) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's share of stage s (issued a stage ago) has landed
+        __builtin_amdgcn_s_barrier();                          // everybody's has; nobody reads the other slot any more
+        asm volatile("" ::: "memory");
+        if (s + 1 < nst) issue(slot ^ 1);
+        const char* base = smem + slot * D::STAGE;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            v2d a = *reinterpret_cast<const v2d*>(base + aoff + kk * (4 * D::ROWB));
+            const v2d b0 = *reinterpret_cast<const v2d*>(base + boff + kk * (4 * D::ROWB));
+            const v2d b1 = *reinterpret_cast<const v2d*>(base + boff + kk * (4 * D::ROWB) + 32 * 8);
+            if (DIAG) sacc += *reinterpret_cast<const double*>(base + D::S_OFF + (4 * kk + q) * 8) * a;
+            if (WEIGHT) a *= *reinterpret_cast<const double*>(base + D::W_OFF + (4 * kk + q) * 8);
+            const double b[4] = {b0[0], b0[1], b1[0], b1[1]};
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+        }
+        slot ^= 1;
+    }
+    // accumulator (tm, tn, r) of lane (i, q) is output row wm0 + 2 (q + 4 r) + tm, column wn0 + 32 (tn >> 1) + 2 i + (tn & 1);
+    // fp64 runs one chunk: the slab is written once
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double* d = slab + (wm0 + 2 * (q + 4 * r) + tm) * D::B + wn0 + 2 * i;
+            *reinterpret_cast<v2d*>(d) = v2d{acc[tm][0][r], acc[tm][1][r]};
+            *reinterpret_cast<v2d*>(d + 32) = v2d{acc[tm][2][r], acc[tm][3][r]};
+        }
+    if constexpr (DIAG) {
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) {
+            double x = sacc[tm];
+            x += __shfl_xor(x, 16); x += __shfl_xor(x, 32);
+            if (q == 0 && wn0 == 0) sideout[wm0 + 2 * i + tm] = x;
+        }
     }
 }
 
@@ -334,7 +434,11 @@ __device__ __forceinline__ void gram_job(
         }
         if (kind == 3) { gram_body<WCfg, WEIGHT, true>(Phi, ld, w, side, r0, r1, chunk, acol, bcol, diag, sideout, slab, nullptr, smem_raw); TRACE_END(kind); return; }
     }
-    gram_body<Cfg, WEIGHT, false>(Phi, ld, w, side, r0, r1, chunk, acol, bcol, diag, sideout, slab, nullptr, smem_raw);
+    if constexpr (!BIG && sizeof(typename Cfg::T) == 8) {      // fp64 square tiles by LDS-DMA
+        if (diag) gram_sq_dma64<WEIGHT, true>(Phi, ld, w, side, r0, r1, acol, bcol, sideout, slab, smem_raw);
+        else gram_sq_dma64<WEIGHT, false>(Phi, ld, w, side, r0, r1, acol, bcol, sideout, slab, smem_raw);
+    } else
+        gram_body<Cfg, WEIGHT, false>(Phi, ld, w, side, r0, r1, chunk, acol, bcol, diag, sideout, slab, nullptr, smem_raw);
     TRACE_END(kind);
 }
 
@@ -471,7 +575,8 @@ void GramKernels<T>::gram(const Geom& g, const T* Phi, const double* w, const do
     const int njobs = gram_jobs(g) * rs.nsplit;
     if (chunk <= 0 || chunk > g.Np) chunk = g.Np;
     chunk = round_up(chunk, 256);                              // splits start and end on 64- or 256-row granules
-    constexpr int L1 = Cfg::LDS_BYTES > SCfg::LDS_BYTES ? Cfg::LDS_BYTES : SCfg::LDS_BYTES;
+    constexpr int L0 = Cfg::LDS_BYTES > SCfg::LDS_BYTES ? Cfg::LDS_BYTES : SCfg::LDS_BYTES;
+    constexpr int L1 = !BIG && GramDma64::LDS_BYTES > L0 ? GramDma64::LDS_BYTES : L0;
     constexpr int L2 = BIG && GramDma::LDS_BYTES > L1 ? GramDma::LDS_BYTES : L1;
     constexpr int LDS = BIG && WCfg::LDS_BYTES > L2 ? WCfg::LDS_BYTES : L2;
     static_assert(2 * LDS <= 160 * 1024, "two workgroups per CU");
