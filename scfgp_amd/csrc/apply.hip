@@ -5,13 +5,14 @@
 #include "tile_cfgs.h"
 
 #include <algorithm>
+#include <utility>
 
 // apply tiles: 256 rows x {256, 128, 64} columns (tile_cfgs.h)
 // Diagnostic build (-DSCFGP_TRACE): every workgroup of the LDS-DMA apply kernel records [start, end] on the 100 MHz constant
 // clock and its XCC id (tools/apply_trace.py); the product build contains none of this
 #ifdef SCFGP_TRACE
 constexpr int ATRACE_CAP = 1 << 16;
-__device__ unsigned long long g_atrace[ATRACE_CAP][3];
+__device__ unsigned long long g_atrace[ATRACE_CAP][5];      // start, end, xcc, first barrier passed, k loop left
 int64_t apply_trace_read(void* host, int64_t max_bytes) {
     const int64_t n = max_bytes < (int64_t)sizeof(g_atrace) ? max_bytes : (int64_t)sizeof(g_atrace);
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_atrace), n) == hipSuccess ? n : -2;
@@ -66,9 +67,9 @@ __device__ __forceinline__ void apply_epilogue_vec2(
     const typename Cfg::MTr::acc_t (&acc)[Cfg::TM][Cfg::TN], const double* __restrict__ Phi, double* V,
     double* __restrict__ vpart, const double* __restrict__ p, const double* __restrict__ q, const double* __restrict__ y,
     const double* __restrict__ alpha, const double* __restrict__ ut, int K, int Kp, int64_t Np, int64_t rb, int cbase, int jtg,
-    double* __restrict__ bpart, char* smem_raw, double* __restrict__ mupart) {
+    double* __restrict__ bpart, char* smem_raw, double* __restrict__ mupart, int tid) {
     static_assert(Cfg::TN == 2 && Cfg::MS == 16 && sizeof(typename Cfg::T) == 8 && (EPI == 0 || EPI == 1 || EPI == 3 || EPI == 4), "VEC2 layout");
-    AccCoord<Cfg> co;
+    AccCoord<Cfg> co(tid);
     const int jg = cbase + co.wn0 + 2 * (co.lane & 15);         // first of this lane's two adjacent columns
     if constexpr (EPI == 4) {
 #pragma unroll
@@ -79,7 +80,7 @@ __device__ __forceinline__ void apply_epilogue_vec2(
     } else if constexpr (EPI == 0 || EPI == 3) {
         double* red = reinterpret_cast<double*>(smem_raw);
         double* red2 = red + Cfg::WGN * Cfg::BM;
-        const int wn = (threadIdx.x >> 6) % Cfg::WGN;
+        const int wn = (tid >> 6) % Cfg::WGN;
         double al[2], live[2];
 #pragma unroll
         for (int k = 0; k < 2; ++k) { live[k] = jg + k < K ? 1.0 : 0.0; al[k] = MU && jg + k < K ? alpha[jg + k] : 0.0; }
@@ -110,12 +111,12 @@ __device__ __forceinline__ void apply_epilogue_vec2(
             }
         }
         __syncthreads();
-        if (threadIdx.x < Cfg::BM) {
+        if (tid < Cfg::BM) {
             double s = 0, s2 = 0;
 #pragma unroll
-            for (int k = 0; k < Cfg::WGN; ++k) { s += red[k * Cfg::BM + threadIdx.x]; if (MU) s2 += red2[k * Cfg::BM + threadIdx.x]; }
-            vpart[(int64_t)jtg * Np + rb * Cfg::BM + threadIdx.x] = s;
-            if (MU && mupart) mupart[(int64_t)jtg * Np + rb * Cfg::BM + threadIdx.x] = s2;
+            for (int k = 0; k < Cfg::WGN; ++k) { s += red[k * Cfg::BM + tid]; if (MU) s2 += red2[k * Cfg::BM + tid]; }
+            vpart[(int64_t)jtg * Np + rb * Cfg::BM + tid] = s;
+            if (MU && mupart) mupart[(int64_t)jtg * Np + rb * Cfg::BM + tid] = s2;
         }
     } else {                                                    // EPI 1
         double bb = 0;
@@ -123,7 +124,7 @@ __device__ __forceinline__ void apply_epilogue_vec2(
 #pragma unroll
         for (int k = 0; k < 2; ++k) { al[k] = alpha[jg + k]; u2[k] = ut[jg + k]; live[k] = jg + k < K ? 1.0 : 0.0; }
         double* rowsc = reinterpret_cast<double*>(smem_raw);      // [BM][3]: 2 q, p, y of the tile's rows (LDS is free after the loop)
-        for (int i = threadIdx.x; i < Cfg::BM; i += Cfg::THREADS) {
+        for (int i = tid; i < Cfg::BM; i += Cfg::THREADS) {
             const int64_t n = rb * Cfg::BM + i;
             rowsc[3 * i] = 2.0 * q[n]; rowsc[3 * i + 1] = p[n]; rowsc[3 * i + 2] = y[n];
         }
@@ -154,9 +155,9 @@ __device__ __forceinline__ void apply_epilogue_vec2(
         double* red = rowsc + 3 * Cfg::BM;
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) bb += __shfl_xor(bb, m);
-        if (co.lane == 0) red[threadIdx.x >> 6] = bb;
+        if (co.lane == 0) red[tid >> 6] = bb;
         __syncthreads();
-        if (threadIdx.x == 0) {
+        if (tid == 0) {
             double s = 0;
             for (int k = 0; k < Cfg::THREADS / 64; ++k) s += red[k];
             bpart[blockIdx.x] = s;
@@ -168,13 +169,13 @@ __device__ __forceinline__ void apply_epilogue(
     const typename Cfg::MTr::acc_t (&acc)[Cfg::TM][Cfg::TN], const typename Cfg::T* __restrict__ Phi, typename Cfg::T* V,
     double* __restrict__ vpart, const double* __restrict__ p, const double* __restrict__ q, const double* __restrict__ y,
     const double* __restrict__ alpha, const double* __restrict__ ut, int K, int Kp, int64_t Np, int64_t rb, int cbase, int jtg,
-    double* __restrict__ bpart, char* smem_raw, double* __restrict__ mupart = nullptr) {
+    double* __restrict__ bpart, char* smem_raw, double* __restrict__ mupart = nullptr, int tid = (int)threadIdx.x) {
     typedef typename Cfg::T T;
     if constexpr (VEC4 && sizeof(T) == 8) {                        // the LDS-DMA tiles in fp64
-        apply_epilogue_vec2<Cfg, EPI, MU>(acc, Phi, V, vpart, p, q, y, alpha, ut, K, Kp, Np, rb, cbase, jtg, bpart, smem_raw, mupart);
+        apply_epilogue_vec2<Cfg, EPI, MU>(acc, Phi, V, vpart, p, q, y, alpha, ut, K, Kp, Np, rb, cbase, jtg, bpart, smem_raw, mupart, tid);
         return;
     }
-    AccCoord<Cfg> co;
+    AccCoord<Cfg> co(tid);
     if constexpr (VEC4 && sizeof(T) == 4) {
         static_assert(Cfg::TN == 4 && Cfg::MS == 16 && sizeof(T) == 4 && (EPI == 0 || EPI == 1 || EPI == 3 || EPI == 4), "VEC4 layout");
         const int c4 = co.wn0 + 4 * (co.lane & 15);               // first of this lane's four adjacent columns
@@ -188,7 +189,7 @@ __device__ __forceinline__ void apply_epilogue(
         } else if constexpr (EPI == 0 || EPI == 3) {
             double* red = reinterpret_cast<double*>(smem_raw);
             double* red2 = red + Cfg::WGN * Cfg::BM;
-            const int wn = (threadIdx.x >> 6) % Cfg::WGN;
+            const int wn = (tid >> 6) % Cfg::WGN;
             double al[4], live[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) { live[k] = jg + k < K ? 1.0 : 0.0; al[k] = MU && jg + k < K ? alpha[jg + k] : 0.0; }
@@ -225,12 +226,12 @@ __device__ __forceinline__ void apply_epilogue(
                 }
             }
             __syncthreads();
-            if (threadIdx.x < Cfg::BM) {
+            if (tid < Cfg::BM) {
                 double s = 0, s2 = 0;
 #pragma unroll
-                for (int k = 0; k < Cfg::WGN; ++k) { s += red[k * Cfg::BM + threadIdx.x]; if (MU) s2 += red2[k * Cfg::BM + threadIdx.x]; }
-                vpart[(int64_t)jtg * Np + rb * Cfg::BM + threadIdx.x] = s;
-                if (MU && mupart) mupart[(int64_t)jtg * Np + rb * Cfg::BM + threadIdx.x] = s2;
+                for (int k = 0; k < Cfg::WGN; ++k) { s += red[k * Cfg::BM + tid]; if (MU) s2 += red2[k * Cfg::BM + tid]; }
+                vpart[(int64_t)jtg * Np + rb * Cfg::BM + tid] = s;
+                if (MU && mupart) mupart[(int64_t)jtg * Np + rb * Cfg::BM + tid] = s2;
             }
         } else {                                                    // EPI 1
             double bb = 0;
@@ -244,7 +245,7 @@ __device__ __forceinline__ void apply_epilogue(
             // and Phi issued for the four rows of an accumulator row group at once: written row by row, the in-place store of a row
             // stood between the loads of the next one and its own (16 dependent round trips per tile; profiles/r03_tuning.md)
             float* rowsc = reinterpret_cast<float*>(smem_raw);        // [BM][3]
-            for (int i = threadIdx.x; i < Cfg::BM; i += Cfg::THREADS) {
+            for (int i = tid; i < Cfg::BM; i += Cfg::THREADS) {
                 const int64_t n = rb * Cfg::BM + i;
                 rowsc[3 * i] = (float)(2.0 * q[n]); rowsc[3 * i + 1] = (float)p[n]; rowsc[3 * i + 2] = (float)y[n];
             }
@@ -281,9 +282,9 @@ __device__ __forceinline__ void apply_epilogue(
             double* red = reinterpret_cast<double*>(rowsc + 4 * Cfg::BM);
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1) bb += __shfl_xor(bb, m);
-            if (co.lane == 0) red[threadIdx.x >> 6] = bb;
+            if (co.lane == 0) red[tid >> 6] = bb;
             __syncthreads();
-            if (threadIdx.x == 0) {
+            if (tid == 0) {
                 double s = 0;
                 for (int k = 0; k < Cfg::THREADS / 64; ++k) s += red[k];
                 bpart[blockIdx.x] = s;
@@ -303,7 +304,7 @@ __device__ __forceinline__ void apply_epilogue(
     } else if (EPI == 0 || EPI == 2 || EPI == 3) {
         double* red = reinterpret_cast<double*>(smem_raw);          // [WGN][BM] (MU: twice); main loop ended with a barrier
         double* red2 = red + Cfg::WGN * Cfg::BM;
-        const int wn = (threadIdx.x >> 6) % Cfg::WGN;
+        const int wn = (tid >> 6) % Cfg::WGN;
         double al[Cfg::TN];
         if (MU) {
 #pragma unroll
@@ -345,12 +346,12 @@ __device__ __forceinline__ void apply_epilogue(
                 }
             }
         __syncthreads();
-        if (threadIdx.x < Cfg::BM) {
+        if (tid < Cfg::BM) {
             double s = 0, s2 = 0;
 #pragma unroll
-            for (int k = 0; k < Cfg::WGN; ++k) { s += red[k * Cfg::BM + threadIdx.x]; if (MU) s2 += red2[k * Cfg::BM + threadIdx.x]; }
-            vpart[(int64_t)jtg * Np + rb * Cfg::BM + threadIdx.x] = s;
-            if (MU && mupart) mupart[(int64_t)jtg * Np + rb * Cfg::BM + threadIdx.x] = s2;
+            for (int k = 0; k < Cfg::WGN; ++k) { s += red[k * Cfg::BM + tid]; if (MU) s2 += red2[k * Cfg::BM + tid]; }
+            vpart[(int64_t)jtg * Np + rb * Cfg::BM + tid] = s;
+            if (MU && mupart) mupart[(int64_t)jtg * Np + rb * Cfg::BM + tid] = s2;
         }
     } else {
         double bb = 0;                                                  // bbar = sum Phibar o Phi  (d cost / d b)
@@ -389,9 +390,9 @@ __device__ __forceinline__ void apply_epilogue(
         double* red = reinterpret_cast<double*>(smem_raw);
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) bb += __shfl_xor(bb, m);
-        if (co.lane == 0) red[threadIdx.x >> 6] = bb;
+        if (co.lane == 0) red[tid >> 6] = bb;
         __syncthreads();
-        if (threadIdx.x == 0) {
+        if (tid == 0) {
             double s = 0;
             for (int k = 0; k < Cfg::THREADS / 64; ++k) s += red[k];
             bpart[blockIdx.x] = s;
@@ -457,27 +458,46 @@ void apply_kernel(
 }
 
 // Apply product with LDS-DMA staging: both operands go global -> LDS by global_load_lds_dwordx4 into a ring of three stages of
-// 16 k each, counted vmcnt, one raw barrier per stage: no staging registers, no ds_write, and the fetch of stage s+2 is in flight
-// while stage s is multiplied.  Bm must hold the k-contiguous COLUMNS of the operand as its rows: the matrix itself when it is
-// symmetric (B and Abar are), else its transpose (factor form: Li for C = Phi Li^T, Li^T for V = C Li).
+// 16 k each, counted vmcnt, one raw barrier per stage: no staging registers, no ds_write, and the fetches of stages s+2 and s+3
+// are in flight while stage s is multiplied.  Bm must hold the k-contiguous COLUMNS of the operand as its rows: the matrix itself
+// when it is symmetric (B and Abar are), else its transpose (factor form: Li for C = Phi Li^T, Li^T for V = C Li).
 //   LDS image of an operand: row x at x * ROWB bytes (ROWB = 16 k: 64 B in fp32, 128 B in fp64) = its 16 k as CPR 16-byte
 //   chunks, chunk c stored at position c ^ swz(x) (source-side swizzle: the DMA itself writes linearly, 1 KiB per wave
-//   instruction).  Lane group q of the 16x16x4 shape takes the 4 k numbered 4q .. 4q+3 -- chunk q in fp32, chunks 2q and 2q+1
-//   in fp64 -- and feeds component e to k-step e: both operands use the same permutation of the 16 k, so the sum is unchanged
-//   and a fragment is ONE ds_read_b128 (fp32) or two (fp64) per stage.  swz makes the four 16-lane groups ds_read_b128 is
-//   served in ({0-3,12-15,20-27}, {4-11,16-19,28-31} and the same + 32: MI355X_MICROARCH.md, LDS) touch 16 distinct
-//   16-byte slots of the 256-byte bank row each.
+//   instruction).  The 16 k of a stage are used as two HALVES of 8: in half h lane group q of the 16x16x4 shape holds 2 k and
+//   feeds component j to k-step 2h + j -- both operands use the same permutation of the 16 k, so the sum is unchanged.
+//     fp32: the 8 bytes (k = 8h + 2q, +1) at offset 8 (q & 1) of chunk 2h + (q >> 1): one ds_read_b64, served in two 32-lane
+//           halves that touch 64 distinct banks each (16 rows x 16 bytes: rows 4 apart share banks and differ in swz);
+//     fp64: chunk 2q + h (k = 4q + 2h, +1): one ds_read_b128, served in four 16-lane groups ({0-3,12-15,20-27},
+//           {4-11,16-19,28-31} and the same + 32: MI355X_MICROARCH.md, LDS) that touch 16 distinct 16-byte slots each.
 //   B rows are staged in the order that leaves an MFMA lane TN ADJACENT output columns (LDS row tn*16 + i of a wave tile holds
 //   operand row TN i + tn), so the epilogue moves V, Phi and Phibar 16 bytes per lane.
 //   EPI 3 / 4 (factor form): the stages run over k < cbase + BN (EPI 3) or k >= cbase (EPI 4) only.
+// Software pipeline across the barrier (apply_dma_kernel's k loop): the barrier that opens stage s+1 stands in the MIDDLE of
+// the arithmetic -- a wave reaches it with the first half of stage s multiplied and the second half's fragments in registers,
+// so it leaves the barrier with 2 TM TN MFMAs that need nothing from the LDS.  Between those MFMAs, one instruction per MFMA,
+// ride the fetch of stage s+3 (into the slot the barrier just freed) and the reads of the first half of stage s+1; between the
+// MFMAs of that half ride the reads of its second half.  Every read has >= 20 MFMAs between issue and first use, the matrix
+// pipe never sees all waves of the CU waiting for the LDS at once (measured: k loop of a 256 x 256 fp32 tile 494 -> 466 us,
+// profiles/r04_tuning.md), and the first SCFGP-PRE MFMAs of the second half are issued in front of the barrier so the pipe
+// has work while it resolves.
+//   The LDS reads are inline assembly with hand-counted waits: the compiler's own lgkmcnt bookkeeping gives up on a load that
+//   is in flight across a loop's back edge (it waits for ALL outstanding reads at the first use, the just-issued ones too).
+//   Each wait statement names the fragment registers it releases as in/out operands, so neither an MFMA nor a register copy
+//   of them can be placed above it; sched_barrier(0) keeps the written order.  tools/isa_inflight.py replays the compiled
+//   instruction stream and fails if anything touches a destination of a read not yet covered by a wait (tests/test_isa_lint.py).
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
+template <int... I, class F> __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+    (f(std::integral_constant<int, I>()), ...);
+}
+template <int N, class F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>(), f); }
 template <typename T, int BN_>
 struct ApplyDma {
     static constexpr int ES = (int)sizeof(T), BM = 256, BN = BN_, ROWB = 16 * ES, CPR = ROWB / 16;
     static constexpr int WN = ES == 4 ? 64 : 32;               // wave tile 64 x 64 (fp32) / 64 x 32 (fp64): 64 accumulator registers
     static constexpr int WAVES = 4 * (BN / WN), STAGE = (BM + BN) * ROWB, STAGES = 3, LDS_BYTES = STAGES * STAGE,
                          DMA_PER_WAVE = STAGE / 1024 / WAVES, ROWS_PER_DMA = 1024 / ROWB;
+    static constexpr int PRE = 2;                              // MFMAs of a stage's second half issued in front of the barrier
     typedef TileCfg<T, BM, BN, 16, 4, BN / WN, 16, true> Cfg;      // wave grid / accumulator map of the epilogue
     static_assert(STAGE / 1024 % WAVES == 0 && LDS_BYTES <= 160 * 1024, "whole DMA instructions per wave; the ring fits the LDS");
     // position swizzle of row x (see above): fp32 f[(x >> 2) & 3], f = (0, 2, 3, 1); fp64 f[(x >> 1) & 7], f = (0, 1, 4, 5, 6, 7, 2, 3)
@@ -500,8 +520,13 @@ void apply_dma_kernel(const T* __restrict__ Phi, const T* __restrict__ Bm, T* V,
                       int K, int Kp, int64_t Np, int njt, double* __restrict__ bpart, double* __restrict__ mu, int col0, int slot0) {
     typedef ApplyDma<T, BN> D;
     typedef typename D::Cfg Cfg;
-    typedef T frag_t __attribute__((ext_vector_type(16 / sizeof(T))));      // one 16-byte LDS read
-    constexpr int NR = 4 * (int)sizeof(T) / 16;                              // reads per fragment: its 4 k are NR chunks
+    typedef T half_t __attribute__((ext_vector_type(2)));      // a lane's 2 k of one half of a stage
+    typedef std::integral_constant<int, 0> H0;
+    typedef std::integral_constant<int, 1> H1;
+    constexpr int DPW = D::DMA_PER_WAVE, NRD = Cfg::TM + Cfg::TN, NM = 2 * Cfg::TM * Cfg::TN, PRE = D::PRE;   // per half: reads, MFMAs
+    static_assert(Cfg::TM == 4 && (Cfg::TN == 4 || Cfg::TN == 2), "fragment lists of the wait statements");
+    static_assert(DPW == 2 || DPW == 3, "vmcnt literals below");
+    static_assert(PRE + DPW + NRD <= NM, "one fetch or read per MFMA behind the barrier");
     SMEM_DECL;
     char* smem = smem_raw;
 #ifdef SCFGP_TRACE
@@ -511,83 +536,162 @@ void apply_dma_kernel(const T* __restrict__ Phi, const T* __restrict__ Bm, T* V,
     const int jt = wid % njt;
     const int64_t rb = wid / njt;
     const int cbase = col0 + jt * D::BN;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // DMA instruction t = DMA_PER_WAVE wave + u of a stage: rows ROWS_PER_DMA t .. of the stacked (A: 256, then B: BN) operand
-    // rows; lane l carries row + l / CPR, position l % CPR <- chunk (l % CPR) ^ swz(row)
-    const char* src[D::DMA_PER_WAVE]; int dst[D::DMA_PER_WAVE];
+    // rows; lane l carries row + l / CPR, position l % CPR <- chunk (l % CPR) ^ swz(row).  Its address is a wave-uniform row
+    // pointer + a 32-bit lane offset; the LDS address (M0) is scalar arithmetic.
+    const char* src[DPW]; unsigned loff[DPW]; int dst[DPW];
 #pragma unroll
-    for (int u = 0; u < D::DMA_PER_WAVE; ++u) {
-        const int t = wave * D::DMA_PER_WAVE + u, x = D::ROWS_PER_DMA * t + lane / D::CPR, c = (lane % D::CPR) ^ D::swz(x);
-        const int xb = x - D::BM, xcol = (xb & ~(D::WN - 1)) + Cfg::TN * (xb & 15) + ((xb >> 4) & (Cfg::TN - 1));
-        const T* rowp = x < D::BM ? Phi + (rb * D::BM + x) * Kp : Bm + (int64_t)(cbase + xcol) * Kp;
-        src[u] = reinterpret_cast<const char*>(rowp) + c * 16 + (EPI == 4 ? (cbase / 16) * D::ROWB : 0);
+    for (int u = 0; u < DPW; ++u) {
+        const int t = wave * DPW + u, x0 = D::ROWS_PER_DMA * t, l = lane / D::CPR, c = (lane % D::CPR) ^ D::swz(x0 + l);
+        const int xb = x0 - D::BM, xcol = (xb & ~(D::WN - 1)) + Cfg::TN * (xb & 15) + ((xb >> 4) & (Cfg::TN - 1));
+        // B rows: LDS row xb + l holds operand row xcol + TN l (a DMA instruction's rows lie inside one group of 16)
+        const T* rowp = x0 < D::BM ? Phi + (rb * D::BM + x0) * Kp : Bm + (int64_t)(cbase + xcol) * Kp;
+        src[u] = reinterpret_cast<const char*>(rowp) + (EPI == 4 ? (cbase / 16) * D::ROWB : 0);
+        loff[u] = (unsigned)((x0 < D::BM ? l : Cfg::TN * l) * Kp * D::ES + c * 16);
         dst[u] = t * 1024;
     }
-    const auto issue = [&](int slot) {
-#pragma unroll
-        for (int u = 0; u < D::DMA_PER_WAVE; ++u) {
-            __builtin_amdgcn_global_load_lds((gbl_void*)src[u], (lds_void*)(smem + slot * D::STAGE + dst[u]), 16, 0, 0);
-            src[u] += D::ROWB;                                  // 16 k further
-        }
+    const auto fetch_one = [&](auto uc, int slot) {
+        constexpr int u = decltype(uc)::value;
+        __builtin_amdgcn_global_load_lds((gbl_void*)(src[u] + loff[u]), (lds_void*)(smem + slot * D::STAGE + dst[u]), 16, 0, 0);
+        src[u] += D::ROWB;                                      // 16 k further
     };
     const int i = lane & 15, qg = lane >> 4;
     const int wm0 = (wave / Cfg::WGN) * Cfg::WM, wn0 = (wave % Cfg::WGN) * Cfg::WN;
-    // byte offsets of this lane's NR chunks inside a fragment row (the wave tile bases are multiples of 16 rows: swz(row) = swz(i))
-    int sw[NR];
-#pragma unroll
-    for (int h = 0; h < NR; ++h) sw[h] = ((NR * qg + h) ^ D::swz(i)) << 4;
-    const int aoff = (wm0 + i) * D::ROWB, boff = D::BM * D::ROWB + (wn0 + i) * D::ROWB;
+    // LDS byte addresses of this lane's 8 (fp32) / 16 (fp64) bytes of half 0 / 1 in the first fragment row of the wave's A and B
+    // tiles (the wave tile bases are multiples of 16 rows: swz(row) = swz(i))
+    const int hoff0 = sizeof(T) == 4 ? (((qg >> 1) ^ D::swz(i)) << 4) + 8 * (qg & 1) : ((2 * qg) ^ D::swz(i)) << 4;
+    const int hoff1 = sizeof(T) == 4 ? (((2 + (qg >> 1)) ^ D::swz(i)) << 4) + 8 * (qg & 1) : ((2 * qg + 1) ^ D::swz(i)) << 4;
+    const int ring = (int)(uintptr_t)smem, aoff = ring + (wm0 + i) * D::ROWB, boff = ring + D::BM * D::ROWB + (wn0 + i) * D::ROWB;
+    const int ra[2] = {aoff + hoff0, aoff + hoff1}, rbb[2] = {boff + hoff0, boff + hoff1};
+    half_t ha[2][Cfg::TM], hb[2][Cfg::TN];
     typename Cfg::MTr::acc_t acc[Cfg::TM][Cfg::TN];
     acc_zero<Cfg>(acc);
     const int nst_all = (K + 15) / 16, nst_tri = (cbase + D::BN + 15) / 16;
     const int nst = (EPI == 3 && nst_tri < nst_all ? nst_tri : nst_all) - (EPI == 4 ? cbase / 16 : 0);
-    issue(0);
-    if (nst > 1) issue(1);
-    int slot = 0, fill = 2;
-    for (int s = 0; s < nst; ++s) {
-        // this wave's share of stage s has landed when only the DMAs of stage s+1 are outstanding
-        if (s + 1 < nst) {
-            if (D::DMA_PER_WAVE == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else if (D::DMA_PER_WAVE == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        }
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                          // everybody's has; nobody reads the slot of stage s-1 any more
+#define SCFGP_LDS_READ(dst, addr, off)                                                                              \
+    do {                                                                                                             \
+        if constexpr (sizeof(T) == 4) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off));   \
+        else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off));                           \
+    } while (0)
+    // read R (A fragments 0 .. TM-1, then B fragments) of half h of the stage at byte `stage` of the ring
+    const auto read_one = [&](auto hc, auto rc, int stage) {
+        constexpr int h = decltype(hc)::value, R = decltype(rc)::value;
+        if constexpr (R < Cfg::TM) SCFGP_LDS_READ(ha[h][R], stage + ra[h], R * 16 * D::ROWB);
+        else SCFGP_LDS_READ(hb[h][R - Cfg::TM], stage + rbb[h], (R - Cfg::TM) * 16 * D::ROWB);
+    };
+#undef SCFGP_LDS_READ
+    // "s_waitcnt <what>" that hands out the fragments of half h
+#define SCFGP_WAIT_FRAGS(what, h)                                                                                                   \
+    do {                                                                                                                            \
+        if constexpr (Cfg::TN == 4)                                                                                                 \
+            asm volatile("s_waitcnt " what : "+v"(ha[h][0]), "+v"(ha[h][1]), "+v"(ha[h][2]), "+v"(ha[h][3]),                        \
+                                             "+v"(hb[h][0]), "+v"(hb[h][1]), "+v"(hb[h][2]), "+v"(hb[h][3]) :: "memory");           \
+        else                                                                                                                        \
+            asm volatile("s_waitcnt " what : "+v"(ha[h][0]), "+v"(ha[h][1]), "+v"(ha[h][2]), "+v"(ha[h][3]),                        \
+                                             "+v"(hb[h][0]), "+v"(hb[h][1]) :: "memory");                                           \
+    } while (0)
+    // MFMA I of half h: k-step 2h + j of accumulator tile (tm, tn), I = (j TM + tm) TN + tn
+    const auto mfma_one = [&](auto hc, auto ic) {
+        constexpr int h = decltype(hc)::value, I = decltype(ic)::value, j = I / (Cfg::TM * Cfg::TN), tm = I / Cfg::TN % Cfg::TM, tn = I % Cfg::TN;
+        Cfg::MTr::mfma(acc[tm][tn], ha[h][tm][j], hb[h][tn][j]);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // the first PRE MFMAs of the second half of stage s (in front of the barrier), then the rest with the fetch of stage s+3
+    // (FETCH; into slot fslot) and the reads of the first half of stage s+1 (at byte `next` of the ring) between them
+    const auto second_half_pre = [&]() { static_for<PRE>([&](auto ic) { mfma_one(H1(), ic); }); };
+    const auto second_half = [&](auto fc, int fslot, int next) {
+        static_for<NM - PRE>([&](auto ic) {
+            constexpr int I = decltype(ic)::value;
+            mfma_one(H1(), std::integral_constant<int, I + PRE>());
+            if constexpr (I < DPW) {
+                if constexpr (decltype(fc)::value) { fetch_one(ic, fslot); __builtin_amdgcn_sched_barrier(0); }
+            } else if constexpr (I - DPW < NRD) {
+                read_one(H0(), std::integral_constant<int, I - DPW>(), next);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        });
+    };
+    // the first half of stage s+1 with the reads of its second half between the MFMAs
+    const auto first_half = [&](int next) {
+        static_for<NM>([&](auto ic) {
+            mfma_one(H0(), ic);
+            if constexpr (decltype(ic)::value < NRD) { read_one(H1(), ic, next); __builtin_amdgcn_sched_barrier(0); }
+        });
+    };
+    static_for<DPW>([&](auto uc) { fetch_one(uc, 0); });
+    if (nst > 1) static_for<DPW>([&](auto uc) { fetch_one(uc, 1); });
+    if (nst > 2) static_for<DPW>([&](auto uc) { fetch_one(uc, 2); });
+    // this wave's share of stage 0 has landed when only the fetches of stages 1 and 2 are outstanding
+    if (nst > 2) { if constexpr (DPW == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+    else if (nst > 1) { if constexpr (DPW == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#ifdef SCFGP_TRACE
+    const unsigned long long tr_l0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    static_for<NRD>([&](auto rc) { read_one(H0(), rc, 0); });
+    static_for<NRD>([&](auto rc) { read_one(H1(), rc, 0); });
+    SCFGP_WAIT_FRAGS("lgkmcnt(0)", 0);
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<NM>([&](auto ic) { mfma_one(H0(), ic); });
+    int slot = 0, s = 0;                                       // slot of stage s; the first half of stage s is multiplied
+    for (; s + 3 < nst; ++s) {                                 // steady state: nothing to decide
+        // this wave's share of stage s+1 has landed when only the fetches of stage s+2 are outstanding; its reads of stage s are done
+        if constexpr (DPW == 2) SCFGP_WAIT_FRAGS("vmcnt(2) lgkmcnt(0)", 1); else SCFGP_WAIT_FRAGS("vmcnt(3) lgkmcnt(0)", 1);
+        __builtin_amdgcn_sched_barrier(0);
+        second_half_pre();
+        __builtin_amdgcn_s_barrier();                          // everybody's has; nobody reads the slot of stage s any more
         asm volatile("" ::: "memory");
-        if (s + 2 < nst) issue(fill);
-        const char* base = smem + slot * D::STAGE;
-        frag_t a[Cfg::TM][NR], b[Cfg::TN][NR];
-#pragma unroll
-        for (int tm = 0; tm < Cfg::TM; ++tm)
-#pragma unroll
-            for (int h = 0; h < NR; ++h) a[tm][h] = *reinterpret_cast<const frag_t*>(base + aoff + tm * 16 * D::ROWB + sw[h]);
-#pragma unroll
-        for (int tn = 0; tn < Cfg::TN; ++tn)
-#pragma unroll
-            for (int h = 0; h < NR; ++h) b[tn][h] = *reinterpret_cast<const frag_t*>(base + boff + tn * 16 * D::ROWB + sw[h]);
-        constexpr int EPC = 16 / (int)sizeof(T);                // k per chunk
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int tm = 0; tm < Cfg::TM; ++tm)
-#pragma unroll
-                for (int tn = 0; tn < Cfg::TN; ++tn) Cfg::MTr::mfma(acc[tm][tn], a[tm][e / EPC][e % EPC], b[tn][e / EPC][e % EPC]);
+        const int fslot = slot;
         slot = slot == 2 ? 0 : slot + 1;
-        fill = fill == 2 ? 0 : fill + 1;
+        __builtin_amdgcn_sched_barrier(0);
+        second_half(std::true_type(), fslot, slot * D::STAGE);
+        SCFGP_WAIT_FRAGS("lgkmcnt(0)", 0);
+        __builtin_amdgcn_sched_barrier(0);
+        first_half(slot * D::STAGE);
     }
+    // (a register copy the allocator places where one loop hands over to the next must not read a fragment still in flight)
+    SCFGP_WAIT_FRAGS("lgkmcnt(0)", 1);
+    for (; s + 1 < nst; ++s) {                                 // the last stages: nothing left to fetch
+        if (s + 2 < nst) { if constexpr (DPW == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        SCFGP_WAIT_FRAGS("lgkmcnt(0)", 1);
+        __builtin_amdgcn_sched_barrier(0);
+        second_half_pre();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        slot = slot == 2 ? 0 : slot + 1;
+        __builtin_amdgcn_sched_barrier(0);
+        second_half(std::false_type(), 0, slot * D::STAGE);
+        SCFGP_WAIT_FRAGS("lgkmcnt(0)", 0);
+        __builtin_amdgcn_sched_barrier(0);
+        first_half(slot * D::STAGE);
+    }
+    SCFGP_WAIT_FRAGS("lgkmcnt(0)", 1);
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<NM>([&](auto ic) { mfma_one(H1(), ic); });
+#undef SCFGP_WAIT_FRAGS
     __syncthreads();
+#ifdef SCFGP_TRACE
+    const unsigned long long tr_l1 = __builtin_amdgcn_s_memrealtime();
+#endif
     constexpr int SLOTS = BN / 128;                            // vpart / mupart slots are 128 columns wide
     const int vslot = slot0 + SLOTS * jt;
-    apply_epilogue<Cfg, EPI, EPI == 0 || EPI == 3, true>(acc, Phi, V, vpart, p, q, y, alpha, ut, K, Kp, Np, rb, cbase, vslot, bpart, smem_raw, mu);
-    if (SLOTS == 2 && (EPI == 0 || EPI == 3) && threadIdx.x < D::BM) {
-        vpart[(int64_t)(vslot + 1) * Np + rb * D::BM + threadIdx.x] = 0.0;
-        if (mu) mu[(int64_t)(vslot + 1) * Np + rb * D::BM + threadIdx.x] = 0.0;
+    int tid = (int)threadIdx.x;
+    asm volatile("" : "+v"(tid));                              // the epilogue's lane arithmetic stays behind the k loop (registers)
+    apply_epilogue<Cfg, EPI, EPI == 0 || EPI == 3, true>(acc, Phi, V, vpart, p, q, y, alpha, ut, K, Kp, Np, rb, cbase, vslot, bpart, smem_raw, mu, tid);
+    if (SLOTS == 2 && (EPI == 0 || EPI == 3) && tid < D::BM) {
+        vpart[(int64_t)(vslot + 1) * Np + rb * D::BM + tid] = 0.0;
+        if (mu) mu[(int64_t)(vslot + 1) * Np + rb * D::BM + tid] = 0.0;
     }
 #ifdef SCFGP_TRACE
     __syncthreads();
     if (threadIdx.x == 0 && blockIdx.x < ATRACE_CAP) {
         g_atrace[blockIdx.x][0] = tr_t0; g_atrace[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
         g_atrace[blockIdx.x][2] = (unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));
+        g_atrace[blockIdx.x][3] = tr_l0; g_atrace[blockIdx.x][4] = tr_l1;
     }
 #endif
 }

@@ -13,13 +13,19 @@ X = synth.make_X(bench.SEED, N, D); y = synth.normal(bench.SEED + 9, 0, N).resha
 params = synth.make_params(bench.SEED + 0x0202, D, S, M, abc=(-1.0, 0.0, -1.0))
 eng = HipEngine(D, S, M, dtype=dtype); eng.set_params(params); eng.set_data(X, y)
 eng.eval(); eng.set_profiling(True)
-eng.pass1(); eng.factor(); eng.pass2(False)                      # the last LDS-DMA launch traced: the 128- or 256-wide tiles of Phi.B
+which = sys.argv[2] if len(sys.argv) > 2 else 'apply_v'         # or apply_phibar
+eng.pass1(); eng.factor()                                        # the last LDS-DMA launch traced: the 128- or 256-wide tiles
+if which == 'apply_v': eng.pass2(False)
+else: eng.pass2(True); eng.adjoint(); eng.pass3()
 tm = dict(eng.timings())
-tr = eng.debug_read('apply_trace', (1 << 16, 3), dtype=np.uint64)
+tr = eng.debug_read('apply_trace', (1 << 16, 5), dtype=np.uint64)
 tr = tr[tr[:, 1] > 0].astype(np.int64)
-tr = tr[tr[:, 0] >= tr[:, 1].max() - int(100e6 * 1.2e-3 * tm['apply_v'])]
+tr = tr[tr[:, 0] >= tr[:, 1].max() - int(100e6 * 1.2e-3 * tm[which])]
 t0 = tr[:, 0].min(); st, en, xcc = (tr[:, 0] - t0) / 100.0, (tr[:, 1] - t0) / 100.0, tr[:, 2] & 0xF
-print('apply_v hipEvent %.2f ms; %d workgroups traced; span %.2f ms' % (tm['apply_v'], len(tr), en.max() / 1e3))
+print('%s hipEvent %.2f ms; %d workgroups traced; span %.2f ms' % (which, tm[which], len(tr), en.max() / 1e3))
+pro, loop, epi = (tr[:, 3] - tr[:, 0]) / 100.0, (tr[:, 4] - tr[:, 3]) / 100.0, (tr[:, 1] - tr[:, 4]) / 100.0
+for nm, a in (('start -> first barrier passed', pro), ('k loop', loop), ('epilogue', epi)):
+    print('  %-30s us: mean %.2f  p10 %.2f  median %.2f  p90 %.2f  max %.2f' % (nm, a.mean(), np.percentile(a, 10), np.median(a), np.percentile(a, 90), a.max()))
 for x in sorted(set(xcc.tolist())):
     m = xcc == x
     print('  xcc %d: %5d workgroups, mean length %.1f us, last start %.2f ms, last end %.2f ms' % (x, m.sum(), (en - st)[m].mean(), st[m].max() / 1e3, en[m].max() / 1e3))
