@@ -5,7 +5,6 @@
 #include "tile_cfgs.h"
 
 #include <algorithm>
-#include <utility>
 
 // apply tiles: 256 rows x {256, 128, 64} columns (tile_cfgs.h)
 // Diagnostic build (-DSCFGP_TRACE): every workgroup of the LDS-DMA apply kernel records [start, end] on the 100 MHz constant
@@ -487,10 +486,6 @@ void apply_kernel(
 //   instruction stream and fails if anything touches a destination of a read not yet covered by a wait (tests/test_isa_lint.py).
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
-template <int... I, class F> __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
-    (f(std::integral_constant<int, I>()), ...);
-}
-template <int N, class F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>(), f); }
 template <typename T, int BN_>
 struct ApplyDma {
     static constexpr int ES = (int)sizeof(T), BM = 256, BN = BN_, ROWB = 16 * ES, CPR = ROWB / 16;

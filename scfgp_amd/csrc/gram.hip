@@ -155,8 +155,10 @@ typedef const __attribute__((address_space(1))) void gbl_void;
 // generic address of an LDS byte -> LDS pointer: the low 32 bits are the LDS offset (the address-space cast proper carries a null
 // check that this compiler mis-selects in one of the kernels below: "V_CMP_NE_U32 0, $src_shared_base")
 __device__ __forceinline__ lds_void* lds_ptr(const char* p) { return (lds_void*)(uintptr_t)((unsigned)(uintptr_t)p); }
+// The diagonal jobs (DIAG: side sums; a dozen more live registers) keep the plain loop: fetch and reads behind the barrier, the
+// compiler counts the waits.
 template <bool WEIGHT, bool DIAG>
-__device__ __forceinline__ void gram_tall_dma(
+__device__ __forceinline__ void gram_tall_dma_diag(
     const float* __restrict__ Phi, int64_t ld, const double* __restrict__ w, const double* __restrict__ side,
     int64_t r0, int64_t r1, int64_t chunk, int acol, int bcol, double* __restrict__ sideout,
     double* __restrict__ slab, double* __restrict__ slab_hi, char* smem) {
@@ -252,6 +254,195 @@ __device__ __forceinline__ void gram_tall_dma(
         }
         first = false;
     }
+}
+
+// The k loop is software-pipelined across the stage barrier like apply.hip's apply_dma_kernel (see there): a stage's four
+// k-steps are two HALVES (k-steps 0,1 and 2,3) with their own fragment registers; the barrier that opens stage s+1 stands between
+// the MFMAs of the first and the second half of stage s, the fetch of stage s+3 and the reads of the next first half ride between
+// the second half's MFMAs, the reads of the next second half between the first half's.  LDS reads are inline assembly with
+// hand-counted waits that name the registers they release (tools/isa_inflight.py checks the compiled stream).
+template <bool WEIGHT, bool DIAG>
+__device__ __forceinline__ void gram_tall_dma(                 // DIAG == false (gram_tall_dma_diag serves the diagonal jobs)
+    const float* __restrict__ Phi, int64_t ld, const double* __restrict__ w, const double* __restrict__ side,
+    int64_t r0, int64_t r1, int64_t chunk, int acol, int bcol, double* __restrict__ sideout,
+    double* __restrict__ slab, double* __restrict__ slab_hi, char* smem) {
+    typedef GramDma D;
+    typedef std::integral_constant<int, 0> H0;
+    typedef std::integral_constant<int, 1> H1;
+    constexpr bool WS = WEIGHT || DIAG;
+    constexpr int DPW = D::DMA_PER_WAVE, NRD = 4 + (WEIGHT ? 2 : 0) + (DIAG ? 2 : 0), NM = 32, PRE = 2;    // per half: reads, MFMAs
+    static_assert(PRE + DPW + 1 + NRD <= NM, "one fetch or read per MFMA behind the barrier");
+    // the thread id behind an opaque move (see gram_body_impl)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), i = lane & 15, q = lane >> 4;
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+    // DMA instruction t = 3 wave + u of a stage: t < 16: row t of the A panel; else rows 2 (t - 16), 2 (t - 16) + 1 of the B panel
+    const char* src[DPW]; int dst[DPW];
+#pragma unroll
+    for (int u = 0; u < DPW; ++u) {
+        const int t = DPW * wave + u;
+        const float* g = t < 16 ? Phi + (r0 + t) * ld + acol + 4 * lane : Phi + (r0 + 2 * (t - 16) + (lane >> 5)) * ld + bcol + 4 * (lane & 31);
+        src[u] = reinterpret_cast<const char*>(g);
+        dst[u] = t * 1024;
+    }
+    const int64_t step = 16 * ld * (int64_t)sizeof(float);
+    // lanes 0..31: the 16 weights (as 32 dwords), lanes 32..63: the 16 side multipliers; an absent one is replaced by the other
+    const double* ws_lo = WEIGHT ? w : side; const double* ws_hi = DIAG ? side : w;
+    const char* wsrc = WS ? reinterpret_cast<const char*>((lane < 32 ? ws_lo : ws_hi) + r0) + 4 * (lane & 31) : nullptr;
+    const bool ws_wave = WS && wave == 0;
+    const auto fetch_one = [&](auto uc, int slot) {            // u < DPW: operand instruction u; u == DPW: the weights / multipliers
+        constexpr int u = decltype(uc)::value;
+        char* base = smem + slot * D::STAGE;
+        if constexpr (u < DPW) {
+            __builtin_amdgcn_global_load_lds((gbl_void*)src[u], lds_ptr(base + dst[u]), 16, 0, 0);
+            src[u] += step;
+        } else if (ws_wave) {
+            __builtin_amdgcn_global_load_lds((gbl_void*)wsrc, lds_ptr(base + D::W_OFF), 4, 0, 0);
+            wsrc += 128;
+        }
+    };
+    // LDS byte addresses (first stage) of this lane's fragment of k row q: 4 adjacent floats of the A / B panel, its weight
+    const int ring = (int)(uintptr_t)smem;
+    const int pa0 = ring + q * (D::BM * 4) + (wm0 + 4 * i) * 4, pb0 = ring + D::A_BYTES + q * (D::BN * 4) + (wn0 + 4 * i) * 4, pw0 = ring + D::W_OFF + q * 8;
+    v4f fa[2][2], fb[2][2];                                    // [half][k-step of the half]
+    double fw[2][2], fs[2][2];
+    v4f acc[4][4];
+    v4f sacc = v4f{0.f, 0.f, 0.f, 0.f};                         // side sums of a chunk: fp32 chains a quarter as long as the MFMAs'
+    // read R of half h of the stage at byte `stage` of the ring: A, A, B, B, (weight, weight), (multiplier, multiplier)
+    const auto read_one = [&](auto hc, auto rc, int stage) {
+        constexpr int h = decltype(hc)::value, R = decltype(rc)::value, kk = 2 * h + (R & 1);
+        (void)&fw; (void)&fs; (void)&pw0;                        // (named outside the discarded branches: the capture is decided here)
+        if constexpr (R < 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[h][R & 1]) : "v"(stage + pa0), "n"(kk * 4 * D::BM * 4));
+        else if constexpr (R < 4) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[h][R & 1]) : "v"(stage + pb0), "n"(kk * 4 * D::BN * 4));
+        else if constexpr (WEIGHT && R < 6) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(fw[h][R & 1]) : "v"(stage + pw0), "n"(kk * 32));
+        else asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(fs[h][R & 1]) : "v"(stage + pw0), "n"(kk * 32 + D::S_OFF - D::W_OFF));
+    };
+    // "s_waitcnt <what>" that hands out the fragments of half h, then the row weights / side sums on them (VALU)
+#define SCFGP_WAIT_FRAGS(what, h)                                                                                                        \
+    do {                                                                                                                                 \
+        if constexpr (WEIGHT)                                                                                                            \
+            asm volatile("s_waitcnt " what :: "v"(fa[h][0]), "v"(fa[h][1]), "v"(fb[h][0]), "v"(fb[h][1]), "v"(fw[h][0]), "v"(fw[h][1]) : "memory"); \
+        else asm volatile("s_waitcnt " what :: "v"(fa[h][0]), "v"(fa[h][1]), "v"(fb[h][0]), "v"(fb[h][1]) : "memory");                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                                               \
+        if constexpr (WEIGHT) { fa[h][0] *= (float)fw[h][0]; fa[h][1] *= (float)fw[h][1]; }                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                                               \
+    } while (0)
+    // MFMA I of half h: k-step 2h + I / 16 of accumulator tile (tm, tn) = (I / 4 % 4, I % 4)
+    const auto mfma_one = [&](auto hc, auto ic) {
+        constexpr int h = decltype(hc)::value, I = decltype(ic)::value, k2 = I / 16, tm = I / 4 % 4, tn = I % 4;
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[h][k2][tm], fb[h][k2][tn], acc[tm][tn], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    const auto second_half_pre = [&]() { static_for<PRE>([&](auto ic) { mfma_one(H1(), ic); }); };
+    // the rest of the second half of stage s with the fetch of stage s+3 (FETCH; slot fslot) and the reads of the first half of
+    // stage s+1 (READ; at byte `next` of the ring) between its MFMAs
+    const auto second_half = [&](auto fc, auto rdc, int fslot, int next) {
+        static_for<NM - PRE>([&](auto ic) {
+            constexpr int I = decltype(ic)::value;
+            mfma_one(H1(), std::integral_constant<int, I + PRE>());
+            if constexpr (I < DPW + 1) {
+                if constexpr (decltype(fc)::value && (I < DPW || WS)) { fetch_one(ic, fslot); __builtin_amdgcn_sched_barrier(0); }
+            } else if constexpr (I - DPW - 1 < NRD) {
+                if constexpr (decltype(rdc)::value) { read_one(H0(), std::integral_constant<int, I - DPW - 1>(), next); __builtin_amdgcn_sched_barrier(0); }
+            }
+        });
+    };
+    const auto first_half = [&](int next) {
+        static_for<NM>([&](auto ic) {
+            mfma_one(H0(), ic);
+            if constexpr (decltype(ic)::value < NRD) { read_one(H1(), ic, next); __builtin_amdgcn_sched_barrier(0); }
+        });
+    };
+    // accumulator (tm, tn, r) of lane (i, q) is output row wm0 + 16 q + 4 r + tm, column wn0 + 4 i + tn
+    double* sl = wm0 >= 128 ? slab_hi + (int64_t)(wm0 - 128) * D::BN : slab + (int64_t)wm0 * D::BN;
+    bool first = true;
+    const auto flush = [&]() {
+        int lf = lane;                                         // (opaque: the 16 slab addresses are formed here, not kept across the k loop)
+        asm volatile("" : "+v"(lf));
+        const int i = lf & 15, q = lf >> 4;
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v4d* d = reinterpret_cast<v4d*>(sl + (16 * q + 4 * r + tm) * D::BN + wn0 + 4 * i);
+                const v4d v = v4d{(double)acc[tm][0][r], (double)acc[tm][1][r], (double)acc[tm][2][r], (double)acc[tm][3][r]};
+                *d = first ? v : *d + v;
+            }
+        if constexpr (DIAG) {                                  // the 4 k rows of a k-step live in the 4 lane groups: sum over q, fp64 across chunks
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm) {
+                double x = (double)sacc[tm];
+                x += __shfl_xor(x, 16); x += __shfl_xor(x, 32);
+                if (q == 0 && wn0 == 0) { double* d = sideout + wm0 + 4 * i + tm; *d = first ? x : *d + x; }
+            }
+            sacc = v4f{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = v4f{0.f, 0.f, 0.f, 0.f};
+        first = false;
+    };
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = v4f{0.f, 0.f, 0.f, 0.f};
+    const int nst = (int)((r1 - r0) / 16), per_chunk = (int)(chunk / 16);
+    if (nst == 0) { flush(); return; }                          // an empty split still owns its slab
+    static_for<DPW + 1>([&](auto uc) { fetch_one(uc, 0); });
+    if (nst > 1) static_for<DPW + 1>([&](auto uc) { fetch_one(uc, 1); });
+    int slot = 0, s = 0;                                        // slot of stage s
+    // A chunk starts with an empty pipeline and drains it before its flush: no fragment is live (or in flight) across the flush,
+    // whose register appetite would otherwise have the allocator spill fragment registers whose data has not arrived yet.
+    while (s < nst) {
+        const int cend = s + per_chunk < nst ? s + per_chunk : nst;
+        // prime: stage s has landed when only the fetches of stage s+1 are outstanding
+        if (s + 1 < nst) { if (ws_wave) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                          // everybody's has; nobody reads the slot of stage s-1 any more
+        asm volatile("" ::: "memory");
+        if (s + 2 < nst) { const int fslot = slot == 0 ? 2 : slot - 1; static_for<DPW + 1>([&](auto uc) { fetch_one(uc, fslot); }); }
+        static_for<NRD>([&](auto rc) { read_one(H0(), rc, slot * D::STAGE); });
+        static_for<NRD>([&](auto rc) { read_one(H1(), rc, slot * D::STAGE); });
+        SCFGP_WAIT_FRAGS("lgkmcnt(0)", 0);
+        static_for<NM>([&](auto ic) { mfma_one(H0(), ic); });
+        for (; s + 1 < cend && s + 3 < nst; ++s) {             // steady state: the first half of stage s is multiplied
+            // this wave's share of stage s+1 has landed when only the fetches of stage s+2 are outstanding; its reads of stage s are done
+            // (the two counts apart from the statement that releases the fragments: one such statement per point of the loop, or
+            // the allocator joins the branches with copies of registers still in flight)
+            if (ws_wave) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            SCFGP_WAIT_FRAGS("lgkmcnt(0)", 1);
+            second_half_pre();
+            __builtin_amdgcn_s_barrier();                      // everybody's has; nobody reads the slot of stage s any more
+            asm volatile("" ::: "memory");
+            const int fslot = slot;
+            slot = slot == 2 ? 0 : slot + 1;
+            __builtin_amdgcn_sched_barrier(0);
+            second_half(std::true_type(), std::true_type(), fslot, slot * D::STAGE);
+            SCFGP_WAIT_FRAGS("lgkmcnt(0)", 0);
+            first_half(slot * D::STAGE);
+        }
+        for (; s + 1 < cend; ++s) {                            // the last stages of the row range: nothing left to fetch
+            if (s + 2 < nst) { if (ws_wave) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            SCFGP_WAIT_FRAGS("lgkmcnt(0)", 1);
+            second_half_pre();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            slot = slot == 2 ? 0 : slot + 1;
+            __builtin_amdgcn_sched_barrier(0);
+            second_half(std::false_type(), std::true_type(), 0, slot * D::STAGE);
+            SCFGP_WAIT_FRAGS("lgkmcnt(0)", 0);
+            first_half(slot * D::STAGE);
+        }
+        SCFGP_WAIT_FRAGS("lgkmcnt(0)", 1);                      // the last stage of the chunk: its second half, nothing issued for the next
+        static_for<NM>([&](auto ic) { mfma_one(H1(), ic); });
+        flush();
+        ++s;
+        slot = slot == 2 ? 0 : slot + 1;
+    }
+#undef SCFGP_WAIT_FRAGS
 }
 
 // fp64 square tile (128 x 128, 8 waves of 32 x 64) with LDS-DMA staging: the same structure as the fp32 tall tile with 16-row
@@ -428,7 +619,7 @@ __device__ __forceinline__ void gram_job(
     if (kind == 1) { gram_body<SCfg, WEIGHT, true>(Phi, ld, w, side, r0, r1, chunk, acol, bcol, diag, sideout, slab, nullptr, smem_raw); TRACE_END(kind); return; }
     if constexpr (BIG) {
         if (kind == 2) {
-            if (diag) gram_tall_dma<WEIGHT, true>(Phi, ld, w, side, r0, r1, chunk, acol, bcol, sideout, slab, slab2, smem_raw);
+            if (diag) gram_tall_dma_diag<WEIGHT, true>(Phi, ld, w, side, r0, r1, chunk, acol, bcol, sideout, slab, slab2, smem_raw);
             else gram_tall_dma<WEIGHT, false>(Phi, ld, w, side, r0, r1, chunk, acol, bcol, sideout, slab, slab2, smem_raw);
             TRACE_END(kind); return;
         }

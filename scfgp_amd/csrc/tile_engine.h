@@ -16,6 +16,14 @@
 #pragma once
 #include "common.h"
 #include "sincos.h"
+#include <utility>
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>), in this order (hand-scheduled instruction sequences whose
+// inline-assembly operands must be compile-time constants)
+template <int... I, class F> __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+    (f(std::integral_constant<int, I>()), ...);
+}
+template <int N, class F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>(), f); }
 
 // MFMA traits: element type T and instruction shape MS (16: 16x16x4, 32: 32x32x2, f32 only).
 //   lane l supplies A[i = l % MS][k = l / MS] and B[k = l / MS][j = l % MS]

@@ -31,3 +31,10 @@ def test_apply_dma_kernels_never_touch_a_fragment_in_flight_and_keep_their_loops
     assert len(loops) >= 12 * 2                                  # 12 instantiations: the steady loop and the tail loop of each
     for name, body in loops:
         assert body['scratch'] == 0 and body['barrier'] == 1 and body['ds_read'] in (12, 16), (name, body)
+
+
+def test_gram_kernels_never_touch_a_fragment_in_flight():
+    """the pipelined 256 x 128 Gram tile (gram_tall_dma) inside the persistent gram_kernel: the flush of a chunk must find the
+    pipeline drained (no spill or copy of a fragment register whose read has not been waited for)"""
+    import isa_inflight
+    assert isa_inflight.main('gram', 'gram_kernel', []) == 0

@@ -2,8 +2,7 @@
 `pattern`, no instruction may read or overwrite the destination registers of a ds_read_* that the lgkmcnt waits seen since
 have not yet covered.  LDS reads return in order, so the check replays the instruction stream in layout order with a queue of
 outstanding reads; `s_waitcnt lgkmcnt(n)` retires all but the newest n.  Scalar loads share the counter and only make the
-real wait longer, so they are ignored.  Layout order is not every path: the check also restarts with an empty queue at every
-label only if `--reset-at-labels` is given; by default the queue is carried through labels (fall-through and loop bodies).
+real wait longer, so they are ignored.  Every path of the control-flow graph is followed.
    python tools/isa_inflight.py apply apply_dma_kernel [-DSCFGP_APPLY_PIPE=1]"""
 import os
 import re
@@ -22,33 +21,64 @@ def regs(tok):
     return out
 
 
+def step(queue, l, ln, bad):
+    """one instruction on the queue of outstanding reads (tuple of (frozenset of destination registers, line)); returns the new queue"""
+    op = l.split()[0]
+    if op == 's_waitcnt':
+        m = re.search(r'lgkmcnt\((\d+)\)', l)
+        if m:
+            keep = int(m.group(1))
+            queue = queue[len(queue) - keep:] if keep else ()
+        return queue
+    if op.startswith('s_'):
+        return queue
+    inflight = frozenset().union(*[q[0] for q in queue]) if queue else frozenset()
+    args = l[len(op):]
+    first = args.split(',')[0]
+    hit = regs(args) & inflight
+    if hit:
+        bad[ln] = (ln, l, sorted(hit))
+    if op.startswith('ds_read'):
+        queue = queue + ((frozenset(regs(first)), ln),)
+    return queue
+
+
 def check(lines, name):
-    queue, bad = [], []                                         # queue of (dst register set, line)
+    """lines: [(line number, text)] of one function.  Every path through its control-flow graph is replayed (a block is visited
+    once per distinct queue of outstanding reads that reaches it)."""
+    ins = []
     for ln, l in lines:
         l = l.split(';')[0].strip()
-        if not l or l.endswith(':') or l.startswith('.'):
-            continue
-        op = l.split()[0]
-        if op == 's_waitcnt':
-            m = re.search(r'lgkmcnt\((\d+)\)', l)
+        if l and not l.startswith('.') or re.match(r'^\.LBB\d+_\d+:', l):
+            ins.append((ln, l))
+    label_at = {l[:-1]: k for k, (_, l) in enumerate(ins) if l.endswith(':')}
+    bad, seen = {}, set()
+    work = [(0, ())]
+    while work:
+        k, queue = work.pop()
+        while k < len(ins):
+            ln, l = ins[k]
+            if l.endswith(':'):
+                key = (k, tuple(q[0] for q in queue))
+                if key in seen:
+                    break
+                seen.add(key)
+                k += 1
+                continue
+            op = l.split()[0]
+            if op == 's_endpgm':
+                break
+            m = re.match(r's_c?branch\w*\s+(\.LBB\d+_\d+)', l)
             if m:
-                keep = int(m.group(1))
-                queue = queue[len(queue) - keep:] if keep else []
-            continue
-        if op == 's_barrier' or op.startswith('s_'):
-            continue
-        inflight = set().union(*[q[0] for q in queue]) if queue else set()
-        args = l[len(op):]
-        first = args.split(',')[0]
-        touched = regs(args)
-        if op.startswith('ds_read'):
-            touched = regs(first) | regs(','.join(args.split(',')[1:]))   # destination (overwrite) and address
-        hit = touched & inflight
-        if hit:
-            bad.append((ln, l, sorted(hit)))
-        if op.startswith('ds_read'):
-            queue.append((regs(first), ln))
-    return bad
+                if m.group(1) in label_at:
+                    work.append((label_at[m.group(1)], queue))
+                if op == 's_branch':
+                    break
+                k += 1
+                continue
+            queue = step(queue, l, ln, bad)
+            k += 1
+    return [bad[k] for k in sorted(bad)]
 
 
 def main(unit, pattern, extra):
