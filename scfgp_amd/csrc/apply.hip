@@ -493,6 +493,9 @@ struct ApplyDma {
     static constexpr int WAVES = 4 * (BN / WN), STAGE = (BM + BN) * ROWB, STAGES = 3, LDS_BYTES = STAGES * STAGE,
                          DMA_PER_WAVE = STAGE / 1024 / WAVES, ROWS_PER_DMA = 1024 / ROWB;
     static constexpr int PRE = 2;                              // MFMAs of a stage's second half issued in front of the barrier
+    // resident waves per SIMD the register budget is cut for: one 16-wave workgroup or two 8-wave ones per CU, two 4-wave ones
+    // of the 64-column remainder tile (the LDS holds no more)
+    static constexpr int WAVES_PER_EU = WAVES == 4 ? 2 : 4;
     typedef TileCfg<T, BM, BN, 16, 4, BN / WN, 16, true> Cfg;      // wave grid / accumulator map of the epilogue
     static_assert(STAGE / 1024 % WAVES == 0 && LDS_BYTES <= 160 * 1024, "whole DMA instructions per wave; the ring fits the LDS");
     // position swizzle of row x (see above): fp32 f[(x >> 2) & 3], f = (0, 2, 3, 1); fp64 f[(x >> 1) & 7], f = (0, 1, 4, 5, 6, 7, 2, 3)
@@ -506,9 +509,10 @@ static_assert(((0x6BEB08u >> 0) & 7) == 0 && ((0x6BEB08u >> 3) & 7) == 1 && ((0x
               "fp64 swizzle table");
 
 // fp32 BN = 256: 16 waves, one workgroup per CU, 32 operand bytes per MFMA; BN = 128: 8 waves, two workgroups per CU, 48 bytes;
-// fp64 BN = 128: 16 waves of 64 x 32, one workgroup per CU (3 x 48 KB of LDS), 96 bytes per MFMA of twice the duration
+// fp64 BN = 128: 16 waves of 64 x 32, one workgroup per CU (3 x 48 KB of LDS), 96 bytes per MFMA of twice the duration;
+// BN = 64 (the ragged last columns): 4 (fp32) / 8 (fp64) waves, 80 / 160 bytes per MFMA
 template <typename T, int EPI, int BN>
-__global__ __launch_bounds__((64 * ApplyDma<T, BN>::WAVES)) __attribute__((amdgpu_waves_per_eu(4, 4)))
+__global__ __launch_bounds__((64 * ApplyDma<T, BN>::WAVES)) __attribute__((amdgpu_waves_per_eu(ApplyDma<T, BN>::WAVES_PER_EU, ApplyDma<T, BN>::WAVES_PER_EU)))
 void apply_dma_kernel(const T* __restrict__ Phi, const T* __restrict__ Bm, T* V,
                       double* __restrict__ vpart, const double* __restrict__ p, const double* __restrict__ q,
                       const double* __restrict__ y, const double* __restrict__ alpha, const double* __restrict__ ut,
@@ -520,7 +524,6 @@ void apply_dma_kernel(const T* __restrict__ Phi, const T* __restrict__ Bm, T* V,
     typedef std::integral_constant<int, 1> H1;
     constexpr int DPW = D::DMA_PER_WAVE, NRD = Cfg::TM + Cfg::TN, NM = 2 * Cfg::TM * Cfg::TN, PRE = D::PRE;   // per half: reads, MFMAs
     static_assert(Cfg::TM == 4 && (Cfg::TN == 4 || Cfg::TN == 2), "fragment lists of the wait statements");
-    static_assert(DPW == 2 || DPW == 3, "vmcnt literals below");
     static_assert(PRE + DPW + NRD <= NM, "one fetch or read per MFMA behind the barrier");
     SMEM_DECL;
     char* smem = smem_raw;
@@ -618,8 +621,8 @@ void apply_dma_kernel(const T* __restrict__ Phi, const T* __restrict__ Bm, T* V,
     if (nst > 1) static_for<DPW>([&](auto uc) { fetch_one(uc, 1); });
     if (nst > 2) static_for<DPW>([&](auto uc) { fetch_one(uc, 2); });
     // this wave's share of stage 0 has landed when only the fetches of stages 1 and 2 are outstanding
-    if (nst > 2) { if constexpr (DPW == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
-    else if (nst > 1) { if constexpr (DPW == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
+    if (nst > 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * DPW) : "memory");
+    else if (nst > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DPW) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -634,7 +637,8 @@ void apply_dma_kernel(const T* __restrict__ Phi, const T* __restrict__ Bm, T* V,
     int slot = 0, s = 0;                                       // slot of stage s; the first half of stage s is multiplied
     for (; s + 3 < nst; ++s) {                                 // steady state: nothing to decide
         // this wave's share of stage s+1 has landed when only the fetches of stage s+2 are outstanding; its reads of stage s are done
-        if constexpr (DPW == 2) SCFGP_WAIT_FRAGS("vmcnt(2) lgkmcnt(0)", 1); else SCFGP_WAIT_FRAGS("vmcnt(3) lgkmcnt(0)", 1);
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DPW) : "memory");
+        SCFGP_WAIT_FRAGS("lgkmcnt(0)", 1);
         __builtin_amdgcn_sched_barrier(0);
         second_half_pre();
         __builtin_amdgcn_s_barrier();                          // everybody's has; nobody reads the slot of stage s any more
@@ -650,7 +654,7 @@ void apply_dma_kernel(const T* __restrict__ Phi, const T* __restrict__ Bm, T* V,
     // (a register copy the allocator places where one loop hands over to the next must not read a fragment still in flight)
     SCFGP_WAIT_FRAGS("lgkmcnt(0)", 1);
     for (; s + 1 < nst; ++s) {                                 // the last stages: nothing left to fetch
-        if (s + 2 < nst) { if constexpr (DPW == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
+        if (s + 2 < nst) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         SCFGP_WAIT_FRAGS("lgkmcnt(0)", 1);
         __builtin_amdgcn_sched_barrier(0);
@@ -672,7 +676,7 @@ void apply_dma_kernel(const T* __restrict__ Phi, const T* __restrict__ Bm, T* V,
 #ifdef SCFGP_TRACE
     const unsigned long long tr_l1 = __builtin_amdgcn_s_memrealtime();
 #endif
-    constexpr int SLOTS = BN / 128;                            // vpart / mupart slots are 128 columns wide
+    constexpr int SLOTS = BN >= 128 ? BN / 128 : 1;            // vpart / mupart slots: one per 128 columns of the full tiles, one per remainder tile
     const int vslot = slot0 + SLOTS * jt;
     int tid = (int)threadIdx.x;
     asm volatile("" : "+v"(tid));                              // the epilogue's lane arithmetic stays behind the k loop (registers)
@@ -737,8 +741,8 @@ static int apply_dma_launch(const Geom& g, int njt, int col0, int slot0, int bof
                        Phi, Bm, V, vpart, p, q, y, alpha, ut, g.K, g.Kp, g.Np, njt, bpart ? bpart + boff : nullptr, mu, col0, slot0);
     return (int)(njt * nrb);
 }
-// dma: 0 = every tile by the register-staged kernel; 1 / 2 = the full 128-column tiles by LDS-DMA, 128 wide / 256 wide (fp32
-//      only; an odd 128-column tile and fp64 stay 128 wide), the ragged 64-wide remainder by the register-staged kernel
+// dma: 0 = every tile by the register-staged kernel; 1 / 2 = LDS-DMA tiles, the full 128-column blocks 128 wide / 256 wide (fp32
+//      only; an odd 128-column block and fp64 stay 128 wide), the ragged 64-column remainder 64 wide
 // BmT: the operand with its k-contiguous columns as rows (what the DMA-fed tiles read); NULL: Bm is symmetric
 template <typename T, int EPI>
 static int apply_launch(const Geom& g, const T* Phi, const T* Bm, T* V, double* vpart, const double* p, const double* q,
@@ -755,9 +759,8 @@ static int apply_launch(const Geom& g, const T* Phi, const T* Bm, T* V, double* 
                 nb += apply_dma_launch<T, EPI, 256>(g, n256, 0, 0, nb, Phi, BmT, V, vpart, p, q, y, alpha, ut, bpart, mu, st);
             }
             nb += apply_dma_launch<T, EPI, 128>(g, pl.count[0] - 2 * n256, 256 * n256, 2 * n256, nb, Phi, BmT, V, vpart, p, q, y, alpha, ut, bpart, mu, st);
-            // beside DMA-fed tiles the mu slices of the remainder are its own column bands (ntot = 0)
-            nb += apply_launch_cfg<typename ApplyCfg<T, 64>::type, EPI, T>(g, pl.count[1], pl.col0[1], pl.jt0[1], nb, Phi, Bm, V, vpart, p, q, y, alpha, ut,
-                                                                          bpart, mu, 0, st);
+            // the ragged 64-column remainder: the same kernel with 256 x 64 tiles (4 / 8 waves, two workgroups per CU)
+            nb += apply_dma_launch<T, EPI, 64>(g, pl.count[1], pl.col0[1], pl.jt0[1], nb, Phi, BmT, V, vpart, p, q, y, alpha, ut, bpart, mu, st);
             return nb;
         }
     }
