@@ -516,7 +516,7 @@ __global__ __launch_bounds__((64 * ApplyDma<T, BN>::WAVES)) __attribute__((amdgp
 void apply_dma_kernel(const T* __restrict__ Phi, const T* __restrict__ Bm, T* V,
                       double* __restrict__ vpart, const double* __restrict__ p, const double* __restrict__ q,
                       const double* __restrict__ y, const double* __restrict__ alpha, const double* __restrict__ ut,
-                      int K, int Kp, int64_t Np, int njt, double* __restrict__ bpart, double* __restrict__ mu, int col0, int slot0) {
+                      int K, int Kp, int64_t Np, int njt, double* __restrict__ bpart, double* __restrict__ mu, int col0, int slot0, int64_t rb0) {
     typedef ApplyDma<T, BN> D;
     typedef typename D::Cfg Cfg;
     typedef T half_t __attribute__((ext_vector_type(2)));      // a lane's 2 k of one half of a stage
@@ -532,7 +532,7 @@ void apply_dma_kernel(const T* __restrict__ Phi, const T* __restrict__ Bm, T* V,
 #endif
     const unsigned wid = xcd_remap(blockIdx.x, gridDim.x);
     const int jt = wid % njt;
-    const int64_t rb = wid / njt;
+    const int64_t rb = rb0 + wid / njt;                        // the launch covers row blocks rb0 ..
     const int cbase = col0 + jt * D::BN;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // DMA instruction t = DMA_PER_WAVE wave + u of a stage: rows ROWS_PER_DMA t .. of the stacked (A: 256, then B: BN) operand
@@ -732,14 +732,23 @@ static int apply_launch_cfg(const Geom& g, int njt, int col0, int jt0, int boff,
 template <typename T, int EPI, int BN>
 static int apply_dma_launch(const Geom& g, int njt, int col0, int slot0, int boff, const T* Phi, const T* Bm, T* V, double* vpart,
                             const double* p, const double* q, const double* y, const double* alpha, const double* ut,
-                            double* bpart, double* mu, hipStream_t st) {
-    if (njt <= 0) return 0;
+                            double* bpart, double* mu, hipStream_t st, int64_t rb0 = 0, int64_t nrb = -1) {
     typedef ApplyDma<T, BN> D;
-    const int64_t nrb = g.Np / D::BM;
+    if (nrb < 0) nrb = g.Np / D::BM;                           // row blocks rb0 .. rb0 + nrb - 1 (default: all)
+    if (njt <= 0 || nrb <= 0) return 0;
     allow_big_lds(apply_dma_kernel<T, EPI, BN>, D::LDS_BYTES);
     hipLaunchKernelGGL((apply_dma_kernel<T, EPI, BN>), dim3((unsigned)(njt * nrb)), dim3(64 * D::WAVES), D::LDS_BYTES, st,
-                       Phi, Bm, V, vpart, p, q, y, alpha, ut, g.K, g.Kp, g.Np, njt, bpart ? bpart + boff : nullptr, mu, col0, slot0);
+                       Phi, Bm, V, vpart, p, q, y, alpha, ut, g.K, g.Kp, g.Np, njt, bpart ? bpart + boff : nullptr, mu, col0, slot0, rb0);
     return (int)(njt * nrb);
+}
+static int apply_num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
 }
 // dma: 0 = every tile by the register-staged kernel; 1 / 2 = LDS-DMA tiles, the full 128-column blocks 128 wide / 256 wide (fp32
 //      only; an odd 128-column block and fp64 stay 128 wide), the ragged 64-column remainder 64 wide
@@ -754,13 +763,26 @@ static int apply_launch(const Geom& g, const T* Phi, const T* Bm, T* V, double* 
     if constexpr (EPI != 2) {
         if (dma && pl.count[0] > 0) {
             int n256 = 0;
+            const int64_t nrb = g.Np / 256;
+            int64_t tail_rb = 0;
             if constexpr (sizeof(T) == 4) {
                 n256 = dma == 2 ? pl.count[0] / 2 : 0;
-                nb += apply_dma_launch<T, EPI, 256>(g, n256, 0, 0, nb, Phi, BmT, V, vpart, p, q, y, alpha, ut, bpart, mu, st);
+                // The 256-wide tiles run one per CU, so a launch is whole rounds of num_cus tiles plus a last, partly filled one that
+                // costs a full tile time.  When that last round would be less than 0.45 full, its row blocks go to 128-wide tiles
+                // instead (at most one 8-wave workgroup per CU: ~0.55 of the tile time): H, 3907 row blocks x 8 = 122.09 rounds.
+                if (n256 > 0 && EPI != 3 && EPI != 4) {
+                    const int64_t ncu = apply_num_cus(), tiles = nrb * n256, rem = tiles % ncu;
+                    if (tiles > ncu && rem > 0 && 20 * rem <= 9 * ncu) tail_rb = (rem + n256 - 1) / n256;
+                }
+                nb += apply_dma_launch<T, EPI, 256>(g, n256, 0, 0, nb, Phi, BmT, V, vpart, p, q, y, alpha, ut, bpart, mu, st, 0, nrb - tail_rb);
             }
-            nb += apply_dma_launch<T, EPI, 128>(g, pl.count[0] - 2 * n256, 256 * n256, 2 * n256, nb, Phi, BmT, V, vpart, p, q, y, alpha, ut, bpart, mu, st);
+            nb += apply_dma_launch<T, EPI, 128>(g, pl.count[0] - 2 * n256, 256 * n256, 2 * n256, nb, Phi, BmT, V, vpart, p, q, y, alpha, ut, bpart, mu, st, 0, nrb - tail_rb);
             // the ragged 64-column remainder: the same kernel with 256 x 64 tiles (4 / 8 waves, two workgroups per CU)
-            nb += apply_dma_launch<T, EPI, 64>(g, pl.count[1], pl.col0[1], pl.jt0[1], nb, Phi, BmT, V, vpart, p, q, y, alpha, ut, bpart, mu, st);
+            nb += apply_dma_launch<T, EPI, 64>(g, pl.count[1], pl.col0[1], pl.jt0[1], nb, Phi, BmT, V, vpart, p, q, y, alpha, ut, bpart, mu, st, 0, nrb - tail_rb);
+            if (tail_rb > 0) {
+                nb += apply_dma_launch<T, EPI, 128>(g, pl.count[0], 0, 0, nb, Phi, BmT, V, vpart, p, q, y, alpha, ut, bpart, mu, st, nrb - tail_rb, tail_rb);
+                nb += apply_dma_launch<T, EPI, 64>(g, pl.count[1], pl.col0[1], pl.jt0[1], nb, Phi, BmT, V, vpart, p, q, y, alpha, ut, bpart, mu, st, nrb - tail_rb, tail_rb);
+            }
             return nb;
         }
     }
