@@ -68,6 +68,8 @@ def parse_args(argv=None):
     ap.add_argument('--backend', default='nccl', help="'gloo' rehearses the multi-rank flow on one GPU")
     ap.add_argument('--native-rccl', action='store_true',
                     help='the three sums by the library itself (scfgp_comm_init: ncclAllReduce on its own stream) instead of torch.distributed')
+    ap.add_argument('--opt', action='append', default=[], metavar='NAME=VALUE',
+                    help='scfgp_set_option on the benchmarked engine (tuning runs only; the bench line records it)')
     a = ap.parse_args(argv)
     N, D, S, M, dt, label = CONFIGS[a.config]
     a.custom = any(v is not None for v in (a.rows, a.D, a.S, a.M))
@@ -332,6 +334,8 @@ def main(a):
     # of host work, so the chip's clock and thermal state have settled again when the warm-up starts
     box = box_probe(local) if rank == 0 else None
     eng = HipEngine(D, S, M, dtype=a.dtype, device=local, stream=torch.cuda.current_stream().cuda_stream)
+    for kv in a.opt:
+        eng.set_option(kv.split('=')[0], int(kv.split('=')[1]))
     X, y, params = build_problem(eng, N, D, S, M, lo, hi, allreduce)
     eng.set_params(params)
     eng.set_data(X, y, n_global=N)
@@ -404,13 +408,14 @@ def main(a):
                                    % (a.config, a.label, N, D, S, M, K),
                        "rows_per_gpu": hi - lo, "parallelism": "row-sharded dp%d, 3 all-reduces/eval%s" % (
                            world, " (ncclAllReduce issued by the library, scfgp_comm_init)" if native else " (torch.distributed)"),
-                       "F_alg_per_eval": falg, "F_alg_TFLOPs": falg / (dt / a.steps) / 1e12},
+                       "F_alg_per_eval": falg, "F_alg_TFLOPs": falg / (dt / a.steps) / 1e12, "options": a.opt},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "apply product (Phi.B / Phi.Abar): one N x K x K product = 2*N*K^2 flops, issued as one launch for the "
                                    "full column tiles (at this size: apply_dma_kernel, fp32 256x256 tiles / fp64 256x128 tiles, for both products; "
-                                   "otherwise apply_kernel, 256x128 tiles) plus a 256x64-tile apply_kernel launch for the ragged remainder; "
-                                   "avg_launch_ms is the median hipEvent time of that pair (rocprof: sum of the two kernels)",
+                                   "otherwise apply_kernel, 256x128 tiles) plus a 256x64-tile launch of the same kernel for the ragged remainder "
+                                   "(and, fp32, 128-wide tiles for the row blocks of a thin last round); "
+                                   "avg_launch_ms is the median hipEvent time of that group (rocprof: sum of its kernels)",
                          "avg_launch_ms": ap_ms},
             "stages_ms": {k: float(np.median(v)) for k, v in per_kernel.items()},
             "stages_statistic": "median over the timed steps",

@@ -729,14 +729,16 @@ static int num_cus() {
 template <typename T>
 int GramKernels<T>::gram_jobs(const Geom& g) { return gram_jobs_per_split<sizeof(T) == 4>(g.gfull, g.gstrip); }
 
-// Row splits: enough workgroups (>> 512 resident) that faster CUs can take more of them, but long jobs -- at least 5120
+// Row splits: enough workgroups (>> 512 resident) that faster CUs can take more of them, but long jobs -- at least 3072
 // rows per unit (fp32) -- so that the slab traffic (nsplit x K^2/2 x 8 B written and re-read by the reduction) and the
-// per-job prologue stay small.  Measured (profiles/r01_tuning.md): the fp32 job list (tall tiles, 89 jobs per split at
-// K = 2112) is fastest at 48 units for N = 2.5e5..1e6 and at Np/5120 below that.  From 16 units on they are dealt to the
-// 8 XCD groups and the last unit of each group is tapered (kernels.h: RowSplits).
+// per-job prologue stay small.  Measured: the fp32 job list (77 jobs per split at K = 2112) is fastest at ~55 units for
+// N = 2.5e5..1e6 (profiles/r01_tuning.md); a 125 000-row shard at 40 units (28.3 ms per evaluation against 29.1 at the 24 the
+// former 5120-row floor gave it: the jobs fill 3.6 rounds of the resident workgroups there, and the last round's tail is a whole
+// tall job; profiles/r04_tuning.md).  From 16 units on they are dealt to the 8 XCD groups and the last unit of each group is
+// tapered (kernels.h: RowSplits).
 RowSplits gram_row_splits(int jobs, int64_t Np, bool f32, int nsplit_override, int taper) {
     int64_t s = ((f32 ? 4224 : 6144) + jobs - 1) / jobs;
-    const int64_t smax = std::max<int64_t>(Np / (f32 ? 5120 : 2048), 1);
+    const int64_t smax = std::max<int64_t>(Np / (f32 ? 3072 : 2048), 1);
     if (s > smax) s = smax;
     // small problems (the job list would leave most of the 512 workgroup slots empty): 64-row granules, as many
     // splits as fill the slots -- each workgroup's k-loop is a chain of dependent fetches, so fewer rows per job
