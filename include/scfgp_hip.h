@@ -226,8 +226,8 @@ int64_t scfgp_debug_read(scfgp_ctx* ctx, const char* name, void* host, int64_t m
  *   "gram_chunk"   fp32 mode: rows between two flushes of the fp32 accumulators into the fp64 slabs (default 4096)
  *   "xtz_nsplit"   row splits of X~^T Zbar (0 = default)
  *   "use_graph"    0: scfgp_train launches every iteration eagerly instead of replaying a captured hipGraph
- *   "apply_dma"    the full 128-column tiles of the apply products staged by LDS-DMA (global_load_lds) instead of through
- *                  registers: -1 automatic (K >= 1024 and >= 65536 rows: fp32 256-wide tiles, fp64 128-wide), 0 off,
+ *   "apply_dma"    the tiles of the apply products staged by LDS-DMA (global_load_lds) instead of through registers:
+ *                  -1 automatic (K > 256 and >= 16384 rows: 128-wide tiles; fp32 from K >= 1024 and 65536 rows: 256-wide), 0 off,
  *                  1 = 128-wide tiles, 2 = 256-wide tiles (fp32; fp64 stays 128 wide)
  *   "gram64"       precision level policy of fp32 mode (scfgp_get_condition): 0 never, 1 always level 1, 2 auto, 3 always level 2
  *   "cond_threshold" / "cond_threshold_w"   the two thresholds of the auto policy

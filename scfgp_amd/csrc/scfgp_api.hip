@@ -170,11 +170,13 @@ struct scfgp_ctx {
 
     double* beta() { return d_vecs; }
     double* alpha() { return d_vecs + g.Kp; }
-    // the apply products by LDS-DMA (apply.hip: apply_dma_kernel).  Auto: large problems only (fp32: 256-wide tiles for both
-    // products, profiles/r03_tuning.md; fp64: 128-wide); the small ones keep the loader-staged tiles, whose single 64-wide
-    // launch per product matters more there
+    // the apply products by LDS-DMA (apply.hip: apply_dma_kernel).  Auto: whenever the column plan has 128-wide tiles (K > 256)
+    // and there are >= 16384 rows -- measured at K = 544 and 992, 16384 .. 100000 rows, both dtypes: 128-wide LDS-DMA tiles are
+    // 4-13 % ahead of the loader-staged ones per product, 256-wide ones behind at these sizes (profiles/r04_tuning.md); fp32
+    // 256-wide tiles from K >= 1024 and 65536 rows (equal to 128-wide at H since both are pipelined, 2/3 of the fabric traffic).
+    // Below that the loader-staged tiles, whose single 64-wide launch per product matters more there
     int dma() const {
-        const int auto_dma = g.K >= 1024 && g.Np >= 65536 ? (dtype == SCFGP_F32 ? 2 : 1) : 0;
+        const int auto_dma = g.K > 256 && g.Np >= 16384 ? (dtype == SCFGP_F32 && g.K >= 1024 && g.Np >= 65536 ? 2 : 1) : 0;
         return apply_dma < 0 ? auto_dma : apply_dma;
     }
     double* u() { return d_vecs + 2 * g.Kp; }
