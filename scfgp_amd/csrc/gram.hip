@@ -261,12 +261,24 @@ __device__ __forceinline__ void gram_tall_dma_diag(
 // the MFMAs of the first and the second half of stage s, the fetch of stage s+3 and the reads of the next first half ride between
 // the second half's MFMAs, the reads of the next second half between the first half's.  LDS reads are inline assembly with
 // hand-counted waits that name the registers they release (tools/isa_inflight.py checks the compiled stream).
-template <bool WEIGHT, bool DIAG>
-__device__ __forceinline__ void gram_tall_dma(                 // DIAG == false (gram_tall_dma_diag serves the diagonal jobs)
+// Two tile shapes share the loop (8 waves of 64 x 64 each, off-diagonal jobs only: the diagonal ones keep the plain loops):
+//   GramDma      256 x 128 (wave grid 4 x 2), ring of three 24 KiB stages
+//   GramDmaWide   64 x 512 (wave grid 1 x 8: four strip tiles side by side), ring of TWO 36 KiB stages (two workgroups per CU
+//                 share the LDS): the fetch of stage s+2 goes into the slot the barrier of stage s+1 frees and has one stage
+//                 to land.  Its 36 operand instructions per stage do not divide by 8 waves: waves 0-3 issue five, 4-7 four
+//                 (every vmcnt wait of the two-slot ring is vmcnt(0), so nothing counts them).
+struct GramDmaWide {
+    static constexpr int BM = 64, BN = 512, A_BYTES = 16 * BM * 4, B_BYTES = 16 * BN * 4, W_OFF = A_BYTES + B_BYTES, S_OFF = W_OFF + 128,
+                         STAGE = W_OFF + 256, STAGES = 2, LDS_BYTES = STAGES * STAGE, NINSTR = (A_BYTES + B_BYTES) / 1024, DMA_PER_WAVE = 5;
+    static_assert(NINSTR == 36 && 2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+};
+template <class D, bool WEIGHT, bool DIAG>
+__device__ __forceinline__ void gram_pipe_dma(                 // DIAG == false (gram_tall_dma_diag / gram_body serve the diagonal jobs)
     const float* __restrict__ Phi, int64_t ld, const double* __restrict__ w, const double* __restrict__ side,
     int64_t r0, int64_t r1, int64_t chunk, int acol, int bcol, double* __restrict__ sideout,
     double* __restrict__ slab, double* __restrict__ slab_hi, char* smem) {
-    typedef GramDma D;
+    constexpr bool WIDE = D::BM == 64;
+    constexpr int RING = D::STAGES;
     typedef std::integral_constant<int, 0> H0;
     typedef std::integral_constant<int, 1> H1;
     constexpr bool WS = WEIGHT || DIAG;
@@ -276,16 +288,21 @@ __device__ __forceinline__ void gram_tall_dma(                 // DIAG == false 
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), i = lane & 15, q = lane >> 4;
-    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
-    // DMA instruction t = 3 wave + u of a stage: t < 16: row t of the A panel; else rows 2 (t - 16), 2 (t - 16) + 1 of the B panel
+    const int wm0 = WIDE ? 0 : (wave >> 1) * 64, wn0 = WIDE ? wave * 64 : (wave & 1) * 64;
+    // DMA instruction t of a stage (1 KiB of the stacked A | B image each)
+    //   tall: t = 3 wave + u; t < 16: row t of the A panel; else rows 2 (t - 16), 2 (t - 16) + 1 of the B panel
+    //   wide: t = wave + 8 u (< 36); t < 4: rows 4t .. 4t+3 of the A panel (256 bytes each); else half (t - 4) & 1 of row (t - 4) / 2 of the B panel
     const char* src[DPW]; int dst[DPW];
 #pragma unroll
     for (int u = 0; u < DPW; ++u) {
-        const int t = DPW * wave + u;
-        const float* g = t < 16 ? Phi + (r0 + t) * ld + acol + 4 * lane : Phi + (r0 + 2 * (t - 16) + (lane >> 5)) * ld + bcol + 4 * (lane & 31);
+        const int t = WIDE ? wave + 8 * u : DPW * wave + u;
+        const float* g;
+        if constexpr (WIDE) g = t < 4 ? Phi + (r0 + 4 * t + (lane >> 4)) * ld + acol + 4 * (lane & 15) : Phi + (r0 + ((t - 4) >> 1)) * ld + bcol + 256 * ((t - 4) & 1) + 4 * lane;
+        else g = t < 16 ? Phi + (r0 + t) * ld + acol + 4 * lane : Phi + (r0 + 2 * (t - 16) + (lane >> 5)) * ld + bcol + 4 * (lane & 31);
         src[u] = reinterpret_cast<const char*>(g);
         dst[u] = t * 1024;
     }
+    const bool last_u = !WIDE || wave < 4;                      // wide: instruction u = 4 exists on waves 0-3 only
     const int64_t step = 16 * ld * (int64_t)sizeof(float);
     // lanes 0..31: the 16 weights (as 32 dwords), lanes 32..63: the 16 side multipliers; an absent one is replaced by the other
     const double* ws_lo = WEIGHT ? w : side; const double* ws_hi = DIAG ? side : w;
@@ -295,8 +312,10 @@ __device__ __forceinline__ void gram_tall_dma(                 // DIAG == false 
         constexpr int u = decltype(uc)::value;
         char* base = smem + slot * D::STAGE;
         if constexpr (u < DPW) {
-            __builtin_amdgcn_global_load_lds((gbl_void*)src[u], lds_ptr(base + dst[u]), 16, 0, 0);
-            src[u] += step;
+            if (u < DPW - 1 || last_u) {
+                __builtin_amdgcn_global_load_lds((gbl_void*)src[u], lds_ptr(base + dst[u]), 16, 0, 0);
+                src[u] += step;
+            }
         } else if (ws_wave) {
             __builtin_amdgcn_global_load_lds((gbl_void*)wsrc, lds_ptr(base + D::W_OFF), 4, 0, 0);
             wsrc += 128;
@@ -354,8 +373,10 @@ __device__ __forceinline__ void gram_tall_dma(                 // DIAG == false 
             if constexpr (decltype(ic)::value < NRD) { read_one(H1(), ic, next); __builtin_amdgcn_sched_barrier(0); }
         });
     };
-    // accumulator (tm, tn, r) of lane (i, q) is output row wm0 + 16 q + 4 r + tm, column wn0 + 4 i + tn
-    double* sl = wm0 >= 128 ? slab_hi + (int64_t)(wm0 - 128) * D::BN : slab + (int64_t)wm0 * D::BN;
+    // accumulator (tm, tn, r) of lane (i, q) is output row wm0 + 16 q + 4 r + tm, column wn0 + 4 i + tn; slabs are 128 x 128:
+    // tall: rows >= 128 in slab_hi; wide: four consecutive slabs, one per 128 columns, rows 0 .. 63 of each
+    double* sl = WIDE ? slab + (int64_t)(wn0 >> 7) * (128 * 128) + (wn0 & 127)
+                      : (wm0 >= 128 ? slab_hi + (int64_t)(wm0 - 128) * 128 : slab + (int64_t)wm0 * 128) + wn0;
     bool first = true;
     const auto flush = [&]() {
         int lf = lane;                                         // (opaque: the 16 slab addresses are formed here, not kept across the k loop)
@@ -365,7 +386,7 @@ __device__ __forceinline__ void gram_tall_dma(                 // DIAG == false 
         for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                v4d* d = reinterpret_cast<v4d*>(sl + (16 * q + 4 * r + tm) * D::BN + wn0 + 4 * i);
+                v4d* d = reinterpret_cast<v4d*>(sl + (16 * q + 4 * r + tm) * 128 + 4 * i);
                 const v4d v = v4d{(double)acc[tm][0][r], (double)acc[tm][1][r], (double)acc[tm][2][r], (double)acc[tm][3][r]};
                 *d = first ? v : *d + v;
             }
@@ -388,49 +409,57 @@ __device__ __forceinline__ void gram_tall_dma(                 // DIAG == false 
     for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = v4f{0.f, 0.f, 0.f, 0.f};
+    const auto strip_rest = [&]() {                             // wide: rows 64 .. 127 of the four slabs, which the strip does not have
+        if constexpr (WIDE)
+            for (int e = tid; e < 4 * 64 * 128; e += 512) slab[(e / (64 * 128)) * (128 * 128) + 64 * 128 + e % (64 * 128)] = 0.0;
+    };
     const int nst = (int)((r1 - r0) / 16), per_chunk = (int)(chunk / 16);
-    if (nst == 0) { flush(); return; }                          // an empty split still owns its slab
+    if (nst == 0) { flush(); strip_rest(); return; }            // an empty split still owns its slab
+    // the fetch of stage s + RING - 1 is issued behind the barrier that opens stage s; before the loop: stages 0 .. RING - 2
     static_for<DPW + 1>([&](auto uc) { fetch_one(uc, 0); });
-    if (nst > 1) static_for<DPW + 1>([&](auto uc) { fetch_one(uc, 1); });
+    if (RING == 3 && nst > 1) static_for<DPW + 1>([&](auto uc) { fetch_one(uc, 1); });
+    const auto wait_landed = [&](bool more) {                   // this wave's share of a stage; `more`: a later stage's fetch may stay outstanding
+        if (RING == 3 && more) { if (ws_wave) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    const auto next_slot = [&](int sl_) { return sl_ == RING - 1 ? 0 : sl_ + 1; };
     int slot = 0, s = 0;                                        // slot of stage s
     // A chunk starts with an empty pipeline and drains it before its flush: no fragment is live (or in flight) across the flush,
     // whose register appetite would otherwise have the allocator spill fragment registers whose data has not arrived yet.
     while (s < nst) {
         const int cend = s + per_chunk < nst ? s + per_chunk : nst;
         // prime: stage s has landed when only the fetches of stage s+1 are outstanding
-        if (s + 1 < nst) { if (ws_wave) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wait_landed(s + 1 < nst);
         __builtin_amdgcn_s_barrier();                          // everybody's has; nobody reads the slot of stage s-1 any more
         asm volatile("" ::: "memory");
-        if (s + 2 < nst) { const int fslot = slot == 0 ? 2 : slot - 1; static_for<DPW + 1>([&](auto uc) { fetch_one(uc, fslot); }); }
+        if (s + RING - 1 < nst) { const int fslot = slot == 0 ? RING - 1 : slot - 1; static_for<DPW + 1>([&](auto uc) { fetch_one(uc, fslot); }); }
         static_for<NRD>([&](auto rc) { read_one(H0(), rc, slot * D::STAGE); });
         static_for<NRD>([&](auto rc) { read_one(H1(), rc, slot * D::STAGE); });
         SCFGP_WAIT_FRAGS("lgkmcnt(0)", 0);
         static_for<NM>([&](auto ic) { mfma_one(H0(), ic); });
-        for (; s + 1 < cend && s + 3 < nst; ++s) {             // steady state: the first half of stage s is multiplied
+        for (; s + 1 < cend && s + RING < nst; ++s) {          // steady state: the first half of stage s is multiplied
             // this wave's share of stage s+1 has landed when only the fetches of stage s+2 are outstanding; its reads of stage s are done
             // (the two counts apart from the statement that releases the fragments: one such statement per point of the loop, or
             // the allocator joins the branches with copies of registers still in flight)
-            if (ws_wave) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            wait_landed(true);
             SCFGP_WAIT_FRAGS("lgkmcnt(0)", 1);
             second_half_pre();
             __builtin_amdgcn_s_barrier();                      // everybody's has; nobody reads the slot of stage s any more
             asm volatile("" ::: "memory");
             const int fslot = slot;
-            slot = slot == 2 ? 0 : slot + 1;
+            slot = next_slot(slot);
             __builtin_amdgcn_sched_barrier(0);
             second_half(std::true_type(), std::true_type(), fslot, slot * D::STAGE);
             SCFGP_WAIT_FRAGS("lgkmcnt(0)", 0);
             first_half(slot * D::STAGE);
         }
         for (; s + 1 < cend; ++s) {                            // the last stages of the row range: nothing left to fetch
-            if (s + 2 < nst) { if (ws_wave) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wait_landed(s + 2 < nst);
             SCFGP_WAIT_FRAGS("lgkmcnt(0)", 1);
             second_half_pre();
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            slot = slot == 2 ? 0 : slot + 1;
+            slot = next_slot(slot);
             __builtin_amdgcn_sched_barrier(0);
             second_half(std::false_type(), std::true_type(), 0, slot * D::STAGE);
             SCFGP_WAIT_FRAGS("lgkmcnt(0)", 0);
@@ -440,8 +469,9 @@ __device__ __forceinline__ void gram_tall_dma(                 // DIAG == false 
         static_for<NM>([&](auto ic) { mfma_one(H1(), ic); });
         flush();
         ++s;
-        slot = slot == 2 ? 0 : slot + 1;
+        slot = next_slot(slot);
     }
+    strip_rest();
 #undef SCFGP_WAIT_FRAGS
 }
 
@@ -620,10 +650,14 @@ __device__ __forceinline__ void gram_job(
     if constexpr (BIG) {
         if (kind == 2) {
             if (diag) gram_tall_dma_diag<WEIGHT, true>(Phi, ld, w, side, r0, r1, chunk, acol, bcol, sideout, slab, slab2, smem_raw);
-            else gram_tall_dma<WEIGHT, false>(Phi, ld, w, side, r0, r1, chunk, acol, bcol, sideout, slab, slab2, smem_raw);
+            else gram_pipe_dma<GramDma, WEIGHT, false>(Phi, ld, w, side, r0, r1, chunk, acol, bcol, sideout, slab, slab2, smem_raw);
             TRACE_END(kind); return;
         }
-        if (kind == 3) { gram_body<WCfg, WEIGHT, true>(Phi, ld, w, side, r0, r1, chunk, acol, bcol, diag, sideout, slab, nullptr, smem_raw); TRACE_END(kind); return; }
+        if (kind == 3) {
+            if (diag) gram_body<WCfg, WEIGHT, true>(Phi, ld, w, side, r0, r1, chunk, acol, bcol, diag, sideout, slab, nullptr, smem_raw);
+            else gram_pipe_dma<GramDmaWide, WEIGHT, false>(Phi, ld, w, side, r0, r1, chunk, acol, bcol, sideout, slab, nullptr, smem_raw);
+            TRACE_END(kind); return;
+        }
     }
     if constexpr (!BIG && sizeof(typename Cfg::T) == 8) {      // fp64 square tiles by LDS-DMA
         if (diag) gram_sq_dma64<WEIGHT, true>(Phi, ld, w, side, r0, r1, acol, bcol, sideout, slab, smem_raw);
@@ -770,7 +804,8 @@ void GramKernels<T>::gram(const Geom& g, const T* Phi, const double* w, const do
     chunk = round_up(chunk, 256);                              // splits start and end on 64- or 256-row granules
     constexpr int L0 = Cfg::LDS_BYTES > SCfg::LDS_BYTES ? Cfg::LDS_BYTES : SCfg::LDS_BYTES;
     constexpr int L1 = !BIG && GramDma64::LDS_BYTES > L0 ? GramDma64::LDS_BYTES : L0;
-    constexpr int L2 = BIG && GramDma::LDS_BYTES > L1 ? GramDma::LDS_BYTES : L1;
+    constexpr int L2a = BIG && GramDma::LDS_BYTES > L1 ? GramDma::LDS_BYTES : L1;
+    constexpr int L2 = BIG && GramDmaWide::LDS_BYTES > L2a ? GramDmaWide::LDS_BYTES : L2a;
     constexpr int LDS = BIG && WCfg::LDS_BYTES > L2 ? WCfg::LDS_BYTES : L2;
     static_assert(2 * LDS <= 160 * 1024, "two workgroups per CU");
     // Persistent launch with per-XCD queues from 6 rounds of jobs up; below that one job per workgroup.  Measured on one box
