@@ -45,11 +45,6 @@ template <typename T> struct GramStripCfg {
 template <typename T> struct GramBigCfg {
     typedef TileCfg<T, 256, 128, SCFGP_BK, Tune<T>::GRAM_WGM, Tune<T>::GRAM_WGN, Tune<T>::MS> type;
 };
-// fp32 only: four strip tiles side by side as one 64 x 512 tile (eight 64 x 64 wave tiles: the MFMA-per-barrier ratio of
-// the tall tile; the 64 x 128 strip tiles ran at half its rate and were 6 % of the launch)
-template <typename T> struct GramWideCfg {
-    typedef TileCfg<T, 64, 512, SCFGP_BK, 1, 8, Tune<T>::MS> type;
-};
 template <typename T> struct XtzCfg { typedef TileCfg<T, 128, 128, 16, 4, 2, Tune<T>::MS> type; };
 // row tiles of X~^T Zbar that hold at most 96 / 64 live rows of X~^T (D + 1 = 65 at the headline shape): same 128-wide
 // slabs, fewer MFMA rows
@@ -135,7 +130,7 @@ __device__ __forceinline__ void gram_body(
 
 // fp32 tall tile (256 x 128, 8 waves of 64 x 64) with LDS-DMA staging: both operand panels go global -> LDS by
 // global_load_lds_dwordx4 into a ring of three stages of 16 rows, counted vmcnt, one raw barrier per stage -- no staging registers,
-// no ds_write, the fetch of stage s+2 in flight while stage s is multiplied (the structure of apply.hip's apply_dma_kernel).
+// no ds_write, the fetches of the next stages in flight while stage s is multiplied (the structure of apply.hip's apply_dma_kernel).
 //   LDS image of a stage: the 16 rows of the A panel (256 floats = 1 KiB each: ONE DMA instruction per row), then the 16 rows of
 //   the B panel (128 floats: one instruction per two rows), k-major and unpadded: a lane of MFMA tile column i reads the FOUR
 //   adjacent floats 4 i .. 4 i + 3 of its k row with one ds_read_b128 -- MFMA tile tm, tile row rho IS output row 4 rho + tm of
@@ -143,8 +138,9 @@ __device__ __forceinline__ void gram_body(
 //   row, and the four lane groups a ds_read_b128 is served in ({0-3,12-15 | 20-27}, ...: two k rows each) touch disjoint slots
 //   because every row starts on a bank-row boundary.  A lane ends up with a 4 x 4 block of the output: 32-byte slab updates.
 //   Row weights (WEIGHT: q_n) and the side vector's multipliers (DIAG: y_n or p_n) of the stage's 16 rows ride in the ring as
-//   one more 256-byte DMA (wave 0); the weight multiplies the A fragment after the LDS read, and the side sums
-//   sum_k s_k Phi[k][acol + m] are formed in fp64 from the same (unweighted) fragments.
+//   one more DMA instruction (wave 0) from an array of (weight, multiplier) float pairs packed before the launch
+//   (gram_pack_ws); the weight multiplies the A fragment after the LDS read, and the side sums sum_k s_k Phi[k][acol + m] are
+//   formed from the same (unweighted) fragments, fp32 over a chunk of rows and fp64 across chunks.
 struct GramDma {
     static constexpr int BM = 256, BN = 128, A_BYTES = 16 * BM * 4, B_BYTES = 16 * BN * 4, W_OFF = A_BYTES + B_BYTES, S_OFF = W_OFF + 128,
                          STAGE = W_OFF + 256, STAGES = 3, LDS_BYTES = STAGES * STAGE, DMA_PER_WAVE = (A_BYTES + B_BYTES) / 1024 / 8;
@@ -155,113 +151,12 @@ typedef const __attribute__((address_space(1))) void gbl_void;
 // generic address of an LDS byte -> LDS pointer: the low 32 bits are the LDS offset (the address-space cast proper carries a null
 // check that this compiler mis-selects in one of the kernels below: "V_CMP_NE_U32 0, $src_shared_base")
 __device__ __forceinline__ lds_void* lds_ptr(const char* p) { return (lds_void*)(uintptr_t)((unsigned)(uintptr_t)p); }
-// The diagonal jobs (DIAG: side sums; a dozen more live registers) keep the plain loop: fetch and reads behind the barrier, the
-// compiler counts the waits.
-template <bool WEIGHT, bool DIAG>
-__device__ __forceinline__ void gram_tall_dma_diag(
-    const float* __restrict__ Phi, int64_t ld, const double* __restrict__ w, const double* __restrict__ side,
-    int64_t r0, int64_t r1, int64_t chunk, int acol, int bcol, double* __restrict__ sideout,
-    double* __restrict__ slab, double* __restrict__ slab_hi, char* smem) {
-    typedef GramDma D;
-    constexpr bool WS = WEIGHT || DIAG;
-    // the thread id behind an opaque move (see gram_body_impl)
-    int tid = threadIdx.x;
-    asm volatile("" : "+v"(tid));
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), i = lane & 15, q = lane >> 4;
-    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
-    // DMA instruction t = 3 wave + u of a stage: t < 16: row t of the A panel; else rows 2 (t - 16), 2 (t - 16) + 1 of the B panel
-    const char* src[D::DMA_PER_WAVE]; int dst[D::DMA_PER_WAVE];
-#pragma unroll
-    for (int u = 0; u < D::DMA_PER_WAVE; ++u) {
-        const int t = D::DMA_PER_WAVE * wave + u;
-        const float* g = t < 16 ? Phi + (r0 + t) * ld + acol + 4 * lane : Phi + (r0 + 2 * (t - 16) + (lane >> 5)) * ld + bcol + 4 * (lane & 31);
-        src[u] = reinterpret_cast<const char*>(g);
-        dst[u] = t * 1024;
-    }
-    const int64_t step = 16 * ld * (int64_t)sizeof(float);
-    // lanes 0..31: the 16 weights (as 32 dwords), lanes 32..63: the 16 side multipliers; an absent one is replaced by the other
-    const double* ws_lo = WEIGHT ? w : side; const double* ws_hi = DIAG ? side : w;
-    const char* wsrc = WS ? reinterpret_cast<const char*>((lane < 32 ? ws_lo : ws_hi) + r0) + 4 * (lane & 31) : nullptr;
-    const bool ws_wave = WS && wave == 0;
-    const auto issue = [&](int slot) {
-        char* base = smem + slot * D::STAGE;
-#pragma unroll
-        for (int u = 0; u < D::DMA_PER_WAVE; ++u) {
-            __builtin_amdgcn_global_load_lds((gbl_void*)src[u], lds_ptr(base + dst[u]), 16, 0, 0);
-            src[u] += step;
-        }
-        if (ws_wave) {
-            __builtin_amdgcn_global_load_lds((gbl_void*)wsrc, lds_ptr(base + D::W_OFF), 4, 0, 0);
-            wsrc += 128;
-        }
-    };
-    const int aoff = q * (D::BM * 4) + (wm0 + 4 * i) * 4, boff = D::A_BYTES + q * (D::BN * 4) + (wn0 + 4 * i) * 4;
-    v4f acc[4][4];
-    const int nst = (int)((r1 - r0) / 16);
-    issue(0);
-    if (nst > 1) issue(1);
-    int s = 0, slot = 0, fill = 2;
-    bool first = true;
-    for (int64_t c0 = r0; c0 < r1 || first; c0 += chunk) {
-        const int64_t c1 = c0 + chunk < r1 ? c0 + chunk : r1;
-        const int ns = c0 < r1 ? (int)((c1 - c0) / 16) : 0;
-#pragma unroll
-        for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = v4f{0.f, 0.f, 0.f, 0.f};
-        v4f sacc = v4f{0.f, 0.f, 0.f, 0.f};                     // side sums of this chunk: fp32 chains a quarter as long as the MFMAs'
-        for (int t = 0; t < ns; ++t, ++s) {
-            // this wave's share of stage s has landed when only the DMAs of stage s+1 are outstanding
-            if (s + 1 < nst) {
-                if (ws_wave) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                      // everybody's has; nobody reads the slot of stage s-1 any more
-            asm volatile("" ::: "memory");
-            if (s + 2 < nst) issue(fill);
-            const char* base = smem + slot * D::STAGE;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                v4f a = *reinterpret_cast<const v4f*>(base + aoff + kk * (4 * D::BM * 4));
-                const v4f b = *reinterpret_cast<const v4f*>(base + boff + kk * (4 * D::BN * 4));
-                if (DIAG) sacc += (float)*reinterpret_cast<const double*>(base + D::S_OFF + (4 * kk + q) * 8) * a;
-                if (WEIGHT) a *= (float)*reinterpret_cast<const double*>(base + D::W_OFF + (4 * kk + q) * 8);
-#pragma unroll
-                for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-                    for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
-            }
-            slot = slot == 2 ? 0 : slot + 1;
-            fill = fill == 2 ? 0 : fill + 1;
-        }
-        // accumulator (tm, tn, r) of lane (i, q) is output row wm0 + 16 q + 4 r + tm, column wn0 + 4 i + tn
-        double* sl = wm0 >= 128 ? slab_hi + (int64_t)(wm0 - 128) * D::BN : slab + (int64_t)wm0 * D::BN;
-#pragma unroll
-        for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                v4d* d = reinterpret_cast<v4d*>(sl + (16 * q + 4 * r + tm) * D::BN + wn0 + 4 * i);
-                const v4d v = v4d{(double)acc[tm][0][r], (double)acc[tm][1][r], (double)acc[tm][2][r], (double)acc[tm][3][r]};
-                *d = first ? v : *d + v;
-            }
-        if constexpr (DIAG) {                                  // the 4 k rows of a k-step live in the 4 lane groups: sum over q, fp64 across chunks
-#pragma unroll
-            for (int tm = 0; tm < 4; ++tm) {
-                double x = (double)sacc[tm];
-                x += __shfl_xor(x, 16); x += __shfl_xor(x, 32);
-                if (q == 0 && wn0 == 0) { double* d = sideout + wm0 + 4 * i + tm; *d = first ? x : *d + x; }
-            }
-        }
-        first = false;
-    }
-}
-
 // The k loop is software-pipelined across the stage barrier like apply.hip's apply_dma_kernel (see there): a stage's four
 // k-steps are two HALVES (k-steps 0,1 and 2,3) with their own fragment registers; the barrier that opens stage s+1 stands between
 // the MFMAs of the first and the second half of stage s, the fetch of stage s+3 and the reads of the next first half ride between
 // the second half's MFMAs, the reads of the next second half between the first half's.  LDS reads are inline assembly with
 // hand-counted waits that name the registers they release (tools/isa_inflight.py checks the compiled stream).
-// Two tile shapes share the loop (8 waves of 64 x 64 each, off-diagonal jobs only: the diagonal ones keep the plain loops):
+// Two tile shapes share the loop (8 waves of 64 x 64 each; diagonal jobs add the side sums, DIAG):
 //   GramDma      256 x 128 (wave grid 4 x 2), ring of three 24 KiB stages
 //   GramDmaWide   64 x 512 (wave grid 1 x 8: four strip tiles side by side), ring of TWO 36 KiB stages (two workgroups per CU
 //                 share the LDS): the fetch of stage s+2 goes into the slot the barrier of stage s+1 frees and has one stage
@@ -273,8 +168,8 @@ struct GramDmaWide {
     static_assert(NINSTR == 36 && 2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
 };
 template <class D, bool WEIGHT, bool DIAG>
-__device__ __forceinline__ void gram_pipe_dma(                 // DIAG == false (gram_tall_dma_diag / gram_body serve the diagonal jobs)
-    const float* __restrict__ Phi, int64_t ld, const double* __restrict__ w, const double* __restrict__ side,
+__device__ __forceinline__ void gram_pipe_dma(
+    const float* __restrict__ Phi, int64_t ld, const float* __restrict__ ws2,
     int64_t r0, int64_t r1, int64_t chunk, int acol, int bcol, double* __restrict__ sideout,
     double* __restrict__ slab, double* __restrict__ slab_hi, char* smem) {
     constexpr bool WIDE = D::BM == 64;
@@ -282,7 +177,7 @@ __device__ __forceinline__ void gram_pipe_dma(                 // DIAG == false 
     typedef std::integral_constant<int, 0> H0;
     typedef std::integral_constant<int, 1> H1;
     constexpr bool WS = WEIGHT || DIAG;
-    constexpr int DPW = D::DMA_PER_WAVE, NRD = 4 + (WEIGHT ? 2 : 0) + (DIAG ? 2 : 0), NM = 32, PRE = 2;    // per half: reads, MFMAs
+    constexpr int DPW = D::DMA_PER_WAVE, NRD = 4 + (WEIGHT || DIAG ? 2 : 0), NM = 32, PRE = 2;              // per half: reads, MFMAs
     static_assert(PRE + DPW + 1 + NRD <= NM, "one fetch or read per MFMA behind the barrier");
     // the thread id behind an opaque move (see gram_body_impl)
     int tid = threadIdx.x;
@@ -304,9 +199,10 @@ __device__ __forceinline__ void gram_pipe_dma(                 // DIAG == false 
     }
     const bool last_u = !WIDE || wave < 4;                      // wide: instruction u = 4 exists on waves 0-3 only
     const int64_t step = 16 * ld * (int64_t)sizeof(float);
-    // lanes 0..31: the 16 weights (as 32 dwords), lanes 32..63: the 16 side multipliers; an absent one is replaced by the other
-    const double* ws_lo = WEIGHT ? w : side; const double* ws_hi = DIAG ? side : w;
-    const char* wsrc = WS ? reinterpret_cast<const char*>((lane < 32 ? ws_lo : ws_hi) + r0) + 4 * (lane & 31) : nullptr;
+    // ws2[n] = (weight of row n or 1, side multiplier of row n or 0) as two floats (gram_pack_ws): a stage's 16 pairs are 128
+    // bytes, fetched by lanes 0..31 of one more instruction on wave 0 (lanes 32..63 bring the next stage's pairs to the 128
+    // bytes behind them, where nobody looks; the array is padded by that much)
+    const char* wsrc = WS ? reinterpret_cast<const char*>(ws2 + 2 * r0) + 4 * lane : nullptr;
     const bool ws_wave = WS && wave == 0;
     const auto fetch_one = [&](auto uc, int slot) {            // u < DPW: operand instruction u; u == DPW: the weights / multipliers
         constexpr int u = decltype(uc)::value;
@@ -324,27 +220,28 @@ __device__ __forceinline__ void gram_pipe_dma(                 // DIAG == false 
     // LDS byte addresses (first stage) of this lane's fragment of k row q: 4 adjacent floats of the A / B panel, its weight
     const int ring = (int)(uintptr_t)smem;
     const int pa0 = ring + q * (D::BM * 4) + (wm0 + 4 * i) * 4, pb0 = ring + D::A_BYTES + q * (D::BN * 4) + (wn0 + 4 * i) * 4, pw0 = ring + D::W_OFF + q * 8;
+    typedef float v2f __attribute__((ext_vector_type(2)));
     v4f fa[2][2], fb[2][2];                                    // [half][k-step of the half]
-    double fw[2][2], fs[2][2];
+    v2f fws[2][2];                                             // (weight, side multiplier) of the lane's k row
     v4f acc[4][4];
     v4f sacc = v4f{0.f, 0.f, 0.f, 0.f};                         // side sums of a chunk: fp32 chains a quarter as long as the MFMAs'
-    // read R of half h of the stage at byte `stage` of the ring: A, A, B, B, (weight, weight), (multiplier, multiplier)
+    // read R of half h of the stage at byte `stage` of the ring: A, A, B, B, (pair, pair)
     const auto read_one = [&](auto hc, auto rc, int stage) {
         constexpr int h = decltype(hc)::value, R = decltype(rc)::value, kk = 2 * h + (R & 1);
-        (void)&fw; (void)&fs; (void)&pw0;                        // (named outside the discarded branches: the capture is decided here)
+        (void)&fws; (void)&pw0; (void)&fa; (void)&fb; (void)&pa0; (void)&pb0;      // (named outside the discarded branches: the capture is decided here)
         if constexpr (R < 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[h][R & 1]) : "v"(stage + pa0), "n"(kk * 4 * D::BM * 4));
         else if constexpr (R < 4) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[h][R & 1]) : "v"(stage + pb0), "n"(kk * 4 * D::BN * 4));
-        else if constexpr (WEIGHT && R < 6) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(fw[h][R & 1]) : "v"(stage + pw0), "n"(kk * 32));
-        else asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(fs[h][R & 1]) : "v"(stage + pw0), "n"(kk * 32 + D::S_OFF - D::W_OFF));
+        else asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(fws[h][R & 1]) : "v"(stage + pw0), "n"(kk * 32));
     };
     // "s_waitcnt <what>" that hands out the fragments of half h, then the row weights / side sums on them (VALU)
 #define SCFGP_WAIT_FRAGS(what, h)                                                                                                        \
     do {                                                                                                                                 \
-        if constexpr (WEIGHT)                                                                                                            \
-            asm volatile("s_waitcnt " what :: "v"(fa[h][0]), "v"(fa[h][1]), "v"(fb[h][0]), "v"(fb[h][1]), "v"(fw[h][0]), "v"(fw[h][1]) : "memory"); \
+        if constexpr (WS)                                                                                                                \
+            asm volatile("s_waitcnt " what :: "v"(fa[h][0]), "v"(fa[h][1]), "v"(fb[h][0]), "v"(fb[h][1]), "v"(fws[h][0]), "v"(fws[h][1]) : "memory"); \
         else asm volatile("s_waitcnt " what :: "v"(fa[h][0]), "v"(fa[h][1]), "v"(fb[h][0]), "v"(fb[h][1]) : "memory");                  \
         __builtin_amdgcn_sched_barrier(0);                                                                                               \
-        if constexpr (WEIGHT) { fa[h][0] *= (float)fw[h][0]; fa[h][1] *= (float)fw[h][1]; }                                              \
+        if constexpr (DIAG) { sacc += fws[h][0][1] * fa[h][0]; sacc += fws[h][1][1] * fa[h][1]; }       /* from the unweighted fragments */ \
+        if constexpr (WEIGHT) { fa[h][0] *= fws[h][0][0]; fa[h][1] *= fws[h][1][0]; }                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                                                               \
     } while (0)
     // MFMA I of half h: k-step 2h + I / 16 of accumulator tile (tm, tn) = (I / 4 % 4, I % 4)
@@ -587,12 +484,13 @@ template <bool BIG> __host__ __device__ inline int gram_jobs_per_split(int nfull
     return R * R + nsb / 4 + R + odd * nfull + nsb % 4;          // tall, wide (4 strip tiles each), small, single strips
 }
 // one job (row split, output tile) of the list
-template <class Cfg, class SCfg, class BCfg, class WCfg, bool WEIGHT, bool BIG>
+template <class Cfg, class SCfg, class BCfg, bool WEIGHT, bool BIG>
 __device__ __forceinline__ void gram_job(
     const int j, const typename Cfg::T* __restrict__ Phi, int64_t ld, const double* __restrict__ w, const double* __restrict__ side,
-    const RowSplits& rs, int64_t chunk, int nfull, int nstrip, double* __restrict__ sidepart, double* __restrict__ slabs, char* smem_raw) {
-    static_assert(Cfg::THREADS == SCfg::THREADS && Cfg::THREADS == BCfg::THREADS && Cfg::THREADS == WCfg::THREADS &&
-                  Cfg::BN == SCfg::BN && Cfg::BN == BCfg::BN && Cfg::BM == Cfg::BN && WCfg::BM == SCfg::BM && WCfg::BN == 4 * Cfg::BN,
+    const float* __restrict__ ws2, const RowSplits& rs, int64_t chunk, int nfull, int nstrip, double* __restrict__ sidepart,
+    double* __restrict__ slabs, char* smem_raw) {
+    static_assert(Cfg::THREADS == SCfg::THREADS && Cfg::THREADS == BCfg::THREADS && Cfg::THREADS == 512 &&
+                  Cfg::BN == SCfg::BN && Cfg::BN == BCfg::BN && Cfg::BM == Cfg::BN && GramDmaWide::BM == SCfg::BM && GramDmaWide::BN == 4 * Cfg::BN,
                   "one launch, four tile shapes");
     TRACE_BEGIN();
     constexpr int B = Cfg::BN;
@@ -649,13 +547,13 @@ __device__ __forceinline__ void gram_job(
     if (kind == 1) { gram_body<SCfg, WEIGHT, true>(Phi, ld, w, side, r0, r1, chunk, acol, bcol, diag, sideout, slab, nullptr, smem_raw); TRACE_END(kind); return; }
     if constexpr (BIG) {
         if (kind == 2) {
-            if (diag) gram_tall_dma_diag<WEIGHT, true>(Phi, ld, w, side, r0, r1, chunk, acol, bcol, sideout, slab, slab2, smem_raw);
-            else gram_pipe_dma<GramDma, WEIGHT, false>(Phi, ld, w, side, r0, r1, chunk, acol, bcol, sideout, slab, slab2, smem_raw);
+            if (diag) gram_pipe_dma<GramDma, WEIGHT, true>(Phi, ld, ws2, r0, r1, chunk, acol, bcol, sideout, slab, slab2, smem_raw);
+            else gram_pipe_dma<GramDma, WEIGHT, false>(Phi, ld, ws2, r0, r1, chunk, acol, bcol, sideout, slab, slab2, smem_raw);
             TRACE_END(kind); return;
         }
         if (kind == 3) {
-            if (diag) gram_body<WCfg, WEIGHT, true>(Phi, ld, w, side, r0, r1, chunk, acol, bcol, diag, sideout, slab, nullptr, smem_raw);
-            else gram_pipe_dma<GramDmaWide, WEIGHT, false>(Phi, ld, w, side, r0, r1, chunk, acol, bcol, sideout, slab, nullptr, smem_raw);
+            if (diag) gram_pipe_dma<GramDmaWide, WEIGHT, true>(Phi, ld, ws2, r0, r1, chunk, acol, bcol, sideout, slab, nullptr, smem_raw);
+            else gram_pipe_dma<GramDmaWide, WEIGHT, false>(Phi, ld, ws2, r0, r1, chunk, acol, bcol, sideout, slab, nullptr, smem_raw);
             TRACE_END(kind); return;
         }
     }
@@ -674,16 +572,16 @@ __device__ __forceinline__ void gram_job(
 // ran 2 % faster idled while the others finished (0.8 ms spread of the last job starts in a 37 ms launch,
 // profiles/r04_gram_trace_H.txt).  head[x] counts the jobs handed out from queue x (zeroed by the host before the launch).
 // Every workgroup leaves when all eight queues are empty: nobody waits for anybody.
-template <class Cfg, class SCfg, class BCfg, class WCfg, bool WEIGHT, bool BIG>
+template <class Cfg, class SCfg, class BCfg, bool WEIGHT, bool BIG>
 __global__ __launch_bounds__(Cfg::THREADS)
 __attribute__((amdgpu_waves_per_eu(4, 4)))       // two 8-wave workgroups per CU: the compiler would take up to 256 VGPRs
 void gram_kernel(
     const typename Cfg::T* __restrict__ Phi, int64_t ld, const double* __restrict__ w, const double* __restrict__ side,
-    RowSplits rs, int64_t chunk, int nfull, int nstrip, double* __restrict__ sidepart, double* __restrict__ slabs,
-    int njobs, int* __restrict__ head) {
+    const float* __restrict__ ws2, RowSplits rs, int64_t chunk, int nfull, int nstrip, double* __restrict__ sidepart,
+    double* __restrict__ slabs, int njobs, int* __restrict__ head) {
     SMEM_DECL;
     if ((int)gridDim.x >= njobs) {                             // short job lists: one job per workgroup, static XCD map
-        gram_job<Cfg, SCfg, BCfg, WCfg, WEIGHT, BIG>((int)xcd_remap(blockIdx.x, gridDim.x), Phi, ld, w, side, rs, chunk, nfull, nstrip, sidepart, slabs, smem_raw);
+        gram_job<Cfg, SCfg, BCfg, WEIGHT, BIG>((int)xcd_remap(blockIdx.x, gridDim.x), Phi, ld, w, side, ws2, rs, chunk, nfull, nstrip, sidepart, slabs, smem_raw);
         return;
     }
     __shared__ int s_job;
@@ -706,7 +604,7 @@ void gram_kernel(
         const int j = s_job;
         __syncthreads();                                       // s_job may be rewritten
         if (j < 0) return;
-        gram_job<Cfg, SCfg, BCfg, WCfg, WEIGHT, BIG>(j, Phi, ld, w, side, rs, chunk, nfull, nstrip, sidepart, slabs, smem_raw);
+        gram_job<Cfg, SCfg, BCfg, WEIGHT, BIG>(j, Phi, ld, w, side, ws2, rs, chunk, nfull, nstrip, sidepart, slabs, smem_raw);
     }
 }
 
@@ -791,22 +689,26 @@ RowSplits gram_row_splits(int jobs, int64_t Np, bool f32, int nsplit_override, i
     return rs;
 }
 
+// ws2[n] = ((float) w[n] or 1, (float) side[n] or 0), n < Np: what the pipelined fp32 tiles read beside their operand panels
+__global__ __launch_bounds__(256) void gram_pack_ws(const double* __restrict__ w, const double* __restrict__ side, float* __restrict__ ws2, int64_t Np) {
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < Np; n += (int64_t)gridDim.x * 256)
+        reinterpret_cast<v2f*>(ws2)[n] = v2f{w ? (float)w[n] : 1.f, side ? (float)side[n] : 0.f};
+}
 template <typename T>
 void GramKernels<T>::gram(const Geom& g, const T* Phi, const double* w, const double* side, const RowSplits& rs, int64_t chunk,
-                          double* slabs, double* sidepart, int* qhead, hipStream_t st) {
+                          double* slabs, double* sidepart, int* qhead, float* ws2, hipStream_t st) {
     typedef typename GramCfg<T, 128>::type Cfg;
     typedef typename GramStripCfg<T>::type SCfg;
     typedef typename GramBigCfg<T>::type BCfg;
-    typedef typename GramWideCfg<T>::type WCfg;
     constexpr bool BIG = sizeof(T) == 4;
     const int njobs = gram_jobs(g) * rs.nsplit;
     if (chunk <= 0 || chunk > g.Np) chunk = g.Np;
     chunk = round_up(chunk, 256);                              // splits start and end on 64- or 256-row granules
     constexpr int L0 = Cfg::LDS_BYTES > SCfg::LDS_BYTES ? Cfg::LDS_BYTES : SCfg::LDS_BYTES;
     constexpr int L1 = !BIG && GramDma64::LDS_BYTES > L0 ? GramDma64::LDS_BYTES : L0;
-    constexpr int L2a = BIG && GramDma::LDS_BYTES > L1 ? GramDma::LDS_BYTES : L1;
-    constexpr int L2 = BIG && GramDmaWide::LDS_BYTES > L2a ? GramDmaWide::LDS_BYTES : L2a;
-    constexpr int LDS = BIG && WCfg::LDS_BYTES > L2 ? WCfg::LDS_BYTES : L2;
+    constexpr int L2 = BIG && GramDma::LDS_BYTES > L1 ? GramDma::LDS_BYTES : L1;
+    constexpr int LDS = BIG && GramDmaWide::LDS_BYTES > L2 ? GramDmaWide::LDS_BYTES : L2;
     static_assert(2 * LDS <= 160 * 1024, "two workgroups per CU");
     // Persistent launch with per-XCD queues from 6 rounds of jobs up; below that one job per workgroup.  Measured on one box
     // (profiles/r04_tuning.md): H (12 rounds) gram + gram_w 72.9-73.1 against 73.0-73.5 ms, C5 293.3 against 297.0, but a
@@ -814,13 +716,14 @@ void GramKernels<T>::gram(const Geom& g, const T* Phi, const double* w, const do
     const int resident = 2 * num_cus();                        // two workgroups per CU
     const bool persistent = njobs >= 6 * resident;
     if (persistent) (void)hipMemsetAsync(qhead, 0, sizeof(int) * 8, st);       // the eight queue heads
+    if (BIG && (w || side)) hipLaunchKernelGGL(gram_pack_ws, dim3((unsigned)std::min<int64_t>((g.Np + 255) / 256, 2048)), dim3(256), 0, st, w, side, ws2, g.Np);
     const auto launch = [&](auto kernel) {
         allow_big_lds(kernel, LDS);
-        hipLaunchKernelGGL(kernel, dim3(persistent ? resident : njobs), dim3(Cfg::THREADS), LDS, st, Phi, (int64_t)g.Kp, w, side, rs, chunk,
+        hipLaunchKernelGGL(kernel, dim3(persistent ? resident : njobs), dim3(Cfg::THREADS), LDS, st, Phi, (int64_t)g.Kp, w, side, (const float*)ws2, rs, chunk,
                            g.gfull, g.gstrip, sidepart, slabs, njobs, qhead);
     };
-    if (w) launch(gram_kernel<Cfg, SCfg, BCfg, WCfg, true, BIG>);
-    else launch(gram_kernel<Cfg, SCfg, BCfg, WCfg, false, BIG>);
+    if (w) launch(gram_kernel<Cfg, SCfg, BCfg, true, BIG>);
+    else launch(gram_kernel<Cfg, SCfg, BCfg, false, BIG>);
 }
 
 // A^T B over the rows, A (Np x Dp, fp64) and B either Zbar formed in the loader (PLAIN false: Bsrc = Phi, Bsrc2 = Phibar) or the

@@ -73,8 +73,10 @@ struct GramKernels {
     // lower tiles of  Phi^T diag(w) Phi  into per-split fp64 slabs (SCFGP.py:104; weighted: backward of :111-113)
     // and, from the diagonal tiles, sidepart[split][Kp] = partials of Phi^T side (side = y: SCFGP.py:108)
     //   qhead: 8 ints of device scratch (the heads of the per-XCD job queues of the persistent launch)
+    //   ws2:   2 (Np + 32) floats of device scratch (fp32 mode: the packed row weights / side multipliers of the LDS-DMA tiles;
+    //          the 64 floats behind the last row are read, never used); unused in fp64 mode
     static void gram(const Geom& g, const T* Phi, const double* w, const double* side, const RowSplits& rs, int64_t chunk,
-                     double* slabs, double* sidepart, int* qhead, hipStream_t st);
+                     double* slabs, double* sidepart, int* qhead, float* ws2, hipStream_t st);
     static int gram_jobs(const Geom& g);        // workgroups per row split of gram() (sizes the row split)
     // X~^T Zbar into per-split fp64 slabs, Zbar[n][j] = Phi[n][j] Phibar[n][J+j] - Phi[n][J+j] Phibar[n][j]
     // formed inside the operand loader

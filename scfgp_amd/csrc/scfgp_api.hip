@@ -122,6 +122,7 @@ struct scfgp_ctx {
     int apply_dma = -1;                                            // option: -1 = by problem size, 0 off, 1 = 128-wide tiles, 2 = 256-wide (fp32)
     double *d_vecs = nullptr;            // beta, alpha, u, ut, alpha_pred (Kp each)
     double *d_scalars = nullptr, *d_yy = nullptr; int* d_flag = nullptr;
+    float* d_ws2 = nullptr;                                        // fp32 mode: packed (weight, side multiplier) rows of the Gram launches (kernels.h)
     double *d_slabs = nullptr; size_t slabs_bytes = 0;
     double *d_partial = nullptr; int64_t n_partial = 0;
     double *d_work = nullptr, *d_grad = nullptr;
@@ -234,7 +235,7 @@ static int xtz_split(int ntiles, int64_t Np) {          // the X~^T Zbar grid ha
 }
 
 static void free_rows(scfgp_ctx* c) {
-    dfree(c->d_Xt); dfree(c->d_y); dfree(c->d_p); dfree(c->d_q); dfree(c->d_mu); dfree(c->d_vpart); dfree(c->d_Tt);
+    dfree(c->d_Xt); dfree(c->d_y); dfree(c->d_p); dfree(c->d_q); dfree(c->d_ws2); dfree(c->d_mu); dfree(c->d_vpart); dfree(c->d_Tt);
     dfree(c->d_Phi); dfree(c->d_V); dfree(c->d_bpart); dfree(c->d_slabs);
     c->Ncap = 0; c->slabs_bytes = 0;
 }
@@ -288,7 +289,7 @@ static int ensure_rows(scfgp_ctx* c, int64_t N) {
     }
     if (int rc = ensure_aux_rows(c)) return rc;
     if (Np <= c->Ncap) return SCFGP_OK;
-    dfree(c->d_Xt); dfree(c->d_y); dfree(c->d_p); dfree(c->d_q); dfree(c->d_mu); dfree(c->d_vpart); dfree(c->d_Tt);
+    dfree(c->d_Xt); dfree(c->d_y); dfree(c->d_p); dfree(c->d_q); dfree(c->d_ws2); dfree(c->d_mu); dfree(c->d_vpart); dfree(c->d_Tt);
     dfree(c->d_Phi); dfree(c->d_V); dfree(c->d_bpart);
     c->Ncap = 0;
     const size_t ts = c->tsize();
@@ -298,6 +299,7 @@ static int ensure_rows(scfgp_ctx* c, int64_t N) {
     if ((rc = dmalloc(c, &c->d_y, sizeof(double) * Np))) return rc;
     if ((rc = dmalloc(c, &c->d_p, sizeof(double) * Np))) return rc;
     if ((rc = dmalloc(c, &c->d_q, sizeof(double) * Np))) return rc;
+    if (c->dtype == SCFGP_F32 && (rc = dmalloc(c, &c->d_ws2, sizeof(float) * 2 * (Np + 32)))) return rc;
     if ((rc = dmalloc(c, &c->d_mu, sizeof(double) * Np * (g.Kp / 64)))) return rc;           // mupart, like vpart
     if ((rc = dmalloc(c, &c->d_vpart, sizeof(double) * Np * (g.Kp / 64)))) return rc;          // <= one entry per 64 columns
     if ((rc = dmalloc(c, &c->d_Phi, ts * Np * g.Kp))) return rc;
@@ -460,7 +462,7 @@ template <typename T> struct Impl {
         const int gs = c->splits.nsplit;
         double* sidepart = c->d_slabs + (size_t)gs * ntiles * g.tile * g.tile;
         { ProfScope ps(c, name);
-          SK::gram(g, Mx, w, side, c->splits, c->dtype == SCFGP_F32 ? c->gram_chunk : 0, c->d_slabs, sidepart, c->d_flag + 8, c->st); }
+          SK::gram(g, Mx, w, side, c->splits, c->dtype == SCFGP_F32 ? c->gram_chunk : 0, c->d_slabs, sidepart, c->d_flag + 8, c->d_ws2, c->st); }
         { ProfScope ps(c, "reduce_tiles"); reduce_tri_tiles(c->d_slabs, gs, nts, g.tile, out, c->st);
           reduce_side(sidepart, gs, g.Kp, g.gfull * g.tile + g.gstrip * 64, out + c->n_pk, c->st); }
     }
@@ -480,7 +482,7 @@ template <typename T> struct Impl {
                 double* sidepart = c->d_slabs + (size_t)gs * ntiles * g.tile * g.tile;
                 { ProfScope ps(c, "featuremap64"); SK64::featuremap(g, c->d_Xt, proj, c->d_sc, (double*)c->d_Phi64, c->st); }
                 { ProfScope ps(c, "gram64");
-                  SK64::gram(g, (const double*)c->d_Phi64, nullptr, c->d_y, c->splits64, 0, c->d_slabs, sidepart, c->d_flag + 8, c->st); }
+                  SK64::gram(g, (const double*)c->d_Phi64, nullptr, c->d_y, c->splits64, 0, c->d_slabs, sidepart, c->d_flag + 8, nullptr, c->st); }
                 { ProfScope ps(c, "reduce_tiles"); reduce_tri_tiles(c->d_slabs, gs, nts, g.tile, c->d_xp1, c->st);
                   reduce_side(sidepart, gs, g.Kp, g.gfull * g.tile + g.gstrip * 64, c->d_xp1 + c->n_pk, c->st); }
             }

@@ -34,7 +34,7 @@ def test_apply_dma_kernels_never_touch_a_fragment_in_flight_and_keep_their_loops
 
 
 def test_gram_kernels_never_touch_a_fragment_in_flight():
-    """the pipelined 256 x 128 Gram tile (gram_tall_dma) inside the persistent gram_kernel: the flush of a chunk must find the
+    """the pipelined Gram tiles (gram_pipe_dma: 256 x 128 and 64 x 512) inside the persistent gram_kernel: the flush of a chunk must find the
     pipeline drained (no spill or copy of a fragment register whose read has not been waited for)"""
     import isa_inflight
     assert isa_inflight.main('gram', 'gram_kernel', []) == 0
