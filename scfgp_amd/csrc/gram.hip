@@ -167,32 +167,44 @@ struct GramDmaWide {
                          STAGE = W_OFF + 256, STAGES = 2, LDS_BYTES = STAGES * STAGE, NINSTR = (A_BYTES + B_BYTES) / 1024, DMA_PER_WAVE = 5;
     static_assert(NINSTR == 36 && 2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
 };
+//   GramDmaSq    128 x 128 (wave grid 4 x 2 of 32 x 64: two MFMA tiles along the rows; the diagonal blocks the tall tiles leave),
+//                 ring of three 16 KiB stages
+struct GramDmaSq {
+    static constexpr int BM = 128, BN = 128, A_BYTES = 16 * BM * 4, B_BYTES = 16 * BN * 4, W_OFF = A_BYTES + B_BYTES, S_OFF = W_OFF + 128,
+                         STAGE = W_OFF + 256, STAGES = 3, LDS_BYTES = STAGES * STAGE, DMA_PER_WAVE = (A_BYTES + B_BYTES) / 1024 / 8;
+    static_assert(DMA_PER_WAVE == 2, "8 waves, 16 KiB of operands per stage");
+};
 template <class D, bool WEIGHT, bool DIAG>
 __device__ __forceinline__ void gram_pipe_dma(
     const float* __restrict__ Phi, int64_t ld, const float* __restrict__ ws2,
     int64_t r0, int64_t r1, int64_t chunk, int acol, int bcol, double* __restrict__ sideout,
     double* __restrict__ slab, double* __restrict__ slab_hi, char* smem) {
-    constexpr bool WIDE = D::BM == 64;
-    constexpr int RING = D::STAGES;
+    constexpr bool WIDE = D::BM == 64, SQ = D::BM == 128;
+    constexpr int RING = D::STAGES, TM = SQ ? 2 : 4;            // MFMA tiles of a wave along the rows (four along the columns)
     typedef std::integral_constant<int, 0> H0;
     typedef std::integral_constant<int, 1> H1;
     constexpr bool WS = WEIGHT || DIAG;
-    constexpr int DPW = D::DMA_PER_WAVE, NRD = 4 + (WEIGHT || DIAG ? 2 : 0), NM = 32, PRE = 2;              // per half: reads, MFMAs
+    constexpr int DPW = D::DMA_PER_WAVE, NRD = 4 + (WEIGHT || DIAG ? 2 : 0), NM = 8 * TM, PRE = 2;          // per half: reads, MFMAs
     static_assert(PRE + DPW + 1 + NRD <= NM, "one fetch or read per MFMA behind the barrier");
     // the thread id behind an opaque move (see gram_body_impl)
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), i = lane & 15, q = lane >> 4;
-    const int wm0 = WIDE ? 0 : (wave >> 1) * 64, wn0 = WIDE ? wave * 64 : (wave & 1) * 64;
+    const int wm0 = WIDE ? 0 : (wave >> 1) * (16 * TM), wn0 = WIDE ? wave * 64 : (wave & 1) * 64;
     // DMA instruction t of a stage (1 KiB of the stacked A | B image each)
     //   tall: t = 3 wave + u; t < 16: row t of the A panel; else rows 2 (t - 16), 2 (t - 16) + 1 of the B panel
     //   wide: t = wave + 8 u (< 36); t < 4: rows 4t .. 4t+3 of the A panel (256 bytes each); else half (t - 4) & 1 of row (t - 4) / 2 of the B panel
+    //   square: t = 2 wave + u; t < 8: rows 2t, 2t+1 of the A panel, the odd row ROTATED by 32 floats (position p holds column
+    //           p - 32 mod 128: the 8-byte A reads of an even and an odd k row then fall into different halves of the 256-byte bank
+    //           row); else rows 2 (t - 8), 2 (t - 8) + 1 of the B panel
     const char* src[DPW]; int dst[DPW];
 #pragma unroll
     for (int u = 0; u < DPW; ++u) {
         const int t = WIDE ? wave + 8 * u : DPW * wave + u;
         const float* g;
-        if constexpr (WIDE) g = t < 4 ? Phi + (r0 + 4 * t + (lane >> 4)) * ld + acol + 4 * (lane & 15) : Phi + (r0 + ((t - 4) >> 1)) * ld + bcol + 256 * ((t - 4) & 1) + 4 * lane;
+        if constexpr (SQ) g = t < 8 ? Phi + (r0 + 2 * t + (lane >> 5)) * ld + acol + ((4 * (lane & 31) - 32 * (lane >> 5)) & 127)
+                                    : Phi + (r0 + 2 * (t - 8) + (lane >> 5)) * ld + bcol + 4 * (lane & 31);
+        else if constexpr (WIDE) g = t < 4 ? Phi + (r0 + 4 * t + (lane >> 4)) * ld + acol + 4 * (lane & 15) : Phi + (r0 + ((t - 4) >> 1)) * ld + bcol + 256 * ((t - 4) & 1) + 4 * lane;
         else g = t < 16 ? Phi + (r0 + t) * ld + acol + 4 * lane : Phi + (r0 + 2 * (t - 16) + (lane >> 5)) * ld + bcol + 4 * (lane & 31);
         src[u] = reinterpret_cast<const char*>(g);
         dst[u] = t * 1024;
@@ -219,17 +231,19 @@ __device__ __forceinline__ void gram_pipe_dma(
     };
     // LDS byte addresses (first stage) of this lane's fragment of k row q: 4 adjacent floats of the A / B panel, its weight
     const int ring = (int)(uintptr_t)smem;
-    const int pa0 = ring + q * (D::BM * 4) + (wm0 + 4 * i) * 4, pb0 = ring + D::A_BYTES + q * (D::BN * 4) + (wn0 + 4 * i) * 4, pw0 = ring + D::W_OFF + q * 8;
+    const int pa0 = SQ ? ring + q * (D::BM * 4) + ((wm0 + 2 * i + 32 * (q & 1)) & 127) * 4 : ring + q * (D::BM * 4) + (wm0 + 4 * i) * 4, pb0 = ring + D::A_BYTES + q * (D::BN * 4) + (wn0 + 4 * i) * 4, pw0 = ring + D::W_OFF + q * 8;
     typedef float v2f __attribute__((ext_vector_type(2)));
-    v4f fa[2][2], fb[2][2];                                    // [half][k-step of the half]
+    typedef float afrag_t __attribute__((ext_vector_type(TM)));   // TM adjacent floats of the A panel's k row: MFMA tile tm, tile row rho = output row TM rho + tm
+    afrag_t fa[2][2]; v4f fb[2][2];                            // [half][k-step of the half]
     v2f fws[2][2];                                             // (weight, side multiplier) of the lane's k row
-    v4f acc[4][4];
-    v4f sacc = v4f{0.f, 0.f, 0.f, 0.f};                         // side sums of a chunk: fp32 chains a quarter as long as the MFMAs'
+    v4f acc[TM][4];
+    afrag_t sacc = 0.f;                                        // side sums of a chunk: fp32 chains a quarter as long as the MFMAs'
     // read R of half h of the stage at byte `stage` of the ring: A, A, B, B, (pair, pair)
     const auto read_one = [&](auto hc, auto rc, int stage) {
         constexpr int h = decltype(hc)::value, R = decltype(rc)::value, kk = 2 * h + (R & 1);
         (void)&fws; (void)&pw0; (void)&fa; (void)&fb; (void)&pa0; (void)&pb0;      // (named outside the discarded branches: the capture is decided here)
-        if constexpr (R < 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[h][R & 1]) : "v"(stage + pa0), "n"(kk * 4 * D::BM * 4));
+        if constexpr (R < 2 && SQ) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(fa[h][R & 1]) : "v"(stage + pa0), "n"(kk * 4 * D::BM * 4));
+        else if constexpr (R < 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[h][R & 1]) : "v"(stage + pa0), "n"(kk * 4 * D::BM * 4));
         else if constexpr (R < 4) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[h][R & 1]) : "v"(stage + pb0), "n"(kk * 4 * D::BN * 4));
         else asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(fws[h][R & 1]) : "v"(stage + pw0), "n"(kk * 32));
     };
@@ -244,9 +258,9 @@ __device__ __forceinline__ void gram_pipe_dma(
         if constexpr (WEIGHT) { fa[h][0] *= fws[h][0][0]; fa[h][1] *= fws[h][1][0]; }                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                                                               \
     } while (0)
-    // MFMA I of half h: k-step 2h + I / 16 of accumulator tile (tm, tn) = (I / 4 % 4, I % 4)
+    // MFMA I of half h: k-step 2h + I / (4 TM) of accumulator tile (tm, tn) = (I / 4 % TM, I % 4)
     const auto mfma_one = [&](auto hc, auto ic) {
-        constexpr int h = decltype(hc)::value, I = decltype(ic)::value, k2 = I / 16, tm = I / 4 % 4, tn = I % 4;
+        constexpr int h = decltype(hc)::value, I = decltype(ic)::value, k2 = I / (4 * TM), tm = I / 4 % TM, tn = I % 4;
         acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[h][k2][tm], fb[h][k2][tn], acc[tm][tn], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -270,7 +284,7 @@ __device__ __forceinline__ void gram_pipe_dma(
             if constexpr (decltype(ic)::value < NRD) { read_one(H1(), ic, next); __builtin_amdgcn_sched_barrier(0); }
         });
     };
-    // accumulator (tm, tn, r) of lane (i, q) is output row wm0 + 16 q + 4 r + tm, column wn0 + 4 i + tn; slabs are 128 x 128:
+    // accumulator (tm, tn, r) of lane (i, q) is output row wm0 + TM (4 q + r) + tm, column wn0 + 4 i + tn; slabs are 128 x 128:
     // tall: rows >= 128 in slab_hi; wide: four consecutive slabs, one per 128 columns, rows 0 .. 63 of each
     double* sl = WIDE ? slab + (int64_t)(wn0 >> 7) * (128 * 128) + (wn0 & 127)
                       : (wm0 >= 128 ? slab_hi + (int64_t)(wm0 - 128) * 128 : slab + (int64_t)wm0 * 128) + wn0;
@@ -280,30 +294,30 @@ __device__ __forceinline__ void gram_pipe_dma(
         asm volatile("" : "+v"(lf));
         const int i = lf & 15, q = lf >> 4;
 #pragma unroll
-        for (int tm = 0; tm < 4; ++tm)
+        for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                v4d* d = reinterpret_cast<v4d*>(sl + (16 * q + 4 * r + tm) * 128 + 4 * i);
+                v4d* d = reinterpret_cast<v4d*>(sl + (TM * (4 * q + r) + tm) * 128 + 4 * i);
                 const v4d v = v4d{(double)acc[tm][0][r], (double)acc[tm][1][r], (double)acc[tm][2][r], (double)acc[tm][3][r]};
                 *d = first ? v : *d + v;
             }
         if constexpr (DIAG) {                                  // the 4 k rows of a k-step live in the 4 lane groups: sum over q, fp64 across chunks
 #pragma unroll
-            for (int tm = 0; tm < 4; ++tm) {
+            for (int tm = 0; tm < TM; ++tm) {
                 double x = (double)sacc[tm];
                 x += __shfl_xor(x, 16); x += __shfl_xor(x, 32);
-                if (q == 0 && wn0 == 0) { double* d = sideout + wm0 + 4 * i + tm; *d = first ? x : *d + x; }
+                if (q == 0 && wn0 == 0) { double* d = sideout + wm0 + TM * i + tm; *d = first ? x : *d + x; }
             }
-            sacc = v4f{0.f, 0.f, 0.f, 0.f};
+            sacc = 0.f;
         }
 #pragma unroll
-        for (int tm = 0; tm < 4; ++tm)
+        for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
             for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = v4f{0.f, 0.f, 0.f, 0.f};
         first = false;
     };
 #pragma unroll
-    for (int tm = 0; tm < 4; ++tm)
+    for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = v4f{0.f, 0.f, 0.f, 0.f};
     const auto strip_rest = [&]() {                             // wide: rows 64 .. 127 of the four slabs, which the strip does not have
@@ -316,7 +330,9 @@ __device__ __forceinline__ void gram_pipe_dma(
     static_for<DPW + 1>([&](auto uc) { fetch_one(uc, 0); });
     if (RING == 3 && nst > 1) static_for<DPW + 1>([&](auto uc) { fetch_one(uc, 1); });
     const auto wait_landed = [&](bool more) {                   // this wave's share of a stage; `more`: a later stage's fetch may stay outstanding
-        if (RING == 3 && more) { if (ws_wave) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
+        if (RING == 3 && more) {                                // one later stage in flight: DPW instructions, one more on the wave that fetches the pairs
+            if (ws_wave) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DPW + 1) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DPW) : "memory");
+        }
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
     const auto next_slot = [&](int sl_) { return sl_ == RING - 1 ? 0 : sl_ + 1; };
@@ -549,6 +565,11 @@ __device__ __forceinline__ void gram_job(
         if (kind == 2) {
             if (diag) gram_pipe_dma<GramDma, WEIGHT, true>(Phi, ld, ws2, r0, r1, chunk, acol, bcol, sideout, slab, slab2, smem_raw);
             else gram_pipe_dma<GramDma, WEIGHT, false>(Phi, ld, ws2, r0, r1, chunk, acol, bcol, sideout, slab, slab2, smem_raw);
+            TRACE_END(kind); return;
+        }
+        if (kind == 0) {
+            if (diag) gram_pipe_dma<GramDmaSq, WEIGHT, true>(Phi, ld, ws2, r0, r1, chunk, acol, bcol, sideout, slab, nullptr, smem_raw);
+            else gram_pipe_dma<GramDmaSq, WEIGHT, false>(Phi, ld, ws2, r0, r1, chunk, acol, bcol, sideout, slab, nullptr, smem_raw);
             TRACE_END(kind); return;
         }
         if (kind == 3) {
