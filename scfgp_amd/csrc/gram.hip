@@ -142,7 +142,7 @@ __device__ __forceinline__ void gram_body(
 //   (gram_pack_ws); the weight multiplies the A fragment after the LDS read, and the side sums sum_k s_k Phi[k][acol + m] are
 //   formed from the same (unweighted) fragments, fp32 over a chunk of rows and fp64 across chunks.
 struct GramDma {
-    static constexpr int BM = 256, BN = 128, A_BYTES = 16 * BM * 4, B_BYTES = 16 * BN * 4, W_OFF = A_BYTES + B_BYTES, S_OFF = W_OFF + 128,
+    static constexpr int BM = 256, BN = 128, A_BYTES = 16 * BM * 4, B_BYTES = 16 * BN * 4, W_OFF = A_BYTES + B_BYTES,   // W_OFF: the 16 (weight, multiplier) pairs
                          STAGE = W_OFF + 256, STAGES = 3, LDS_BYTES = STAGES * STAGE, DMA_PER_WAVE = (A_BYTES + B_BYTES) / 1024 / 8;
     static_assert(DMA_PER_WAVE == 3, "8 waves, 24 KiB of operands per stage");
 };
@@ -156,21 +156,21 @@ __device__ __forceinline__ lds_void* lds_ptr(const char* p) { return (lds_void*)
 // the MFMAs of the first and the second half of stage s, the fetch of stage s+3 and the reads of the next first half ride between
 // the second half's MFMAs, the reads of the next second half between the first half's.  LDS reads are inline assembly with
 // hand-counted waits that name the registers they release (tools/isa_inflight.py checks the compiled stream).
-// Two tile shapes share the loop (8 waves of 64 x 64 each; diagonal jobs add the side sums, DIAG):
-//   GramDma      256 x 128 (wave grid 4 x 2), ring of three 24 KiB stages
-//   GramDmaWide   64 x 512 (wave grid 1 x 8: four strip tiles side by side), ring of TWO 36 KiB stages (two workgroups per CU
+// Three tile shapes share the loop (8 waves; diagonal jobs add the side sums, DIAG):
+//   GramDma      256 x 128 (wave grid 4 x 2 of 64 x 64), ring of three 24 KiB stages
+//   GramDmaWide   64 x 512 (wave grid 1 x 8 of 64 x 64: four strip tiles side by side), ring of TWO 36 KiB stages (two workgroups per CU
 //                 share the LDS): the fetch of stage s+2 goes into the slot the barrier of stage s+1 frees and has one stage
 //                 to land.  Its 36 operand instructions per stage do not divide by 8 waves: waves 0-3 issue five, 4-7 four
 //                 (every vmcnt wait of the two-slot ring is vmcnt(0), so nothing counts them).
 struct GramDmaWide {
-    static constexpr int BM = 64, BN = 512, A_BYTES = 16 * BM * 4, B_BYTES = 16 * BN * 4, W_OFF = A_BYTES + B_BYTES, S_OFF = W_OFF + 128,
+    static constexpr int BM = 64, BN = 512, A_BYTES = 16 * BM * 4, B_BYTES = 16 * BN * 4, W_OFF = A_BYTES + B_BYTES,   // W_OFF: the 16 (weight, multiplier) pairs
                          STAGE = W_OFF + 256, STAGES = 2, LDS_BYTES = STAGES * STAGE, NINSTR = (A_BYTES + B_BYTES) / 1024, DMA_PER_WAVE = 5;
     static_assert(NINSTR == 36 && 2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
 };
 //   GramDmaSq    128 x 128 (wave grid 4 x 2 of 32 x 64: two MFMA tiles along the rows; the diagonal blocks the tall tiles leave),
 //                 ring of three 16 KiB stages
 struct GramDmaSq {
-    static constexpr int BM = 128, BN = 128, A_BYTES = 16 * BM * 4, B_BYTES = 16 * BN * 4, W_OFF = A_BYTES + B_BYTES, S_OFF = W_OFF + 128,
+    static constexpr int BM = 128, BN = 128, A_BYTES = 16 * BM * 4, B_BYTES = 16 * BN * 4, W_OFF = A_BYTES + B_BYTES,   // W_OFF: the 16 (weight, multiplier) pairs
                          STAGE = W_OFF + 256, STAGES = 3, LDS_BYTES = STAGES * STAGE, DMA_PER_WAVE = (A_BYTES + B_BYTES) / 1024 / 8;
     static_assert(DMA_PER_WAVE == 2, "8 waves, 16 KiB of operands per stage");
 };
@@ -507,7 +507,7 @@ __device__ __forceinline__ void gram_job(
     double* __restrict__ slabs, char* smem_raw) {
     static_assert(Cfg::THREADS == SCfg::THREADS && Cfg::THREADS == BCfg::THREADS && Cfg::THREADS == 512 &&
                   Cfg::BN == SCfg::BN && Cfg::BN == BCfg::BN && Cfg::BM == Cfg::BN && GramDmaWide::BM == SCfg::BM && GramDmaWide::BN == 4 * Cfg::BN,
-                  "one launch, four tile shapes");
+                  "one launch, five tile shapes");
     TRACE_BEGIN();
     constexpr int B = Cfg::BN;
     const int nall = nfull + nstrip, ntile_all = nall * (nall + 1) / 2;
