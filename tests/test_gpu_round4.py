@@ -275,3 +275,33 @@ def test_one_rank_under_the_launcher_with_the_sums_inside_the_library():
     assert 'issued by the library' in o2['config']['parallelism']
     st = o2['stages_ms']
     assert all(('exchange%d' % k) in st and st['exchange%d' % k] >= 0 for k in (1, 2, 3))
+
+
+@pytest.mark.parametrize('S,M', [(32, 288), (32, 320), (16, 432), (32, 1024)])
+def test_fp32_gram_tile_kinds_repeat_bit_for_bit_and_agree_with_fp64(S, M):
+    """The fp32 Gram's job list by column count: K = 640 (five 128-blocks: an UNPAIRED last block row of off-diagonal 128 x 128
+    tiles), 704 (the same + a 64-column strip), 896 (seven blocks: three tall pairs, unpaired row, no strip), 2112 (the headline
+    list: tall, wide strip, diagonal blocks, strip).  All of them run on the hand-scheduled LDS-DMA loop whose `vmcnt` / `lgkmcnt`
+    waits are counted by hand: a wrong count shows as results that differ between repeats (it did once, at 6e-10), a wrong tile
+    map as a disagreement with fp64 mode (SCFGP/SCFGP.py:104-105,108: A = Phi^T Phi + ..., Phi^T y; backward of :111-113)."""
+    from scfgp_amd import synth
+    from scfgp_amd.engine import HipEngine
+    N, D = 40000, 16
+    X = synth.make_X(0x5CF60777 + M, N, D)
+    y = synth.normal(0x5CF60778 + M, 0, N).reshape(-1, 1)
+    params = synth.make_params(0x5CF60779 + M, D, S, M, abc=(-1.0, 0.0, -1.0))
+    outs = {}
+    for dtype in ('f32', 'f64'):
+        e = HipEngine(D, S, M, dtype)
+        if dtype == 'f32':
+            e.set_option('gram64', 0)                               # stay in fp32 whatever the condition estimate says
+        e.set_params(params); e.set_data(X, y)
+        a = e.eval(want_grad=True)
+        b = e.eval(want_grad=True)
+        assert float(a[0]) == float(b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+        outs[dtype] = a
+        e.close()
+    (c32, g32, a32, L32), (c64, g64, a64, L64) = outs['f32'], outs['f64']
+    # fp32 Gram without the precision levels: loose bounds (a misplaced tile is an O(1) error), the repeats above are exact
+    assert abs(float(c32) - float(c64)) < 1e-5 * max(1.0, abs(float(c64)))
+    assert rel(a32, a64) < 5e-3 and rel(L32, L64) < 1e-3 and rel(g32, g64) < 2e-2
