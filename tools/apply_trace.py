@@ -21,6 +21,10 @@ tm = dict(eng.timings())
 tr = eng.debug_read('apply_trace', (1 << 16, 5), dtype=np.uint64)
 tr = tr[tr[:, 1] > 0].astype(np.int64)
 tr = tr[tr[:, 0] >= tr[:, 1].max() - int(100e6 * 1.2e-3 * tm[which])]
+# the short launches that follow in the same stage (ragged 64 columns, 128-wide tiles of a thin last round) overwrite the first
+# entries of the stamp array: keep the 256-wide launch's own workgroups
+dur = tr[:, 1] - tr[:, 0]
+tr = tr[dur > 0.6 * np.median(dur)]
 t0 = tr[:, 0].min(); st, en, xcc = (tr[:, 0] - t0) / 100.0, (tr[:, 1] - t0) / 100.0, tr[:, 2] & 0xF
 print('%s hipEvent %.2f ms; %d workgroups traced; span %.2f ms' % (which, tm[which], len(tr), en.max() / 1e3))
 pro, loop, epi = (tr[:, 3] - tr[:, 0]) / 100.0, (tr[:, 4] - tr[:, 3]) / 100.0, (tr[:, 1] - tr[:, 4]) / 100.0
