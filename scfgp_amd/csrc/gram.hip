@@ -174,18 +174,27 @@ struct GramDmaSq {
                          STAGE = W_OFF + 256, STAGES = 3, LDS_BYTES = STAGES * STAGE, DMA_PER_WAVE = (A_BYTES + B_BYTES) / 1024 / 8;
     static_assert(DMA_PER_WAVE == 2, "8 waves, 16 KiB of operands per stage");
 };
+//   GramDmaPair  TWO diagonal 128 x 128 blocks side by side as one 256-row tile (wave grid 4 x 2 of 64 x 64: four waves per block):
+//                 a diagonal block's B panel IS its A panel, so the stage holds only the 256-column A image (columns of block 1,
+//                 then of block 2) and the B fragments are read from it; 64 MFMAs per wave and barrier like the tall tile
+struct GramDmaPair {
+    static constexpr int BM = 256, BN = 128, A_BYTES = 16 * BM * 4, B_BYTES = 0, W_OFF = A_BYTES,   // W_OFF: the 16 (weight, multiplier) pairs
+                         STAGE = W_OFF + 256, STAGES = 3, LDS_BYTES = STAGES * STAGE, DMA_PER_WAVE = A_BYTES / 1024 / 8;
+    static_assert(DMA_PER_WAVE == 2, "8 waves, 16 KiB of operands per stage");
+};
 template <class D, bool WEIGHT, bool DIAG>
 __device__ __forceinline__ void gram_pipe_dma(
     const float* __restrict__ Phi, int64_t ld, const float* __restrict__ ws2,
     int64_t r0, int64_t r1, int64_t chunk, int acol, int bcol, double* __restrict__ sideout,
     double* __restrict__ slab, double* __restrict__ slab_hi, char* smem) {
-    constexpr bool WIDE = D::BM == 64, SQ = D::BM == 128;
+    constexpr bool WIDE = D::BM == 64, SQ = D::BM == 128, PAIR = D::B_BYTES == 0;      // PAIR: acol / bcol are the two blocks' columns
     constexpr int RING = D::STAGES, TM = SQ ? 2 : 4;            // MFMA tiles of a wave along the rows (four along the columns)
     typedef std::integral_constant<int, 0> H0;
     typedef std::integral_constant<int, 1> H1;
     constexpr bool WS = WEIGHT || DIAG;
     constexpr int DPW = D::DMA_PER_WAVE, NRD = 4 + (WEIGHT || DIAG ? 2 : 0), NM = 8 * TM, PRE = 2;          // per half: reads, MFMAs
     static_assert(PRE + DPW + 1 + NRD <= NM, "one fetch or read per MFMA behind the barrier");
+    static_assert(!(PAIR && DIAG), "the paired diagonal blocks carry no side sums");
     // the thread id behind an opaque move (see gram_body_impl)
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
@@ -194,6 +203,7 @@ __device__ __forceinline__ void gram_pipe_dma(
     // DMA instruction t of a stage (1 KiB of the stacked A | B image each)
     //   tall: t = 3 wave + u; t < 16: row t of the A panel; else rows 2 (t - 16), 2 (t - 16) + 1 of the B panel
     //   wide: t = wave + 8 u (< 36); t < 4: rows 4t .. 4t+3 of the A panel (256 bytes each); else half (t - 4) & 1 of row (t - 4) / 2 of the B panel
+    //   pair: t = 2 wave + u: row t of the A image, lanes 0-31 from block 1's columns, lanes 32-63 from block 2's
     //   square: t = 2 wave + u; t < 8: rows 2t, 2t+1 of the A panel, the odd row ROTATED by 32 floats (position p holds column
     //           p - 32 mod 128: the 8-byte A reads of an even and an odd k row then fall into different halves of the 256-byte bank
     //           row); else rows 2 (t - 8), 2 (t - 8) + 1 of the B panel
@@ -202,7 +212,8 @@ __device__ __forceinline__ void gram_pipe_dma(
     for (int u = 0; u < DPW; ++u) {
         const int t = WIDE ? wave + 8 * u : DPW * wave + u;
         const float* g;
-        if constexpr (SQ) g = t < 8 ? Phi + (r0 + 2 * t + (lane >> 5)) * ld + acol + ((4 * (lane & 31) - 32 * (lane >> 5)) & 127)
+        if constexpr (PAIR) g = Phi + (r0 + t) * ld + (lane < 32 ? acol : bcol - 128) + 4 * lane;
+        else if constexpr (SQ) g = t < 8 ? Phi + (r0 + 2 * t + (lane >> 5)) * ld + acol + ((4 * (lane & 31) - 32 * (lane >> 5)) & 127)
                                     : Phi + (r0 + 2 * (t - 8) + (lane >> 5)) * ld + bcol + 4 * (lane & 31);
         else if constexpr (WIDE) g = t < 4 ? Phi + (r0 + 4 * t + (lane >> 4)) * ld + acol + 4 * (lane & 15) : Phi + (r0 + ((t - 4) >> 1)) * ld + bcol + 256 * ((t - 4) & 1) + 4 * lane;
         else g = t < 16 ? Phi + (r0 + t) * ld + acol + 4 * lane : Phi + (r0 + 2 * (t - 16) + (lane >> 5)) * ld + bcol + 4 * (lane & 31);
@@ -231,7 +242,7 @@ __device__ __forceinline__ void gram_pipe_dma(
     };
     // LDS byte addresses (first stage) of this lane's fragment of k row q: 4 adjacent floats of the A / B panel, its weight
     const int ring = (int)(uintptr_t)smem;
-    const int pa0 = SQ ? ring + q * (D::BM * 4) + ((wm0 + 2 * i + 32 * (q & 1)) & 127) * 4 : ring + q * (D::BM * 4) + (wm0 + 4 * i) * 4, pb0 = ring + D::A_BYTES + q * (D::BN * 4) + (wn0 + 4 * i) * 4, pw0 = ring + D::W_OFF + q * 8;
+    const int pa0 = SQ ? ring + q * (D::BM * 4) + ((wm0 + 2 * i + 32 * (q & 1)) & 127) * 4 : ring + q * (D::BM * 4) + (wm0 + 4 * i) * 4, pb0 = PAIR ? ring + q * (D::BM * 4) + ((wm0 & 128) + wn0 + 4 * i) * 4 : ring + D::A_BYTES + q * (D::BN * 4) + (wn0 + 4 * i) * 4, pw0 = ring + D::W_OFF + q * 8;
     typedef float v2f __attribute__((ext_vector_type(2)));
     typedef float afrag_t __attribute__((ext_vector_type(TM)));   // TM adjacent floats of the A panel's k row: MFMA tile tm, tile row rho = output row TM rho + tm
     afrag_t fa[2][2]; v4f fb[2][2];                            // [half][k-step of the half]
@@ -244,7 +255,7 @@ __device__ __forceinline__ void gram_pipe_dma(
         (void)&fws; (void)&pw0; (void)&fa; (void)&fb; (void)&pa0; (void)&pb0;      // (named outside the discarded branches: the capture is decided here)
         if constexpr (R < 2 && SQ) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(fa[h][R & 1]) : "v"(stage + pa0), "n"(kk * 4 * D::BM * 4));
         else if constexpr (R < 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[h][R & 1]) : "v"(stage + pa0), "n"(kk * 4 * D::BM * 4));
-        else if constexpr (R < 4) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[h][R & 1]) : "v"(stage + pb0), "n"(kk * 4 * D::BN * 4));
+        else if constexpr (R < 4) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[h][R & 1]) : "v"(stage + pb0), "n"(kk * 4 * (PAIR ? D::BM : D::BN) * 4));
         else asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(fws[h][R & 1]) : "v"(stage + pw0), "n"(kk * 32));
     };
     // "s_waitcnt <what>" that hands out the fragments of half h, then the row weights / side sums on them (VALU)
@@ -497,7 +508,7 @@ __device__ __forceinline__ void gram_sq_dma64(
 template <bool BIG> __host__ __device__ inline int gram_jobs_per_split(int nfull, int nstrip) {
     if (!BIG) return nfull * (nfull + 1) / 2 + nstrip * (nfull + 1);
     const int R = nfull / 2, odd = nfull & 1, nsb = nstrip * (nfull + 1);
-    return R * R + nsb / 4 + R + odd * nfull + nsb % 4;          // tall, wide (4 strip tiles each), small, single strips
+    return R * R + nsb / 4 + (R + 1) / 2 + odd * nfull + nsb % 4;    // tall, wide (4 strip tiles each), diagonal blocks two by two, unpaired row, single strips
 }
 // one job (row split, output tile) of the list
 template <class Cfg, class SCfg, class BCfg, bool WEIGHT, bool BIG>
@@ -513,11 +524,11 @@ __device__ __forceinline__ void gram_job(
     const int nall = nfull + nstrip, ntile_all = nall * (nall + 1) / 2;
     const int per_split = gram_jobs_per_split<BIG>(nfull, nstrip);
     const int split = j / per_split;
-    int u = j % per_split, acol, bcol, slab_t, slab_t2 = 0, kind = 0;     // kind 0: 128-row tile, 1: strip, 2: 256-row tile, 3: wide strip
+    int u = j % per_split, acol, bcol, slab_t, slab_t2 = 0, kind = 0;     // kind 0: 128-row tile, 1: strip, 2: 256-row tile, 3: wide strip, 4: two diagonal blocks
     bool diag = false;
     const auto tri = [](int ti, int tj) { return ti * (ti + 1) / 2 + tj; };
     if (BIG) {
-        const int R = nfull / 2, nbig = R * R, nsmall = R + (nfull & 1) * nfull, nwide = nstrip * (nfull + 1) / 4;
+        const int R = nfull / 2, Rp = (R + 1) / 2, nbig = R * R, nsmall = Rp + (nfull & 1) * nfull, nwide = nstrip * (nfull + 1) / 4;
         if (u < nbig) {                                        // tall tile (a, b), u = a^2 + b
             int a = (int)sqrtf((float)u);
             while ((a + 1) * (a + 1) <= u) ++a;
@@ -529,11 +540,12 @@ __device__ __forceinline__ void gram_job(
             const int q = u - nbig;
             acol = nfull * B; bcol = 4 * q * B; slab_t = tri(nfull, 4 * q); kind = 3;
             diag = side != nullptr && nfull >= 4 * q && nfull < 4 * q + 4;
-        } else if (u < nbig + nwide + R) {                     // diagonal block of the second row of a pair
-            const int i = 2 * (u - nbig - nwide) + 1;
+        } else if (u < nbig + nwide + Rp) {                    // diagonal blocks of the second rows of two pairs (or of the last one)
+            const int m = u - nbig - nwide, i = 2 * (2 * m) + 1;
             acol = bcol = i * B; slab_t = tri(i, i);
+            if (2 * m + 1 < R) { const int i2 = 2 * (2 * m + 1) + 1; bcol = i2 * B; slab_t2 = tri(i2, i2); kind = 4; }
         } else if (u < nbig + nwide + nsmall) {                // unpaired last block row
-            const int i = nfull - 1, b = u - nbig - nwide - R;
+            const int i = nfull - 1, b = u - nbig - nwide - Rp;
             acol = i * B; bcol = b * B; slab_t = tri(i, b); diag = side != nullptr && b == i;
         } else {                                               // the strip tiles that do not fill a wide one
             const int tj = 4 * nwide + u - nbig - nwide - nsmall;
@@ -565,6 +577,10 @@ __device__ __forceinline__ void gram_job(
         if (kind == 2) {
             if (diag) gram_pipe_dma<GramDma, WEIGHT, true>(Phi, ld, ws2, r0, r1, chunk, acol, bcol, sideout, slab, slab2, smem_raw);
             else gram_pipe_dma<GramDma, WEIGHT, false>(Phi, ld, ws2, r0, r1, chunk, acol, bcol, sideout, slab, slab2, smem_raw);
+            TRACE_END(kind); return;
+        }
+        if (kind == 4) {                                       // two diagonal blocks (their columns' side sums come from the tall diagonal tiles)
+            gram_pipe_dma<GramDmaPair, WEIGHT, false>(Phi, ld, ws2, r0, r1, chunk, acol, bcol, sideout, slab, slab2, smem_raw);
             TRACE_END(kind); return;
         }
         if (kind == 0) {
