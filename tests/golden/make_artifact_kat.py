@@ -18,6 +18,13 @@ Fixture contents (float64):
   S, M, D
   Xraw, yraw           the raw rows of that split (scikit-learn's Boston table)
   xs_*, ys_*, *_algo   the fitted X / y scaler dictionaries stored in the pickle (SCFGP/Scaler.py:23-24,39-97)
+Predict side (the only reference-held numbers for pred_func):
+  val_rows             the 106 rows of the table that are not in the training split (what optimize() received as Xv, yv)
+  Xv_raw, yv_raw       their raw features / targets (scikit-learn's table)
+  val_metrics          evals[MAE, NMAE, MSE, NMSE, MNLP, SCORE][1][-1]: what SCFGP.predict (SCFGP/SCFGP.py:285-293) appended in
+                       the last call of optimize() (:268-269), i.e. with the stored alpha / Li and the trained vector
+  val_changed          position inside val_rows of table row 445, whose FEATURES differ between the 2016 copy of the table the
+                       reference ran on and today's (its error alone closes both the MAE and the MSE gap, checked below)
 """
 import collections
 import os
@@ -131,13 +138,33 @@ def main():
         rel(Li_o, Li), rel(al, alpha), abs(cost - cost_rec) / abs(cost_rec)))
     # the fitted scaler dictionaries (numbers from the pickle) and the raw rows of the split (scikit-learn's Boston table, not
     # part of the reference): tests/test_oracle_golden.py drives scfgp_amd/scaler.py with them and must land on X, y above
+    # ---- predict side: the 106 complement rows through SCFGP.predict's arithmetic (SCFGP/SCFGP.py:278-293) ----
+    va = np.setdiff1d(np.arange(Xraw.shape[0]), tr)
+    names = ('MAE', 'NMAE', 'MSE', 'NMSE', 'MNLP', 'SCORE')
+    rec = np.array([float(d['evals'][k][1][-1]) for k in names])
+    Xv, yv = Xraw[va], yraw[va]
+    mu_f, std_f = O.predict(x_scaler.forward_transform(Xv), alpha, Li, params, S, M)
+    mu_y = y_scaler.backward_transform(mu_f)
+    e = (mu_y - yv).ravel()
+    assert abs(np.var(yv) - rec[2] / rec[3]) < 1e-13 * np.var(yv), 'validation rows are not the complement'
+    # which single row's error closes sum|e| and sum e^2 at once?  (two equations, one unknown)
+    closure = []
+    for i in range(len(va)):
+        keep = np.arange(len(va)) != i
+        ep = len(va) * rec[0] - np.abs(e[keep]).sum()
+        closure.append(abs(len(va) * rec[2] - (e[keep] ** 2).sum() - ep * ep))
+    changed = int(np.argmin(closure))
+    print('validation: %d rows, var(yv) == MSE/NMSE, changed row = table row %d (closure %.2e; next best %.2e)' % (
+        len(va), va[changed], closure[changed], np.partition(closure, 1)[1]))
+    assert closure[changed] < 1e-10 and va[changed] == 445
     sc = {}
     for tag, sd in (('xs', x_scaler), ('ys', y_scaler)):
         for k, v in sd.data.items():
             sc['%s_%s' % (tag, k)] = np.asarray(v)
     np.savez_compressed(os.path.join(HERE, 'artifact_kat.npz'), X=X, y=y, params=params,
                         Li=Li, alpha=alpha, cost=cost_rec, S=S, M=M, D=D, train_rows=tr,
-                        Xraw=Xraw[tr], yraw=yraw[tr], xs_algo=x_scaler.algo, ys_algo=y_scaler.algo, **sc)
+                        Xraw=Xraw[tr], yraw=yraw[tr], xs_algo=x_scaler.algo, ys_algo=y_scaler.algo,
+                        val_rows=va, Xv_raw=Xv, yv_raw=yv, val_metrics=rec, val_changed=changed, **sc)
 
 
 if __name__ == '__main__':

@@ -131,3 +131,27 @@ def test_row_chunked_literal_graph_equals_the_unchunked_one():
     c1, g1, a1, L1 = AR.value_and_grad_chunked(X, y, p, S, M, chunk=700)
     assert abs(c1 - c0) < 1e-13 * abs(c0) and np.linalg.norm(g1 - g0) < 1e-12 * np.linalg.norm(g0)
     assert np.linalg.norm(a1 - a0) < 1e-10 * np.linalg.norm(a0) and np.linalg.norm(L1 - L0) < 1e-10 * np.linalg.norm(L0)
+
+
+def test_oracle_predict_side_closes_the_artifacts_recorded_validation_metrics():
+    """Row h of the coverage table: the predictive mean / band of SCFGP/SCFGP.py:138-148,278-293 on the artifact's 106
+    validation rows against the MAE / NMAE / MSE / NMSE / MNLP / SCORE the reference itself recorded (tests/artifact_predict.py
+    states the relations).  Here: the oracle; tests/test_gpu_round5.py runs the same checker over the HIP path."""
+    from tests import artifact_predict as AP
+    z = AP.load()
+    S, M = int(z['S']), int(z['M'])
+    pred = lambda Xs, alpha, Li: O.predict(Xs, alpha, Li, z['params'], S, M)
+    mu_y, std_y = AP.host_tail(pred, z)
+    got = AP.check(mu_y, std_y, z)
+    assert got['closure'] < 1e-12 and abs(abs(got['e_changed_2016']) - 3.4613474221682736) < 1e-10
+    # the checker has teeth: 1e-7 on ONE predictive mean, or 1e-4 relative on every sigma (towards larger), breaks it
+    bad = mu_y.copy(); bad[17] += 1e-7
+    with pytest.raises(AssertionError):
+        AP.check(bad, std_y, z)
+    with pytest.raises(AssertionError):
+        AP.check(mu_y, std_y * (1 + 2e-3), z)
+    # our own metrics over all 106 rows differ from the record exactly by the changed row's share
+    m = AP.metrics(mu_y, std_y, z['yv_raw'])
+    rec = z['val_metrics']
+    assert abs(106 * (rec[0] - m[0]) - (abs(got['e_changed_2016']) - abs(got['e_changed_today']))) < 1e-11
+    assert abs(106 * (rec[2] - m[2]) - (got['e_changed_2016'] ** 2 - got['e_changed_today'] ** 2)) < 1e-10
