@@ -258,12 +258,14 @@ __device__ __forceinline__ void gram_pipe_dma(
         else if constexpr (R < 4) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[h][R & 1]) : "v"(stage + pb0), "n"(kk * 4 * (PAIR ? D::BM : D::BN) * 4));
         else asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(fws[h][R & 1]) : "v"(stage + pw0), "n"(kk * 32));
     };
-    // "s_waitcnt <what>" that hands out the fragments of half h, then the row weights / side sums on them (VALU)
+    // "s_waitcnt <what>" that hands out the fragments of half h, then the row weights / side sums on them (VALU).  The fragments
+    // are in-out operands ("+v", as in apply.hip): their values are formally PRODUCED by the wait, so no use, copy or spill of
+    // them can be ordered before it at the IR level either
 #define SCFGP_WAIT_FRAGS(what, h)                                                                                                        \
     do {                                                                                                                                 \
         if constexpr (WS)                                                                                                                \
-            asm volatile("s_waitcnt " what :: "v"(fa[h][0]), "v"(fa[h][1]), "v"(fb[h][0]), "v"(fb[h][1]), "v"(fws[h][0]), "v"(fws[h][1]) : "memory"); \
-        else asm volatile("s_waitcnt " what :: "v"(fa[h][0]), "v"(fa[h][1]), "v"(fb[h][0]), "v"(fb[h][1]) : "memory");                  \
+            asm volatile("s_waitcnt " what : "+v"(fa[h][0]), "+v"(fa[h][1]), "+v"(fb[h][0]), "+v"(fb[h][1]), "+v"(fws[h][0]), "+v"(fws[h][1]) :: "memory"); \
+        else asm volatile("s_waitcnt " what : "+v"(fa[h][0]), "+v"(fa[h][1]), "+v"(fb[h][0]), "+v"(fb[h][1]) :: "memory");              \
         __builtin_amdgcn_sched_barrier(0);                                                                                               \
         if constexpr (DIAG) { sacc += fws[h][0][1] * fa[h][0]; sacc += fws[h][1][1] * fa[h][1]; }       /* from the unweighted fragments */ \
         if constexpr (WEIGHT) { fa[h][0] *= fws[h][0][0]; fa[h][1] *= fws[h][1][0]; }                                                    \

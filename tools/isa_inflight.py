@@ -3,13 +3,20 @@
 have not yet covered.  LDS reads return in order, so the check replays the instruction stream in layout order with a queue of
 outstanding reads; `s_waitcnt lgkmcnt(n)` retires all but the newest n.  Scalar loads share the counter and only make the
 real wait longer, so they are ignored.  Every path of the control-flow graph is followed.
-   python tools/isa_inflight.py apply apply_dma_kernel [-DSCFGP_APPLY_PIPE=1]"""
+
+The same replay carries the counted `s_waitcnt vmcnt(n)` of the LDS-DMA rings (ring_check): inside every loop that issues
+`global_load_lds` fetches, a counted wait lets exactly ONE later stage stay in flight (three-slot rings: apply.hip,
+gram.hip), so every non-zero n waited on inside the loop must be the number of fetch instructions some path through the loop
+body issues -- a vmcnt(3) in a loop whose waves fetch two instructions per stage (round 4's non-determinism at 6e-10) fails.
+
+   python tools/isa_inflight.py apply apply_dma_kernel [-DSCFGP_APPLY_PIPE=1]      compile the source (Makefile flags + the -D)
+   python tools/isa_inflight.py --shipped apply_dma_kernel                         the code objects inside scfgp_amd/lib/libscfgp_hip.so"""
 import os
 import re
-import subprocess
 import sys
 
-CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'scfgp_amd', 'csrc')
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import isa_source                                                     # noqa: E402
 
 
 def regs(tok):
@@ -81,26 +88,85 @@ def check(lines, name):
     return [bad[k] for k in sorted(bad)]
 
 
-def main(unit, pattern, extra):
-    asm = '/tmp/%s.inflight.s' % unit
-    subprocess.run(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '--offload-arch=gfx950', '--cuda-device-only', '-S', '-I' + CSRC,
-                    os.path.join(CSRC, unit + '.hip'), '-o', asm] + extra, check=True, stderr=subprocess.DEVNULL)
-    lines = open(asm).read().split('\n')
-    starts = [(i, l.split(':')[0]) for i, l in enumerate(lines) if re.match(r'^_Z\w+:', l) and pattern in l]
-    names = subprocess.run(['c++filt'], input='\n'.join(n for _, n in starts), capture_output=True, text=True).stdout.split('\n')
-    total = 0
-    for (i, _), name in zip(starts, names):
-        j = i
-        while not lines[j].startswith('.Lfunc_end'):
-            j += 1
-        bad = check([(k - i, lines[k]) for k in range(i, j)], name)
-        print('%s: %d reads of registers in flight' % (name.split('(')[0], len(bad)))
+def loops_with_fetches(ins):
+    """{head index: last index} of the loops (a head label with every backward branch to it: a rotated loop has several) whose
+    body issues LDS-DMA fetches and MFMAs"""
+    label_at = {l[:-1]: k for k, l in enumerate(ins) if l.endswith(':')}
+    out = {}
+    for k, l in enumerate(ins):
+        m = re.match(r's_c?branch\w*\s+(\.LBB\d+_\d+)', l)
+        if m and m.group(1) in label_at and label_at[m.group(1)] < k:
+            j = label_at[m.group(1)]
+            out[j] = max(out.get(j, 0), k)
+    return {j: k for j, k in out.items()
+            if any('global_load_lds' in x for x in ins[j:k + 1]) and any(x.startswith('v_mfma') for x in ins[j:k + 1])}
+
+
+def ring_check(ins, max_paths=1 << 14):
+    """Counted vmcnt waits of the LDS-DMA ring.  For every INNERMOST fetch-carrying loop: F = {number of global_load_lds issued on
+    a path from the loop's head around to a branch back to it}, W = {n of every `s_waitcnt vmcnt(n)` on such a path, n > 0};
+    returns [(first, last, sorted F, sorted W)] of the loops where W is not a subset of F (a wave would then let part of the
+    stage it is about to read stay in flight, or wait for its newest stage too), and the number of loops examined."""
+    loops = loops_with_fetches(ins)
+    inner = [(j, k) for j, k in loops.items() if not any(j2 != j and j <= j2 and k2 <= k for j2, k2 in loops.items())]
+    label_at = {l[:-1]: k for k, l in enumerate(ins) if l.endswith(':')}
+    bad = []
+    for j, k in inner:
+        F, W, npaths = set(), set(), 0
+        work = [(j + 1, 0, frozenset())]
+        while work:
+            pos, f, w = work.pop()
+            while pos <= k:
+                l = ins[pos]
+                m = re.match(r's_c?branch\w*\s+(\.LBB\d+_\d+)', l)
+                if m:
+                    t = label_at.get(m.group(1), -1)
+                    if t == j:                                          # a back edge: one trip around the loop is complete
+                        F.add(f); W.update(w); npaths += 1
+                    elif j < t <= k and t > pos:
+                        work.append((t, f, w))                          # forward branch inside the body
+                    # (branches that leave the loop end the path there: the tail is another loop's business)
+                    if l.split()[0] == 's_branch':
+                        break
+                elif 'global_load_lds' in l:
+                    f += 1
+                elif l.startswith('s_waitcnt'):
+                    mm = re.search(r'vmcnt\((\d+)\)', l)
+                    if mm and int(mm.group(1)) > 0:
+                        w = w | {int(mm.group(1))}
+                pos += 1
+            if npaths > max_paths:
+                raise RuntimeError('too many paths through the loop at %d-%d' % (j, k))
+        if not W <= F:
+            bad.append((j, k, sorted(F), sorted(W)))
+    return bad, len(inner)
+
+
+def run(unit, pattern, extra=(), shipped=None):
+    """{'functions': n checked, 'inflight': total hazards, 'ring': total ring violations, 'ring_loops': loops examined, 'mfma_loops': ...}"""
+    res = {'functions': 0, 'inflight': 0, 'ring': 0, 'ring_loops': 0, 'ds_reads': 0}
+    for name, body in isa_source.functions(unit, pattern, extra, shipped):
+        short = re.sub(r'^void ', '', name).split('(')[0]
+        bad = check(list(enumerate(body)), name)
+        rbad, nloops = ring_check(body)
+        print('%s: %d reads of registers in flight; %d of %d fetch loops with a vmcnt count that is no path\'s fetch count'
+              % (short, len(bad), len(rbad), nloops))
         for ln, l, hit in bad[:8]:
             print('    +%d  %s   <- v%s' % (ln, l, hit))
-        total += len(bad)
-    return total
+        for j, k, F, W in rbad:
+            print('    loop +%d..+%d: fetch instructions per trip %s, counted waits %s' % (j, k, F, W))
+        res['functions'] += 1; res['inflight'] += len(bad); res['ring'] += len(rbad); res['ring_loops'] += nloops
+        res['ds_reads'] += sum(l.startswith('ds_read') for l in body)
+    return res
+
+
+def main(unit, pattern, extra, shipped=None):
+    r = run(unit, pattern, extra, shipped)
+    return r['inflight'] + r['ring']
 
 
 if __name__ == '__main__':
     args = sys.argv[1:]
+    if args[0] == '--shipped':
+        sys.exit(1 if main(None, args[1], [], isa_source.SHIPPED) else 0)
     sys.exit(1 if main(args[0], args[1], [a for a in args[2:] if a.startswith('-')]) else 0)

@@ -1,50 +1,40 @@
-"""Per-loop instruction census of a HIP source's gfx950 ISA (CPU only): for every kernel whose mangled name contains `pattern`,
-every backward branch's loop body with its MFMA / scratch / barrier / LDS / global counts -- where the spills are and what an
-inner loop issues per MFMA.   python tools/isa_loops.py gram gram_kernel [-DSOMETHING]"""
+"""Per-loop instruction census of gfx950 ISA (CPU only): for every kernel whose mangled name contains `pattern`, every backward
+branch's loop body with its MFMA / scratch / barrier / LDS / global counts -- where the spills are and what an inner loop
+issues per MFMA.
+   python tools/isa_loops.py gram gram_kernel [-DSOMETHING]      compile the source (Makefile flags + the -D)
+   python tools/isa_loops.py --shipped gram_kernel               the code objects inside scfgp_amd/lib/libscfgp_hip.so"""
 import os
 import re
-import subprocess
 import sys
 
-CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'scfgp_amd', 'csrc')
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import isa_source                                                     # noqa: E402
 
 
-def census(unit, pattern, extra):
+def census(unit, pattern, extra=(), shipped=None):
     """[(kernel name, {'first', 'last', 'instr', 'mfma', 'scratch', 'barrier', 'ds_read', 'ds_write', 'global_load', 'waitcnt'})] for
-    every MFMA-carrying loop (backward branch) of the kernels whose mangled name contains `pattern`"""
-    asm = '/tmp/%s.isa.s' % unit
-    subprocess.run(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '--offload-arch=gfx950', '--cuda-device-only', '-S', '-I' + CSRC,
-                    os.path.join(CSRC, unit + '.hip'), '-o', asm] + extra, check=True, stderr=subprocess.DEVNULL)
-    lines = open(asm).read().split('\n')
-    starts = [(i, l.split(':')[0]) for i, l in enumerate(lines) if re.match(r'^_Z\w+:', l) and pattern in l]
-    names = subprocess.run(['c++filt'], input='\n'.join(n for _, n in starts), capture_output=True, text=True).stdout.split('\n')
+    every MFMA-carrying loop (backward branch) of the kernels whose mangled name contains `pattern`; each kernel is preceded
+    by (name, {'lines': n})"""
     out = []
-    for (i, _), name in zip(starts, names):
-        j = i
-        while not lines[j].startswith('.Lfunc_end'):
-            j += 1
-        body = lines[i:j]
-        labels = {}
+    for name, body in isa_source.functions(unit, pattern, extra, shipped):
+        name = re.sub(r'^void ', '', name)[:200]
+        labels = {l[:-1]: k for k, l in enumerate(body) if l.endswith(':')}
+        out.append((name, {'lines': len(body)}))
         for k, l in enumerate(body):
-            m = re.match(r'^(\.LBB\d+_\d+):', l)
-            if m:
-                labels[m.group(1)] = k
-        out.append((re.sub(r'^void ', '', name)[:200], {'lines': len(body)}))
-        for k, l in enumerate(body):
-            m = re.search(r's_c?branch\w* (\.LBB\d+_\d+)', l)
+            m = re.match(r's_c?branch\w*\s+(\.LBB\d+_\d+)', l)
             if m and m.group(1) in labels and labels[m.group(1)] < k:
                 seg = body[labels[m.group(1)]:k + 1]
-                c = lambda pat: sum(pat in x.split(';')[0] for x in seg)
+                c = lambda pat: sum(pat in x for x in seg)
                 if c('v_mfma'):
-                    out.append((out[-1][0] if 'lines' not in out[-1][1] else name, {
+                    out.append((name, {
                         'first': labels[m.group(1)], 'last': k, 'instr': len(seg), 'mfma': c('v_mfma'), 'scratch': c('scratch_'),
                         'barrier': c('s_barrier'), 'ds_read': c('ds_read'), 'ds_write': c('ds_write'), 'global_load': c('global_load'),
                         'waitcnt': c('s_waitcnt')}))
     return out
 
 
-def main(unit, pattern, extra):
-    for name, b in census(unit, pattern, extra):
+def main(unit, pattern, extra, shipped=None):
+    for name, b in census(unit, pattern, extra, shipped):
         if 'lines' in b:
             print(name, '--', b['lines'], 'lines')
         else:
@@ -53,4 +43,7 @@ def main(unit, pattern, extra):
 
 
 if __name__ == '__main__':
-    main(sys.argv[1], sys.argv[2], sys.argv[3:])
+    if sys.argv[1] == '--shipped':
+        main(None, sys.argv[2], [], isa_source.SHIPPED)
+    else:
+        main(sys.argv[1], sys.argv[2], sys.argv[3:])
