@@ -12,8 +12,8 @@
  * remains user-extensible; the library returns the exact gradient it needs.
  *
  * Conventions
- *   - every function returns 0 or a negative error code (scfgp_finish may also return SCFGP_REDO = 1); nothing throws
- *     across the ABI;
+ *   - every function returns 0 or a negative error code (scfgp_finish and scfgp_factor may also return SCFGP_REDO = 1);
+ *     nothing throws across the ABI;
  *     scfgp_last_error() gives a message for the last failure on that context
  *   - the caller owns every host buffer; the library owns all device memory
  *   - host matrices are row-major, C-contiguous float64 regardless of compute dtype
@@ -41,9 +41,15 @@ typedef struct scfgp_ctx scfgp_ctx;
                                    the reference raises numpy.linalg.LinAlgError from its
                                    Cholesky op (SCFGP/SCFGP.py:106)                      */
 #define SCFGP_ENONFINITE   -4   /* cost is NaN/Inf                                       */
-#define SCFGP_REDO          1   /* not an error, staged API only (scfgp_finish): the evaluation
+#define SCFGP_EPEER        -5   /* row shards: ANOTHER rank failed in this evaluation (its exchange
+                                   buffers carried the failure mark, scfgp_fail_stage): every rank
+                                   returns this from scfgp_finish / scfgp_eval / scfgp_train; the
+                                   results are not valid, the context stays usable            */
+#define SCFGP_REDO          1   /* not an error, staged API only.  scfgp_finish: the evaluation
                                    ran at a lower precision level than its own condition estimate
-                                   asks for; the level has been raised -- run the stages again
+                                   asks for; the level has been raised.  scfgp_factor: the ranks
+                                   have just agreed on a lower level than some of them ran pass 1
+                                   at.  Either way: run the stages again from scfgp_pass1
                                    (scfgp_eval / scfgp_eval_rows do that themselves)      */
 
 #define SCFGP_F64 0             /* fp64 MFMA everywhere (reference numerics)             */
@@ -132,13 +138,27 @@ int scfgp_predict_y(scfgp_ctx* ctx, const double* Xs_raw, int64_t T, const doubl
  *   scfgp_finish  -> outputs on the host
  *
  * These calls only enqueue work on the context's stream (asynchronous); scfgp_finish
- * synchronises.  scfgp_eval is exactly this sequence without the sums. */
+ * synchronises.  scfgp_eval is exactly this sequence without the sums.
+ *
+ * Ranks decide together.  The last four of the 8 scalars that close every exchange buffer are a status word: each rank
+ * writes 0 / 1 there, the sum over ranks turns them into COUNTS that every rank reads alike --
+ *   [4] ranks whose pass 1 ran at precision level >= 1        [5] / [6] ranks that cannot reach level 1 / 2 (their row
+ *   buffers were refused)            (exchange 1)             [7] ranks that failed in this sweep (exchanges 1, 2, 3).
+ * After a precision level was raised (the decision comes from the summed matrix, so every rank tries in the same
+ * evaluation) scfgp_factor reads the summed word once -- one stream synchronisation in that evaluation only -- and every
+ * rank commits to the lowest level any rank can reach; if that changes the form of pass 1 on some rank, scfgp_factor
+ * returns SCFGP_REDO on ALL ranks.  scfgp_get_condition()[1] then reports the common level, scfgp_last_error the refusal.
+ * A rank whose sweep fails calls scfgp_fail_stage for that and every later exchange of the evaluation (stage 1..3; stage 3
+ * only with want_grad): the buffer is marked, the sum still happens (inside the library with a communicator, else by the
+ * host framework as usual), nobody waits in a collective for a rank that has left, and scfgp_finish returns SCFGP_EPEER on
+ * every other rank.  scfgp_eval / scfgp_eval_rows / scfgp_train do this themselves when the sums run inside the library. */
 int scfgp_pass1(scfgp_ctx* ctx);
 int scfgp_factor(scfgp_ctx* ctx);
 int scfgp_pass2(scfgp_ctx* ctx, int want_grad);
 int scfgp_adjoint(scfgp_ctx* ctx);
 int scfgp_pass3(scfgp_ctx* ctx);
 int scfgp_finish(scfgp_ctx* ctx, int want_grad, double* cost, double* grad, double* alpha, double* Li);
+int scfgp_fail_stage(scfgp_ctx* ctx, int stage, int want_grad);
 /* optional, any time after scfgp_factor, best after the remaining stages are queued: copies alpha (K) and
  * Li (K*K) to the host on a second stream through pinned staging and returns once they are in the caller's
  * arrays.  It waits for the factor stage only, so the transfer and the host-side copy overlap passes 2 and 3
@@ -162,10 +182,15 @@ int scfgp_stream_fence(scfgp_ctx* ctx, void* peer_stream, int direction);
  * From then on the three sums of the row sums of SCFGP/SCFGP.py:104,108,126 and of the reverse sweep -- exchange buffers 1..3
  * above -- are ncclAllReduce(fp64, sum) calls the library enqueues itself on the context's stream at the end of scfgp_pass1 /
  * scfgp_pass2 / scfgp_pass3, so scfgp_eval and scfgp_eval_rows are complete sharded evaluations (set the rows of the rank with
- * scfgp_set_data(..., n_global = sum of the ranks' N)); the precision level is decided from the summed matrix, alike on every
- * rank.  scfgp_train stays single-GPU.  librccl.so is looked up at run time (a copy the process already carries is reused):
- * the library has no link-time dependency on it and single-GPU users never load it.  A caller that prefers to run the sums in
- * its own framework leaves the communicator out and uses scfgp_exchange + scfgp_stream_fence as before. */
+ * scfgp_set_data(..., n_global = sum of the ranks' N)); the precision level is decided from the summed matrix and committed
+ * through the status word above, alike on every rank.  scfgp_train runs its iterations with the three sums inside (every rank
+ * applies the same deterministic rule to the same summed gradient: the parameter vectors stay bit-equal without a broadcast;
+ * eager launches by default, the captured graph only with option "use_graph" = 2).  librccl.so is looked up at run time (a copy
+ * the process already carries is reused, wherever it was loaded from): the library has no link-time dependency on it and
+ * single-GPU users never load it.  A caller that prefers to run the sums in its own framework leaves the communicator out and
+ * uses scfgp_exchange + scfgp_stream_fence as before.
+ * STATUS: the communicator path has run on hardware with ONE rank only (the build pool hands out single GPUs); with two or
+ * more ranks it is covered by construction and by the in-process / gloo rehearsals of the same protocol, not by a measurement. */
 int scfgp_comm_unique_id(void* id128);
 int scfgp_comm_init(scfgp_ctx* ctx, int nranks, int rank, const void* id128);
 int scfgp_comm_destroy(scfgp_ctx* ctx);
@@ -178,7 +203,7 @@ int scfgp_comm_destroy(scfgp_ctx* ctx);
  *   hyper  [learning_rate, beta1 (rho for rmsprop/adadelta), beta2, epsilon]
  *   momentum  Nesterov momentum as the reference applies it (SCFGP/Optimizer.py:62-97, on the FIRST
  *             state of the rule's update dictionary); negative = none
- * scfgp_train runs n_iters x (evaluate + update) on the resident rows (single GPU), returns the cost
+ * scfgp_train runs n_iters x (evaluate + update) on the resident rows (of this rank: see the communicator above), returns the cost
  * of every iteration (each at its pre-update parameters, like train_iter_func) and, if non-NULL,
  * alpha / Li of the LAST evaluation; the updated vector is read with scfgp_get_params.
  * scfgp_opt_state copies optimiser state to (set=0) or from (set=1) the host: which 0,1 = the rule's
@@ -218,14 +243,16 @@ int scfgp_get_dims(scfgp_ctx* ctx, int64_t* out, int n);
 int scfgp_set_profiling(scfgp_ctx* ctx, int enable);
 int scfgp_get_timings(scfgp_ctx* ctx, double* ms, const char** names, int n);
 /* copy an internal device buffer to the host for tests ("Phi","V","G","W","XZ","Li","B","Abar",
- * "p","q","vecs","Fall","Xt","scalars"); returns the number of bytes copied or <0 */
+ * "p","q","vecs","Fall","Xt","scalars"); returns the number of bytes copied or <0.  "G" is exchange buffer 1 unpacked
+ * (the summed Gram, Phi^T y, y^T y and the status word) at any stage; "W" is exchange buffer 2 as the adjoint stage left it */
 int64_t scfgp_debug_read(scfgp_ctx* ctx, const char* name, void* host, int64_t max_bytes);
 /* options (name, value):
  *   "gram_nsplit"  row-split units of the Gram products (0 = default)
  *   "gram_taper"   1: the last unit of every XCD group is cut into 1/2, 1/4, 1/8, 1/8; t >= 2: into t + 3 pieces down to 1/2^(t+2)
  *   "gram_chunk"   fp32 mode: rows between two flushes of the fp32 accumulators into the fp64 slabs (default 4096)
  *   "xtz_nsplit"   row splits of X~^T Zbar (0 = default)
- *   "use_graph"    0: scfgp_train launches every iteration eagerly instead of replaying a captured hipGraph
+ *   "use_graph"    0: scfgp_train launches every iteration eagerly instead of replaying a captured hipGraph (1, default: the
+ *                  graph unless a communicator is attached; 2: the graph with a communicator too)
  *   "apply_dma"    the tiles of the apply products staged by LDS-DMA (global_load_lds) instead of through registers:
  *                  -1 automatic (K > 256 and >= 16384 rows: 128-wide tiles; fp32 from K >= 1024 and 65536 rows: 256-wide), 0 off,
  *                  1 = 128-wide tiles, 2 = 256-wide tiles (fp32; fp64 stays 128 wide)
@@ -236,6 +263,8 @@ int64_t scfgp_debug_read(scfgp_ctx* ctx, const char* name, void* host, int64_t m
  *                  columns and U fits): the reverse sweep of F = l_F r_F^T through T~^T Zbar and X~^T (Zbar_L + Zbar_M r_F)
  *                  instead of the dense X~^T Zbar; exchange buffer 3 then holds those two
  *   "roctx"        1: push a roctx range per stage for `rocprofv3 --marker-trace` (off by default; also SCFGP_ROCTX=1)
+ *   "test_deny_level" / "test_fail_stage"   fault injection for the tests of "ranks decide together": precision levels >= value
+ *                  are refused as if their buffers could not be allocated / the next sweep `value` (1..3) fails before it enqueues
  * Experiments of earlier rounds that measured equal or slower (feature map fused into the Gram loaders, lock-step Gram
  * schedule, pass 3 in row parts on two streams, Zbar written by the Phibar product, 8-wave and hand-pipelined LDS-DMA
  * tiles, the bf16x3 split-precision dtype) are no longer part of the library: profiles/r02_tuning.md, r03_tuning.md hold

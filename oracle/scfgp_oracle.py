@@ -251,14 +251,49 @@ def fd_grad(X, y, params, S, M, idx, h=1e-6):
 # staged engine: the same 3-sweep algorithm split at the three exchange points,
 # used by tests of the row-sharded driver (gloo, world_size 2) -- tests only.
 # --------------------------------------------------------------------------
+class PeerFailed(RuntimeError):
+    """another rank marked an exchange of this evaluation as failed (the library's SCFGP_EPEER)"""
+
+
+XS_RAN1, XS_CAP1, XS_CAP2, XS_FAIL = 4, 5, 6, 7          # status slots of the 8 scalars closing every exchange buffer (common.h)
+
+
 class OracleEngine(object):
     """Implements the staged interface scfgp_amd.sharded.ShardedEvaluator drives
-    (pass1/factor/pass2/adjoint/pass3/finish + exchange buffers) on the CPU."""
+    (pass1/factor/pass2/adjoint/pass3/finish + exchange buffers) on the CPU.  Every exchange buffer ends, like the
+    library's (include/scfgp_hip.h, "ranks decide together"), in 8 scalars: [0..3] row sums, [4..7] the status word whose sum
+    over ranks counts the ranks that ran pass 1 at a raised level / cannot reach level 1 / level 2 / failed.  The oracle
+    computes in float64 throughout, so its `level` is bookkeeping only: `want_level` plays the condition estimate's demand,
+    `deny_level` an allocation that fails on this rank, `fail_at` a sweep that fails -- enough to rehearse, over gloo, the
+    protocol by which the ranks commit to one level and fail together."""
 
     def __init__(self, D, S, M):
         self.D, self.S, self.M = D, S, M
         self.J = S + M; self.K = 2 * self.J
         self.params = None
+        self.level, self.want_level, self.deny_level, self.fail_at = 0, 0, 0, 0
+        self.denied, self.unsettled, self.ran_level, self.stage = 0, False, 0, 0
+
+    def cap(self):
+        return self.denied - 1 if self.denied > 0 else 2
+
+    def _tail(self, vals, fail=0.0):
+        t = np.zeros(8); t[:len(vals)] = vals
+        t[XS_CAP1] = float(self.cap() < 1); t[XS_CAP2] = float(self.cap() < 2); t[XS_FAIL] = fail
+        return t
+
+    def _maybe_fail(self, stage):
+        if self.fail_at == stage:
+            self.fail_at = 0
+            raise RuntimeError('pass%d: injected failure' % stage)
+
+    def fail_stage(self, stage, want_grad=True):
+        """scfgp_fail_stage: this rank owes the sum of exchange `stage` but cannot compute it"""
+        K, D, J = self.K, self.D, self.J
+        n = {1: K * K + K, 2: (K * K + K) if want_grad else 0, 3: D * J + J}[stage]
+        buf = np.concatenate((np.zeros(n), self._tail([], fail=1.0)))
+        setattr(self, 'x%d' % stage, buf)
+        self.stage = 0
 
     def set_params(self, p):
         self.params = np.asarray(p, np.float64).copy()
@@ -271,23 +306,41 @@ class OracleEngine(object):
         return feature_map(self.X, self.params, self.D, self.S, self.M)
 
     def pass1(self):
+        self._maybe_fail(1)
         Ph = self._phi(); self.Ph = Ph
         K = self.K
-        self.x1 = np.concatenate(((Ph.T @ Ph).ravel(), Ph.T @ self.y, [(self.y ** 2).sum()]))
+        self.ran_level = self.level
+        t = self._tail([(self.y ** 2).sum()]); t[XS_RAN1] = float(self.level >= 1)
+        self.x1 = np.concatenate(((Ph.T @ Ph).ravel(), Ph.T @ self.y, t))
+        self.stage = 1
 
     def exchange(self, stage):
         return {1: self.x1, 2: getattr(self, 'x2', None), 3: getattr(self, 'x3', None)}[stage]
 
     def factor(self):
+        """False: start again at pass1 (the library's SCFGP_REDO from scfgp_factor, settle_level)"""
         K = self.K; a = self.params[0]
-        G = self.x1[:K * K].reshape(K, K); self.g = self.x1[K * K:K * K + K]; self.yy = self.x1[-1]
+        if self.unsettled:                                       # commit to the lowest level any rank can reach
+            self.unsettled = False
+            xs = self.x1[K * K + K:]
+            agreed = 0 if xs[XS_CAP1] > 0.5 else (1 if xs[XS_CAP2] > 0.5 else 2)
+            if agreed < self.cap():
+                self.denied = agreed + 1
+            self.level = min(self.level, agreed)
+            if agreed < 1 and xs[XS_RAN1] > 0.5:
+                self.stage = 0
+                return False
+            self.ran_level = self.level
+        G = self.x1[:K * K].reshape(K, K); self.g = self.x1[K * K:K * K + K]; self.yy = self.x1[K * K + K]
         A = G + (np.exp(2 * a) + EPSILON) * np.eye(K)
         L = np.linalg.cholesky(A)
         self.Li = np.linalg.solve(L, np.eye(K)); self.B = self.Li.T @ self.Li
         self.alpha = self.Li.T @ (self.Li @ self.g)
         self.T1 = 2 * np.log(np.diagonal(L)).sum()
+        return True
 
     def pass2(self, want_grad=True):
+        self._maybe_fail(2)
         Ph = self.Ph; c = self.params[2]; kappa = np.log1p(np.exp(c)); y = self.y
         mu = Ph @ self.alpha; v = ((Ph @ self.B) * Ph).sum(1); d = kappa * (v + 1); r = mu - y
         T2 = ((r * r + v) / d + np.log(2 * np.pi * d)).sum()
@@ -297,26 +350,44 @@ class OracleEngine(object):
         K = self.K
         # second exchange: B W B = V^T diag(q) V and u = B Phi^T p = V^T p with V = Phi B (row sums, like W and Phi^T p)
         V = Ph @ self.B
-        BWB = V.T @ (self.q[:, None] * V) if want_grad else np.zeros((K, K))
-        self.x2 = np.concatenate((BWB.ravel(), V.T @ self.p, [T2, kbar]))
+        if want_grad:
+            self.x2 = np.concatenate(((V.T @ (self.q[:, None] * V)).ravel(), V.T @ self.p, self._tail([T2, kbar])))
+        else:
+            self.x2 = self._tail([T2, kbar])                    # forward only: the 8 scalars (scfgp_exchange, stage 2)
 
     def adjoint(self):
         K = self.K; a = self.params[0]
         BWB = self.x2[:K * K].reshape(K, K); u = self.x2[K * K:K * K + K]
-        self.T2, self.kbar = self.x2[-2], self.x2[-1]
         em2a = np.exp(-2 * a); B = self.B; al = self.alpha
         self.Abar = B - BWB - 0.5 * (np.outer(u, al) + np.outer(al, u)) + em2a * np.outer(al, al)
         self.ut = u - 2 * em2a * al
 
     def pass3(self):
+        self._maybe_fail(3)
         Ph = self.Ph; J = self.J
         Pb = (np.outer(self.p, self.alpha) + np.outer(self.y, self.ut)
               + 2 * self.q[:, None] * (Ph @ self.B) + 2 * (Ph @ self.Abar))
         Zb = Ph[:, :J] * Pb[:, J:] - Ph[:, J:] * Pb[:, :J]
-        self.x3 = np.concatenate(((self.X.T @ Zb).ravel(), Zb.sum(0), [(Pb * Ph).sum()]))
+        self.x3 = np.concatenate(((self.X.T @ Zb).ravel(), Zb.sum(0), self._tail([(Pb * Ph).sum()])))
 
     def finish(self, want_grad=True):
         D, S, M, J, K = self.D, self.S, self.M, self.J, self.K
+        self.stage = 0
+        fails = self.x1[-8 + XS_FAIL] + self.x2[-8 + XS_FAIL] + (self.x3[-8 + XS_FAIL] if want_grad else 0.0)
+        if fails > 0.5:
+            raise PeerFailed('a rank failed in this evaluation')
+        self.T2, self.kbar = self.x2[-8], self.x2[-7]
+        # update_level of the library: the (summed) condition estimate asks for `want_level`; every rank tries to raise its
+        # level in this same evaluation; what each could allocate travels with the next exchange 1 (settle_level in factor)
+        top = min(self.want_level, self.cap())
+        if top > self.level:
+            self.unsettled = True
+            lvl = top
+            while lvl > self.level and self.deny_level and lvl >= self.deny_level:
+                self.denied = lvl; lvl -= 1
+            self.level = lvl
+        if top > self.ran_level:                                 # `top` is common to the ranks; what this one could allocate is not
+            return None                                          # SCFGP_REDO
         a, b, c, l_F, r_F, F, l_FC, FC = unpack_params(self.params, D, S, M)
         em2a = np.exp(-2 * a); Ng = self.Ng
         T3 = em2a * (self.yy - self.g @ self.alpha); T4 = 2 * (Ng - M) * a
@@ -325,6 +396,6 @@ class OracleEngine(object):
         if want_grad:
             abar = 2 * np.exp(2 * a) * np.trace(self.Abar) - 2 * T3 + 2 * (Ng - M)
             cbar = self.kbar / (1 + np.exp(-c))
-            st3 = dict(XZ=self.x3[:D * J].reshape(D, J), colsum=self.x3[D * J:D * J + J], bbar=self.x3[-1])
+            st3 = dict(XZ=self.x3[:D * J].reshape(D, J), colsum=self.x3[D * J:D * J + J], bbar=self.x3[D * J + J])
             grad = _epilogue(self.params, D, S, M, st3, abar, cbar, Ng)
         return float(cost), grad, self.alpha.reshape(-1, 1).copy(), self.Li.copy()

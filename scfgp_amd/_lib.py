@@ -13,8 +13,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libscfgp_hip%s.so' % os.environ.get('SCFGP_LIB_VARIANT', ''))
 
 SCFGP_F64, SCFGP_F32 = 0, 1
-SCFGP_REDO = 1                           # scfgp_finish: run the stages again (precision level raised), not an error
-ERRORS = {-1: 'bad argument', -2: 'HIP error', -3: 'not positive definite', -4: 'non-finite cost'}
+SCFGP_REDO = 1                           # scfgp_finish / scfgp_factor: run the stages again (precision level raised or agreed lower), not an error
+SCFGP_EPEER = -5
+ERRORS = {-1: 'bad argument', -2: 'HIP error', -3: 'not positive definite', -4: 'non-finite cost', -5: 'another rank failed'}
 
 _c_double_p = C.POINTER(C.c_double)
 _c_i64_p = C.POINTER(C.c_int64)
@@ -42,6 +43,7 @@ SIGNATURES = {
     'scfgp_adjoint': (C.c_int, [C.c_void_p]),
     'scfgp_pass3': (C.c_int, [C.c_void_p]),
     'scfgp_finish': (C.c_int, [C.c_void_p, C.c_int, _c_double_p, _c_double_p, _c_double_p, _c_double_p]),
+    'scfgp_fail_stage': (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     'scfgp_fetch_factors': (C.c_int, [C.c_void_p, _c_double_p, _c_double_p]),
     'scfgp_exchange': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), _c_i64_p]),
     'scfgp_stream_fence': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),

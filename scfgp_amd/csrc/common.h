@@ -31,6 +31,15 @@ enum {
     R_COUNT
 };
 
+// Status word of a row-sharded evaluation: slots of the 8 scalars that close every exchange buffer ([0..3] carry row sums: y^T y;
+// T2, kbar, ...; bbar).  Every rank writes its own 0 / 1 before the sum over ranks, so the summed slots COUNT ranks and every
+// rank reads the same numbers (include/scfgp_hip.h, "ranks decide together"):
+//   XS_RAN1  ranks whose pass 1 ran at precision level >= 1 (fp64 Gram)          exchange 1
+//   XS_CAP1  ranks that cannot reach level 1 (its row buffer was refused)        exchange 1
+//   XS_CAP2  ranks that cannot reach level 2                                     exchange 1
+//   XS_FAIL  ranks that could not compute this stage (scfgp_fail_stage)          exchanges 1, 2, 3
+enum { XS_RAN1 = 4, XS_CAP1 = 5, XS_CAP2 = 6, XS_FAIL = 7 };
+
 // Dynamic LDS above 64 KiB needs an explicit opt-in per kernel on HIP.
 extern thread_local bool g_scfgp_capturing;      // set while a hipGraph is being captured (scfgp_api.hip)
 template <typename Kern>

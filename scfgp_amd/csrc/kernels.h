@@ -160,6 +160,8 @@ void grad_epilogue(const Geom& g, const double* params, const double* F, const d
 // yy -> y^T y, t2kb -> (T2, kbar), bbar -> bbar: device scalars living in the exchange buffers
 void finalize_cost(const Geom& g, const Scal* sc, double* scalars, const double* yy, const double* t2kb, const double* bbar,
                    int64_t Nglobal, double* grad, int want_grad, hipStream_t st);
+// xs[XS_RAN1 .. XS_FAIL] = the four status slots of an exchange buffer's scalar tail (common.h)
+void write_status(double* xs, double ran1, double cap1, double cap2, double fail, hipStream_t st);
 // Xt (Np x Dp) = [X[idx] | 1 | 0], zero rows >= N; y padded with zeros; idx == NULL: rows in order
 // mode/sp: optional per-column input scaling (SCFGP/Scaler.py forward_transform) applied on the fly
 void pack_data(const Geom& g, const double* Xraw, const double* yraw, const int64_t* idx, double* Xt, double* y, hipStream_t st,

@@ -200,6 +200,13 @@ void grad_epilogue(const Geom& g, const double* params, const double* F, const d
                        1.0 / (double)Nglobal, grad, TZ, ldtz, XU, ldxu);
 }
 
+__global__ void status_kernel(double* __restrict__ xs, double ran1, double cap1, double cap2, double fail) {
+    if (threadIdx.x == 0) { xs[XS_RAN1] = ran1; xs[XS_CAP1] = cap1; xs[XS_CAP2] = cap2; xs[XS_FAIL] = fail; }
+}
+void write_status(double* xs, double ran1, double cap1, double cap2, double fail, hipStream_t st) {
+    hipLaunchKernelGGL(status_kernel, dim3(1), dim3(64), 0, st, xs, ran1, cap1, cap2, fail);
+}
+
 // cost and the three scalar gradient entries  (SCFGP.py:125-128)
 __global__ void finalize_kernel(const Scal* __restrict__ sc, double* __restrict__ scalars, const double* __restrict__ yy,
                                 const double* __restrict__ t2kb, const double* __restrict__ bbar, int M, double N,

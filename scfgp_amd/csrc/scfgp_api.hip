@@ -4,7 +4,25 @@
 #include "kernels.h"
 
 #include <dlfcn.h>
-#include <rccl/rccl.h>          // types only: the library is looked up at run time (scfgp_comm_init), no link-time dependency
+// RCCL: types and prototypes only -- the library is looked up at run time (scfgp_comm_init), no link-time dependency.  A ROCm
+// install without the RCCL development headers still builds: the handful of declarations used here are then spelled out
+// (they are RCCL's public, NCCL-compatible ABI).
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#else
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclFloat64 = 8 } ncclDataType_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+ncclResult_t ncclGetUniqueId(ncclUniqueId*);
+ncclResult_t ncclCommInitRank(ncclComm_t*, int, ncclUniqueId, int);
+ncclResult_t ncclAllReduce(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
+ncclResult_t ncclCommDestroy(ncclComm_t);
+const char* ncclGetErrorString(ncclResult_t);
+}
+#endif
 
 #include <algorithm>
 #include <cmath>
@@ -65,17 +83,26 @@ struct Rccl {
     decltype(&ncclGetUniqueId) get_id = nullptr; decltype(&ncclCommInitRank) init_rank = nullptr;
     decltype(&ncclAllReduce) all_reduce = nullptr; decltype(&ncclCommDestroy) destroy = nullptr;
     decltype(&ncclGetErrorString) err_string = nullptr;
+    bool resolved = false;
+    bool bind(void* from) {
+        get_id = (decltype(get_id))dlsym(from, "ncclGetUniqueId"); init_rank = (decltype(init_rank))dlsym(from, "ncclCommInitRank");
+        all_reduce = (decltype(all_reduce))dlsym(from, "ncclAllReduce"); destroy = (decltype(destroy))dlsym(from, "ncclCommDestroy");
+        err_string = (decltype(err_string))dlsym(from, "ncclGetErrorString");
+        return get_id && init_rank && all_reduce && destroy && err_string;
+    }
     Rccl() {
+        // a copy the process already carries, WHEREVER it was loaded from (a host framework bundles its own librccl under its
+        // own path and may have loaded it RTLD_GLOBAL): the global symbol scope first, then an already-mapped copy by soname
+        // (RTLD_NOLOAD; never promoted to RTLD_GLOBAL), and only then ROCm's copy, privately
+        if (dlsym(RTLD_DEFAULT, "ncclAllReduce") && bind(RTLD_DEFAULT)) { resolved = true; return; }
         const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
-        for (const char* n : names) if (!h) h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);     // a copy the process already has
+        for (const char* n : names) if (!h) h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL);
         for (const char* n : names) if (!h) h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
         if (!h) return;
-        get_id = (decltype(get_id))dlsym(h, "ncclGetUniqueId"); init_rank = (decltype(init_rank))dlsym(h, "ncclCommInitRank");
-        all_reduce = (decltype(all_reduce))dlsym(h, "ncclAllReduce"); destroy = (decltype(destroy))dlsym(h, "ncclCommDestroy");
-        err_string = (decltype(err_string))dlsym(h, "ncclGetErrorString");
-        if (!get_id || !init_rank || !all_reduce || !destroy || !err_string) h = nullptr;
+        if (bind(h)) resolved = true;
+        else { dlclose(h); h = nullptr; }
     }
-    bool ok() const { return h != nullptr; }
+    bool ok() const { return resolved; }
 };
 static Rccl& rccl() { static Rccl r; return r; }
 
@@ -95,6 +122,13 @@ struct scfgp_ctx {
         return fits && (lowrank_bwd == 1 || (lowrank_bwd < 0 && g.Dp >= 4 * g.Sp));
     }
     double* x3_scalars() { return d_x3 + (int64_t)Dpp * g.Jp; }
+    double* xs1() { return d_xp1 + n_pk + g.Kp; }                           // the 8 scalars that close exchange buffers 1 and 2
+    double* xs2() { return d_xp2 + n_pk + g.Kp; }
+    // Ranks decide together (common.h: XS_*).  `unsettled`: a precision level was raised (or refused) since the last sum over
+    // ranks, so the next exchange 1 carries every rank's attainable level and scfgp_factor commits to the lowest before pass 2
+    // runs; cap(): the highest level this rank can run at.  test_*: fault injection for the tests (scfgp_set_option).
+    bool unsettled = false; int test_deny_level = 0, test_fail_stage = 0;
+    int cap() const { return esc_denied > 0 ? esc_denied - 1 : 2; }
     double* x3_xu() { return d_x3 + (int64_t)Dpp * g.Jp + 8; }
     hipEvent_t ev_fence = nullptr;                                          // scfgp_stream_fence
     ncclComm_t comm = nullptr; int comm_ranks = 0, comm_rank = 0;           // scfgp_comm_init: the three sums run inside the library
@@ -490,7 +524,8 @@ template <typename T> struct Impl {
         { ProfScope ps(c, "featuremap"); SK::featuremap(g, c->d_Xt, proj, c->d_sc, (T*)c->d_Phi, c->st); }
         if (!use64) gram_to(c, (const T*)c->d_Phi, nullptr, c->d_y, c->d_xp1, "gram");
         c->last_used64 = use64 || sizeof(T) == 8; c->last_level = sizeof(T) == 8 ? 0 : c->level();
-        HIPCHK(c, hipMemcpyAsync(c->d_xp1 + c->n_pk + g.Kp, c->d_yy, sizeof(double), hipMemcpyDeviceToDevice, c->st));
+        HIPCHK(c, hipMemcpyAsync(c->xs1(), c->d_yy, sizeof(double), hipMemcpyDeviceToDevice, c->st));
+        write_status(c->xs1(), c->last_level >= 1 ? 1.0 : 0.0, c->cap() < 1 ? 1.0 : 0.0, c->cap() < 2 ? 1.0 : 0.0, 0.0, c->st);
         HIPCHK(c, hipGetLastError());
         return SCFGP_OK;
     }
@@ -524,7 +559,8 @@ template <typename T> struct Impl {
         const int nb = (int)std::min<int64_t>(g.Np / 4, 2048);
         { ProfScope ps(c, "rowstats");
           SK::rowstats(g, c->d_mu, c->d_vpart, c->d_y, c->d_sc, c->d_p, c->d_q, c->d_partial, nb, c->st);
-          reduce_scalars(c->d_partial, nb, 2, c->d_xp2 + c->n_pk + g.Kp, 0, c->st); }
+          reduce_scalars(c->d_partial, nb, 2, c->xs2(), 0, c->st);
+          write_status(c->xs2(), 0.0, 0.0, 0.0, 0.0, c->st); }
         if (want_grad) {
             // factor form: C^T diag(q) C and C^T p (the K x K stage turns them into B W B and u); else V^T diag(q) V = B W B, V^T p = u
             gram_to(c, c->last_cform ? (const T*)c->d_C : (const T*)c->d_V, c->d_q, c->d_p, c->d_xp2, "gram_w");
@@ -546,7 +582,8 @@ template <typename T> struct Impl {
         { ProfScope ps(c, "apply_phibar");
           const int nb = SK::apply_phibar(g, (const T*)c->d_Phi, (const T*)c->d_AbarT, (T*)c->d_V, c->d_p, c->d_q, c->d_y, c->alpha(), c->ut(),
                                           c->d_bpart, c->st, c->dma());
-          reduce_scalars(c->d_bpart, nb, 1, c->x3_scalars(), 0, c->st); }
+          reduce_scalars(c->d_bpart, nb, 1, c->x3_scalars(), 0, c->st);
+          write_status(c->x3_scalars(), 0.0, 0.0, 0.0, 0.0, c->st); }
         const int ntm = c->Dpp / XT, ntn = g.Jp / XT;
         const int64_t chunk = c->dtype == SCFGP_F32 ? c->gram_chunk : 0;
         c->last_lrb = c->want_lrb();
@@ -613,10 +650,51 @@ static int comm_sum(scfgp_ctx* c, int stage, const char* name) {
     return SCFGP_OK;
 }
 
+// test-only fault injection (option "test_fail_stage"): the next call of sweep `stage` fails before it enqueues anything
+static int injected_failure(scfgp_ctx* c, int stage) {
+    if (c->test_fail_stage != stage) return SCFGP_OK;
+    c->test_fail_stage = 0;
+    c->err = "pass" + std::to_string(stage) + ": injected failure (option test_fail_stage)";
+    return SCFGP_EHIP;
+}
+
+// Ranks commit to ONE precision level (auto policy of fp32 mode).  A level is raised when the condition estimate asks for it --
+// the estimate comes from the summed matrix, so every rank tries at the same evaluation -- but whether the row buffers of the
+// level can be allocated is a rank's own affair.  The evaluation after such an attempt therefore carries, in the scalar tail of
+// exchange 1 (common.h: XS_CAP1, XS_CAP2, XS_RAN1), how many ranks cannot reach level 1 / level 2 and how many formed their
+// pass-1 Gram in fp64; once the sum over ranks is there every rank reads the same counts and
+//   * takes the lowest attainable level as its own limit (a refusal anywhere is then recorded everywhere),
+//   * continues if pass 1 of every rank already had the form of that level (levels 1 and 2 share pass 1),
+//   * else asks for the stages again (SCFGP_REDO) -- all ranks do, the refusing one included --
+// before pass 2, whose exchange would otherwise sum C^T diag(q) C on one rank with B W B on another.  One stream
+// synchronisation, in that evaluation only.  Without peers the counts are the context's own and nothing changes.
+static int settle_level(scfgp_ctx* c) {
+    if (!c->unsettled || c->dtype != SCFGP_F32 || c->gram64 != 2) { c->unsettled = false; return SCFGP_OK; }
+    double xs[8];
+    HIPCHK(c, hipMemcpyAsync(xs, c->xs1(), sizeof(xs), hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    c->unsettled = false;
+    const int agreed = xs[XS_CAP1] > 0.5 ? 0 : (xs[XS_CAP2] > 0.5 ? 1 : 2);
+    if (agreed < c->cap()) {
+        c->esc_denied = agreed + 1;
+        c->err = "precision level " + std::to_string(agreed + 1) + " refused on another rank; every rank stays at level " + std::to_string(agreed) + " or below";
+    }
+    if (c->esc_level > agreed) {
+        c->esc_level = agreed;
+        if (c->gexec) { hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
+        if (c->graph) { hipGraphDestroy(c->graph); c->graph = nullptr; }
+        c->warm = false;
+    }
+    if (agreed < 1 && xs[XS_RAN1] > 0.5) { c->stage = 0; return SCFGP_REDO; }   // some rank's G is an fp64 one: everybody forms it again in fp32
+    c->last_cform = c->want_cform(); c->last_level = c->level();               // pass 2 in the form of the agreed level
+    return SCFGP_OK;
+}
+
 extern "C" int scfgp_pass1(scfgp_ctx* c) {
     if (int rc = ready(c)) return rc;
     if (int rc = restore_full_set(c)) return rc;
     if (c->prof) { c->recs.clear(); c->pool_used = 0; }
+    if (int rc = injected_failure(c, 1)) return rc;
     if (int rc = DISPATCH(c, pass1, c)) return rc;
     c->stage = 1;
     return comm_sum(c, 1, "exchange1");
@@ -624,6 +702,7 @@ extern "C" int scfgp_pass1(scfgp_ctx* c) {
 extern "C" int scfgp_factor(scfgp_ctx* c) {
     if (int rc = ready(c)) return rc;
     if (c->stage != 1) { c->err = "factor: call pass1 first"; return SCFGP_EARG; }
+    if (int rc = settle_level(c)) return rc;                     // SCFGP_REDO: start again at scfgp_pass1
     if (int rc = DISPATCH(c, factor, c)) return rc;
     if (!g_scfgp_capturing) HIPCHK(c, hipEventRecord(c->ev_factor, c->st));
     c->stage = 2; return SCFGP_OK;
@@ -631,6 +710,7 @@ extern "C" int scfgp_factor(scfgp_ctx* c) {
 extern "C" int scfgp_pass2(scfgp_ctx* c, int want_grad) {
     if (int rc = ready(c)) return rc;
     if (c->stage != 2) { c->err = "pass2: call factor first"; return SCFGP_EARG; }
+    if (int rc = injected_failure(c, 2)) return rc;
     if (int rc = DISPATCH(c, pass2, c, want_grad)) return rc;
     c->last_want_grad = want_grad; c->stage = 3;
     return comm_sum(c, 2, "exchange2");
@@ -644,9 +724,35 @@ extern "C" int scfgp_adjoint(scfgp_ctx* c) {
 extern "C" int scfgp_pass3(scfgp_ctx* c) {
     if (int rc = ready(c)) return rc;
     if (c->stage != 4) { c->err = "pass3: call adjoint first"; return SCFGP_EARG; }
+    if (int rc = injected_failure(c, 3)) return rc;
     if (int rc = DISPATCH(c, pass3, c)) return rc;
     c->stage = 5;
     return comm_sum(c, 3, "exchange3");
+}
+
+// A rank that cannot compute sweep `stage` of the evaluation in progress still owes its peers the sum that ends the sweep:
+// this marks exchange buffer `stage` as failed (XS_FAIL; its other contents are whatever they were) and, with a communicator
+// attached, enqueues the all-reduce.  Called for every remaining exchange of the evaluation (want_grad sizes exchange 2 and
+// decides whether there is a third), it lets the peers run to their scfgp_finish, where the summed XS_FAIL makes all of them
+// return SCFGP_EPEER -- nobody waits in a collective for a rank that has left.  A sticky HIP error
+// (a faulted kernel) cannot be helped this way: the calls below fail too.
+extern "C" int scfgp_fail_stage(scfgp_ctx* c, int stage, int want_grad) {
+    if (!c || stage < 1 || stage > 3 || (stage == 3 && !want_grad)) return SCFGP_EARG;
+    const std::string keep = c->err;                             // the caller still wants the message of what failed
+    if (hipSetDevice(c->device) != hipSuccess) return SCFGP_EHIP;
+    c->last_want_grad = want_grad;
+    double* xs = stage == 1 ? c->xs1() : (stage == 2 ? c->xs2() : c->x3_scalars());
+    write_status(xs, 0.0, c->cap() < 1 ? 1.0 : 0.0, c->cap() < 2 ? 1.0 : 0.0, 1.0, c->st);
+    const int rc = comm_sum(c, stage, stage == 1 ? "exchange1" : (stage == 2 ? "exchange2" : "exchange3"));
+    c->stage = 0;
+    if (rc == SCFGP_OK) c->err = keep;
+    return rc;
+}
+// the exchanges of the evaluation in progress that have not been summed yet, all failed (native sums: scfgp_eval, scfgp_train)
+static void fail_rest(scfgp_ctx* c, int want_grad) {
+    const int st = c->stage, next = st < 1 ? 1 : (st < 3 ? 2 : (st < 5 ? 3 : 4));
+    for (int s = next; s <= (want_grad ? 3 : 2); ++s)
+        if (scfgp_fail_stage(c, s, want_grad) != SCFGP_OK) return;
 }
 
 extern "C" int scfgp_exchange(scfgp_ctx* c, int stage, void** dev_ptr, int64_t* count) {
@@ -719,19 +825,26 @@ static int update_level(scfgp_ctx* c, bool notpd, bool want_grad, bool may_redo 
     if (top > c->esc_level) {
         // the buffers of the higher level first; the level is committed only when they exist.  If they cannot be allocated
         // (~17 GB at the headline shape for level 1, N Kp 4 bytes more for level 2) the context stays usable at the level below:
-        // scfgp_get_condition keeps reporting the estimate and the predicted error, last_error says what was refused.  A
-        // row-sharded caller must treat that message as fatal: the ranks would no longer agree on the level.
+        // scfgp_get_condition keeps reporting the estimate and the predicted error, last_error says what was refused.  Row
+        // shards: every rank is at this point in the same evaluation (the estimate is the summed matrix's), and the next
+        // exchange 1 tells them all what each could allocate (settle_level) -- until then the level is `unsettled`.
         const int old = c->esc_level;
+        c->unsettled = true;
         for (int lvl = top; lvl > old; --lvl) {                  // level 2 refused: level 1 may still fit
             c->esc_level = lvl;
-            if (ensure_aux_rows(c) == SCFGP_OK) break;
+            if (!(c->test_deny_level > 0 && lvl >= c->test_deny_level) && ensure_aux_rows(c) == SCFGP_OK) break;
+            if (c->test_deny_level > 0 && lvl >= c->test_deny_level) c->err = "refused by option test_deny_level";
             (void)hipGetLastError();
             c->esc_level = lvl - 1; c->esc_denied = lvl;
             c->err = "precision level " + std::to_string(lvl) + " refused (auxiliary row buffers could not be allocated); staying at level " +
                      std::to_string(lvl - 1) + ": " + c->err;
         }
     }
-    want = std::min(want, std::max(c->esc_level, 0));
+    // Whether the evaluation is repeated depends on `top` -- the demand of the summed estimate under the limit the ranks last agreed
+    // on, the same number on every rank -- and NOT on what this rank could allocate just now: a rank whose buffers were refused
+    // repeats with the others (at its lower level) and tells them in the next exchange 1 (settle_level); deciding from its own
+    // outcome it would return while they wait for it in that exchange.
+    want = top;
     // level 2 only serves the gradient: a forward-only evaluation at level 1 is final
     if (may_redo && (want_grad ? want : std::min(want, 1)) > c->last_level) {
         if (c->gexec) { hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
@@ -764,9 +877,12 @@ extern "C" int scfgp_finish(scfgp_ctx* c, int want_grad, double* cost, double* g
     if ((want_grad && c->stage != 5) || (!want_grad && c->stage != 3)) { c->err = "finish: evaluation incomplete"; return SCFGP_EARG; }
     const Geom& g = c->g;
     enqueue_epilogue(c, want_grad);
-    double h_cost = 0; int h_flag[4] = {0, 0, 0, 0};
+    double h_cost = 0, h_fail[3] = {0, 0, 0}; int h_flag[4] = {0, 0, 0, 0};
     {
         ProfScope ps(c, "d2h");
+        HIPCHK(c, hipMemcpyAsync(&h_fail[0], c->xs1() + XS_FAIL, sizeof(double), hipMemcpyDeviceToHost, c->st));
+        HIPCHK(c, hipMemcpyAsync(&h_fail[1], c->xs2() + XS_FAIL, sizeof(double), hipMemcpyDeviceToHost, c->st));
+        if (want_grad) HIPCHK(c, hipMemcpyAsync(&h_fail[2], c->x3_scalars() + XS_FAIL, sizeof(double), hipMemcpyDeviceToHost, c->st));
         HIPCHK(c, hipMemcpyAsync(&h_cost, c->d_scalars + R_COST, sizeof(double), hipMemcpyDeviceToHost, c->st));
         HIPCHK(c, hipMemcpyAsync(c->cond, c->d_scalars + R_LMIN2, sizeof(double) * 3, hipMemcpyDeviceToHost, c->st));
         HIPCHK(c, hipMemcpyAsync(h_flag, c->d_flag, sizeof(int) * 4, hipMemcpyDeviceToHost, c->st));
@@ -779,6 +895,12 @@ extern "C" int scfgp_finish(scfgp_ctx* c, int want_grad, double* cost, double* g
     HIPCHK(c, hipGetLastError());
     c->stage = 0; c->warm = true;
     if (cost) *cost = h_cost;
+    if (h_fail[0] + h_fail[1] + h_fail[2] > 0.5) {              // summed over the ranks: the same verdict everywhere, no level decision from it
+        c->cond_valid = false;
+        c->err = "a rank failed in this evaluation (exchange 1 / 2 / 3: " + std::to_string((int)h_fail[0]) + " / " + std::to_string((int)h_fail[1]) +
+                 " / " + std::to_string((int)h_fail[2]) + " ranks): its results are not valid on any rank";
+        return SCFGP_EPEER;
+    }
     if (int rc = update_level(c, h_flag[0] != 0, want_grad != 0)) return rc;    // SCFGP_REDO: repeat the evaluation at the higher level
     c->cond_valid = true;
     if (h_flag[0]) { c->err = "Phi^T Phi + (e^{2a}+1e-6) I is not positive definite"; return SCFGP_ENOTPD; }
@@ -789,19 +911,23 @@ extern "C" int scfgp_finish(scfgp_ctx* c, int want_grad, double* cost, double* g
 static int pass1_current(scfgp_ctx* c) {                  // pass 1 on the working set as it stands (full or gathered)
     if (int rc = ready(c)) return rc;
     if (c->prof) { c->recs.clear(); c->pool_used = 0; }
+    if (int rc = injected_failure(c, 1)) return rc;
     if (int rc = DISPATCH(c, pass1, c)) return rc;
     c->stage = 1;
     return comm_sum(c, 1, "exchange1");
 }
 static int run_eval(scfgp_ctx* c, int want_grad, double* cost, double* grad, double* alpha, double* Li, bool subset = false) {
     int rc = SCFGP_OK;
-    for (int attempt = 0; attempt < 3; ++attempt) {              // at most two escalations (levels 0 -> 1 -> 2)
-        if ((rc = subset ? pass1_current(c) : scfgp_pass1(c))) return rc;
-        if ((rc = scfgp_factor(c))) return rc;
-        if ((rc = scfgp_pass2(c, want_grad))) return rc;
+    // with the sums inside the library a rank that fails still posts the remaining all-reduces of the evaluation (fail_rest)
+    const auto leave = [&](int code) { if (code < 0 && c->comm) fail_rest(c, want_grad); return code; };
+    for (int attempt = 0; attempt < 5; ++attempt) {              // at most two escalations (levels 0 -> 1 -> 2) and their settling
+        if ((rc = subset ? pass1_current(c) : scfgp_pass1(c))) return leave(rc);
+        if ((rc = scfgp_factor(c)) == SCFGP_REDO) continue;       // the ranks agreed on a lower level than some of them ran pass 1 at
+        if (rc) return leave(rc);
+        if ((rc = scfgp_pass2(c, want_grad))) return leave(rc);
         if (want_grad) {
-            if ((rc = scfgp_adjoint(c))) return rc;
-            if ((rc = scfgp_pass3(c))) return rc;
+            if ((rc = scfgp_adjoint(c))) return leave(rc);
+            if ((rc = scfgp_pass3(c))) return leave(rc);
         }
         // everything is queued: the factor outputs now stream to the host beside passes 2 and 3
         if ((alpha || Li) && (rc = scfgp_fetch_factors(c, alpha, Li))) return rc;
@@ -1010,6 +1136,7 @@ extern "C" int scfgp_opt_state(scfgp_ctx* c, int set, int which, double* buf) {
 extern "C" int scfgp_opt_step(scfgp_ctx* c, const double* grad, int P) {
     if (!c || !grad || P != c->g.P) { if (c) c->err = "opt_step: wrong gradient length"; return SCFGP_EARG; }
     if (c->opt_algo < 0 || !c->have_params) { c->err = "opt_step: call scfgp_set_params and scfgp_opt_init first"; return SCFGP_EARG; }
+    if (c->stage != 0) { c->err = "opt_step: a staged evaluation is in progress (finish it first: its later stages would run on other parameters)"; return SCFGP_EARG; }
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpyAsync(c->d_grad, grad, sizeof(double) * P, hipMemcpyHostToDevice, c->st));
     opt_update(c->opt_algo, c->opt_h, P, c->d_params, c->d_grad, c->d_opt, c->d_tctr, c->d_scalars, nullptr, 0, c->st);
@@ -1021,13 +1148,29 @@ extern "C" int scfgp_opt_step(scfgp_ctx* c, const double* grad, int P) {
     return SCFGP_OK;
 }
 
+// One training iteration, enqueued.  With a communicator attached the three sums over ranks are part of it (ncclAllReduce on
+// the context's stream right behind each sweep); every rank then applies the same deterministic rule to the same summed
+// gradient, so the parameter vectors stay bit-equal without a broadcast.  c->stage follows the sweeps so that a failing rank
+// can tell which exchanges it still owes (fail_rest).
 static int enqueue_train_iter(scfgp_ctx* c) {
     int rc;
+    c->stage = 0; c->last_want_grad = 1;
+    if ((rc = injected_failure(c, 1))) return rc;
     if ((rc = DISPATCH(c, pass1, c))) return rc;
+    c->stage = 1;
+    if ((rc = comm_sum(c, 1, "exchange1"))) return rc;
     if ((rc = DISPATCH(c, factor, c))) return rc;
+    c->stage = 2;
+    if ((rc = injected_failure(c, 2))) return rc;
     if ((rc = DISPATCH(c, pass2, c, 1))) return rc;
+    c->stage = 3;
+    if ((rc = comm_sum(c, 2, "exchange2"))) return rc;
     if ((rc = DISPATCH(c, adjoint, c))) return rc;
+    c->stage = 4;
+    if ((rc = injected_failure(c, 3))) return rc;
     if ((rc = DISPATCH(c, pass3, c))) return rc;
+    c->stage = 5;
+    if ((rc = comm_sum(c, 3, "exchange3"))) return rc;
     enqueue_epilogue(c, 1);
     opt_update(c->opt_algo, c->opt_h, c->g.P, c->d_params, c->d_grad, c->d_opt, c->d_tctr, c->d_scalars, c->d_hist, c->hist_cap, c->st);
     unpack_params(c->g, c->d_params, c->d_F, c->d_Fall, c->d_Lall, c->d_Rall, c->d_sc, c->st);
@@ -1038,7 +1181,6 @@ static int enqueue_train_iter(scfgp_ctx* c) {
 extern "C" int scfgp_train(scfgp_ctx* c, int n_iters, double* cost_hist, double* alpha, double* Li) {
     if (int rc = ready(c)) return rc;
     if (c->opt_algo < 0 || n_iters < 1) { c->err = "train: call scfgp_opt_init first"; return SCFGP_EARG; }
-    if (c->comm) { c->err = "train: the on-device training loop is single-GPU; with a communicator use scfgp_eval + scfgp_opt_step"; return SCFGP_EARG; }
     if (int rc = restore_full_set(c)) return rc;
     const Geom& g = c->g;
     if (n_iters > c->hist_cap) {
@@ -1050,21 +1192,34 @@ extern "C" int scfgp_train(scfgp_ctx* c, int n_iters, double* cost_hist, double*
     }
     // auto precision level, condition of the current parameters unknown (no evaluation since they or the rows were set):
     // one pass 1 + factor stage as a probe, so that the iterations of this call run at the level their first one needs
-    if (c->dtype == SCFGP_F32 && c->gram64 == 2 && !c->cond_valid) {
+    // (row shards: the probe ends in exchange 1 like any pass 1, and a level raised or refused since the last sum over ranks
+    // is settled here, before the iterations -- possibly one captured graph -- are enqueued)
+    for (int round = 0; round < 5 && c->dtype == SCFGP_F32 && c->gram64 == 2 && (!c->cond_valid || c->unsettled); ++round) {
         int rc;
         if ((rc = DISPATCH(c, pass1, c))) return rc;
+        c->stage = 1;
+        if ((rc = comm_sum(c, 1, "exchange1"))) return rc;
+        if ((rc = settle_level(c)) == SCFGP_REDO) continue;
+        if (rc) return rc;
         if ((rc = DISPATCH(c, factor, c))) return rc;
-        int h_flag[4] = {0, 0, 0, 0};
+        int h_flag[4] = {0, 0, 0, 0}; double h_fail = 0;
         HIPCHK(c, hipMemcpyAsync(c->cond, c->d_scalars + R_LMIN2, sizeof(double) * 3, hipMemcpyDeviceToHost, c->st));
         HIPCHK(c, hipMemcpyAsync(h_flag, c->d_flag, sizeof(int) * 4, hipMemcpyDeviceToHost, c->st));
+        HIPCHK(c, hipMemcpyAsync(&h_fail, c->xs1() + XS_FAIL, sizeof(double), hipMemcpyDeviceToHost, c->st));
         HIPCHK(c, hipStreamSynchronize(c->st));
+        c->stage = 0;
+        if (h_fail > 0.5) { c->err = "train: a rank failed in the probe evaluation"; return SCFGP_EPEER; }
         if ((rc = update_level(c, h_flag[0] != 0, true, false))) return rc;
+        c->cond_valid = true;
     }
+    if (c->unsettled) { c->err = "train: the ranks' precision level did not settle"; return SCFGP_EHIP; }
     HIPCHK(c, hipMemsetAsync(c->d_flag, 0, sizeof(int) * 4, c->st));
     HIPCHK(c, hipMemsetAsync(c->d_tctr + 1, 0, sizeof(double), c->st));
     c->in_train = true;
     int rc = SCFGP_OK, done = 0;
-    const bool graph_ok = c->use_graph && !c->prof;
+    // the captured iteration: always without a communicator; with one only on request (option use_graph = 2) -- capturing
+    // ncclAllReduce is RCCL's business and has not run here with more than one rank, eager launches queue far ahead of the GPU anyway
+    const bool graph_ok = c->use_graph && !c->prof && (!c->comm || c->use_graph >= 2);
     if (graph_ok && !c->warm) {                                  // first touch of every kernel: eager
         rc = enqueue_train_iter(c); done = 1;
         if (rc == SCFGP_OK) c->warm = true;
@@ -1095,8 +1250,20 @@ extern "C" int scfgp_train(scfgp_ctx* c, int n_iters, double* cost_hist, double*
         rc = enqueue_train_iter(c);
     }
     c->in_train = false;
-    if (rc != SCFGP_OK) return rc;
-    int h_flag[4] = {0, 0, 0, 0};
+    if (rc != SCFGP_OK) {
+        // the peers are enqueueing all n_iters iterations: this rank owes them every remaining sum (XS_FAIL set), or they wait
+        // in an all-reduce for good; they learn of it from the summed XS_FAIL when their call ends
+        if (c->comm && rc < 0) {
+            fail_rest(c, 1);
+            for (; done < n_iters; ++done) { c->stage = 0; fail_rest(c, 1); }
+        }
+        c->stage = 0;
+        return rc;
+    }
+    int h_flag[4] = {0, 0, 0, 0}; double h_fail[3] = {0, 0, 0};
+    HIPCHK(c, hipMemcpyAsync(&h_fail[0], c->xs1() + XS_FAIL, sizeof(double), hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipMemcpyAsync(&h_fail[1], c->xs2() + XS_FAIL, sizeof(double), hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipMemcpyAsync(&h_fail[2], c->x3_scalars() + XS_FAIL, sizeof(double), hipMemcpyDeviceToHost, c->st));
     if (cost_hist) HIPCHK(c, hipMemcpyAsync(cost_hist, c->d_hist, sizeof(double) * n_iters, hipMemcpyDeviceToHost, c->st));
     HIPCHK(c, hipMemcpyAsync(c->h_params.data(), c->d_params, sizeof(double) * g.P, hipMemcpyDeviceToHost, c->st));
     HIPCHK(c, hipMemcpyAsync(h_flag, c->d_flag, sizeof(int) * 4, hipMemcpyDeviceToHost, c->st));
@@ -1107,6 +1274,11 @@ extern "C" int scfgp_train(scfgp_ctx* c, int n_iters, double* cost_hist, double*
     HIPCHK(c, hipStreamSynchronize(c->st));
     HIPCHK(c, hipGetLastError());
     c->stage = 0;
+    if (h_fail[0] + h_fail[1] + h_fail[2] > 0.5) {
+        c->cond_valid = false;
+        c->err = "train: a rank failed; parameters and optimiser state of this call are not valid on any rank";
+        return SCFGP_EPEER;
+    }
     // the precision level is fixed inside one call; the last iteration's condition estimate sets it for the next call
     if (int rc = update_level(c, h_flag[0] != 0, true, false)) return rc;
     c->cond_valid = true;
@@ -1220,6 +1392,8 @@ extern "C" int scfgp_set_option(scfgp_ctx* c, const char* name, int64_t value) {
     else if (s == "cond_threshold") c->esc_thr = (double)value;
     else if (s == "cond_threshold_w") c->escw_thr = (double)value;
     else if (s == "roctx") c->roctx_on = value != 0;
+    else if (s == "test_deny_level") { c->test_deny_level = (int)value; return SCFGP_OK; }       // tests: levels >= value are refused as if out of memory
+    else if (s == "test_fail_stage") { c->test_fail_stage = (int)value; return SCFGP_OK; }       // tests: the next sweep `value` (1..3) fails
     else { c->err = "unknown option " + s; return SCFGP_EARG; }
     // kernels not run so far, buffers not allocated so far: the next scfgp_train starts with an eager iteration again
     c->warm = false; c->cond_valid = false;
@@ -1254,9 +1428,13 @@ extern "C" int64_t scfgp_debug_read(scfgp_ctx* c, const char* name, void* host, 
     const int64_t K2 = (int64_t)g.Kp * g.Kp;
     const size_t ts = c->tsize();
     const void* src = nullptr; int64_t bytes = 0;
+    DevTmp tmp;
     if (s == "Phi") { src = c->d_Phi; bytes = ts * g.Np * g.Kp; }
     else if (s == "V") { src = c->d_V; bytes = ts * g.Np * g.Kp; }
-    else if (s == "G") { if (c->stage == 1) unpack_exchange(c, c->d_xp1, c->d_x1); src = c->d_x1; bytes = 8 * c->n_x1; }
+    else if (s == "G") {                                         // exchange buffer 1 unpacked into a buffer of its own: d_x1 is the
+        if (dmalloc(c, &tmp.p, 8 * c->n_x1)) return SCFGP_EHIP;  // factorisation's working matrix from scfgp_factor on
+        unpack_exchange(c, c->d_xp1, tmp.p); src = tmp.p; bytes = 8 * c->n_x1;
+    }
     else if (s == "W") { if (c->stage == 3) unpack_exchange(c, c->d_xp2, c->d_x2); src = c->d_x2; bytes = 8 * c->n_x2; }
     else if (s == "XZ") { src = c->d_x3; bytes = 8 * c->n_x3; }
     else if (s == "Li") { src = c->d_Li; bytes = 8 * K2; }

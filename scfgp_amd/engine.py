@@ -23,6 +23,10 @@ def num_params(D, S, M):
     return 3 + D * S + M * S + S + M
 
 
+class PeerFailed(RuntimeError):
+    """Row shards: another rank failed in this evaluation (SCFGP_EPEER); no rank's results are valid."""
+
+
 class HipEngine(object):
 
     def __init__(self, D, S, M, dtype='f64', device=0, stream=None):
@@ -74,6 +78,8 @@ class HipEngine(object):
             raise FloatingPointError('%s: %s' % (what, msg))
         if rc == -1:
             raise ValueError('%s: %s' % (what, msg))
+        if rc == _lib.SCFGP_EPEER:
+            raise PeerFailed('%s: %s' % (what, msg))
         raise RuntimeError('%s failed (%d, %s): %s' % (what, rc, _lib.ERRORS.get(rc, '?'), msg))
 
     # -- state --------------------------------------------------------------------------
@@ -230,8 +236,20 @@ class HipEngine(object):
         self._check(self.lib.scfgp_pass1(self.ctx), 'pass1')
 
     def factor(self):
-        self._check(self.lib.scfgp_factor(self.ctx), 'factor')
+        """False when the library asks for the stages again from pass1 (SCFGP_REDO: the ranks have just agreed on a lower
+        precision level than some of them ran pass 1 at -- every rank gets the same answer); True otherwise."""
+        rc = self.lib.scfgp_factor(self.ctx)
         self._early = None
+        if rc == _lib.SCFGP_REDO:
+            return False
+        self._check(rc, 'factor')
+        return True
+
+    def fail_stage(self, stage, want_grad=True):
+        """This rank cannot compute sweep `stage` (1..3) of the evaluation in progress: mark its exchange buffer failed and, with
+        a communicator attached, run the sum -- so that the peers reach their finish() and raise PeerFailed there instead of
+        waiting in a collective (include/scfgp_hip.h, "ranks decide together")."""
+        self._check(self.lib.scfgp_fail_stage(self.ctx, int(stage), int(bool(want_grad))), 'fail_stage')
 
     def fetch_factors(self):
         """Fetch alpha / Li as soon as the factor stage is done (overlaps the sweeps already queued); finish() returns them."""
@@ -347,6 +365,10 @@ class HipEngine(object):
         out = np.zeros(len(self.CONDITION))
         self._check(self.lib.scfgp_get_condition(self.ctx, dptr(out), out.size), 'get_condition')
         return dict(zip(self.CONDITION, out.tolist()))
+
+    def last_error(self):
+        """Message of the last failure -- or refusal (a precision level whose buffers could not be had) -- on this context."""
+        return self.lib.scfgp_last_error(self.ctx).decode()
 
     def set_profiling(self, on=True):
         self._check(self.lib.scfgp_set_profiling(self.ctx, int(bool(on))), 'set_profiling')

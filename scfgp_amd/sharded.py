@@ -125,18 +125,37 @@ class ShardedEvaluator(object):
         except ImportError:
             return False
 
+    def _fail_rest(self, owed, want_grad):
+        """This rank's evaluation has failed with the exchanges `owed`.. still to come: mark each as failed and run its sum
+        anyway (engine.fail_stage does the sum itself when the communicator lives inside the library), so that the peers reach
+        their finish() -- which then raises PeerFailed on every one of them -- instead of waiting in a collective."""
+        e = self.engine
+        if not hasattr(e, 'fail_stage'):
+            return
+        for stage in range(owed, 4 if want_grad else 3):
+            e.fail_stage(stage, want_grad)
+            self._sum(stage)
+
     def eval(self, want_grad=True):
         e = self.engine
-        for _ in range(3):
-            e.pass1(); self._sum(1)
-            e.factor()
-            e.pass2(want_grad); self._sum(2)
-            if want_grad:
-                e.adjoint()
-                e.pass3(); self._sum(3)
+        for _ in range(5):
+            owed = 1                        # the next exchange this rank owes its peers
+            try:
+                e.pass1(); self._sum(1); owed = 2
+                # False: the summed status word of exchange 1 says some rank cannot run the precision level others ran
+                # pass 1 at -- every rank reads the same word and starts again at the common level
+                if e.factor() is False:
+                    continue
+                e.pass2(want_grad); self._sum(2); owed = 3
+                if want_grad:
+                    e.adjoint()
+                    e.pass3(); self._sum(3); owed = 4
+            except Exception:
+                self._fail_rest(owed, want_grad)
+                raise
             if hasattr(e, 'fetch_factors'):
                 e.fetch_factors()           # everything is queued: alpha / Li reach the host beside the remaining sweeps
-            out = e.finish(want_grad)
+            out = e.finish(want_grad)       # raises engine.PeerFailed on every rank when any rank failed
             # None: the library raised its precision level (condition estimate of A too high for an fp32 Gram) and wants
             # the stages again.  Every rank factors the same summed matrix, so every rank takes the same decision.
             if out is not None:

@@ -45,7 +45,7 @@ def stages(name, dtype):
     G = x1[:Kp * Kp].reshape(Kp, Kp)
     out.append(('G', rel(G[:K, :K], ora.x1[:K * K].reshape(K, K))))
     out.append(('g', rel(x1[Kp * Kp:Kp * Kp + K], ora.x1[K * K:K * K + K])))
-    out.append(('yy', abs(x1[Kp * Kp + Kp] - ora.x1[-1]) / abs(ora.x1[-1])))
+    out.append(('yy', abs(x1[Kp * Kp + Kp] - ora.x1[K * K + K]) / abs(ora.x1[K * K + K])))
     eng.factor(); ora.factor()
     Li = eng.debug_read('Li', (Kp, Kp)); B = eng.debug_read('B', (Kp, Kp)); vecs = eng.debug_read('vecs', (5, Kp))
     out.append(('Li', rel(Li[:K, :K], ora.Li)))
@@ -58,7 +58,7 @@ def stages(name, dtype):
     x2 = eng.debug_read('W', (Kp * Kp + Kp + 8,))
     out.append(('W', rel(x2[:Kp * Kp].reshape(Kp, Kp)[:K, :K], ora.x2[:K * K].reshape(K, K))))
     out.append(('h', rel(x2[Kp * Kp:Kp * Kp + K], ora.x2[K * K:K * K + K])))
-    out.append(('T2kb', rel(x2[Kp * Kp + Kp:Kp * Kp + Kp + 2], ora.x2[-2:])))
+    out.append(('T2kb', rel(x2[Kp * Kp + Kp:Kp * Kp + Kp + 2], ora.x2[K * K + K:K * K + K + 2])))
     eng.adjoint(); ora.adjoint()
     Abar = eng.debug_read('Abar', (Kp, Kp))
     out.append(('Abar', rel(Abar[:K, :K], ora.Abar)))
@@ -68,7 +68,7 @@ def stages(name, dtype):
     XZ = x3[:Dpp * Jp].reshape(Dpp, Jp)
     out.append(('XZ', rel(XZ[:D, :J], ora.x3[:D * J].reshape(D, J))))
     out.append(('colsumZ', float(np.abs(XZ[D, :J] - ora.x3[D * J:D * J + J]).max())))
-    out.append(('bbar', abs(x3[Dpp * Jp] - ora.x3[-1]) / max(1.0, abs(ora.x3[-1]))))
+    out.append(('bbar', abs(x3[Dpp * Jp] - ora.x3[D * J + J]) / max(1.0, abs(ora.x3[D * J + J]))))
     cost, grad, alpha, Li_h = eng.finish(True)
     c_o, g_o, al_o, Li_o = ora.finish(True)
     out.append(('cost', abs(cost - c_o) / abs(c_o)))

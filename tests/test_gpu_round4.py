@@ -212,7 +212,7 @@ def test_sums_inside_the_library_with_a_one_rank_communicator(dtype):
     """scfgp_comm_unique_id / scfgp_comm_init (include/scfgp_hip.h): with a communicator attached the staged calls end in their
     own ncclAllReduce on the library's stream.  One rank is all a one-GPU box can supply (RCCL refuses two ranks on one device):
     the sum over one rank changes nothing, so eval(), the staged calls, eval_rows() and predict() return the plain context's
-    numbers bit for bit, the profile shows the three exchanges, scfgp_train is refused, and the communicator can be dropped."""
+    numbers bit for bit, the profile shows the three exchanges, scfgp_train runs with them inside, and the communicator can be dropped."""
     from scfgp_amd.engine import HipEngine
     from tests.golden.make_oracle_kats import CASES, case_inputs
     name = 'kin8nm_like'
@@ -238,9 +238,10 @@ def test_sums_inside_the_library_with_a_one_rank_communicator(dtype):
     cr, gr, _, _ = eng.eval_rows(idx)
     cr0, gr0, _, _ = plain.eval_rows(idx)
     assert float(cr) == float(cr0) and np.array_equal(gr, gr0)
-    eng.opt_init('adam')
-    with pytest.raises(ValueError):
-        eng.train(2)
+    eng.opt_init('adam'); plain.opt_init('adam')               # round 5: the on-device loop carries the sums too
+    h1, _, _ = eng.train(2); h0, _, _ = plain.train(2)
+    assert np.array_equal(h1, h0) and np.array_equal(eng.get_params(), plain.get_params())
+    eng.set_params(params); plain.set_params(params)
     eng.comm_destroy()
     eng.set_profiling(True)
     c2, _, _, _ = eng.eval()

@@ -72,3 +72,178 @@ def test_facade_predict_on_the_artifacts_validation_rows(device_scaler):
     m = AP.metrics(mu_y, std_y, z['yv_raw'])
     assert np.allclose([model.evals[k][1][-1] for k in AP.NAMES], m, rtol=1e-12, atol=0)
     assert got['closure'] < 1e-10
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Ranks decide together (include/scfgp_hip.h): two contexts on one card play two ranks, their
+# exchange buffers summed in process the way the all-reduce would.
+# ---------------------------------------------------------------------------------------------------------------------------
+def _two_ranks(dtype='f32', opts=(), name='kin8nm_like'):
+    import torch
+    from scfgp_amd.engine import HipEngine
+    from scfgp_amd.sharded import shard_rows
+    from tests.golden.make_oracle_kats import CASES, case_inputs
+    N, D, S, M, T, seed = CASES[name]
+    X, y, params, _ = case_inputs(name)
+    stream = torch.cuda.current_stream().cuda_stream
+    engs = []
+    for r in range(2):
+        lo, hi = shard_rows(N, r, 2)
+        e = HipEngine(D, S, M, dtype, stream=stream)
+        for k, v in opts:
+            e.set_option(k, v)
+        e.set_params(params); e.set_data(X[lo:hi], y[lo:hi], n_global=N)
+        engs.append(e)
+    return engs
+
+
+def _allsum(engs, stage):
+    bufs = [e.exchange(stage) for e in engs]
+    assert len({b.numel() for b in bufs}) == 1
+    tot = bufs[0].clone()
+    for b in bufs[1:]:
+        tot += b
+    for b in bufs:
+        b.copy_(tot)
+
+
+def _sharded_eval(engs, want_grad=True, count=None):
+    """the staged evaluation over in-process ranks; every rank must take every REDO decision alike"""
+    for _ in range(6):
+        if count is not None:
+            count['pass1'] = count.get('pass1', 0) + 1
+        for e in engs: e.pass1()
+        _allsum(engs, 1)
+        go = [e.factor() for e in engs]
+        assert len(set(go)) == 1, go
+        if go[0] is False:
+            if count is not None:
+                count['factor_redo'] = count.get('factor_redo', 0) + 1
+            continue
+        for e in engs: e.pass2(want_grad)
+        _allsum(engs, 2)
+        if want_grad:
+            for e in engs: e.adjoint()
+            for e in engs: e.pass3()
+            _allsum(engs, 3)
+        outs = [e.finish(want_grad) for e in engs]
+        assert all(o is None for o in outs) or all(o is not None for o in outs)
+        if outs[0] is not None:
+            return outs
+    raise AssertionError('did not settle')
+
+
+@pytest.mark.parametrize('deny,agreed,npass1,nfredo', [(2, 1, 2, 0), (1, 0, 3, 1)])
+def test_two_row_shards_commit_to_the_precision_level_both_can_reach(deny, agreed, npass1, nfredo):
+    """fp32 mode, auto policy, thresholds 0: the summed matrix asks for level 2 on both ranks; rank 1's buffers of level `deny`
+    and up are refused (option test_deny_level).  Both ranks must finish at the same level, with the refusal on record on both,
+    after the same number of rounds, with the numbers of two contexts that were told to run that level from the start."""
+    want2 = (('cond_threshold', 0), ('cond_threshold_w', 0))
+    engs = _two_ranks('f32', want2)
+    engs[1].set_option('test_deny_level', deny)
+    n = {}
+    outs = _sharded_eval(engs, True, n)
+    assert n['pass1'] == npass1 and n.get('factor_redo', 0) == nfredo
+    lv = [e.condition()['level'] for e in engs]
+    assert lv == [agreed, agreed]
+    assert 'refused' in engs[0].last_error() and 'refused' in engs[1].last_error()
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a, b)                              # replicated K x K stage on equal sums: bit-equal ranks
+    ref = _two_ranks('f32', (('gram64', {0: 0, 1: 1}[agreed]),))
+    routs = _sharded_eval(ref, True)
+    for a, b in zip(outs[0], routs[0]):
+        assert np.array_equal(a, b)
+    n2 = {}
+    outs2 = _sharded_eval(engs, True, n2)                        # settled: one round, the refused level is not tried again
+    assert n2 == {'pass1': 1} and np.array_equal(outs2[0][1], outs[0][1])
+    for e in engs + ref:
+        e.close()
+
+
+@pytest.mark.parametrize('stage,want_grad', [(1, True), (2, True), (3, True), (2, False)])
+def test_a_failing_rank_marks_its_exchanges_and_every_rank_fails_together(stage, want_grad):
+    """rank 1's sweep `stage` fails (option test_fail_stage): it calls scfgp_fail_stage for that and every later exchange, the
+    sums still happen, rank 0 runs to its finish and gets SCFGP_EPEER there; both contexts then evaluate as if nothing happened"""
+    from scfgp_amd.engine import PeerFailed
+    engs = _two_ranks('f64')
+    good = _sharded_eval(engs, want_grad)
+    a, b = engs
+    b.set_option('test_fail_stage', stage)
+    failed = False
+
+    def sweep(s, fn):
+        nonlocal failed
+        if failed:
+            b.fail_stage(s, want_grad)
+            return
+        try:
+            fn(b)
+        except RuntimeError as ex:
+            assert 'injected failure' in str(ex)
+            failed = True
+            b.fail_stage(s, want_grad)
+
+    a.pass1(); sweep(1, lambda e: e.pass1()); _allsum(engs, 1)
+    a.factor()
+    if not failed: b.factor()
+    a.pass2(want_grad); sweep(2, lambda e: e.pass2(want_grad)); _allsum(engs, 2)
+    if want_grad:
+        a.adjoint()
+        if not failed: b.adjoint()
+        a.pass3(); sweep(3, lambda e: e.pass3()); _allsum(engs, 3)
+    assert failed
+    with pytest.raises(PeerFailed):
+        a.finish(want_grad)
+    again = _sharded_eval(engs, want_grad)
+    assert float(again[0][0]) == float(good[0][0]) and np.array_equal(again[1][2], good[1][2])
+    for e in engs:
+        e.close()
+
+
+@pytest.mark.parametrize('dtype', ['f64', 'f32'])
+def test_training_with_the_sums_inside_the_library_equals_the_plain_loop(dtype):
+    """scfgp_train with a (one-rank) communicator attached: the iteration carries its three ncclAllReduce calls, eagerly and --
+    option use_graph = 2 -- as a captured graph; parameters, cost history and optimiser state equal the plain context's bit for
+    bit (the sum over one rank changes nothing).  A sweep that fails inside the loop still posts every sum it owes: the profile
+    of the failed call shows them, and the context trains on afterwards."""
+    from scfgp_amd.engine import HipEngine
+    from tests.golden.make_oracle_kats import CASES, case_inputs
+    name = 'kin8nm_like'
+    N, D, S, M, T, seed = CASES[name]
+    X, y, params, _ = case_inputs(name)
+
+    def fresh(comm, graph=None):
+        e = HipEngine(D, S, M, dtype); e.set_params(params); e.set_data(X, y, n_global=N)
+        if comm:
+            e.comm_init(1, 0, e.comm_unique_id())
+        if graph is not None:
+            e.set_option('use_graph', graph)
+        e.opt_init('adam', learning_rate=0.02)
+        return e
+
+    plain = fresh(False)
+    h0, a0, L0 = plain.train(4)
+    p0 = plain.get_params()
+    for graph in (None, 2):
+        e = fresh(True, graph)
+        h1, a1, L1 = e.train(4)
+        assert np.array_equal(h1, h0) and np.array_equal(e.get_params(), p0) and np.array_equal(a1, a0) and np.array_equal(L1, L0)
+        for w in range(4):
+            assert np.array_equal(e.opt_state(w), plain.opt_state(w))
+        e.close()
+    e = fresh(True)
+    e.set_option('test_fail_stage', 2)
+    with pytest.raises(RuntimeError, match='injected failure'):
+        e.train(3)
+    e.set_params(params); e.opt_init('adam', learning_rate=0.02)
+    h2, _, _ = e.train(4)
+    assert np.array_equal(h2, h0)
+    # the evaluation entry point: scfgp_eval posts the sums it owes too, then evaluates as before
+    c0 = float(e.eval()[0])
+    e.set_option('test_fail_stage', 3)
+    e.set_profiling(True)
+    with pytest.raises(RuntimeError, match='injected failure'):
+        e.eval()
+    assert [n for n, _ in e.timings() if n.startswith('exchange')] == ['exchange1', 'exchange2', 'exchange3']
+    assert float(e.eval()[0]) == c0
+    e.close(); plain.close()
