@@ -130,11 +130,12 @@ int scfgp_predict_y(scfgp_ctx* ctx, const double* Xs_raw, int64_t T, const doubl
  *
  *   scfgp_pass1   -> exchange 1 = [G, packed lower 128x128 tiles | Phi^T y (Kp) | y^T y ...]
  *   scfgp_factor     (replicated: Cholesky, Li, alpha, log det)
- *   scfgp_pass2   -> exchange 2 = [B W B = V^T diag(q) V, packed lower tiles | B Phi^T p = V^T p (Kp) | T2, kbar ...]
+ *   scfgp_pass2   -> exchange 2 = [B W B = V^T diag(q) V, packed lower tiles | B Phi^T p = V^T p (Kp) | T2, kbar, sum q v, sum p mu ...]
  *                    (at precision level 2 of fp32 mode, scfgp_get_condition: [C^T diag(q) C | C^T p | ...], C = Phi Li^T --
  *                    still row sums, so the sum over ranks is the same operation)
  *   scfgp_adjoint    (replicated: Abar)                      [want_grad only]
- *   scfgp_pass3   -> exchange 3 = [X~^T Zbar | bbar ...]     [want_grad only]
+ *   scfgp_pass3   -> exchange 3 = [X~^T Zbar | ...]          [want_grad only]  (d cost / d b is formed in closed form from the
+ *                    summed exchanges 1 and 2: 2 tr(Abar G) + ut^T Phi^T y + 2 sum q v + sum p mu -- no row sweep, no slot here)
  *   scfgp_finish  -> outputs on the host
  *
  * These calls only enqueue work on the context's stream (asynchronous); scfgp_finish

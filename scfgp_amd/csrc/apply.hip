@@ -35,7 +35,7 @@ template <typename T, int TILE> struct ApplyCfg {
 //   EPI 4 (factor form): V = C . Li, Bm = Li lower triangular (Bm[k][j] = 0 for k < j): the contraction of column tile jt
 //          STARTS at its first column; plain store, no row sums
 // --------------------------------------------------------------------------
-// epilogues of the apply product: V and the row dots (EPI 0) or Phibar and bbar (EPI 1) from the accumulators
+// epilogues of the apply product: V and the row dots (EPI 0) or Phibar (EPI 1) from the accumulators
 //   MU (EPI 0 only): also mupart[jtg][n] = sum_{j in tile} Phi[n][j] alpha[j] from the Phi values the row dot reads anyway
 //   (the DMA-fed kernel has no operand values in registers for the loader-side dot)
 //   VEC4 (the LDS-DMA kernels, fp32, 64-wide wave tiles of four 16-column MFMA tiles): the B operand's rows were staged in a
@@ -66,7 +66,7 @@ __device__ __forceinline__ void apply_epilogue_vec2(
     const typename Cfg::MTr::acc_t (&acc)[Cfg::TM][Cfg::TN], const double* __restrict__ Phi, double* V,
     double* __restrict__ vpart, const double* __restrict__ p, const double* __restrict__ q, const double* __restrict__ y,
     const double* __restrict__ alpha, const double* __restrict__ ut, int K, int Kp, int64_t Np, int64_t rb, int cbase, int jtg,
-    double* __restrict__ bpart, char* smem_raw, double* __restrict__ mupart, int tid) {
+    char* smem_raw, double* __restrict__ mupart, int tid) {
     static_assert(Cfg::TN == 2 && Cfg::MS == 16 && sizeof(typename Cfg::T) == 8 && (EPI == 0 || EPI == 1 || EPI == 3 || EPI == 4), "VEC2 layout");
     AccCoord<Cfg> co(tid);
     const int jg = cbase + co.wn0 + 2 * (co.lane & 15);         // first of this lane's two adjacent columns
@@ -117,11 +117,10 @@ __device__ __forceinline__ void apply_epilogue_vec2(
             vpart[(int64_t)jtg * Np + rb * Cfg::BM + tid] = s;
             if (MU && mupart) mupart[(int64_t)jtg * Np + rb * Cfg::BM + tid] = s2;
         }
-    } else {                                                    // EPI 1
-        double bb = 0;
-        double al[2], u2[2], live[2];
+    } else {                                                    // EPI 1 (bbar is a K x K affair now: kstage_bbar)
+        double al[2], u2[2];
 #pragma unroll
-        for (int k = 0; k < 2; ++k) { al[k] = alpha[jg + k]; u2[k] = ut[jg + k]; live[k] = jg + k < K ? 1.0 : 0.0; }
+        for (int k = 0; k < 2; ++k) { al[k] = alpha[jg + k]; u2[k] = ut[jg + k]; }
         double* rowsc = reinterpret_cast<double*>(smem_raw);      // [BM][3]: 2 q, p, y of the tile's rows (LDS is free after the loop)
         for (int i = tid; i < Cfg::BM; i += Cfg::THREADS) {
             const int64_t n = rb * Cfg::BM + i;
@@ -130,13 +129,12 @@ __device__ __forceinline__ void apply_epilogue_vec2(
         __syncthreads();
 #pragma unroll
         for (int tm = 0; tm < Cfg::TM; ++tm) {
-            v2d vv[4], ph[4];
+            v2d vv[4];
             int64_t off[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 off[r] = (rb * Cfg::BM + co.row(tm, r)) * Kp + jg;
                 vv[r] = *reinterpret_cast<const v2d*>(V + off[r]);
-                ph[r] = *reinterpret_cast<const v2d*>(Phi + off[r]);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -144,22 +142,9 @@ __device__ __forceinline__ void apply_epilogue_vec2(
                 const double qn = rowsc[3 * row], pn = rowsc[3 * row + 1], yn = rowsc[3 * row + 2];
                 v2d o;
 #pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    o[k] = 2.0 * acc[tm][k][r] + qn * vv[r][k] + pn * al[k] + yn * u2[k];
-                    bb = fma(o[k], ph[r][k] * live[k], bb);
-                }
+                for (int k = 0; k < 2; ++k) o[k] = 2.0 * acc[tm][k][r] + qn * vv[r][k] + pn * al[k] + yn * u2[k];
                 *reinterpret_cast<v2d*>(V + off[r]) = o;
             }
-        }
-        double* red = rowsc + 3 * Cfg::BM;
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) bb += __shfl_xor(bb, m);
-        if (co.lane == 0) red[tid >> 6] = bb;
-        __syncthreads();
-        if (tid == 0) {
-            double s = 0;
-            for (int k = 0; k < Cfg::THREADS / 64; ++k) s += red[k];
-            bpart[blockIdx.x] = s;
         }
     }
 }
@@ -168,10 +153,10 @@ __device__ __forceinline__ void apply_epilogue(
     const typename Cfg::MTr::acc_t (&acc)[Cfg::TM][Cfg::TN], const typename Cfg::T* __restrict__ Phi, typename Cfg::T* V,
     double* __restrict__ vpart, const double* __restrict__ p, const double* __restrict__ q, const double* __restrict__ y,
     const double* __restrict__ alpha, const double* __restrict__ ut, int K, int Kp, int64_t Np, int64_t rb, int cbase, int jtg,
-    double* __restrict__ bpart, char* smem_raw, double* __restrict__ mupart = nullptr, int tid = (int)threadIdx.x) {
+    char* smem_raw, double* __restrict__ mupart = nullptr, int tid = (int)threadIdx.x) {
     typedef typename Cfg::T T;
     if constexpr (VEC4 && sizeof(T) == 8) {                        // the LDS-DMA tiles in fp64
-        apply_epilogue_vec2<Cfg, EPI, MU>(acc, Phi, V, vpart, p, q, y, alpha, ut, K, Kp, Np, rb, cbase, jtg, bpart, smem_raw, mupart, tid);
+        apply_epilogue_vec2<Cfg, EPI, MU>(acc, Phi, V, vpart, p, q, y, alpha, ut, K, Kp, Np, rb, cbase, jtg, smem_raw, mupart, tid);
         return;
     }
     AccCoord<Cfg> co(tid);
@@ -233,16 +218,14 @@ __device__ __forceinline__ void apply_epilogue(
                 if (MU && mupart) mupart[(int64_t)jtg * Np + rb * Cfg::BM + tid] = s2;
             }
         } else {                                                    // EPI 1
-            double bb = 0;
-            double al[4], u4[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { al[k] = alpha[jg + k]; u4[k] = ut[jg + k]; }
             float alf[4], u4f[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { alf[k] = (float)al[k]; u4f[k] = (float)u4[k]; }
-            // per-row scalars (2 q, p, y) of the tile's rows through LDS (free after the loop's last barrier), and the re-reads of V
-            // and Phi issued for the four rows of an accumulator row group at once: written row by row, the in-place store of a row
-            // stood between the loads of the next one and its own (16 dependent round trips per tile; profiles/r03_tuning.md)
+            for (int k = 0; k < 4; ++k) { alf[k] = (float)alpha[jg + k]; u4f[k] = (float)ut[jg + k]; }
+            // per-row scalars (2 q, p, y) of the tile's rows through LDS (free after the loop's last barrier), and the re-read of V
+            // issued for the four rows of an accumulator row group at once: written row by row, the in-place store of a row
+            // stood between the loads of the next one and its own (16 dependent round trips per tile; profiles/r03_tuning.md).
+            // Phi is not read here any more: bbar = sum Phibar o Phi was its only use, and that sum needs neither matrix
+            // (kernels_kstage.hip: kstage_bbar)
             float* rowsc = reinterpret_cast<float*>(smem_raw);        // [BM][3]
             for (int i = tid; i < Cfg::BM; i += Cfg::THREADS) {
                 const int64_t n = rb * Cfg::BM + i;
@@ -251,42 +234,24 @@ __device__ __forceinline__ void apply_epilogue(
             __syncthreads();
 #pragma unroll
             for (int tm = 0; tm < Cfg::TM; ++tm) {
-                v4f vv[4], ph[4];
+                v4f vv[4];
                 int64_t off[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     off[r] = (rb * Cfg::BM + co.row(tm, r)) * Kp + jg;
                     vv[r] = *reinterpret_cast<const v4f*>(V + off[r]);
-                    ph[r] = *reinterpret_cast<const v4f*>(Phi + off[r]);
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = co.row(tm, r);
                     // Phibar is stored in fp32: its four terms are combined in fp32 FMAs (one rounding per term instead of one at
-                    // the end; the accumulator itself carries ~1e-7 of the product), and the b-bar dot takes the four products of a
-                    // lane in fp32 and everything above them in fp64 -- the fp64 conversions and FMAs of the all-fp64 form were
-                    // ~1 ms of the launch (profiles/r03_tuning.md)
+                    // the end; the accumulator itself carries ~1e-7 of the product)
                     const float qn = rowsc[3 * row], pn = rowsc[3 * row + 1], yn = rowsc[3 * row + 2];
                     v4f o;
-                    float dot = 0.f;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        o[k] = fmaf(qn, vv[r][k], fmaf(pn, alf[k], fmaf(yn, u4f[k], 2.0f * acc[tm][k][r])));
-                        dot = fmaf(o[k], jg + k < K ? ph[r][k] : 0.f, dot);
-                    }
-                    bb += (double)dot;
+                    for (int k = 0; k < 4; ++k) o[k] = fmaf(qn, vv[r][k], fmaf(pn, alf[k], fmaf(yn, u4f[k], 2.0f * acc[tm][k][r])));
                     *reinterpret_cast<v4f*>(V + off[r]) = o;
                 }
-            }
-            double* red = reinterpret_cast<double*>(rowsc + 4 * Cfg::BM);
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) bb += __shfl_xor(bb, m);
-            if (co.lane == 0) red[tid >> 6] = bb;
-            __syncthreads();
-            if (tid == 0) {
-                double s = 0;
-                for (int k = 0; k < Cfg::THREADS / 64; ++k) s += red[k];
-                bpart[blockIdx.x] = s;
             }
         }
         return;
@@ -352,8 +317,7 @@ __device__ __forceinline__ void apply_epilogue(
             vpart[(int64_t)jtg * Np + rb * Cfg::BM + tid] = s;
             if (MU && mupart) mupart[(int64_t)jtg * Np + rb * Cfg::BM + tid] = s2;
         }
-    } else {
-        double bb = 0;                                                  // bbar = sum Phibar o Phi  (d cost / d b)
+    } else {                                                        // EPI 1: Phibar over V (bbar: kstage_bbar)
         [[maybe_unused]] float alf[Cfg::TN], utf[Cfg::TN];
         if constexpr (sizeof(T) == 4) {
 #pragma unroll
@@ -368,34 +332,17 @@ __device__ __forceinline__ void apply_epilogue(
                 const double qn = 2.0 * q[n], pn = p[n], yn = y[n];
                 if constexpr (sizeof(T) == 4) {                     // fp32 storage: fp32 FMAs, as in the VEC4 path above
                     const float qf = (float)qn, pf = (float)pn, yf = (float)yn;
-                    float dot = 0.f;
 #pragma unroll
-                    for (int tn = 0; tn < Cfg::TN; ++tn) {
-                        const float o = fmaf(qf, V[off + co.col(tn)], fmaf(pf, alf[tn], fmaf(yf, utf[tn], 2.0f * acc[tm][tn][r])));
-                        V[off + co.col(tn)] = o;
-                        if (cbase + co.col(tn) < K) dot = fmaf(o, Phi[off + co.col(tn)], dot);
-                    }
-                    bb += (double)dot;
+                    for (int tn = 0; tn < Cfg::TN; ++tn)
+                        V[off + co.col(tn)] = fmaf(qf, V[off + co.col(tn)], fmaf(pf, alf[tn], fmaf(yf, utf[tn], 2.0f * acc[tm][tn][r])));
                 } else {
 #pragma unroll
                     for (int tn = 0; tn < Cfg::TN; ++tn) {
                         const int j = cbase + co.col(tn);
-                        const double v = 2.0 * (double)acc[tm][tn][r] + qn * (double)V[off + co.col(tn)] + pn * alpha[j] + yn * ut[j];
-                        V[off + co.col(tn)] = (T)v;
-                        if (j < K) bb += v * (double)Phi[off + co.col(tn)];
+                        V[off + co.col(tn)] = (T)(2.0 * (double)acc[tm][tn][r] + qn * (double)V[off + co.col(tn)] + pn * alpha[j] + yn * ut[j]);
                     }
                 }
             }
-        double* red = reinterpret_cast<double*>(smem_raw);
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) bb += __shfl_xor(bb, m);
-        if (co.lane == 0) red[tid >> 6] = bb;
-        __syncthreads();
-        if (tid == 0) {
-            double s = 0;
-            for (int k = 0; k < Cfg::THREADS / 64; ++k) s += red[k];
-            bpart[blockIdx.x] = s;
-        }
     }
 }
 // one output tile (column tile jt of this launch, row block rb) of the apply product, operands staged through registers
@@ -404,7 +351,7 @@ __device__ __forceinline__ void apply_tile(
     const typename Cfg::T* __restrict__ Phi, const typename Cfg::T* __restrict__ Bm, typename Cfg::T* V,
     double* __restrict__ vpart, const double* __restrict__ p, const double* __restrict__ q, const double* __restrict__ y,
     const double* __restrict__ alpha, const double* __restrict__ ut, int K, int Kp, int64_t Np, int njt,
-    double* __restrict__ bpart, int col0, int jt0, double* __restrict__ mu, int ntot, int jt, int64_t rb, char* smem_raw) {
+    int col0, int jt0, double* __restrict__ mu, int ntot, int jt, int64_t rb, char* smem_raw) {
     typedef typename Cfg::T T;
     T* smem = reinterpret_cast<T*>(smem_raw);
     const int cbase = col0 + jt * Cfg::BN;
@@ -429,7 +376,7 @@ __device__ __forceinline__ void apply_tile(
     NatLoader<T, T, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS, false, false> lb(Bm + (int64_t)kt0 * Cfg::BK * Kp + cbase, Kp, threadIdx.x);
     tile_mainloop<Cfg>(la, lb, nkt, acc, smem);
     if constexpr (EPI != 1 && EPI != 4) { if (want_mu) la.dot_reduce(mu + (int64_t)(jt0 + jt) * Np + rb * Cfg::BM); }
-    apply_epilogue<Cfg, EPI>(acc, Phi, V, vpart, p, q, y, alpha, ut, K, Kp, Np, rb, cbase, jt0 + jt, bpart, smem_raw);
+    apply_epilogue<Cfg, EPI>(acc, Phi, V, vpart, p, q, y, alpha, ut, K, Kp, Np, rb, cbase, jt0 + jt, smem_raw);
 }
 
 template <class Cfg, int EPI>
@@ -438,7 +385,7 @@ void apply_kernel(
     const typename Cfg::T* __restrict__ Phi, const typename Cfg::T* __restrict__ Bm, typename Cfg::T* V,
     double* __restrict__ vpart, const double* __restrict__ p, const double* __restrict__ q, const double* __restrict__ y,
     const double* __restrict__ alpha, const double* __restrict__ ut, int K, int Kp, int64_t Np, int njt,
-    double* __restrict__ bpart, int col0, int jt0, double* __restrict__ mu, int ntot) {
+    int col0, int jt0, double* __restrict__ mu, int ntot) {
     // this launch covers columns [col0, col0 + njt*BN); jt0 = index of its first tile in vpart
     SMEM_DECL;
     const unsigned wid = xcd_remap(blockIdx.x, gridDim.x);
@@ -447,13 +394,13 @@ void apply_kernel(
         // workgroup takes tile t AND tile njt - 1 - t -- every workgroup of the launch then does the same amount of work
         const int np = (njt + 1) / 2, t = (int)(wid % np), o = njt - 1 - t;
         const int64_t rb = wid / np;
-        apply_tile<Cfg, EPI>(Phi, Bm, V, vpart, p, q, y, alpha, ut, K, Kp, Np, njt, bpart, col0, jt0, mu, ntot, t, rb, smem_raw);
+        apply_tile<Cfg, EPI>(Phi, Bm, V, vpart, p, q, y, alpha, ut, K, Kp, Np, njt, col0, jt0, mu, ntot, t, rb, smem_raw);
         if (o != t) {
             __syncthreads();                                     // the first tile's epilogue is done with the LDS
-            apply_tile<Cfg, EPI>(Phi, Bm, V, vpart, p, q, y, alpha, ut, K, Kp, Np, njt, bpart, col0, jt0, mu, ntot, o, rb, smem_raw);
+            apply_tile<Cfg, EPI>(Phi, Bm, V, vpart, p, q, y, alpha, ut, K, Kp, Np, njt, col0, jt0, mu, ntot, o, rb, smem_raw);
         }
     } else
-        apply_tile<Cfg, EPI>(Phi, Bm, V, vpart, p, q, y, alpha, ut, K, Kp, Np, njt, bpart, col0, jt0, mu, ntot, (int)(wid % njt), wid / njt, smem_raw);
+        apply_tile<Cfg, EPI>(Phi, Bm, V, vpart, p, q, y, alpha, ut, K, Kp, Np, njt, col0, jt0, mu, ntot, (int)(wid % njt), wid / njt, smem_raw);
 }
 
 // Apply product with LDS-DMA staging: both operands go global -> LDS by global_load_lds_dwordx4 into a ring of three stages of
@@ -516,7 +463,7 @@ __global__ __launch_bounds__((64 * ApplyDma<T, BN>::WAVES)) __attribute__((amdgp
 void apply_dma_kernel(const T* __restrict__ Phi, const T* __restrict__ Bm, T* V,
                       double* __restrict__ vpart, const double* __restrict__ p, const double* __restrict__ q,
                       const double* __restrict__ y, const double* __restrict__ alpha, const double* __restrict__ ut,
-                      int K, int Kp, int64_t Np, int njt, double* __restrict__ bpart, double* __restrict__ mu, int col0, int slot0, int64_t rb0) {
+                      int K, int Kp, int64_t Np, int njt, double* __restrict__ mu, int col0, int slot0, int64_t rb0) {
     typedef ApplyDma<T, BN> D;
     typedef typename D::Cfg Cfg;
     typedef T half_t __attribute__((ext_vector_type(2)));      // a lane's 2 k of one half of a stage
@@ -680,7 +627,7 @@ void apply_dma_kernel(const T* __restrict__ Phi, const T* __restrict__ Bm, T* V,
     const int vslot = slot0 + SLOTS * jt;
     int tid = (int)threadIdx.x;
     asm volatile("" : "+v"(tid));                              // the epilogue's lane arithmetic stays behind the k loop (registers)
-    apply_epilogue<Cfg, EPI, EPI == 0 || EPI == 3, true>(acc, Phi, V, vpart, p, q, y, alpha, ut, K, Kp, Np, rb, cbase, vslot, bpart, smem_raw, mu, tid);
+    apply_epilogue<Cfg, EPI, EPI == 0 || EPI == 3, true>(acc, Phi, V, vpart, p, q, y, alpha, ut, K, Kp, Np, rb, cbase, vslot, smem_raw, mu, tid);
     if (SLOTS == 2 && (EPI == 0 || EPI == 3) && tid < D::BM) {
         vpart[(int64_t)(vslot + 1) * Np + rb * D::BM + tid] = 0.0;
         if (mu) mu[(int64_t)(vslot + 1) * Np + rb * D::BM + tid] = 0.0;
@@ -718,27 +665,27 @@ template <typename T> struct ApplyPlan {
     }
 };
 template <class Cfg, int EPI, typename T>
-static int apply_launch_cfg(const Geom& g, int njt, int col0, int jt0, int boff, const T* Phi, const T* Bm, T* V, double* vpart,
+static int apply_launch_cfg(const Geom& g, int njt, int col0, int jt0, const T* Phi, const T* Bm, T* V, double* vpart,
                             const double* p, const double* q, const double* y, const double* alpha, const double* ut,
-                            double* bpart, double* mu, int ntot, hipStream_t st) {
+                            double* mu, int ntot, hipStream_t st) {
     if (njt <= 0) return 0;
     const int64_t nrb = g.Np / Cfg::BM;
     const int wgs_per_rb = EPI == 3 || EPI == 4 ? (njt + 1) / 2 : njt;          // triangular products pair their column tiles
     allow_big_lds(apply_kernel<Cfg, EPI>, Cfg::LDS_BYTES);
     hipLaunchKernelGGL((apply_kernel<Cfg, EPI>), dim3((unsigned)(wgs_per_rb * nrb)), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st,
-                       Phi, Bm, V, vpart, p, q, y, alpha, ut, g.K, g.Kp, g.Np, njt, bpart ? bpart + boff : nullptr, col0, jt0, mu, ntot);
+                       Phi, Bm, V, vpart, p, q, y, alpha, ut, g.K, g.Kp, g.Np, njt, col0, jt0, mu, ntot);
     return (int)(njt * nrb);
 }
 template <typename T, int EPI, int BN>
-static int apply_dma_launch(const Geom& g, int njt, int col0, int slot0, int boff, const T* Phi, const T* Bm, T* V, double* vpart,
+static int apply_dma_launch(const Geom& g, int njt, int col0, int slot0, const T* Phi, const T* Bm, T* V, double* vpart,
                             const double* p, const double* q, const double* y, const double* alpha, const double* ut,
-                            double* bpart, double* mu, hipStream_t st, int64_t rb0 = 0, int64_t nrb = -1) {
+                            double* mu, hipStream_t st, int64_t rb0 = 0, int64_t nrb = -1) {
     typedef ApplyDma<T, BN> D;
     if (nrb < 0) nrb = g.Np / D::BM;                           // row blocks rb0 .. rb0 + nrb - 1 (default: all)
     if (njt <= 0 || nrb <= 0) return 0;
     allow_big_lds(apply_dma_kernel<T, EPI, BN>, D::LDS_BYTES);
     hipLaunchKernelGGL((apply_dma_kernel<T, EPI, BN>), dim3((unsigned)(njt * nrb)), dim3(64 * D::WAVES), D::LDS_BYTES, st,
-                       Phi, Bm, V, vpart, p, q, y, alpha, ut, g.K, g.Kp, g.Np, njt, bpart ? bpart + boff : nullptr, mu, col0, slot0, rb0);
+                       Phi, Bm, V, vpart, p, q, y, alpha, ut, g.K, g.Kp, g.Np, njt, mu, col0, slot0, rb0);
     return (int)(njt * nrb);
 }
 static int apply_num_cus() {
@@ -755,7 +702,7 @@ static int apply_num_cus() {
 // BmT: the operand with its k-contiguous columns as rows (what the DMA-fed tiles read); NULL: Bm is symmetric
 template <typename T, int EPI>
 static int apply_launch(const Geom& g, const T* Phi, const T* Bm, T* V, double* vpart, const double* p, const double* q,
-                        const double* y, const double* alpha, const double* ut, double* bpart, double* mu, hipStream_t st,
+                        const double* y, const double* alpha, const double* ut, double* mu, hipStream_t st,
                         int dma = 0, const T* BmT = nullptr) {
     if (!BmT) BmT = Bm;
     const ApplyPlan<T> pl(g.K);
@@ -774,70 +721,67 @@ static int apply_launch(const Geom& g, const T* Phi, const T* Bm, T* V, double* 
                     const int64_t ncu = apply_num_cus(), tiles = nrb * n256, rem = tiles % ncu;
                     if (tiles > ncu && rem > 0 && 20 * rem <= 9 * ncu) tail_rb = (rem + n256 - 1) / n256;
                 }
-                nb += apply_dma_launch<T, EPI, 256>(g, n256, 0, 0, nb, Phi, BmT, V, vpart, p, q, y, alpha, ut, bpart, mu, st, 0, nrb - tail_rb);
+                nb += apply_dma_launch<T, EPI, 256>(g, n256, 0, 0, Phi, BmT, V, vpart, p, q, y, alpha, ut, mu, st, 0, nrb - tail_rb);
             }
-            nb += apply_dma_launch<T, EPI, 128>(g, pl.count[0] - 2 * n256, 256 * n256, 2 * n256, nb, Phi, BmT, V, vpart, p, q, y, alpha, ut, bpart, mu, st, 0, nrb - tail_rb);
+            nb += apply_dma_launch<T, EPI, 128>(g, pl.count[0] - 2 * n256, 256 * n256, 2 * n256, Phi, BmT, V, vpart, p, q, y, alpha, ut, mu, st, 0, nrb - tail_rb);
             // the ragged 64-column remainder: the same kernel with 256 x 64 tiles (4 / 8 waves, two workgroups per CU)
-            nb += apply_dma_launch<T, EPI, 64>(g, pl.count[1], pl.col0[1], pl.jt0[1], nb, Phi, BmT, V, vpart, p, q, y, alpha, ut, bpart, mu, st, 0, nrb - tail_rb);
+            nb += apply_dma_launch<T, EPI, 64>(g, pl.count[1], pl.col0[1], pl.jt0[1], Phi, BmT, V, vpart, p, q, y, alpha, ut, mu, st, 0, nrb - tail_rb);
             if (tail_rb > 0) {
-                nb += apply_dma_launch<T, EPI, 128>(g, pl.count[0], 0, 0, nb, Phi, BmT, V, vpart, p, q, y, alpha, ut, bpart, mu, st, nrb - tail_rb, tail_rb);
-                nb += apply_dma_launch<T, EPI, 64>(g, pl.count[1], pl.col0[1], pl.jt0[1], nb, Phi, BmT, V, vpart, p, q, y, alpha, ut, bpart, mu, st, nrb - tail_rb, tail_rb);
+                nb += apply_dma_launch<T, EPI, 128>(g, pl.count[0], 0, 0, Phi, BmT, V, vpart, p, q, y, alpha, ut, mu, st, nrb - tail_rb, tail_rb);
+                nb += apply_dma_launch<T, EPI, 64>(g, pl.count[1], pl.col0[1], pl.jt0[1], Phi, BmT, V, vpart, p, q, y, alpha, ut, mu, st, nrb - tail_rb, tail_rb);
             }
             return nb;
         }
     }
-    nb += apply_launch_cfg<typename ApplyCfg<T, 128>::type, EPI, T>(g, pl.count[0], pl.col0[0], pl.jt0[0], nb, Phi, Bm, V, vpart, p, q, y, alpha, ut, bpart, mu, pl.total, st);
-    nb += apply_launch_cfg<typename ApplyCfg<T, 64>::type, EPI, T>(g, pl.count[1], pl.col0[1], pl.jt0[1], nb, Phi, Bm, V, vpart, p, q, y, alpha, ut, bpart, mu, pl.total, st);
+    nb += apply_launch_cfg<typename ApplyCfg<T, 128>::type, EPI, T>(g, pl.count[0], pl.col0[0], pl.jt0[0], Phi, Bm, V, vpart, p, q, y, alpha, ut, mu, pl.total, st);
+    nb += apply_launch_cfg<typename ApplyCfg<T, 64>::type, EPI, T>(g, pl.count[1], pl.col0[1], pl.jt0[1], Phi, Bm, V, vpart, p, q, y, alpha, ut, mu, pl.total, st);
     return nb;
 }
 
 template <typename T>
 void ApplyKernels<T>::apply_v(const Geom& g, const T* Phi, const T* Bm, T* V, double* vpart, const double* alpha, double* mu,
                               hipStream_t st, int dma) {
-    apply_launch<T, 0>(g, Phi, Bm, V, vpart, nullptr, nullptr, nullptr, alpha, nullptr, nullptr, mu, st, dma);
+    apply_launch<T, 0>(g, Phi, Bm, V, vpart, nullptr, nullptr, nullptr, alpha, nullptr, mu, st, dma);
 }
 template <typename T>
 void ApplyKernels<T>::apply_predict(const Geom& g, const T* Phi, const T* LiT, double* vpart, const double* alpha, double* mu,
                                     hipStream_t st) {
-    apply_launch<T, 2>(g, Phi, LiT, (T*)nullptr, vpart, nullptr, nullptr, nullptr, alpha, nullptr, nullptr, mu, st);
+    apply_launch<T, 2>(g, Phi, LiT, (T*)nullptr, vpart, nullptr, nullptr, nullptr, alpha, nullptr, mu, st);
 }
 // Out[n][c] = sum_{k < Kc} A[n][k] Bm[k][c] for c < ncols (rounded up to 64-wide tiles), everything with leading dimension Kp;
 // Bm[k][c] = 0 for k < c is assumed (the contraction of a column tile starts at its first column)
 template <typename T>
 void ApplyKernels<T>::apply_plain(const Geom& g, const T* A, const T* Bm, T* Out, int Kc, int ncols, hipStream_t st) {
     Geom gk = g; gk.K = Kc;
-    apply_launch_cfg<typename ApplyCfg<T, 64>::type, 4, T>(gk, (ncols + 63) / 64, 0, 0, 0, A, Bm, Out, nullptr, nullptr, nullptr, nullptr, nullptr,
-                                                           nullptr, nullptr, nullptr, ApplyPlan<T>(Kc).total, st);
+    apply_launch_cfg<typename ApplyCfg<T, 64>::type, 4, T>(gk, (ncols + 63) / 64, 0, 0, A, Bm, Out, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                                           nullptr, nullptr, ApplyPlan<T>(Kc).total, st);
 }
 
 template <typename T>
 void ApplyKernels<T>::apply_c(const Geom& g, const T* Phi, const T* LiT, const T* Li, T* C, double* vpart, const double* alpha,
                               double* mu, hipStream_t st, int dma) {
-    apply_launch<T, 3>(g, Phi, LiT, C, vpart, nullptr, nullptr, nullptr, alpha, nullptr, nullptr, mu, st, dma, Li);
+    apply_launch<T, 3>(g, Phi, LiT, C, vpart, nullptr, nullptr, nullptr, alpha, nullptr, mu, st, dma, Li);
 }
 template <typename T>
 void ApplyKernels<T>::apply_vc(const Geom& g, const T* C, const T* Li, const T* LiT, T* V, hipStream_t st, int dma) {
-    apply_launch<T, 4>(g, C, Li, V, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, st, dma, LiT);
+    apply_launch<T, 4>(g, C, Li, V, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, st, dma, LiT);
 }
 template <typename T>
-int ApplyKernels<T>::apply_phibar(const Geom& g, const T* Phi, const T* Abar, T* V, const double* p, const double* q,
-                                  const double* y, const double* alpha, const double* ut, double* bpart, hipStream_t st, int dma) {
-    return apply_launch<T, 1>(g, Phi, Abar, V, nullptr, p, q, y, alpha, ut, bpart, nullptr, st, dma);
+void ApplyKernels<T>::apply_phibar(const Geom& g, const T* Phi, const T* Abar, T* V, const double* p, const double* q,
+                                   const double* y, const double* alpha, const double* ut, hipStream_t st, int dma) {
+    apply_launch<T, 1>(g, Phi, Abar, V, nullptr, p, q, y, alpha, ut, nullptr, st, dma);
 }
 
 // number of column tiles of the apply kernel (vpart leading count)
 template <typename T> static int apply_njt(const Geom& g) { return ApplyPlan<T>(g.K).total; }
-template <typename T>
-int ApplyKernels<T>::apply_blocks(const Geom& g) {
-    return (int)(apply_njt<T>(g) * (g.Np / Tune<T>::APPLY_BM));
-}
 
 
 // --------------------------------------------------------------------------
 // per-row statistics from apply_v's per-tile by-products: one thread per row.
 //   mu = sum_jt mupart, v = sum_jt vpart, d = kappa (v+1), r = mu - y
 //   MODE 0 (train): p = 2r/d, e = 1/d - (r^2+v)/d^2, q = 1/d + kappa e; block partials of
-//                   T2 = (r^2+v)/d + log(2 pi d) and kbar = e (v+1)
+//                   T2 = (r^2+v)/d + log(2 pi d), kbar = e (v+1) and the two row sums of bbar = sum_n Phibar_n . phi_n that
+//                   are not K x K work: sum_n q_n v_n and sum_n p_n mu_n (kernels_kstage.hip: kstage_bbar)
 //   MODE 1 (predict): mu, sd = sqrt(kappa (1+v))
 // --------------------------------------------------------------------------
 template <int MODE>
@@ -845,9 +789,9 @@ __global__ __launch_bounds__(256) void rowstats_kernel(const double* __restrict_
                                                        const double* __restrict__ y, const Scal* __restrict__ sc,
                                                        double* __restrict__ o1, double* __restrict__ o2,
                                                        double* __restrict__ partial, int64_t N, int64_t Np) {
-    __shared__ double red[2][256];
+    __shared__ double red[4][256];
     const double kappa = sc->kappa;
-    double t2 = 0, kb = 0;
+    double t2 = 0, kb = 0, qv = 0, pm = 0;
     for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < Np; n += (int64_t)gridDim.x * 256) {
         double v = 0, mu = 0;
         for (int t = 0; t < njt; ++t) { v += vpart[(int64_t)t * Np + n]; mu += mupart[(int64_t)t * Np + n]; }
@@ -862,6 +806,7 @@ __global__ __launch_bounds__(256) void rowstats_kernel(const double* __restrict_
                 qn = 1.0 / d + kappa * e;
                 t2 += rv / d + log(2.0 * M_PI * d);
                 kb += e * (v + 1.0);
+                qv += qn * v; pm += pn * mu;
             }
             o1[n] = pn; o2[n] = qn;
         } else if (n < N) {
@@ -869,13 +814,14 @@ __global__ __launch_bounds__(256) void rowstats_kernel(const double* __restrict_
         }
     }
     if (MODE == 0) {
-        red[0][threadIdx.x] = t2; red[1][threadIdx.x] = kb;
+        red[0][threadIdx.x] = t2; red[1][threadIdx.x] = kb; red[2][threadIdx.x] = qv; red[3][threadIdx.x] = pm;
         __syncthreads();
         for (int w = 128; w >= 1; w >>= 1) {
-            if ((int)threadIdx.x < w) { red[0][threadIdx.x] += red[0][threadIdx.x + w]; red[1][threadIdx.x] += red[1][threadIdx.x + w]; }
+            if ((int)threadIdx.x < w)
+                for (int k = 0; k < 4; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + w];
             __syncthreads();
         }
-        if (threadIdx.x < 2) partial[blockIdx.x * 2 + threadIdx.x] = red[threadIdx.x][0];
+        if (threadIdx.x < 4) partial[blockIdx.x * 4 + threadIdx.x] = red[threadIdx.x][0];
     }
 }
 

@@ -28,6 +28,7 @@ struct Scal {
 enum {
     R_YY = 0, R_LOGDET, R_T2, R_KBAR, R_BBAR, R_TRABAR, R_GTALPHA, R_PEN, R_COST, R_FLAG,
     R_LMIN2, R_LMAX2, R_BMAX,      // min / max of L_ii^2 and max_j (A^-1)_jj of the last factorisation (condition estimate)
+    R_TRAG, R_UTG,                 // tr(Abar G) and ut^T (Phi^T y): the K x K part of bbar (kstage_bbar)
     R_COUNT
 };
 

@@ -709,6 +709,12 @@ int GramKernels<T>::gram_jobs(const Geom& g) { return gram_jobs_per_split<sizeof
 // tapered (kernels.h: RowSplits).
 RowSplits gram_row_splits(int jobs, int64_t Np, bool f32, int nsplit_override, int taper) {
     int64_t s = ((f32 ? 4224 : 6144) + jobs - 1) / jobs;
+    // ... but never fewer than 56 units where the rows allow it: a long job list per split (K = 4224: 297 jobs) would otherwise get
+    // 15 units -- below the 16 from which the units are dealt to the XCD groups and tapered -- i.e. 8.7 rounds of 11 ms jobs whose
+    // ragged end left the launch 14 ms of tail (profiles/r05_gram_trace_C5.txt: slot occupancy 0.939); with 56 units (80 splits
+    // after the taper, the structure of the headline shape) C5's gram + gram_w go 282.6 -> 265.0 ms for 2.3 ms more slab
+    // reduction (profiles/r05_tuning.md)
+    s = std::max<int64_t>(s, 56);
     const int64_t smax = std::max<int64_t>(Np / (f32 ? 3072 : 2048), 1);
     if (s > smax) s = smax;
     // small problems (the job list would leave most of the 512 workgroup slots empty): 64-row granules, as many

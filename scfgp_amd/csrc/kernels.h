@@ -113,14 +113,12 @@ struct ApplyKernels {
     static void apply_c(const Geom& g, const T* Phi, const T* LiT, const T* Li, T* C, double* vpart, const double* alpha,
                         double* mupart, hipStream_t st, int dma = 0);
     static void apply_vc(const Geom& g, const T* C, const T* Li, const T* LiT, T* V, hipStream_t st, int dma = 0);
-    // Phibar = 2 Phi.Abar + 2 q V + p alpha^T + y ut^T  (in place over V); bpart[block] = partial of
-    // bbar = sum Phibar o Phi.  Returns the number of blocks (= partials written).
-    static int apply_phibar(const Geom& g, const T* Phi, const T* Abar, T* V, const double* p, const double* q,
-                            const double* y, const double* alpha, const double* ut, double* bpart, hipStream_t st, int dma = 0);
-    static int apply_blocks(const Geom& g);
+    // Phibar = 2 Phi.Abar + 2 q V + p alpha^T + y ut^T  (in place over V)
+    static void apply_phibar(const Geom& g, const T* Phi, const T* Abar, T* V, const double* p, const double* q,
+                             const double* y, const double* alpha, const double* ut, hipStream_t st, int dma = 0);
     // Out = A . Bm over k < Kc for ncols columns (64-wide tiles, leading dimension Kp everywhere; Bm[k][c] = 0 for k < c)
     static void apply_plain(const Geom& g, const T* A, const T* Bm, T* Out, int Kc, int ncols, hipStream_t st);
-    // per-row moments and adjoint scalars; block partials of (T2, kbar)  (SCFGP.py:111-113,121-124)
+    // per-row moments and adjoint scalars; block partials (4 per block) of T2, kbar, sum q v, sum p mu  (SCFGP.py:111-113,121-124)
     static void rowstats(const Geom& g, const double* mupart, const double* vpart, const double* y,
                          const Scal* sc, double* p, double* q, double* partial, int nblocks, hipStream_t st);
     // predictive mean / std                                          (SCFGP.py:143-144)
@@ -157,8 +155,8 @@ void unpack_params(const Geom& g, const double* params, double* F, double* Fall,
 void grad_epilogue(const Geom& g, const double* params, const double* F, const double* XZ, int64_t ldxz,
                    double* work, double* scalars, int64_t Nglobal, double* grad, hipStream_t st,
                    const double* TZ = nullptr, int64_t ldtz = 0, const double* XU = nullptr, int64_t ldxu = 0);
-// yy -> y^T y, t2kb -> (T2, kbar), bbar -> bbar: device scalars living in the exchange buffers
-void finalize_cost(const Geom& g, const Scal* sc, double* scalars, const double* yy, const double* t2kb, const double* bbar,
+// yy -> y^T y, t2kb -> (T2, kbar, sum q v, sum p mu): device scalars living in the exchange buffers (summed over ranks)
+void finalize_cost(const Geom& g, const Scal* sc, double* scalars, const double* yy, const double* t2kb,
                    int64_t Nglobal, double* grad, int want_grad, hipStream_t st);
 // xs[XS_RAN1 .. XS_FAIL] = the four status slots of an exchange buffer's scalar tail (common.h)
 void write_status(double* xs, double ran1, double cap1, double cap2, double fail, hipStream_t st);
@@ -201,3 +199,5 @@ struct KStage {
 void kstage_factor(const KStage& k, const double* packed, const Scal* sc, hipStream_t st);
 void kstage_adjoint(const KStage& k, const double* BWB, double* Abar, const Scal* sc, hipStream_t st);
 void kstage_adjoint_factor_form(const KStage& k, double* McBWB, double* Abar, const Scal* sc, hipStream_t st);
+// scalars[R_TRAG] = tr(Abar G), scalars[R_UTG] = ut^T Phi^T y from the summed packed G of exchange buffer 1 (after the adjoint)
+void kstage_bbar(const KStage& k, const double* packed, const double* Abar, double* part, hipStream_t st);

@@ -561,6 +561,56 @@ __global__ __launch_bounds__(256) void adjoint_vec_kernel(const double* __restri
     if (threadIdx.x == 0) scalars[R_TRABAR] = r1[0];
 }
 
+// bbar = d(N cost)/db = sum_n Phibar_n . phi_n with Phibar_n = p_n alpha + y_n ut + 2 q_n B phi_n + 2 Abar phi_n is
+//      2 tr(Abar G) + ut^T (Phi^T y) + 2 sum_n q_n v_n + sum_n p_n mu_n :
+// a K x K trace over the summed Gram (still in exchange buffer 1 as packed lower 128 x 128 tiles: G and Abar are symmetric, so an
+// off-diagonal tile counts twice; diagonal tiles carry both triangles), a K-dot, and two row sums rowstats_kernel forms beside p
+// and q (exchange buffer 2).  Neither Phi nor Phibar is needed, and the K x K part is computed once per evaluation on the sums
+// over ranks instead of per output tile of the Phibar product.  part[t] = tile t's share of tr(Abar G).
+__global__ __launch_bounds__(256) void trace_ag_kernel(const double* __restrict__ packed, const double* __restrict__ Abar, int64_t ld,
+                                                       int K, double* __restrict__ part) {
+    constexpr int B = 128;
+    __shared__ double r1[256];
+    const int t = blockIdx.x;
+    int ti = (int)((sqrtf(8.0f * t + 1.0f) - 1.0f) * 0.5f);
+    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    while (ti * (ti + 1) / 2 > t) --ti;
+    const int tj = t - ti * (ti + 1) / 2;
+    double s = 0;
+    for (int e = threadIdx.x; e < B * B; e += 256) {
+        const int i = ti * B + e / B, j = tj * B + e % B;
+        if (i < K && j < K) s += packed[(int64_t)t * B * B + e] * Abar[(int64_t)i * ld + j];
+    }
+    r1[threadIdx.x] = s;
+    __syncthreads();
+    for (int m = 128; m >= 1; m >>= 1) {
+        if (threadIdx.x < m) r1[threadIdx.x] += r1[threadIdx.x + m];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[t] = (ti == tj ? 1.0 : 2.0) * r1[0];
+}
+// scalars[R_TRAG] = sum of the tile shares (fixed order), scalars[R_UTG] = ut^T g
+__global__ __launch_bounds__(256) void bbar_sums_kernel(const double* __restrict__ part, int ntiles, const double* __restrict__ ut,
+                                                        const double* __restrict__ g, int K, double* __restrict__ scalars) {
+    __shared__ double r1[256], r2[256];
+    double s = 0, d = 0;
+    for (int t = threadIdx.x; t < ntiles; t += 256) s += part[t];
+    for (int i = threadIdx.x; i < K; i += 256) d += ut[i] * g[i];
+    r1[threadIdx.x] = s; r2[threadIdx.x] = d;
+    __syncthreads();
+    for (int m = 128; m >= 1; m >>= 1) {
+        if (threadIdx.x < m) { r1[threadIdx.x] += r1[threadIdx.x + m]; r2[threadIdx.x] += r2[threadIdx.x + m]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { scalars[R_TRAG] = r1[0]; scalars[R_UTG] = r2[0]; }
+}
+// packed: the summed exchange buffer 1 (G); part: nts (nts + 1) / 2 doubles of scratch; call after kstage_adjoint (Abar, k.ut)
+void kstage_bbar(const KStage& k, const double* packed, const double* Abar, double* part, hipStream_t st) {
+    const int nts = k.Kp / 128, ntiles = nts * (nts + 1) / 2;
+    hipLaunchKernelGGL(trace_ag_kernel, dim3(ntiles), dim3(256), 0, st, packed, Abar, (int64_t)k.Kp, k.K, part);
+    hipLaunchKernelGGL(bbar_sums_kernel, dim3(1), dim3(256), 0, st, part, ntiles, k.ut, k.g, k.K, k.scalars);
+}
+
 // ---------------------------------------------------------------------------
 // host drivers
 // ---------------------------------------------------------------------------

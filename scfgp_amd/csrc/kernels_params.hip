@@ -209,7 +209,7 @@ void write_status(double* xs, double ran1, double cap1, double cap2, double fail
 
 // cost and the three scalar gradient entries  (SCFGP.py:125-128)
 __global__ void finalize_kernel(const Scal* __restrict__ sc, double* __restrict__ scalars, const double* __restrict__ yy,
-                                const double* __restrict__ t2kb, const double* __restrict__ bbar, int M, double N,
+                                const double* __restrict__ t2kb, int M, double N,
                                 double* __restrict__ grad, int want_grad) {
     if (threadIdx.x != 0) return;
     const double T1 = scalars[R_LOGDET], T2 = t2kb[0];
@@ -218,13 +218,15 @@ __global__ void finalize_kernel(const Scal* __restrict__ sc, double* __restrict_
     scalars[R_COST] = (T1 + T2 + T3 + T4 + scalars[R_PEN]) / N;
     if (want_grad) {
         grad[0] = (2.0 * sc->e2a * scalars[R_TRABAR] - 2.0 * T3 + 2.0 * (N - M)) / N;
-        grad[1] = bbar[0] / N;
+        // bbar = sum_n Phibar_n . phi_n in closed form (kernels_kstage.hip: kstage_bbar; t2kb[2], [3] = sum q v, sum p mu)
+        scalars[R_BBAR] = 2.0 * scalars[R_TRAG] + scalars[R_UTG] + 2.0 * t2kb[2] + t2kb[3];
+        grad[1] = scalars[R_BBAR] / N;
         grad[2] = t2kb[1] * sc->sigc / N;
     }
 }
-void finalize_cost(const Geom& g, const Scal* sc, double* scalars, const double* yy, const double* t2kb, const double* bbar,
+void finalize_cost(const Geom& g, const Scal* sc, double* scalars, const double* yy, const double* t2kb,
                    int64_t Nglobal, double* grad, int want_grad, hipStream_t st) {
-    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, st, sc, scalars, yy, t2kb, bbar, g.M, (double)Nglobal, grad, want_grad);
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, st, sc, scalars, yy, t2kb, g.M, (double)Nglobal, grad, want_grad);
 }
 
 // ---------------------------------------------------------------------------

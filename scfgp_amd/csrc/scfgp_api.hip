@@ -145,7 +145,7 @@ struct scfgp_ctx {
     int64_t* d_idx = nullptr; int64_t idx_cap = 0;
     // rows
     double *d_Xt = nullptr, *d_y = nullptr, *d_p = nullptr, *d_q = nullptr, *d_mu = nullptr, *d_vpart = nullptr;
-    void *d_Phi = nullptr, *d_V = nullptr; double* d_bpart = nullptr;
+    void *d_Phi = nullptr, *d_V = nullptr;
     // exchange buffers and K-stage
     // exchange buffers xp1/xp2 = [packed lower tiles | vector Kp | 8 scalars], x3 = [X~^T Zbar | 8 scalars];
     // x1/x2 = the same matrices unpacked to full Kp x Kp (+ vector) for the K x K stage
@@ -270,7 +270,7 @@ static int xtz_split(int ntiles, int64_t Np) {          // the X~^T Zbar grid ha
 
 static void free_rows(scfgp_ctx* c) {
     dfree(c->d_Xt); dfree(c->d_y); dfree(c->d_p); dfree(c->d_q); dfree(c->d_ws2); dfree(c->d_mu); dfree(c->d_vpart); dfree(c->d_Tt);
-    dfree(c->d_Phi); dfree(c->d_V); dfree(c->d_bpart); dfree(c->d_slabs);
+    dfree(c->d_Phi); dfree(c->d_V); dfree(c->d_slabs);
     c->Ncap = 0; c->slabs_bytes = 0;
 }
 
@@ -324,7 +324,7 @@ static int ensure_rows(scfgp_ctx* c, int64_t N) {
     if (int rc = ensure_aux_rows(c)) return rc;
     if (Np <= c->Ncap) return SCFGP_OK;
     dfree(c->d_Xt); dfree(c->d_y); dfree(c->d_p); dfree(c->d_q); dfree(c->d_ws2); dfree(c->d_mu); dfree(c->d_vpart); dfree(c->d_Tt);
-    dfree(c->d_Phi); dfree(c->d_V); dfree(c->d_bpart);
+    dfree(c->d_Phi); dfree(c->d_V);
     c->Ncap = 0;
     const size_t ts = c->tsize();
     int rc;
@@ -338,7 +338,6 @@ static int ensure_rows(scfgp_ctx* c, int64_t N) {
     if ((rc = dmalloc(c, &c->d_vpart, sizeof(double) * Np * (g.Kp / 64)))) return rc;          // <= one entry per 64 columns
     if ((rc = dmalloc(c, &c->d_Phi, ts * Np * g.Kp))) return rc;
     if ((rc = dmalloc(c, &c->d_V, ts * Np * g.Kp))) return rc;
-    if ((rc = dmalloc(c, &c->d_bpart, sizeof(double) * (g.Kp / 64) * (Np / 128)))) return rc;
     HIPCHK(c, hipMemsetAsync(c->d_Phi, 0, ts * Np * g.Kp, c->st));       // padding columns >= K stay zero forever
     HIPCHK(c, hipMemsetAsync(c->d_V, 0, ts * Np * g.Kp, c->st));         // columns >= K are never written
     c->Ncap = Np;
@@ -559,7 +558,7 @@ template <typename T> struct Impl {
         const int nb = (int)std::min<int64_t>(g.Np / 4, 2048);
         { ProfScope ps(c, "rowstats");
           SK::rowstats(g, c->d_mu, c->d_vpart, c->d_y, c->d_sc, c->d_p, c->d_q, c->d_partial, nb, c->st);
-          reduce_scalars(c->d_partial, nb, 2, c->xs2(), 0, c->st);
+          reduce_scalars(c->d_partial, nb, 4, c->xs2(), 0, c->st);       // T2, kbar, sum q v, sum p mu
           write_status(c->xs2(), 0.0, 0.0, 0.0, 0.0, c->st); }
         if (want_grad) {
             // factor form: C^T diag(q) C and C^T p (the K x K stage turns them into B W B and u); else V^T diag(q) V = B W B, V^T p = u
@@ -572,7 +571,9 @@ template <typename T> struct Impl {
         const Geom& g = c->g;
         { ProfScope ps(c, "kstage_adjoint"); unpack_exchange(c, c->d_xp2, c->d_x2);
           if (c->last_cform) kstage_adjoint_factor_form(c->kstage(), c->d_x2, c->d_Abar, c->d_sc, c->st);
-          else kstage_adjoint(c->kstage(), c->d_x2, c->d_Abar, c->d_sc, c->st); }
+          else kstage_adjoint(c->kstage(), c->d_x2, c->d_Abar, c->d_sc, c->st);
+          // the K x K part of bbar from the summed G (exchange buffer 1 is intact until the next pass 1) and Abar
+          kstage_bbar(c->kstage(), c->d_xp1, c->d_Abar, c->d_partial, c->st); }
         SK::convert(c->d_Abar, (T*)c->d_AbarT, g.K, g.Kp, c->st);
         HIPCHK(c, hipGetLastError());
         return SCFGP_OK;
@@ -580,9 +581,7 @@ template <typename T> struct Impl {
     static int pass3(scfgp_ctx* c) {
         const Geom& g = c->g;
         { ProfScope ps(c, "apply_phibar");
-          const int nb = SK::apply_phibar(g, (const T*)c->d_Phi, (const T*)c->d_AbarT, (T*)c->d_V, c->d_p, c->d_q, c->d_y, c->alpha(), c->ut(),
-                                          c->d_bpart, c->st, c->dma());
-          reduce_scalars(c->d_bpart, nb, 1, c->x3_scalars(), 0, c->st);
+          SK::apply_phibar(g, (const T*)c->d_Phi, (const T*)c->d_AbarT, (T*)c->d_V, c->d_p, c->d_q, c->d_y, c->alpha(), c->ut(), c->st, c->dma());
           write_status(c->x3_scalars(), 0.0, 0.0, 0.0, 0.0, c->st); }
         const int ntm = c->Dpp / XT, ntn = g.Jp / XT;
         const int64_t chunk = c->dtype == SCFGP_F32 ? c->gram_chunk : 0;
@@ -810,8 +809,7 @@ static void enqueue_epilogue(scfgp_ctx* c, int want_grad) {
         grad_epilogue(g, c->d_params, c->d_F, nullptr, 0, c->d_work, c->d_scalars, c->Nglobal, c->d_grad, c->st, c->d_x3, g.Jp, c->x3_xu(), c->Sq);
     else
         grad_epilogue(g, c->d_params, c->d_F, c->d_x3, g.Jp, c->d_work, c->d_scalars, c->Nglobal, want_grad ? c->d_grad : nullptr, c->st);
-    finalize_cost(g, c->d_sc, c->d_scalars, c->d_xp1 + c->n_pk + g.Kp, c->d_xp2 + c->n_pk + g.Kp, c->x3_scalars(),
-                  c->Nglobal, c->d_grad, want_grad, c->st);
+    finalize_cost(g, c->d_sc, c->d_scalars, c->xs1(), c->xs2(), c->Nglobal, c->d_grad, want_grad, c->st);
 }
 
 // Automatic precision level for the NEXT evaluation from the condition estimate of the one just finished (and, when that

@@ -68,7 +68,6 @@ def stages(name, dtype):
     XZ = x3[:Dpp * Jp].reshape(Dpp, Jp)
     out.append(('XZ', rel(XZ[:D, :J], ora.x3[:D * J].reshape(D, J))))
     out.append(('colsumZ', float(np.abs(XZ[D, :J] - ora.x3[D * J:D * J + J]).max())))
-    out.append(('bbar', abs(x3[Dpp * Jp] - ora.x3[D * J + J]) / max(1.0, abs(ora.x3[D * J + J]))))
     cost, grad, alpha, Li_h = eng.finish(True)
     c_o, g_o, al_o, Li_o = ora.finish(True)
     out.append(('cost', abs(cost - c_o) / abs(c_o)))
