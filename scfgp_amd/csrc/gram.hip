@@ -182,7 +182,12 @@ struct GramDmaPair {
                          STAGE = W_OFF + 256, STAGES = 3, LDS_BYTES = STAGES * STAGE, DMA_PER_WAVE = A_BYTES / 1024 / 8;
     static_assert(DMA_PER_WAVE == 2, "8 waves, 16 KiB of operands per stage");
 };
-template <class D, bool WEIGHT, bool DIAG>
+//   TRANS (tall tiles only): the accumulators are flushed TRANSPOSED -- output row = B-panel column, output column = A-panel column,
+//   A-panel columns 0..127 into `slab`, 128..255 into `slab_hi` -- which lets a 256 x 128 tile compute two blocks of a block ROW:
+//   the unpaired last block row of an odd block count (K = 4224: 32 of its 33 tiles) as 16 tall tiles with A = two column blocks
+//   and B = the row's own block, instead of 32 square tiles at 0.73 of the matrix peak (profiles/r05_gram_trace_C5.txt).  A lane's
+//   accumulators (tm = 0..3, tn, r) are four consecutive A-panel columns of one B-panel column: still one 32-byte slab update.
+template <class D, bool WEIGHT, bool DIAG, bool TRANS = false>
 __device__ __forceinline__ void gram_pipe_dma(
     const float* __restrict__ Phi, int64_t ld, const float* __restrict__ ws2,
     int64_t r0, int64_t r1, int64_t chunk, int acol, int bcol, double* __restrict__ sideout,
@@ -195,6 +200,7 @@ __device__ __forceinline__ void gram_pipe_dma(
     constexpr int DPW = D::DMA_PER_WAVE, NRD = 4 + (WEIGHT || DIAG ? 2 : 0), NM = 8 * TM, PRE = 2;          // per half: reads, MFMAs
     static_assert(PRE + DPW + 1 + NRD <= NM, "one fetch or read per MFMA behind the barrier");
     static_assert(!(PAIR && DIAG), "the paired diagonal blocks carry no side sums");
+    static_assert(!TRANS || (D::BM == 256 && D::B_BYTES != 0 && !DIAG), "transposed flush: off-diagonal tall tiles");
     // the thread id behind an opaque move (see gram_body_impl)
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
@@ -299,13 +305,24 @@ __device__ __forceinline__ void gram_pipe_dma(
     };
     // accumulator (tm, tn, r) of lane (i, q) is output row wm0 + TM (4 q + r) + tm, column wn0 + 4 i + tn; slabs are 128 x 128:
     // tall: rows >= 128 in slab_hi; wide: four consecutive slabs, one per 128 columns, rows 0 .. 63 of each
-    double* sl = WIDE ? slab + (int64_t)(wn0 >> 7) * (128 * 128) + (wn0 & 127)
-                      : (wm0 >= 128 ? slab_hi + (int64_t)(wm0 - 128) * 128 : slab + (int64_t)wm0 * 128) + wn0;
+    double* sl = TRANS ? (wm0 >= 128 ? slab_hi : slab) + (int64_t)wn0 * 128 + (wm0 & 127)
+               : WIDE  ? slab + (int64_t)(wn0 >> 7) * (128 * 128) + (wn0 & 127)
+                       : (wm0 >= 128 ? slab_hi + (int64_t)(wm0 - 128) * 128 : slab + (int64_t)wm0 * 128) + wn0;
     bool first = true;
     const auto flush = [&]() {
         int lf = lane;                                         // (opaque: the 16 slab addresses are formed here, not kept across the k loop)
         asm volatile("" : "+v"(lf));
         const int i = lf & 15, q = lf >> 4;
+        if constexpr (TRANS) {                                 // slab row 4 i + tn (B-panel column), columns 4 (4 q + r) .. + 3 (A-panel columns)
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v4d* d = reinterpret_cast<v4d*>(sl + (4 * i + tn) * 128 + 4 * (4 * q + r));
+                    const v4d v = v4d{(double)acc[0][tn][r], (double)acc[1][tn][r], (double)acc[2][tn][r], (double)acc[3][tn][r]};
+                    *d = first ? v : *d + v;
+                }
+        } else {
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -314,6 +331,7 @@ __device__ __forceinline__ void gram_pipe_dma(
                 const v4d v = v4d{(double)acc[tm][0][r], (double)acc[tm][1][r], (double)acc[tm][2][r], (double)acc[tm][3][r]};
                 *d = first ? v : *d + v;
             }
+        }
         if constexpr (DIAG) {                                  // the 4 k rows of a k-step live in the 4 lane groups: sum over q, fp64 across chunks
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) {
@@ -501,16 +519,18 @@ __device__ __forceinline__ void gram_sq_dma64(
 // Job list of one row split (all kernels of the launch have 8 waves):
 //   !BIG  diagonal 128 x 128 tiles, strictly lower tiles row by row, strip tiles
 //    BIG  (fp32) pairs of 128-row blocks are covered by 256 x 128 tiles (64 x 64 wave tiles, the shape of the apply
-//         product): tile (a, b), b <= 2a, is blocks (2a, b) and (2a+1, b); the diagonal blocks (2a+1, 2a+1), an
-//         unpaired last block row and the strip stay 128- / 64-row tiles.  Tall tiles with b == 2a hold the diagonal
-//         block of both of their column blocks' rows and carry the side vector for all 256 columns.
+//         product): tile (a, b), b <= 2a, is blocks (2a, b) and (2a+1, b); the diagonal blocks (2a+1, 2a+1) and the strip stay
+//         128- / 64-row tiles.  Tall tiles with b == 2a hold the diagonal block of both of their column blocks' rows and carry
+//         the side vector for all 256 columns.  An unpaired last block row i (odd block count) runs as tall tiles too, TRANSPOSED:
+//         A = column blocks (2b', 2b'+1), B = block i, flushed into tiles (i, 2b') and (i, 2b'+1); its diagonal block is a
+//         128 x 128 tile with the side sums of its columns.
 // Jobs are split-major and the XCD map hands each XCD a contiguous range of them (whole splits), so the workgroups
 // running together on one L2 work on the same rows and share operand panels; inside a split the longest jobs come
 // first and the short strip jobs last.
 template <bool BIG> __host__ __device__ inline int gram_jobs_per_split(int nfull, int nstrip) {
     if (!BIG) return nfull * (nfull + 1) / 2 + nstrip * (nfull + 1);
     const int R = nfull / 2, odd = nfull & 1, nsb = nstrip * (nfull + 1);
-    return R * R + nsb / 4 + (R + 1) / 2 + odd * nfull + nsb % 4;    // tall, wide (4 strip tiles each), diagonal blocks two by two, unpaired row, single strips
+    return R * R + nsb / 4 + (R + 1) / 2 + odd * (R + 1) + nsb % 4;  // tall, wide (4 strip tiles each), diagonal blocks two by two, unpaired row (R transposed tall + its diagonal block), single strips
 }
 // one job (row split, output tile) of the list
 template <class Cfg, class SCfg, class BCfg, bool WEIGHT, bool BIG>
@@ -526,11 +546,11 @@ __device__ __forceinline__ void gram_job(
     const int nall = nfull + nstrip, ntile_all = nall * (nall + 1) / 2;
     const int per_split = gram_jobs_per_split<BIG>(nfull, nstrip);
     const int split = j / per_split;
-    int u = j % per_split, acol, bcol, slab_t, slab_t2 = 0, kind = 0;     // kind 0: 128-row tile, 1: strip, 2: 256-row tile, 3: wide strip, 4: two diagonal blocks
+    int u = j % per_split, acol, bcol, slab_t, slab_t2 = 0, kind = 0;     // kind 0: 128-row tile, 1: strip, 2: 256-row tile, 3: wide strip, 4: two diagonal blocks, 5: transposed 256-row tile
     bool diag = false;
     const auto tri = [](int ti, int tj) { return ti * (ti + 1) / 2 + tj; };
     if (BIG) {
-        const int R = nfull / 2, Rp = (R + 1) / 2, nbig = R * R, nsmall = Rp + (nfull & 1) * nfull, nwide = nstrip * (nfull + 1) / 4;
+        const int R = nfull / 2, Rp = (R + 1) / 2, nbig = R * R, nsmall = Rp + (nfull & 1) * (R + 1), nwide = nstrip * (nfull + 1) / 4;
         if (u < nbig) {                                        // tall tile (a, b), u = a^2 + b
             int a = (int)sqrtf((float)u);
             while ((a + 1) * (a + 1) <= u) ++a;
@@ -546,9 +566,10 @@ __device__ __forceinline__ void gram_job(
             const int m = u - nbig - nwide, i = 2 * (2 * m) + 1;
             acol = bcol = i * B; slab_t = tri(i, i);
             if (2 * m + 1 < R) { const int i2 = 2 * (2 * m + 1) + 1; bcol = i2 * B; slab_t2 = tri(i2, i2); kind = 4; }
-        } else if (u < nbig + nwide + nsmall) {                // unpaired last block row
+        } else if (u < nbig + nwide + nsmall) {                // unpaired last block row i: R transposed tall tiles, then its diagonal block
             const int i = nfull - 1, b = u - nbig - nwide - Rp;
-            acol = i * B; bcol = b * B; slab_t = tri(i, b); diag = side != nullptr && b == i;
+            if (b < R) { acol = 2 * b * B; bcol = i * B; slab_t = tri(i, 2 * b); slab_t2 = tri(i, 2 * b + 1); kind = 5; }
+            else { acol = bcol = i * B; slab_t = tri(i, i); diag = side != nullptr; }
         } else {                                               // the strip tiles that do not fill a wide one
             const int tj = 4 * nwide + u - nbig - nwide - nsmall;
             acol = nfull * B; bcol = tj * B; slab_t = tri(nfull, tj); kind = 1; diag = side != nullptr && tj == nfull;
@@ -579,6 +600,10 @@ __device__ __forceinline__ void gram_job(
         if (kind == 2) {
             if (diag) gram_pipe_dma<GramDma, WEIGHT, true>(Phi, ld, ws2, r0, r1, chunk, acol, bcol, sideout, slab, slab2, smem_raw);
             else gram_pipe_dma<GramDma, WEIGHT, false>(Phi, ld, ws2, r0, r1, chunk, acol, bcol, sideout, slab, slab2, smem_raw);
+            TRACE_END(kind); return;
+        }
+        if (kind == 5) {
+            gram_pipe_dma<GramDma, WEIGHT, false, true>(Phi, ld, ws2, r0, r1, chunk, acol, bcol, sideout, slab, slab2, smem_raw);
             TRACE_END(kind); return;
         }
         if (kind == 4) {                                       // two diagonal blocks (their columns' side sums come from the tall diagonal tiles)
@@ -764,7 +789,14 @@ void GramKernels<T>::gram(const Geom& g, const T* Phi, const double* w, const do
     if (BIG && (w || side)) hipLaunchKernelGGL(gram_pack_ws, dim3((unsigned)std::min<int64_t>((g.Np + 255) / 256, 2048)), dim3(256), 0, st, w, side, ws2, g.Np);
     const auto launch = [&](auto kernel) {
         allow_big_lds(kernel, LDS);
-        hipLaunchKernelGGL(kernel, dim3(persistent ? resident : njobs), dim3(Cfg::THREADS), LDS, st, Phi, (int64_t)g.Kp, w, side, (const float*)ws2, rs, chunk,
+#ifdef SCFGP_GRAM_LD0
+        // diagnostic build only (tools/ab_bench.sh with VARIANT=_ld0): every operand row is row 0, so the launch runs out of the
+        // caches -- what the Gram would cost if its panels never crossed the fabric.  Results are meaningless, timing only.
+        const int64_t ld = 0;
+#else
+        const int64_t ld = g.Kp;
+#endif
+        hipLaunchKernelGGL(kernel, dim3(persistent ? resident : njobs), dim3(Cfg::THREADS), LDS, st, Phi, ld, w, side, (const float*)ws2, rs, chunk,
                            g.gfull, g.gstrip, sidepart, slabs, njobs, qhead);
     };
     if (w) launch(gram_kernel<Cfg, SCfg, BCfg, true, BIG>);

@@ -48,11 +48,11 @@ def main():
         hwid = tr[:, 2] >> 8
         cu = xcc * 256 + ((hwid >> 8) & 0xFF)                      # (xcc, se/sh/cu bits of HW_ID)
         print('gram hipEvent %.2f ms; %d workgroups; span %.2f ms' % (tm.get('gram', -1), len(tr), en.max() / 1e3))
-        names = {0: '128x128', 1: 'strip', 2: '256x128', 3: 'wide 64x512', 4: 'two 128x128'}
-        area = {0: 128 * 128, 1: 64 * 128, 2: 256 * 128, 3: 64 * 512, 4: 2 * 128 * 128}
+        names = {0: '128x128', 1: 'strip', 2: '256x128', 3: 'wide 64x512', 4: 'two 128x128', 5: '256x128 transposed'}
+        area = {0: 128 * 128, 1: 64 * 128, 2: 256 * 128, 3: 64 * 512, 4: 2 * 128 * 128, 5: 256 * 128}
         Kp = eng.dims()['Kp']; nfull = Kp // 128 - (1 if (2 * (S + M) + 63) // 64 % 2 else 0); nstrip = Kp // 128 - nfull
         R = nfull // 2; nsb = nstrip * (nfull + 1)
-        per_split = {2: R * R, 3: nsb // 4, 4: R // 2, 0: R % 2 + (nfull & 1) * nfull, 1: nsb % 4} if dtype == 'f32' else \
+        per_split = {2: R * R, 3: nsb // 4, 4: R // 2, 0: R % 2 + (nfull & 1), 5: (nfull & 1) * R, 1: nsb % 4} if dtype == 'f32' else \
                     {0: nfull * (nfull + 1) // 2, 1: nsb}
         for k in sorted(set(kind.tolist())):
             d = (en - st)[kind == k]
