@@ -10,8 +10,8 @@
 // Diagnostic build (-DSCFGP_TRACE): every workgroup of the LDS-DMA apply kernel records [start, end] on the 100 MHz constant
 // clock and its XCC id (tools/apply_trace.py); the product build contains none of this
 #ifdef SCFGP_TRACE
-constexpr int ATRACE_CAP = 1 << 16;
-__device__ unsigned long long g_atrace[ATRACE_CAP][5];      // start, end, xcc, first barrier passed, k loop left
+constexpr int ATRACE_CAP = 1 << 16;                         // per epilogue kind (EPI 0 .. 4): the launches of one stage do not overwrite each other's
+__device__ unsigned long long g_atrace[5 * ATRACE_CAP][5];  // start, end, xcc | column tile << 8 | stages << 20, first barrier passed, k loop left
 int64_t apply_trace_read(void* host, int64_t max_bytes) {
     const int64_t n = max_bytes < (int64_t)sizeof(g_atrace) ? max_bytes : (int64_t)sizeof(g_atrace);
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_atrace), n) == hipSuccess ? n : -2;
@@ -635,9 +635,11 @@ void apply_dma_kernel(const T* __restrict__ Phi, const T* __restrict__ Bm, T* V,
 #ifdef SCFGP_TRACE
     __syncthreads();
     if (threadIdx.x == 0 && blockIdx.x < ATRACE_CAP) {
-        g_atrace[blockIdx.x][0] = tr_t0; g_atrace[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
-        g_atrace[blockIdx.x][2] = (unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));
-        g_atrace[blockIdx.x][3] = tr_l0; g_atrace[blockIdx.x][4] = tr_l1;
+        unsigned long long* rec = g_atrace[EPI * ATRACE_CAP + blockIdx.x];
+        rec[0] = tr_t0; rec[1] = __builtin_amdgcn_s_memrealtime();
+        rec[2] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xF) | ((unsigned long long)jt << 8) |
+                                  ((unsigned long long)nst << 20);
+        rec[3] = tr_l0; rec[4] = tr_l1;
     }
 #endif
 }
