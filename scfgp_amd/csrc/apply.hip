@@ -36,8 +36,10 @@ template <typename T, int TILE> struct ApplyCfg {
 //          STARTS at its first column; plain store, no row sums
 // --------------------------------------------------------------------------
 // epilogues of the apply product: V and the row dots (EPI 0) or Phibar (EPI 1) from the accumulators
-//   MU (EPI 0 only): also mupart[jtg][n] = sum_{j in tile} Phi[n][j] alpha[j] from the Phi values the row dot reads anyway
-//   (the DMA-fed kernel has no operand values in registers for the loader-side dot)
+//   MU (EPI 0): also mupart[jtg][n] = sum_{j in tile} Phi[n][j] alpha[j] from the Phi values the row dot reads anyway
+//   (the DMA-fed kernel has no operand values in registers for the loader-side dot); EPI 3 (C = Phi Li^T): the `alpha` argument is
+//   BETA = Li Phi^T y and mupart = sum_j C[n][j] beta[j] -- the same mu_n = phi_n . alpha (alpha = Li^T beta) from the accumulators,
+//   so the factor form's epilogue does not read Phi at all
 //   VEC4 (the LDS-DMA kernels, fp32, 64-wide wave tiles of four 16-column MFMA tiles): the B operand's rows were staged in a
 //   permuted order, so that MFMA tile tn, lane column i IS output column 4 i + tn of the wave tile -- a lane then holds four
 //   ADJACENT columns of each of its rows and the epilogue moves V, Phi and Phibar 16 bytes per lane (256 contiguous bytes per
@@ -90,7 +92,7 @@ __device__ __forceinline__ void apply_epilogue_vec2(
 #pragma unroll
             for (int r = 0; r < 4; ++r) {                       // the four re-reads of Phi at once, not one dependent round trip per row
                 off[r] = (rb * Cfg::BM + co.row(tm, r)) * Kp + jg;
-                if (EPI == 0 || MU) ph[r] = *reinterpret_cast<const v2d*>(Phi + off[r]);
+                if (EPI == 0) ph[r] = *reinterpret_cast<const v2d*>(Phi + off[r]);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -100,7 +102,8 @@ __device__ __forceinline__ void apply_epilogue_vec2(
                 double part, mup = 0;
                 if (EPI == 3) part = fma(c0, c0, c1 * c1);
                 else part = fma(ph[r][0] * live[0], c0, ph[r][1] * live[1] * c1);
-                if (MU) mup = fma(ph[r][0], al[0], ph[r][1] * al[1]);
+                // EPI 3: mu_n = phi_n . alpha = (Li phi_n) . beta = C_n . beta (alpha = Li^T beta): from the accumulators, no re-read of Phi
+                if (MU) mup = EPI == 3 ? fma(c0, al[0], c1 * al[1]) : fma(ph[r][0], al[0], ph[r][1] * al[1]);
                 part = row16_sum(part);
                 if ((co.lane & 15) == 0) red[wn * Cfg::BM + row] = part;
                 if (MU) {
@@ -186,7 +189,7 @@ __device__ __forceinline__ void apply_epilogue(
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     off[r] = (rb * Cfg::BM + co.row(tm, r)) * Kp + jg;
-                    if (EPI == 0 || MU) ph[r] = *reinterpret_cast<const v4f*>(Phi + off[r]);
+                    if (EPI == 0) ph[r] = *reinterpret_cast<const v4f*>(Phi + off[r]);
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -196,7 +199,7 @@ __device__ __forceinline__ void apply_epilogue(
                     double part = 0, mup = 0;
                     if (EPI == 3) {
                         part = (double)(c[0] * c[0]) + (double)(c[1] * c[1]) + (double)(c[2] * c[2]) + (double)(c[3] * c[3]);
-                        if (MU) mup = (double)ph[r][0] * al[0] + (double)ph[r][1] * al[1] + (double)ph[r][2] * al[2] + (double)ph[r][3] * al[3];
+                        if (MU) mup = (double)c[0] * al[0] + (double)c[1] * al[1] + (double)c[2] * al[2] + (double)c[3] * al[3];     // C_n . beta
                     } else {
 #pragma unroll
                         for (int k = 0; k < 4; ++k) { part += (double)ph[r][k] * (double)c[k] * live[k]; if (MU) mup += (double)ph[r][k] * al[k]; }
@@ -287,7 +290,8 @@ __device__ __forceinline__ void apply_epilogue(
                     if (EPI != 2) V[off + co.col(tn)] = c;
                     if (EPI != 0) {                                   // v_n = || Li phi_n ||^2
                         part += (double)c * (double)c;
-                        if (MU && cbase + co.col(tn) < K) mup += (double)Phi[off + co.col(tn)] * al[tn];
+                        // mu_n: predict (EPI 2) Phi* . alpha with the caller's alpha; factor form (EPI 3) C_n . beta
+                        if (MU && cbase + co.col(tn) < K) mup += (EPI == 3 ? (double)c : (double)Phi[off + co.col(tn)]) * al[tn];
                     } else if (cbase + co.col(tn) < K) {              // v_n = phi_n . (B phi_n)
                         const double ph = (double)Phi[off + co.col(tn)];
                         part += ph * (double)c;
@@ -478,7 +482,12 @@ void apply_dma_kernel(const T* __restrict__ Phi, const T* __restrict__ Bm, T* V,
     const unsigned long long tr_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
     const unsigned wid = xcd_remap(blockIdx.x, gridDim.x);
-    const int jt = wid % njt;
+    // Triangular products (EPI 3 / 4): a column tile's k range, and with it the workgroup's duration, grows with jt.  The
+    // hardware deals the workgroups of an XCD to its four shader engines round-robin in launch order and balances only inside
+    // an engine, so with jt = wid % njt (njt a multiple of 4) one engine got every longest tile and one every shortest -- a
+    // quarter of the workgroup slots idle for the whole launch, and a k loop per stage that is periodic in jt mod 4
+    // (profiles/r05_apply_tri_trace.txt).  Rotating the column tile by the row block hands every engine every length in turn.
+    const int jt = EPI == 3 || EPI == 4 ? (int)((wid % njt + wid / njt) % njt) : (int)(wid % njt);
     const int64_t rb = rb0 + wid / njt;                        // the launch covers row blocks rb0 ..
     const int cbase = col0 + jt * D::BN;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -760,9 +769,9 @@ void ApplyKernels<T>::apply_plain(const Geom& g, const T* A, const T* Bm, T* Out
 }
 
 template <typename T>
-void ApplyKernels<T>::apply_c(const Geom& g, const T* Phi, const T* LiT, const T* Li, T* C, double* vpart, const double* alpha,
+void ApplyKernels<T>::apply_c(const Geom& g, const T* Phi, const T* LiT, const T* Li, T* C, double* vpart, const double* beta,
                               double* mu, hipStream_t st, int dma) {
-    apply_launch<T, 3>(g, Phi, LiT, C, vpart, nullptr, nullptr, nullptr, alpha, nullptr, mu, st, dma, Li);
+    apply_launch<T, 3>(g, Phi, LiT, C, vpart, nullptr, nullptr, nullptr, beta, nullptr, mu, st, dma, Li);
 }
 template <typename T>
 void ApplyKernels<T>::apply_vc(const Geom& g, const T* C, const T* Li, const T* LiT, T* V, hipStream_t st, int dma) {

@@ -544,11 +544,12 @@ template <typename T> struct Impl {
     static int pass2(scfgp_ctx* c, int want_grad) {
         const Geom& g = c->g;
         if (c->last_cform) {
-            // triangular products: the loader-staged 256 x 128 tiles (two workgroups per CU) ride out the unequal k ranges best
-            // (C3: 41.7 / 40.1 ms against 43.9 / 41.6 by LDS-DMA 128 wide and 49.8 / 46.9 by 256-wide tiles); LDS-DMA on request only
-            const int dma = c->apply_dma > 0 ? c->apply_dma : 0;
+            // triangular products: 128-wide LDS-DMA tiles wherever the square products use LDS-DMA.  With the column tile rotated
+            // by the row block (apply.hip: the shader engines' round-robin) they beat the loader-staged tiles that pair a long
+            // and a short column tile per workgroup: C3 34.4 / 33.5 ms against 40.0 / 34.9 (profiles/r05_tuning.md)
+            const int dma = c->dma() ? 1 : 0;
             { ProfScope ps(c, "apply_c");
-              SK::apply_c(g, (const T*)c->d_Phi, (const T*)c->d_AbarT, (const T*)c->d_BT, (T*)c->d_C, c->d_vpart, c->alpha(), c->d_mu, c->st, dma); }
+              SK::apply_c(g, (const T*)c->d_Phi, (const T*)c->d_AbarT, (const T*)c->d_BT, (T*)c->d_C, c->d_vpart, c->beta(), c->d_mu, c->st, dma); }
             { ProfScope ps(c, "apply_vc");
               SK::apply_vc(g, (const T*)c->d_C, (const T*)c->d_BT, (const T*)c->d_AbarT, (T*)c->d_V, c->st, dma); }
         } else {
