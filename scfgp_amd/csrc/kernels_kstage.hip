@@ -633,6 +633,8 @@ void kstage_factor(const KStage& k, const double* packed, const Scal* sc, hipStr
     cholesky_inverse_gram(k, st);
     // alpha = Li^T (Li g) = B g  (SCFGP.py:108-110); B is symmetric, so one coalesced row-dot GEMV
     hipLaunchKernelGGL(gemv_rows_kernel, dim3((Kp + 3) / 4), dim3(256), 0, st, k.B, ld, k.g, k.alpha, Kp);
+    // beta = Li g (SCFGP.py:109): what the factor form of pass 2 multiplies C = Phi Li^T with to get mu = Phi alpha = C beta
+    hipLaunchKernelGGL(gemv_rows_kernel, dim3((Kp + 3) / 4), dim3(256), 0, st, k.Li, ld, k.g, k.beta, Kp);
     hipLaunchKernelGGL(factor_scalars_kernel, dim3(1), dim3(256), 0, st, k.T2, k.B, ld, k.K, k.g, k.alpha, k.scalars);
 }
 
