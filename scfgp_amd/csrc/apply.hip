@@ -769,9 +769,12 @@ void ApplyKernels<T>::apply_plain(const Geom& g, const T* A, const T* Bm, T* Out
 }
 
 template <typename T>
-void ApplyKernels<T>::apply_c(const Geom& g, const T* Phi, const T* LiT, const T* Li, T* C, double* vpart, const double* beta,
-                              double* mu, hipStream_t st, int dma) {
-    apply_launch<T, 3>(g, Phi, LiT, C, vpart, nullptr, nullptr, nullptr, beta, nullptr, mu, st, dma, Li);
+void ApplyKernels<T>::apply_c(const Geom& g, const T* Phi, const T* LiT, const T* Li, T* C, double* vpart, const double* alpha,
+                              const double* beta, double* mu, hipStream_t st, int dma) {
+    // mu = Phi alpha: the loader-staged tiles form it from the Phi values they stage (alpha); the LDS-DMA tiles have no operand
+    // values in registers and take it from their accumulators instead, mu = C beta (apply_epilogue, EPI 3)
+    const bool by_dma = dma && ApplyPlan<T>(g.K).count[0] > 0;
+    apply_launch<T, 3>(g, Phi, LiT, C, vpart, nullptr, nullptr, nullptr, by_dma ? beta : alpha, nullptr, mu, st, dma, Li);
 }
 template <typename T>
 void ApplyKernels<T>::apply_vc(const Geom& g, const T* C, const T* Li, const T* LiT, T* V, hipStream_t st, int dma) {

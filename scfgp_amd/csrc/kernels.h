@@ -106,13 +106,13 @@ struct ApplyKernels {
     static void apply_predict(const Geom& g, const T* Phi, const T* LiT, double* vpart, const double* alpha, double* mupart,
                               hipStream_t st);
     // Factor form of pass 2 (the reference's own products, SCFGP/SCFGP.py:112: v = rowsum((Phi Li^T)^2)): C = Phi . LiT
-    // (triangular: half the flops), vpart = slices of rowsum(C^2), mupart = slices of C . beta (= Phi . alpha, SCFGP.py:109-111:
-    // alpha = Li^T beta; pass BETA where apply_v takes alpha); then V = C . Li = Phi B (triangular).
+    // (triangular: half the flops), vpart = slices of rowsum(C^2), mupart = slices of mu = Phi . alpha = C . beta (SCFGP.py:109-111:
+    // alpha = Li^T beta, beta = Li Phi^T y; the LDS-DMA tiles use the second form); then V = C . Li = Phi B (triangular).
     // Li / LiT: the typed K x K copies of L^-1 and its transpose (padding zeroed).  Rounding errors of C are amplified by
     // cond(L) = sqrt(cond(A)) where those of V = Phi . B computed directly are amplified by cond(A)
     // (profiles/r03_c3_owner.md).
-    static void apply_c(const Geom& g, const T* Phi, const T* LiT, const T* Li, T* C, double* vpart, const double* beta,
-                        double* mupart, hipStream_t st, int dma = 0);
+    static void apply_c(const Geom& g, const T* Phi, const T* LiT, const T* Li, T* C, double* vpart, const double* alpha,
+                        const double* beta, double* mupart, hipStream_t st, int dma = 0);
     static void apply_vc(const Geom& g, const T* C, const T* Li, const T* LiT, T* V, hipStream_t st, int dma = 0);
     // Phibar = 2 Phi.Abar + 2 q V + p alpha^T + y ut^T  (in place over V)
     static void apply_phibar(const Geom& g, const T* Phi, const T* Abar, T* V, const double* p, const double* q,

@@ -549,7 +549,7 @@ template <typename T> struct Impl {
             // and a short column tile per workgroup: C3 34.4 / 33.5 ms against 40.0 / 34.9 (profiles/r05_tuning.md)
             const int dma = c->dma() ? 1 : 0;
             { ProfScope ps(c, "apply_c");
-              SK::apply_c(g, (const T*)c->d_Phi, (const T*)c->d_AbarT, (const T*)c->d_BT, (T*)c->d_C, c->d_vpart, c->beta(), c->d_mu, c->st, dma); }
+              SK::apply_c(g, (const T*)c->d_Phi, (const T*)c->d_AbarT, (const T*)c->d_BT, (T*)c->d_C, c->d_vpart, c->alpha(), c->beta(), c->d_mu, c->st, dma); }
             { ProfScope ps(c, "apply_vc");
               SK::apply_vc(g, (const T*)c->d_C, (const T*)c->d_BT, (const T*)c->d_AbarT, (T*)c->d_V, c->st, dma); }
         } else {
