@@ -65,6 +65,7 @@ def parse_args(argv=None):
     ap.add_argument('--cpu-rows', type=int, default=100000)
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-secondary', action='store_true', help='skip the fp64 leg and the parity block')
+    ap.add_argument('--triple', action='store_true', help='with a custom shape (--rows): still time the triple and the on-device loop (secondary.through_triple)')
     ap.add_argument('--backend', default='nccl', help="'gloo' rehearses the multi-rank flow on one GPU")
     ap.add_argument('--native-rccl', action='store_true',
                     help='the three sums by the library itself (scfgp_comm_init: ncclAllReduce on its own stream) instead of torch.distributed')
@@ -199,15 +200,15 @@ def box_probe(device):
     """What this device delivers: fp32 MFMA TFLOP/s of a register-only loop, the clock it held, streaming copy GB/s."""
     import ctypes as C
     from scfgp_amd import _lib
-    out = (C.c_double * 6)()
-    rc = _lib.load().scfgp_box_probe(int(device), out, 6)
+    out = (C.c_double * 7)()
+    rc = _lib.load().scfgp_box_probe(int(device), out, 7)
     if rc != 0:
         return {"error": rc}
     return {"mfma_f32_TFLOPs": out[0], "mfma_f32_frac_of_peak": out[0] / PEAK_TFLOPS['f32'], "mfma_clock_GHz": out[1],
             "mfma_f32_TFLOPs_at_1_2_8_waves_per_simd": [out[3], out[4], out[5]],
-            "copy_GBs": out[2], "copy_frac_of_8TBs": out[2] / HBM_PEAK_GBS,
+            "copy_GBs": out[2], "copy_frac_of_8TBs": out[2] / HBM_PEAK_GBS, "read_GBs": out[6], "read_frac_of_8TBs": out[6] / HBM_PEAK_GBS,
             "what": "scfgp_box_probe before the engine is created: register-only v_mfma_f32_16x16x4_f32 loop on random operands "
-                    "(no memory traffic), shader clock held during it, 1 GiB -> 1 GiB streaming copy (read + write)"}
+                    "(no memory traffic), shader clock held during it, 1 GiB -> 1 GiB streaming copy (read + write), read-only stream of the same 2 GiB"}
 
 
 def rel(a, b):
@@ -267,6 +268,24 @@ def through_triple(X, y, params, D, S, M, local, n=3):
     cf.engine.close()
     res["note"] = ("CompiledFuncs.train_iter_func (host adam + Nesterov), median of %d calls; never `value`.  read_only_arrays is the "
                    "drop-in path (SCFGP.optimize on the arrays SCFGP.set_data froze); writeable_arrays pays a full hash per call" % n)
+    # the on-device loop (scfgp_train: evaluation + update rule, no host between iterations): the captured graph, and -- what a
+    # rank of a row-sharded job runs -- eager launches with the three sums inside the library (a one-rank communicator here)
+    from scfgp_amd.engine import HipEngine
+    iters = 8
+    for tag, comm in (('device_loop', False), ('device_loop_sums_inside', True)):
+        try:
+            e = HipEngine(D, S, M, dtype='f32', device=local)
+            e.set_params(params); e.set_data(X, y, n_global=X.shape[0])
+            if comm:
+                e.comm_init(1, 0, e.comm_unique_id())
+            e.opt_init('adam', learning_rate=1e-3)
+            e.train(2, want_factors=False)
+            t0 = time.perf_counter()
+            e.train(iters, want_factors=True)
+            res[tag] = {"ms_per_iteration": (time.perf_counter() - t0) * 1e3 / iters, "iterations_per_call": iters}
+            e.close()
+        except Exception as ex:                                      # e.g. no librccl on the box
+            res[tag] = {"error": repr(ex)}
     return res
 
 
@@ -470,7 +489,7 @@ def main(a):
                 X, y, params, D, S, M, local, (cost, grad, alpha, Li), eng)
             if plain is not None:
                 out["secondary"]["plain_fp32"] = plain
-        if world == 1 and not a.no_secondary and a.dtype == 'f32' and not a.custom:
+        if world == 1 and not a.no_secondary and a.dtype == 'f32' and (not a.custom or a.triple):
             out["secondary"]["through_triple"] = through_triple(X, y, params, D, S, M, local)
         if not a.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(X, y, params, S, M, N, a.cpu_rows)

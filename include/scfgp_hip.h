@@ -274,7 +274,8 @@ int scfgp_set_option(scfgp_ctx* ctx, const char* name, int64_t value);
 
 /* Box probe (no reference counterpart; bench.py's `secondary.box`): ~100 ms of device work on `device`, no context needed.
  * out[0] = fp32 MFMA TFLOP/s of a register-only v_mfma_f32_16x16x4_f32 loop (best of 1, 2, 8 waves per SIMD; n >= 6: each
- * in out[3..5]), out[1] = shader clock it held (GHz), out[2] = GB/s of a 1 GiB -> 1 GiB streaming copy (read + write).
+ * in out[3..5]), out[1] = shader clock it held (GHz), out[2] = GB/s of a 1 GiB -> 1 GiB streaming copy (read + write), n >= 7:
+ * out[6] = GB/s of a read-only stream over the same 2 GiB (the ceiling of the sweeps that only read).
  * Lets two timings from two devices be normalised. */
 int scfgp_box_probe(int device, double* out, int n);
 

@@ -675,6 +675,9 @@ void gram_kernel(
 // Row tile ti0 + (t / ntn) of the output (tiles are 128 rows apart whatever Cfg::BM is: a narrower Cfg multiplies only the
 // first BM rows of its tile and zeroes the rest of the 128 x 128 slab)
 //   PLAIN: the B operand is a stored matrix (Phi[n][j], j < J; Pb unused) instead of Zbar formed from Phi and Phibar
+#ifndef SCFGP_XTZ_DEEP
+#define SCFGP_XTZ_DEEP 0           // measured, not shipped: see the comment in the kernel
+#endif
 template <class Cfg, typename S, bool PLAIN = false>
 __global__ __launch_bounds__(Cfg::THREADS) void xtz_kernel(
     const double* __restrict__ Xt, int Dp, const S* __restrict__ Phi, const S* __restrict__ Pb, int64_t ld, int J, int64_t Np,
@@ -695,15 +698,26 @@ __global__ __launch_bounds__(Cfg::THREADS) void xtz_kernel(
         const int64_t c1 = c0 + chunk < r1 ? c0 + chunk : r1;
         acc_zero<Cfg>(acc);
         if (c0 < r1) {
-            NatLoader<double, T, Cfg::BM, Cfg::BK, Cfg::LDA, Cfg::THREADS, false, true> la(
+            // The product is bound by the stream of Phi and Phibar (44 KB per 16-row k-tile and workgroup against 0.4 MFLOP).  Fetching
+            // three k-tiles ahead (three register sets in the loaders, tile_mainloop_deep3; -DSCFGP_XTZ_DEEP=1) was measured and is NOT
+            // what it lacks: 180 VGPRs leave one workgroup per CU and the launch went 3.6-3.9 -> 4.05 ms at the headline shape (C5:
+            // equal).  At 4.3-4.7 TB/s it already runs at what a read-only stream reaches on these boxes (scfgp_box_probe out[6];
+            // profiles/r05_tuning.md).
+            constexpr bool DEEP = SCFGP_XTZ_DEEP && sizeof(T) == 4;      // fp64: three sets of doubles do not fit the registers
+            constexpr int NS = DEEP ? 3 : 1;
+            NatLoader<double, T, Cfg::BM, Cfg::BK, Cfg::LDA, Cfg::THREADS, false, true, false, NS> la(
                 Xt + c0 * Dp + (int64_t)ti * 128, Dp, threadIdx.x, nullptr, Dp - ti * 128);
+            const auto run = [&](auto& lb) {
+                if constexpr (DEEP) tile_mainloop_deep3<Cfg>(la, lb, (int)((c1 - c0) / Cfg::BK), acc, smem);
+                else tile_mainloop<Cfg>(la, lb, (int)((c1 - c0) / Cfg::BK), acc, smem);
+            };
             if constexpr (PLAIN) {
-                NatLoader<S, T, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS, false, true> lb(Phi + c0 * ld + tj * Cfg::BN, ld, threadIdx.x, nullptr,
-                                                                                         J - tj * Cfg::BN);
-                tile_mainloop<Cfg>(la, lb, (int)((c1 - c0) / Cfg::BK), acc, smem);
+                NatLoader<S, T, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS, false, true, false, NS> lb(Phi + c0 * ld + tj * Cfg::BN, ld, threadIdx.x, nullptr,
+                                                                                                    J - tj * Cfg::BN);
+                run(lb);
             } else {
-                ZbarLoader<S, T, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS> lb(Phi + c0 * ld, Pb + c0 * ld, ld, J, tj * Cfg::BN, threadIdx.x);
-                tile_mainloop<Cfg>(la, lb, (int)((c1 - c0) / Cfg::BK), acc, smem);
+                ZbarLoader<S, T, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS, NS> lb(Phi + c0 * ld, Pb + c0 * ld, ld, J, tj * Cfg::BN, threadIdx.x);
+                run(lb);
             }
         }
         slab_flush<Cfg>(acc, slab, first);

@@ -295,14 +295,15 @@ struct TrLoader {
 //   s[k=n][x=j] = Phi[n][j] * Phibar[n][J+j] - Phi[n][J+j] * Phibar[n][j]      (0 for j >= J)
 // the cotangent of the phase argument (cos' = -sin, sin' = cos), so no N x J buffer exists.
 // ---------------------------------------------------------------------------
-template <typename S, typename T, int BX, int BK, int LD, int THREADS>
+//   NSETS: register sets for fetches more than one k-tile ahead (tile_mainloop_deep3), as in NatLoader
+template <typename S, typename T, int BX, int BK, int LD, int THREADS, int NSETS = 1>
 struct ZbarLoader {
     static constexpr int VS = Vec16<S>::N;
     static constexpr int VPR = BX / VS;
     static constexpr int NV = (BK * VPR + THREADS - 1) / THREADS;
     const S* phi; const S* pb; int64_t ld; int J, j0, tid; bool vec; int kt = 0;   // consecutive k-tiles
     typedef typename Vec16<S>::type vec_t;
-    vec_t raw[NV][4];                                         // fc, fs, bc, bs: combined in store(), after the MFMAs
+    vec_t raw[NSETS][NV][4];                                  // fc, fs, bc, bs: combined in store(), after the MFMAs
     __device__ __forceinline__ ZbarLoader(const S* phi_, const S* pb_, int64_t ld_, int J_, int j0_, int t)
         : phi(phi_), pb(pb_), ld(ld_), J(J_), j0(j0_), tid(t), vec(J_ % VS == 0) {}
     template <int SET = 0>
@@ -315,14 +316,14 @@ struct ZbarLoader {
             const S* f = phi + (int64_t)(kt * BK + k) * ld;
             const S* b = pb + (int64_t)(kt * BK + k) * ld;
             if (ok && vec && j + VS <= J) {
-                raw[i][0] = *reinterpret_cast<const vec_t*>(f + j); raw[i][1] = *reinterpret_cast<const vec_t*>(f + J + j);
-                raw[i][2] = *reinterpret_cast<const vec_t*>(b + j); raw[i][3] = *reinterpret_cast<const vec_t*>(b + J + j);
+                raw[SET][i][0] = *reinterpret_cast<const vec_t*>(f + j); raw[SET][i][1] = *reinterpret_cast<const vec_t*>(f + J + j);
+                raw[SET][i][2] = *reinterpret_cast<const vec_t*>(b + j); raw[SET][i][3] = *reinterpret_cast<const vec_t*>(b + J + j);
             } else {
 #pragma unroll
                 for (int e = 0; e < VS; ++e) {
                     const bool in = ok && j + e < J;
-                    raw[i][0][e] = in ? f[j + e] : (S)0; raw[i][1][e] = in ? f[J + j + e] : (S)0;
-                    raw[i][2][e] = in ? b[j + e] : (S)0; raw[i][3][e] = in ? b[J + j + e] : (S)0;
+                    raw[SET][i][0][e] = in ? f[j + e] : (S)0; raw[SET][i][1][e] = in ? f[J + j + e] : (S)0;
+                    raw[SET][i][2][e] = in ? b[j + e] : (S)0; raw[SET][i][3][e] = in ? b[J + j + e] : (S)0;
                 }
             }
         }
@@ -336,7 +337,7 @@ struct ZbarLoader {
             if ((BK * VPR) % THREADS != 0 && v >= BK * VPR) continue;
             T* d = s + (v / VPR) * LD + (v % VPR) * VS;
 #pragma unroll
-            for (int e = 0; e < VS; ++e) d[e] = (T)raw[i][0][e] * (T)raw[i][3][e] - (T)raw[i][1][e] * (T)raw[i][2][e];
+            for (int e = 0; e < VS; ++e) d[e] = (T)raw[SET][i][0][e] * (T)raw[SET][i][3][e] - (T)raw[SET][i][1][e] * (T)raw[SET][i][2][e];
         }
     }
 };
