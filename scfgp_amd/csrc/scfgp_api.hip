@@ -259,8 +259,12 @@ struct DevTmp {
     operator double*() const { return p; }
 };
 
-static int xtz_split(int ntiles, int64_t Np) {          // the X~^T Zbar grid has few tiles: ~1152 workgroups measured best
-    int64_t s = (1152 + ntiles - 1) / ntiles;
+// Row splits of the X~^T Zbar grid (few output tiles, equally long workgroups, two per CU): ONE round of the 512 resident
+// workgroups.  The former "about 1152 workgroups" were 2.25 rounds at the headline shape (9 tiles x 128 splits) -- a third
+// round a quarter full: 4.00 ms against 3.24 at 56 splits = 504 workgroups, 3.28-3.32 at two to six full rounds
+// (profiles/r05_tuning.md).
+static int xtz_split(int ntiles, int64_t Np) {
+    int64_t s = std::max(1, 512 / ntiles);
     int64_t smax = std::max<int64_t>(Np / 2048, 1);
     if (ntiles * smax < 256) smax = std::max<int64_t>(Np / 64, 1);      // small problems: short dependent k-loops instead of few long ones
     if (s > smax) s = smax;
