@@ -409,7 +409,7 @@ def main(a):
         peak = PEAK_TFLOPS[a.dtype]
         falg = 10.0 * N * K * K + 4.0 * N * D * J
         traffic, traffic_src, pmc = None, None, {}
-        tp = next((f for f in (os.path.join(ROOT, 'profiles', 'r%02d_pmc_traffic.json' % r) for r in (4, 3, 2)) if os.path.exists(f)), '')
+        tp = next((f for f in (os.path.join(ROOT, 'profiles', 'r%02d_pmc_traffic.json' % r) for r in (5, 4, 3, 2)) if os.path.exists(f)), '')
         if os.path.exists(tp) and not a.custom and world == 1:
             # HBM-side bytes per launch of the same kernels on the same workload, from rocprofv3 PMC passes
             # (FETCH_SIZE x2 + WRITE_SIZE, one counter per pass): they cannot be collected inside this process

@@ -905,10 +905,22 @@ template struct GramKernels<float>;
 __global__ __launch_bounds__(256) void reduce_tri_kernel(const double* __restrict__ slabs, int nsplit, int ntiles, int B,
                                                          double* __restrict__ packed) {
     const int t = blockIdx.x;
-    for (int e = blockIdx.y * 256 + threadIdx.x; e < B * B; e += gridDim.y * 256) {
-        double s = 0;
-        for (int sp = 0; sp < nsplit; ++sp) s += slabs[((int64_t)sp * ntiles + t) * (B * B) + e];
-        packed[(int64_t)t * B * B + e] = s;
+    // two doubles per thread and eight splits' loads in flight before the first add (the adds themselves stay in split order):
+    // the launch streams 1.6 GB at the headline shape and was bound by one dependent load per iteration
+    for (int e = 2 * (blockIdx.y * 256 + threadIdx.x); e < B * B; e += 2 * gridDim.y * 256) {
+        const double* src = slabs + (int64_t)t * (B * B) + e;
+        const int64_t step = (int64_t)ntiles * (B * B);
+        v2d s = v2d{0, 0};
+        int sp = 0;
+        for (; sp + 8 <= nsplit; sp += 8) {
+            v2d x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const v2d*>(src + (sp + u) * step);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += x[u];
+        }
+        for (; sp < nsplit; ++sp) s += *reinterpret_cast<const v2d*>(src + sp * step);
+        *reinterpret_cast<v2d*>(packed + (int64_t)t * B * B + e) = s;
     }
 }
 void reduce_tri_tiles(const double* slabs, int nsplit, int nts, int tile, double* packed, hipStream_t st) {
