@@ -1185,6 +1185,11 @@ extern "C" int scfgp_train(scfgp_ctx* c, int n_iters, double* cost_hist, double*
     if (int rc = ready(c)) return rc;
     if (c->opt_algo < 0 || n_iters < 1) { c->err = "train: call scfgp_opt_init first"; return SCFGP_EARG; }
     if (int rc = restore_full_set(c)) return rc;
+    if (!c->comm && c->Nglobal != c->g.N) {                      // a shard without its peers would train on its own rows' sums
+        c->err = "train: the resident rows are a shard (n_global != N) but no communicator is attached (scfgp_comm_init); the "
+                 "on-device loop needs the sums over ranks inside the library";
+        return SCFGP_EARG;
+    }
     const Geom& g = c->g;
     if (n_iters > c->hist_cap) {
         dfree(c->d_hist);
@@ -1199,7 +1204,11 @@ extern "C" int scfgp_train(scfgp_ctx* c, int n_iters, double* cost_hist, double*
     // is settled here, before the iterations -- possibly one captured graph -- are enqueued)
     for (int round = 0; round < 5 && c->dtype == SCFGP_F32 && c->gram64 == 2 && (!c->cond_valid || c->unsettled); ++round) {
         int rc;
-        if ((rc = DISPATCH(c, pass1, c))) return rc;
+        c->stage = 0;
+        if ((rc = injected_failure(c, 1)) || (rc = DISPATCH(c, pass1, c))) {
+            if (c->comm) (void)scfgp_fail_stage(c, 1, 1);         // the peers' probes wait in exchange 1; they read the mark and stop there too
+            return rc;
+        }
         c->stage = 1;
         if ((rc = comm_sum(c, 1, "exchange1"))) return rc;
         if ((rc = settle_level(c)) == SCFGP_REDO) continue;

@@ -247,3 +247,9 @@ def test_training_with_the_sums_inside_the_library_equals_the_plain_loop(dtype):
     assert [n for n, _ in e.timings() if n.startswith('exchange')] == ['exchange1', 'exchange2', 'exchange3']
     assert float(e.eval()[0]) == c0
     e.close(); plain.close()
+    # a shard without its peers: the on-device loop would train on its own rows' sums -- refused
+    lone = HipEngine(D, S, M, dtype); lone.set_params(params); lone.set_data(X[:N // 2], y[:N // 2], n_global=N)
+    lone.opt_init('adam')
+    with pytest.raises(ValueError, match='communicator'):
+        lone.train(2)
+    lone.close()
