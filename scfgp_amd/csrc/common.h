@@ -33,7 +33,7 @@ enum {
 };
 
 // Status word of a row-sharded evaluation: slots of the 8 scalars that close every exchange buffer ([0..3] carry row sums: y^T y;
-// T2, kbar, ...; bbar).  Every rank writes its own 0 / 1 before the sum over ranks, so the summed slots COUNT ranks and every
+// T2, kbar, sum q v, sum p mu; nothing in exchange 3).  Every rank writes its own 0 / 1 before the sum over ranks, so the summed slots COUNT ranks and every
 // rank reads the same numbers (include/scfgp_hip.h, "ranks decide together"):
 //   XS_RAN1  ranks whose pass 1 ran at precision level >= 1 (fp64 Gram)          exchange 1
 //   XS_CAP1  ranks that cannot reach level 1 (its row buffer was refused)        exchange 1
