@@ -37,7 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 SEED = 0x5CF600FF
-PEAK_TFLOPS = {'f32': 157.3, 'f64': 78.6}     # dense MFMA peaks, MI355X_MICROARCH.md / datasheet
+PEAK_TFLOPS = {'f32': 157.3, 'f64': 78.6, 'f16x3': 157.3}     # dense MFMA peaks, MI355X_MICROARCH.md / datasheet ('f16x3': a secondary mode, priced as fp32-equivalent work)
 HBM_PEAK_GBS = 8000.0
 
 # BASELINE.json `configs` (C1..C5) and the headline metric (H): N, D, S (rank), M, compute dtype
@@ -321,8 +321,31 @@ def f64_leg_and_parity(X, y, params, D, S, M, local, f32_out, f32_eng, steps=5, 
                  "cost": float(outp[0]), "cond_est": cdp['cond_est'], "alpha_err_predicted": cdp['alpha_err_fp32'],
                  "parity_at_size": _parity(outp, ref, ep, e64, D, S, M, "plain fp32 (gram64 = 0) vs fp64 " + base)}
         ep.close()
+    # SECONDARY mode f16x3 (include/scfgp_hip.h: SCFGP_F16X3): fp32 mode whose two square apply products run as a three-term
+    # fp16 split on the fp16 matrix pipe.  Same rows, its own parity block against fp64 mode; never `value`, never `dtype: f32`
+    f16 = None
+    try:
+        e16 = HipEngine(D, S, M, dtype='f16x3', device=local)
+        e16.set_params(params); e16.set_data(X, y, n_global=N)
+        ms16, st16, out16 = _timed_leg(e16, steps, warmup)
+        ap16 = float(np.median([st16.get('apply_v', 0), st16.get('apply_phibar', 0)]))
+        n256 = (K // 128) // 2                                     # the 256-wide tiles run the split; the ragged remainder stays exact fp32
+        fl16 = 2.0 * (2.0 * N * (256.0 * n256) * K)                 # two v_mfma_f32_16x16x32_f16 per tile and 16 k: 2 x the product's flops
+        f16 = {"what": "fp32 mode with V = Phi B and Phibar = 2 Phi Abar + ... as a three-term fp16 split (h.h + l.h + h.l, fp32 accumulators, "
+                       "power-of-two operand scales; scfgp_amd/csrc/apply_f16.hip); Gram products, feature map and everything else exact fp32 mode",
+               "evals_per_s": 1e3 / ms16, "ms_per_step": ms16, "steps": steps, "statistic": "median", "stages_ms": st16,
+               "cost": float(out16[0]), "precision_level": int(e16.condition()['level']),
+               "roofline": {"bound": "mfma", "achieved": fl16 / (ap16 * 1e-3) / 1e12 if ap16 > 0 else 0.0, "peak": 2500.0,
+                            "unit": "TFLOP/s (fp16 MFMA, executed: two instructions per output tile and 16 k)",
+                            "frac": (fl16 / (ap16 * 1e-3) / 1e12 / 2500.0) if ap16 > 0 else 0.0, "avg_launch_ms": ap16,
+                            "fp32_equivalent_TFLOPs": 2.0 * N * K * K / (ap16 * 1e-3) / 1e12 if ap16 > 0 else 0.0,
+                            "kernel": "apply_f16_kernel (256-wide tiles) + the exact-fp32 64-wide remainder of the same product"},
+               "parity_at_size": _parity(out16, ref, e16, e64, D, S, M, "f16x3 mode vs fp64 " + base)}
+        e16.close()
+    except Exception as ex:
+        f16 = {"error": repr(ex)}
     e64.close()
-    return sec, parity, plain
+    return sec, parity, plain, f16
 
 
 def main(a):
@@ -485,8 +508,9 @@ def main(a):
         # the fp64 leg and the fp32-vs-fp64 parity block: at the headline shape and at the two other 1e6-row fp32 configs (C3's
         # D = 8 makes A ill-conditioned: that is where fp32 products cost the most accuracy, and the line says so)
         if world == 1 and a.config in ('H', 'C3', 'C5') and a.dtype == 'f32' and not a.custom and not a.no_secondary:
-            out["secondary"]["f64"], out["parity_at_size"], plain = f64_leg_and_parity(
+            out["secondary"]["f64"], out["parity_at_size"], plain, f16 = f64_leg_and_parity(
                 X, y, params, D, S, M, local, (cost, grad, alpha, Li), eng)
+            out["secondary"]["f16x3"] = f16
             if plain is not None:
                 out["secondary"]["plain_fp32"] = plain
         if world == 1 and not a.no_secondary and a.dtype == 'f32' and (not a.custom or a.triple):

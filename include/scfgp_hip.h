@@ -55,6 +55,12 @@ typedef struct scfgp_ctx scfgp_ctx;
 #define SCFGP_F64 0             /* fp64 MFMA everywhere (reference numerics)             */
 #define SCFGP_F32 1             /* N-sized products in exact-fp32 MFMA, fp64 projection,
                                    fp64 cross-chunk accumulation and fp64 K x K stage    */
+#define SCFGP_F16X3 2           /* SECONDARY mode, never what a benchmark headline quotes: SCFGP_F32 in everything but the two
+                                   square apply products (V = Phi B, Phibar = 2 Phi Abar + ...), which run as a THREE-TERM fp16
+                                   split on the fp16 matrix pipe wherever fp32 mode uses its 256-wide LDS-DMA tiles (K >= 1024,
+                                   >= 65536 rows): x = (h + l) 2^-e, h, l fp16, one power-of-two scale per operand matrix;
+                                   h.h + l.h + h.l in fp32 accumulators (fp16 products are exact in fp32).  Errors within
+                                   1-3.5x of SCFGP_F32's (scfgp_amd/csrc/apply_f16.hip); it runs fp32 mode's parity tier        */
 
 /* ---- life cycle --------------------------------------------------------------------
  * Replaces SCFGP.build_theano_models (SCFGP/SCFGP.py:92-148): "compile" becomes "create a

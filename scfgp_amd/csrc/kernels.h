@@ -93,14 +93,20 @@ struct GramKernels {
                          hipStream_t st);
 };
 
+// operands of one apply product in compute mode SCFGP_F16X3 (apply_f16.hip): Phi as packed (h, l) fp16 pairs (Np x Kp x 4 bytes), the
+// K x K operand as derived pairs (Kp x Kp x 8 bytes), scale[0] = 2^-(e_Phi + e_operand) on the device
+struct F16Operands { const unsigned* Phi16; const char* B16; const float* scale; };
+
 // ---- apply.hip: NT products (contraction over the feature columns) and the per-row statistics ------------------------
 //   dma: 0 = operands staged through registers; 1 / 2 = the full 128-column tiles by LDS-DMA, 128 / 256 wide (256: fp32 only)
 template <typename T>
 struct ApplyKernels {
     // V = Phi . Bm, vpart[jt][n] = sum_{j in tile} Phi[n][j] V[n][j]    (SCFGP.py:112); column tile jt also forms
     // mupart[jt][n] = its slice of mu = Phi . alpha (SCFGP.py:111 / :143) from the rows it stages
+    //   f16 (fp32 mode only, dma == 2): the 256-wide tiles by the three-term fp16 split instead (apply_f16.hip); the narrower tiles of
+    //   the launch plan stay exact fp32
     static void apply_v(const Geom& g, const T* Phi, const T* Bm, T* V, double* vpart, const double* alpha, double* mupart,
-                        hipStream_t st, int dma = 0);
+                        hipStream_t st, int dma = 0, const F16Operands* f16 = nullptr);
     // predict: vpart[jt][n] = slices of v_n = || Li phi_n ||^2 (the reference's rowsum((Phi Li^T)^2), SCFGP.py:144) from the
     // triangular product Phi . LiT, LiT[k][j] = Li[j][k] (convert_transposed); mupart as apply_v.  Half the flops of apply_v.
     static void apply_predict(const Geom& g, const T* Phi, const T* LiT, double* vpart, const double* alpha, double* mupart,
@@ -116,7 +122,7 @@ struct ApplyKernels {
     static void apply_vc(const Geom& g, const T* C, const T* Li, const T* LiT, T* V, hipStream_t st, int dma = 0);
     // Phibar = 2 Phi.Abar + 2 q V + p alpha^T + y ut^T  (in place over V)
     static void apply_phibar(const Geom& g, const T* Phi, const T* Abar, T* V, const double* p, const double* q,
-                             const double* y, const double* alpha, const double* ut, hipStream_t st, int dma = 0);
+                             const double* y, const double* alpha, const double* ut, hipStream_t st, int dma = 0, const F16Operands* f16 = nullptr);
     // Out = A . Bm over k < Kc for ncols columns (64-wide tiles, leading dimension Kp everywhere; Bm[k][c] = 0 for k < c)
     static void apply_plain(const Geom& g, const T* A, const T* Bm, T* Out, int Kc, int ncols, hipStream_t st);
     // per-row moments and adjoint scalars; block partials (4 per block) of T2, kbar, sum q v, sum p mu  (SCFGP.py:111-113,121-124)
@@ -125,6 +131,20 @@ struct ApplyKernels {
     // predictive mean / std                                          (SCFGP.py:143-144)
     static void rowpredict(const Geom& g, const double* mupart, const double* vpart, const Scal* sc, double* mu, double* sd,
                            hipStream_t st);
+};
+
+// ---- apply_f16.hip: compute mode SCFGP_F16X3 -- the square apply products as a three-term fp16 split (a labelled secondary mode) ----
+// operands of one product: Phi as packed (h, l) fp16 pairs (Np x Kp x 4 bytes), the K x K operand as derived pairs (Kp x Kp x 8 bytes),
+// scale[0] = 2^-(e_Phi + e_operand) on the device
+struct F16x3Kernels {
+    static void split_phi(const Geom& g, const float* Phi, unsigned* Phi16, const Scal* sc, hipStream_t st);
+    // M: fp64, symmetric, K x K inside Kp x Kp; part: >= 512 doubles of scratch
+    static void split_operand(const Geom& g, const double* M, char* B16, float* scale, double* part, const Scal* sc, hipStream_t st);
+    // the 256-wide column tiles [0, 256 njt) of row blocks 0 .. nrb-1, epilogue EPI 0 (V, row dots) or 1 (Phibar); returns the tile count
+    template <int EPI>
+    static int apply(const Geom& g, int njt, const float* Phi, const unsigned* Phi16, const char* B16, const float* scale, float* V,
+                     double* vpart, const double* p, const double* q, const double* y, const double* alpha, const double* ut, double* mu,
+                     hipStream_t st, int64_t nrb);
 };
 
 // everything that sweeps the rows, under one name

@@ -146,6 +146,11 @@ struct scfgp_ctx {
     // rows
     double *d_Xt = nullptr, *d_y = nullptr, *d_p = nullptr, *d_q = nullptr, *d_mu = nullptr, *d_vpart = nullptr;
     void *d_Phi = nullptr, *d_V = nullptr;
+    // compute mode SCFGP_F16X3 (apply_f16.hip): fp32 mode whose two square apply products run as a three-term fp16 split wherever
+    // fp32 mode would use its 256-wide LDS-DMA tiles; Phi16 = Phi as packed (h, l) pairs, B16 = the K x K operand's derived pairs
+    bool split16 = false; unsigned* d_Phi16 = nullptr; char* d_B16 = nullptr; float* d_f16scale = nullptr;
+    bool f16_on() const { return split16 && dma() == 2; }
+    F16Operands f16ops() const { return F16Operands{d_Phi16, d_B16, d_f16scale}; }
     // exchange buffers and K-stage
     // exchange buffers xp1/xp2 = [packed lower tiles | vector Kp | 8 scalars], x3 = [X~^T Zbar | 8 scalars];
     // x1/x2 = the same matrices unpacked to full Kp x Kp (+ vector) for the K x K stage
@@ -274,7 +279,7 @@ static int xtz_split(int ntiles, int64_t Np) {
 
 static void free_rows(scfgp_ctx* c) {
     dfree(c->d_Xt); dfree(c->d_y); dfree(c->d_p); dfree(c->d_q); dfree(c->d_ws2); dfree(c->d_mu); dfree(c->d_vpart); dfree(c->d_Tt);
-    dfree(c->d_Phi); dfree(c->d_V); dfree(c->d_slabs);
+    dfree(c->d_Phi); dfree(c->d_V); dfree(c->d_Phi16); dfree(c->d_slabs);
     c->Ncap = 0; c->slabs_bytes = 0;
 }
 
@@ -328,7 +333,7 @@ static int ensure_rows(scfgp_ctx* c, int64_t N) {
     if (int rc = ensure_aux_rows(c)) return rc;
     if (Np <= c->Ncap) return SCFGP_OK;
     dfree(c->d_Xt); dfree(c->d_y); dfree(c->d_p); dfree(c->d_q); dfree(c->d_ws2); dfree(c->d_mu); dfree(c->d_vpart); dfree(c->d_Tt);
-    dfree(c->d_Phi); dfree(c->d_V);
+    dfree(c->d_Phi); dfree(c->d_V); dfree(c->d_Phi16);
     c->Ncap = 0;
     const size_t ts = c->tsize();
     int rc;
@@ -342,6 +347,7 @@ static int ensure_rows(scfgp_ctx* c, int64_t N) {
     if ((rc = dmalloc(c, &c->d_vpart, sizeof(double) * Np * (g.Kp / 64)))) return rc;          // <= one entry per 64 columns
     if ((rc = dmalloc(c, &c->d_Phi, ts * Np * g.Kp))) return rc;
     if ((rc = dmalloc(c, &c->d_V, ts * Np * g.Kp))) return rc;
+    if (c->split16 && (rc = dmalloc(c, &c->d_Phi16, sizeof(unsigned) * Np * g.Kp))) return rc;
     HIPCHK(c, hipMemsetAsync(c->d_Phi, 0, ts * Np * g.Kp, c->st));       // padding columns >= K stay zero forever
     HIPCHK(c, hipMemsetAsync(c->d_V, 0, ts * Np * g.Kp, c->st));         // columns >= K are never written
     c->Ncap = Np;
@@ -349,9 +355,11 @@ static int ensure_rows(scfgp_ctx* c, int64_t N) {
 }
 
 extern "C" int scfgp_create(scfgp_ctx** out, int D, int S, int M, int dtype, int device, void* stream) {
-    if (!out || D < 1 || S < 1 || M < 1 || (dtype != SCFGP_F64 && dtype != SCFGP_F32)) return SCFGP_EARG;
+    if (!out || D < 1 || S < 1 || M < 1 || (dtype != SCFGP_F64 && dtype != SCFGP_F32 && dtype != SCFGP_F16X3)) return SCFGP_EARG;
     scfgp_ctx* c = new scfgp_ctx();
     *out = c;
+    c->split16 = dtype == SCFGP_F16X3;                            // fp32 mode in everything but the two square apply products
+    if (c->split16) dtype = SCFGP_F32;
     c->dtype = dtype; c->device = device;
     Geom& g = c->g;
     derive_geom(g, D, S, M);
@@ -389,6 +397,10 @@ extern "C" int scfgp_create(scfgp_ctx** out, int D, int S, int M, int dtype, int
     if ((rc = dmalloc(c, &c->d_Abar, sizeof(double) * K2))) return rc;
     if ((rc = dmalloc(c, &c->d_BT, c->tsize() * K2))) return rc;        // sweep operands: typed, padding zeroed
     if ((rc = dmalloc(c, &c->d_AbarT, c->tsize() * K2))) return rc;
+    if (c->split16) {
+        if ((rc = dmalloc(c, &c->d_B16, 8 * (size_t)K2))) return rc;
+        if ((rc = dmalloc(c, &c->d_f16scale, sizeof(float) * 4))) return rc;
+    }
     if ((rc = dmalloc(c, &c->d_vecs, sizeof(double) * 5 * Kp))) return rc;
     if ((rc = dmalloc(c, &c->d_scalars, sizeof(double) * 32))) return rc;
     if ((rc = dmalloc(c, &c->d_yy, sizeof(double) * 8))) return rc;
@@ -415,7 +427,7 @@ extern "C" void scfgp_destroy(scfgp_ctx* c) {
     dfree(c->d_Phi64); dfree(c->d_C); dfree(c->d_Xraw); dfree(c->d_yraw); dfree(c->d_idx); dfree(c->d_xscale); dfree(c->d_yscale);
     dfree(c->d_params); dfree(c->d_F); dfree(c->d_Fall); dfree(c->d_Lall); dfree(c->d_Rall); dfree(c->d_sc); dfree(c->p_Tt);
     dfree(c->d_xp1); dfree(c->d_xp2); dfree(c->d_x1); dfree(c->d_x2); dfree(c->d_x3); dfree(c->d_Li); dfree(c->d_B); dfree(c->d_T1); dfree(c->d_T2);
-    dfree(c->d_Abar); dfree(c->d_BT); dfree(c->d_AbarT); dfree(c->d_vecs); dfree(c->d_scalars); dfree(c->d_yy);
+    dfree(c->d_Abar); dfree(c->d_BT); dfree(c->d_AbarT); dfree(c->d_B16); dfree(c->d_f16scale); dfree(c->d_vecs); dfree(c->d_scalars); dfree(c->d_yy);
     dfree(c->d_flag); dfree(c->d_partial); dfree(c->d_work); dfree(c->d_grad);
     dfree(c->p_Xt); dfree(c->p_vpart); dfree(c->p_mupart); dfree(c->p_Phi);
     if (c->gexec) hipGraphExecDestroy(c->gexec);
@@ -525,6 +537,9 @@ template <typename T> struct Impl {
             }
         }
         { ProfScope ps(c, "featuremap"); SK::featuremap(g, c->d_Xt, proj, c->d_sc, (T*)c->d_Phi, c->st); }
+        if constexpr (sizeof(T) == 4) {
+            if (c->f16_on()) { ProfScope ps(c, "split_phi"); F16x3Kernels::split_phi(g, (const float*)c->d_Phi, c->d_Phi16, c->d_sc, c->st); }
+        }
         if (!use64) gram_to(c, (const T*)c->d_Phi, nullptr, c->d_y, c->d_xp1, "gram");
         c->last_used64 = use64 || sizeof(T) == 8; c->last_level = sizeof(T) == 8 ? 0 : c->level();
         HIPCHK(c, hipMemcpyAsync(c->xs1(), c->d_yy, sizeof(double), hipMemcpyDeviceToDevice, c->st));
@@ -540,8 +555,10 @@ template <typename T> struct Impl {
         if (c->last_cform) {                                   // factor form: the typed operands are Li (in B's place) and Li^T (scratch)
             SK::convert(c->d_Li, (T*)c->d_BT, g.K, g.Kp, c->st);
             SK::convert_transposed(c->d_Li, (T*)c->d_AbarT, g.K, g.Kp, c->st);
-        } else
+        } else {
             SK::convert(c->d_B, (T*)c->d_BT, g.K, g.Kp, c->st);
+            if (c->f16_on()) F16x3Kernels::split_operand(g, c->d_B, c->d_B16, c->d_f16scale, c->d_partial, c->d_sc, c->st);
+        }
         HIPCHK(c, hipGetLastError());
         return SCFGP_OK;
     }
@@ -558,7 +575,8 @@ template <typename T> struct Impl {
               SK::apply_vc(g, (const T*)c->d_C, (const T*)c->d_BT, (const T*)c->d_AbarT, (T*)c->d_V, c->st, dma); }
         } else {
             ProfScope ps(c, "apply_v");
-            SK::apply_v(g, (const T*)c->d_Phi, (const T*)c->d_BT, (T*)c->d_V, c->d_vpart, c->alpha(), c->d_mu, c->st, c->dma());
+            const F16Operands f16 = c->f16ops();
+            SK::apply_v(g, (const T*)c->d_Phi, (const T*)c->d_BT, (T*)c->d_V, c->d_vpart, c->alpha(), c->d_mu, c->st, c->dma(), c->f16_on() ? &f16 : nullptr);
         }
         const int nb = (int)std::min<int64_t>(g.Np / 4, 2048);
         { ProfScope ps(c, "rowstats");
@@ -580,13 +598,16 @@ template <typename T> struct Impl {
           // the K x K part of bbar from the summed G (exchange buffer 1 is intact until the next pass 1) and Abar
           kstage_bbar(c->kstage(), c->d_xp1, c->d_Abar, c->d_partial, c->st); }
         SK::convert(c->d_Abar, (T*)c->d_AbarT, g.K, g.Kp, c->st);
+        if (c->f16_on()) F16x3Kernels::split_operand(g, c->d_Abar, c->d_B16, c->d_f16scale, c->d_partial, c->d_sc, c->st);
         HIPCHK(c, hipGetLastError());
         return SCFGP_OK;
     }
     static int pass3(scfgp_ctx* c) {
         const Geom& g = c->g;
         { ProfScope ps(c, "apply_phibar");
-          SK::apply_phibar(g, (const T*)c->d_Phi, (const T*)c->d_AbarT, (T*)c->d_V, c->d_p, c->d_q, c->d_y, c->alpha(), c->ut(), c->st, c->dma());
+          const F16Operands f16 = c->f16ops();
+          SK::apply_phibar(g, (const T*)c->d_Phi, (const T*)c->d_AbarT, (T*)c->d_V, c->d_p, c->d_q, c->d_y, c->alpha(), c->ut(), c->st, c->dma(),
+                           c->f16_on() ? &f16 : nullptr);
           write_status(c->x3_scalars(), 0.0, 0.0, 0.0, 0.0, c->st); }
         const int ntm = c->Dpp / XT, ntn = g.Jp / XT;
         const int64_t chunk = c->dtype == SCFGP_F32 ? c->gram_chunk : 0;

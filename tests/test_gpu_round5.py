@@ -253,3 +253,84 @@ def test_training_with_the_sums_inside_the_library_equals_the_plain_loop(dtype):
     with pytest.raises(ValueError, match='communicator'):
         lone.train(2)
     lone.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Compute mode f16x3 (include/scfgp_hip.h: SCFGP_F16X3; scfgp_amd/csrc/apply_f16.hip): a labelled SECONDARY mode -- fp32 mode whose two
+# square apply products run as a three-term fp16 split.  It must pass fp32 mode's parity tier (|dcost| <= 1e-5
+# max(1, |cost|), per-block gradient norms <= 1e-3, alpha / Li / mu* / sigma* as fp32 mode) against fp64 mode = the reference's arithmetic.
+# ---------------------------------------------------------------------------------------------------------------------------
+def _blocks(g, D, S, M):
+    o = 3 + D * S
+    return g[:3], g[3:o], g[o:o + M * S]
+
+
+@pytest.mark.parametrize('N,D,S,M,abc', [(20000, 16, 16, 256, (-1.0, 0.0, -1.0)), (33000, 8, 32, 256, (-1.0, 0.0, -1.0)),
+                                          (40000, 32, 16, 496, (-2.0, 0.5, -1.0)), (30000, 24, 20, 300, (-0.5, -0.5, -2.0))])
+def test_f16x3_mode_passes_fp32_modes_parity_tier(N, D, S, M, abc):
+    """K = 544, 576, 1024, 640: two or four 256-wide column tiles on the split (option apply_dma = 2 forces the 256-wide tiles below the
+    size from which fp32 mode picks them itself) + an exact-fp32 remainder of 32 / 64 / 0 / 128 columns.  Against fp64 mode with fp32
+    mode's tolerances, against fp32 mode itself (no worse than 4x its error where that error is measurable), and bit-equal repeats."""
+    from scfgp_amd import synth
+    from scfgp_amd.engine import HipEngine
+    seed = 0x5CF60A00 + M
+    X = synth.make_X(seed, N, D); y = synth.normal(seed + 1, 0, N).reshape(-1, 1)
+    params = synth.make_params(seed + 2, D, S, M, abc=abc)
+    Xs = synth.make_X(seed + 3, 3000, D)
+    outs = {}
+    for dtype in ('f64', 'f32', 'f16x3'):
+        e = HipEngine(D, S, M, dtype)
+        if dtype != 'f64':
+            e.set_option('gram64', 0); e.set_option('apply_dma', 2)      # plain fp32 Gram in both: the comparison is about the apply products
+        e.set_params(params); e.set_data(X, y)
+        e.set_profiling(True)
+        a = e.eval()
+        names = [n for n, _ in e.timings()]
+        assert ('split_phi' in names) == (dtype == 'f16x3')              # the split path ran (and only there)
+        b = e.eval()
+        assert float(a[0]) == float(b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+        mu, sd = e.predict(Xs, a[2], a[3])
+        outs[dtype] = a + (mu, sd)
+        e.close()
+    c64, g64, a64, L64, mu64, sd64 = outs['f64']
+    err = {}
+    for dtype in ('f32', 'f16x3'):
+        c, g, a, L, mu, sd = outs[dtype]
+        err[dtype] = dict(cost=abs(float(c) - float(c64)) / max(1.0, abs(float(c64))), alpha=rel(a, a64), Li=rel(L, L64), mu=rel(mu, mu64),
+                          sd=rel(sd, sd64), **{'g%d' % k: rel(u, v) for k, (u, v) in enumerate(zip(_blocks(g, D, S, M), _blocks(g64, D, S, M)))})
+    print('\nf32  ', {k: '%.1e' % v for k, v in err['f32'].items()})
+    print('f16x3', {k: '%.1e' % v for k, v in err['f16x3'].items()})
+    e16, e32 = err['f16x3'], err['f32']
+    assert e16['cost'] < 1e-5 and e16['g0'] < 1e-3 and e16['g1'] < 1e-3 and e16['g2'] < 1e-3
+    # alpha and Li come from pass 1 (the fp32 Gram, untouched by the mode): identical to fp32 mode's
+    assert np.array_equal(outs['f16x3'][2], outs['f32'][2]) and np.array_equal(outs['f16x3'][3], outs['f32'][3])
+    for k in ('cost', 'g0', 'g1', 'g2'):
+        assert e16[k] <= 4 * e32[k] + 1e-9, (k, e16[k], e32[k])
+
+
+def test_f16x3_mode_at_the_headline_shape():
+    """N = 1e6, D = 64, S = 32, M = 1024 (the library picks the 256-wide tiles itself): f16x3 against fp32 mode on the same rows --
+    cost to 1e-9, gradient blocks to 2e-5 (fp32 mode itself is 2.5e-6 from fp64 mode there), alpha / Li bit-equal (pass 1 is
+    untouched), repeats bit-equal -- and the two apply stages at least twice as fast."""
+    import bench
+    from scfgp_amd.engine import HipEngine
+    N, D, S, M = bench.CONFIGS['H'][:4]
+    e0 = HipEngine(D, S, M, 'f32')
+    X, y, params = bench.build_problem(e0, N, D, S, M, 0, N, None)
+    e0.set_params(params); e0.set_data(X, y)
+    e0.eval(); e0.set_profiling(True)
+    c0, g0, a0, L0 = e0.eval(); t0 = dict(e0.timings())
+    e0.close()
+    e1 = HipEngine(D, S, M, 'f16x3'); e1.set_params(params); e1.set_data(X, y)
+    e1.eval(); e1.set_profiling(True)
+    c1, g1, a1, L1 = e1.eval(); t1 = dict(e1.timings())
+    c2, g2, _, _ = e1.eval()
+    e1.close()
+    assert float(c1) == float(c2) and np.array_equal(g1, g2)
+    assert np.array_equal(a1, a0) and np.array_equal(L1, L0)
+    assert abs(float(c1) - float(c0)) < 1e-9 * max(1.0, abs(float(c0)))
+    for u, v in zip(_blocks(g1, D, S, M), _blocks(g0, D, S, M)):
+        assert rel(u, v) < 2e-5, rel(u, v)
+    print('\napply_v %.2f -> %.2f ms, apply_phibar %.2f -> %.2f ms, split_phi %.2f ms' % (
+        t0['apply_v'], t1['apply_v'], t0['apply_phibar'], t1['apply_phibar'], t1['split_phi']))
+    assert t1['apply_v'] < 0.5 * t0['apply_v'] and t1['apply_phibar'] < 0.5 * t0['apply_phibar']
