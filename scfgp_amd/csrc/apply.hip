@@ -420,10 +420,18 @@ static int apply_launch(const Geom& g, const T* Phi, const T* Bm, T* V, double* 
                     const int64_t ncu = apply_num_cus(), tiles = nrb * n256, rem = tiles % ncu;
                     if (tiles > ncu && rem > 0 && 20 * rem <= 9 * ncu) tail_rb = (rem + n256 - 1) / n256;
                 }
-                if (f16 && (EPI == 0 || EPI == 1))               // compute mode SCFGP_F16X3: these tiles by the three-term fp16 split
-                    nb += F16x3Kernels::apply<EPI == 1 ? 1 : 0>(g, n256, Phi, f16->Phi16, f16->B16, f16->scale, V, vpart, p, q, y, alpha, ut, mu, st, nrb - tail_rb);
-                else
-                    nb += apply_dma_launch<T, EPI, 256>(g, n256, 0, 0, Phi, BmT, V, vpart, p, q, y, alpha, ut, mu, st, 0, nrb - tail_rb);
+                if (f16 && (EPI == 0 || EPI == 1)) {             // compute mode SCFGP_F16X3: the same launch plan on the three-term fp16 split
+                    constexpr int E = EPI == 1 ? 1 : 0;
+                    nb += F16x3Kernels::apply<E, 256>(g, n256, 0, 0, Phi, *f16, V, vpart, p, q, y, alpha, ut, mu, st, 0, nrb - tail_rb);
+                    nb += F16x3Kernels::apply<E, 128>(g, pl.count[0] - 2 * n256, 256 * n256, 2 * n256, Phi, *f16, V, vpart, p, q, y, alpha, ut, mu, st, 0, nrb - tail_rb);
+                    nb += F16x3Kernels::apply<E, 64>(g, pl.count[1], pl.col0[1], pl.jt0[1], Phi, *f16, V, vpart, p, q, y, alpha, ut, mu, st, 0, nrb - tail_rb);
+                    if (tail_rb > 0) {
+                        nb += F16x3Kernels::apply<E, 128>(g, pl.count[0], 0, 0, Phi, *f16, V, vpart, p, q, y, alpha, ut, mu, st, nrb - tail_rb, tail_rb);
+                        nb += F16x3Kernels::apply<E, 64>(g, pl.count[1], pl.col0[1], pl.jt0[1], Phi, *f16, V, vpart, p, q, y, alpha, ut, mu, st, nrb - tail_rb, tail_rb);
+                    }
+                    return nb;
+                }
+                nb += apply_dma_launch<T, EPI, 256>(g, n256, 0, 0, Phi, BmT, V, vpart, p, q, y, alpha, ut, mu, st, 0, nrb - tail_rb);
             }
             nb += apply_dma_launch<T, EPI, 128>(g, pl.count[0] - 2 * n256, 256 * n256, 2 * n256, Phi, BmT, V, vpart, p, q, y, alpha, ut, mu, st, 0, nrb - tail_rb);
             // the ragged 64-column remainder: the same kernel with 256 x 64 tiles (4 / 8 waves, two workgroups per CU)

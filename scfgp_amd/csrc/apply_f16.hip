@@ -26,23 +26,32 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
 
 namespace {
-constexpr int BM = 256, BN = 256, WAVES = 16, ROWA = 64, ROWB = 128;       // bytes of one row's 16 k: packed pairs / derived pairs
-constexpr int STAGE = BM * ROWA + BN * ROWB, STAGES = 3, LDS_BYTES = STAGES * STAGE, DPW = STAGE / 1024 / WAVES;
-static_assert(DPW == 3 && LDS_BYTES <= 160 * 1024, "48 DMA instructions per stage on 16 waves; the ring fits the LDS");
-typedef TileCfg<float, BM, BN, 16, 4, 4, 16, true> Cfg;                     // wave grid 4 x 4 of 64 x 64: the fp32 tile's accumulator map
+constexpr int BM = 256, ROWA = 64, ROWB = 128;                              // bytes of one row's 16 k: packed pairs / derived pairs
+// tile widths as in fp32 mode's launch plan (apply.hip): 256 (16 waves), 128 (8 waves: an odd 128-column block, the thin last round's
+// row blocks), 64 (4 waves: the ragged remainder, K = 2112 = 8 x 256 + 64); wave tiles 64 x 64 throughout
+template <int BN_> struct F16Tile {
+    static constexpr int BN = BN_, WAVES = 4 * (BN / 64), STAGE = BM * ROWA + BN * ROWB, STAGES = 3, LDS_BYTES = STAGES * STAGE,
+                         DPW = STAGE / 1024 / WAVES, WAVES_PER_EU = WAVES == 4 ? 2 : 4;
+    static_assert(STAGE / 1024 % WAVES == 0 && LDS_BYTES <= 160 * 1024, "whole DMA instructions per wave; the ring fits the LDS");
+    typedef TileCfg<float, BM, BN, 16, 4, BN / 64, 16, true> Cfg;           // the fp32 tile's accumulator map (apply_epilogue.h)
+};
 // position swizzles of the two images (apply.hip): 64-byte rows f[(x >> 2) & 3], f = (0, 2, 3, 1); 128-byte rows f[(x >> 1) & 7]
 __device__ __forceinline__ int swz4(int x) { return (0x78 >> (2 * ((x >> 2) & 3))) & 3; }
 __device__ __forceinline__ int swz8(int x) { return (int)((0x6BEB08u >> (3 * ((x >> 1) & 7))) & 7); }
 }
 
-// One 256 x 256 tile: column tile jt of the launch, row block rb0 + wid / njt.  Phi16: Np x Kp packed pairs; B16: Kp rows (= output
+// One 256 x BN tile: column tile jt of the launch, row block rb0 + wid / njt.  Phi16: Np x Kp packed pairs; B16: Kp rows (= output
 // columns) of Kp derived elements, 128 bytes per 16 k: [16 x (bh, bh) | 16 x (bl, 0)]; scale[0] = 2^-(e_Phi + e_B).
-template <int EPI>
-__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 4)))
+template <int EPI, int BN>
+__global__ __launch_bounds__((64 * F16Tile<BN>::WAVES))
+__attribute__((amdgpu_waves_per_eu(F16Tile<BN>::WAVES_PER_EU, F16Tile<BN>::WAVES_PER_EU)))
 void apply_f16_kernel(const float* __restrict__ Phi, const unsigned* __restrict__ Phi16, const char* __restrict__ B16, const float* __restrict__ scale,
                       float* V, double* __restrict__ vpart, const double* __restrict__ p, const double* __restrict__ q,
                       const double* __restrict__ y, const double* __restrict__ alpha, const double* __restrict__ ut,
                       int K, int Kp, int64_t Np, int njt, double* __restrict__ mu, int col0, int slot0, int64_t rb0) {
+    typedef F16Tile<BN> D;
+    typedef typename D::Cfg Cfg;
+    constexpr int DPW = D::DPW, STAGE = D::STAGE;
     SMEM_DECL;
     char* smem = smem_raw;
     const unsigned wid = xcd_remap(blockIdx.x, gridDim.x);
@@ -116,11 +125,12 @@ void apply_f16_kernel(const float* __restrict__ Phi, const unsigned* __restrict_
     for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn) acc[tm][tn] *= sc;
-    const int vslot = slot0 + 2 * jt;                          // one vpart / mupart slot per 128 columns
+    constexpr int SLOTS = BN >= 128 ? BN / 128 : 1;            // vpart / mupart slots: one per 128 columns of the full tiles, one per remainder tile
+    const int vslot = slot0 + SLOTS * jt;
     int tid = (int)threadIdx.x;
     asm volatile("" : "+v"(tid));
     apply_epilogue<Cfg, EPI, EPI == 0, true>(acc, Phi, V, vpart, p, q, y, alpha, ut, K, Kp, Np, rb, cbase, vslot, smem_raw, mu, tid);
-    if (EPI == 0 && tid < BM) {
+    if (SLOTS == 2 && EPI == 0 && tid < BM) {
         vpart[(int64_t)(vslot + 1) * Np + rb * BM + tid] = 0.0;
         if (mu) mu[(int64_t)(vslot + 1) * Np + rb * BM + tid] = 0.0;
     }
@@ -184,17 +194,19 @@ void F16x3Kernels::split_operand(const Geom& g, const double* M, char* B16, floa
     hipLaunchKernelGGL(maxabs_kernel, dim3(NP), dim3(256), 0, st, M, g.K, g.Kp, part);
     hipLaunchKernelGGL(split_operand_kernel, dim3(2048), dim3(256), 0, st, M, g.K, g.Kp, (const double*)part, NP, sc, B16, scale);
 }
-template <int EPI>
-int F16x3Kernels::apply(const Geom& g, int njt, const float* Phi, const unsigned* Phi16, const char* B16, const float* scale, float* V,
+template <int EPI, int BN>
+int F16x3Kernels::apply(const Geom& g, int njt, int col0, int slot0, const float* Phi, const F16Operands& f, float* V,
                         double* vpart, const double* p, const double* q, const double* y, const double* alpha, const double* ut, double* mu,
-                        hipStream_t st, int64_t nrb) {
+                        hipStream_t st, int64_t rb0, int64_t nrb) {
+    typedef F16Tile<BN> D;
     if (njt <= 0 || nrb <= 0) return 0;
-    allow_big_lds(apply_f16_kernel<EPI>, LDS_BYTES);
-    hipLaunchKernelGGL((apply_f16_kernel<EPI>), dim3((unsigned)(njt * nrb)), dim3(64 * WAVES), LDS_BYTES, st,
-                       Phi, Phi16, B16, scale, V, vpart, p, q, y, alpha, ut, g.K, g.Kp, g.Np, njt, mu, 0, 0, (int64_t)0);
+    allow_big_lds(apply_f16_kernel<EPI, BN>, D::LDS_BYTES);
+    hipLaunchKernelGGL((apply_f16_kernel<EPI, BN>), dim3((unsigned)(njt * nrb)), dim3(64 * D::WAVES), D::LDS_BYTES, st,
+                       Phi, f.Phi16, f.B16, f.scale, V, vpart, p, q, y, alpha, ut, g.K, g.Kp, g.Np, njt, mu, col0, slot0, rb0);
     return (int)(njt * nrb);
 }
-template int F16x3Kernels::apply<0>(const Geom&, int, const float*, const unsigned*, const char*, const float*, float*, double*, const double*,
-                                    const double*, const double*, const double*, const double*, double*, hipStream_t, int64_t);
-template int F16x3Kernels::apply<1>(const Geom&, int, const float*, const unsigned*, const char*, const float*, float*, double*, const double*,
-                                    const double*, const double*, const double*, const double*, double*, hipStream_t, int64_t);
+#define SCFGP_F16_INST(EPI, BN)                                                                                                                       \
+    template int F16x3Kernels::apply<EPI, BN>(const Geom&, int, int, int, const float*, const F16Operands&, float*, double*, const double*,          \
+                                              const double*, const double*, const double*, const double*, double*, hipStream_t, int64_t, int64_t)
+SCFGP_F16_INST(0, 256); SCFGP_F16_INST(1, 256); SCFGP_F16_INST(0, 128); SCFGP_F16_INST(1, 128); SCFGP_F16_INST(0, 64); SCFGP_F16_INST(1, 64);
+#undef SCFGP_F16_INST

@@ -140,11 +140,12 @@ struct F16x3Kernels {
     static void split_phi(const Geom& g, const float* Phi, unsigned* Phi16, const Scal* sc, hipStream_t st);
     // M: fp64, symmetric, K x K inside Kp x Kp; part: >= 512 doubles of scratch
     static void split_operand(const Geom& g, const double* M, char* B16, float* scale, double* part, const Scal* sc, hipStream_t st);
-    // the 256-wide column tiles [0, 256 njt) of row blocks 0 .. nrb-1, epilogue EPI 0 (V, row dots) or 1 (Phibar); returns the tile count
-    template <int EPI>
-    static int apply(const Geom& g, int njt, const float* Phi, const unsigned* Phi16, const char* B16, const float* scale, float* V,
+    // column tiles [col0, col0 + BN njt) (BN = 256, 128 or 64; vpart slots from slot0) of row blocks rb0 .. rb0 + nrb - 1, epilogue EPI 0
+    // (V, row dots) or 1 (Phibar); returns the tile count
+    template <int EPI, int BN>
+    static int apply(const Geom& g, int njt, int col0, int slot0, const float* Phi, const F16Operands& f, float* V,
                      double* vpart, const double* p, const double* q, const double* y, const double* alpha, const double* ut, double* mu,
-                     hipStream_t st, int64_t nrb);
+                     hipStream_t st, int64_t rb0, int64_t nrb);
 };
 
 // everything that sweeps the rows, under one name
