@@ -122,6 +122,109 @@ __global__ __launch_bounds__(1024) void tile_loop(const char* __restrict__ A, co
     if (sum == 123.456f) out[blockIdx.x] = sum;                           // never true: keeps the loop alive
 }
 
+// ---- the Gram's k loop (contraction over the ROWS n): G tile = sum_n Phi[n][acol ..]^T Phi[n][bcol ..] -------------------------------------
+// k-major LDS image, as the fp32 Gram's (gram.hip): a stage is 32 rows n of the A panel (256 elements = 1 KiB per row = ONE DMA instruction)
+// and of the B panel; rows 1056 bytes apart, so that the rows 4 G + q and 16 + 4 G + q a 32-lane half touches fall into 64 distinct banks.
+// Elements in the "plane per 16 columns" form [16 x h | 16 x l] (64 bytes): ds_read_b64_tr_b16 (the transposing LDS read of gfx950) hands
+// lane i of a 16-lane group column i of a block of 4 rows x 16 halves, i.e. the four consecutive-n values of ONE element's h (or l) -- two
+// such reads are a lane's 8 k of v_mfma_f32_16x16x32_f16, and since both operands come as separate planes the three terms are three
+// instructions into one accumulator: Ah.Bh + Al.Bh + Ah.Bl.  256 x 256 tile, 16 waves of 64 x 64, ring of two 66 KB stages.
+typedef __fp16 f4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) f4 lds_f4;
+constexpr int GRS = 1056, GSTAGE = 64 * GRS, GROWS = 12544;                 // rows per job: the headline's row split
+__device__ __forceinline__ h8 tr8(const char* p) {                          // rows r0 .. r0+3 (p points at them) and r0+16 .. r0+19
+    const f4 a = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_f4*)(uintptr_t)(unsigned)(uintptr_t)p);
+    const f4 b = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_f4*)(uintptr_t)(unsigned)(uintptr_t)(p + 16 * GRS));
+    return __builtin_shufflevector(__builtin_bit_cast(h4, a), __builtin_bit_cast(h4, b), 0, 1, 2, 3, 4, 5, 6, 7);
+}
+template <int MODE>
+__global__ __launch_bounds__(1024) void gram_loop(const char* __restrict__ A, float* __restrict__ out, int64_t lda, int ntile) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int t = blockIdx.x % ntile; const int64_t split = blockIdx.x / ntile;
+    int ti = (int)((sqrtf(8.0f * t + 1.0f) - 1.0f) * 0.5f);
+    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    while (ti * (ti + 1) / 2 > t) --ti;
+    const int tj = t - ti * (ti + 1) / 2;
+    const int wm0 = (wave >> 2) * 64, wn0 = (wave & 3) * 64;
+    const char* src[4]; int dst[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int r = 4 * wave + u;                                         // 0..31: A rows, 32..63: B rows
+        src[u] = A + (split * GROWS + (r & 31)) * lda + (int64_t)(r < 32 ? ti : tj) * 1024 + lane * 16;
+        dst[u] = r * GRS;
+    }
+    const auto fetch = [&](int slot) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            __builtin_amdgcn_global_load_lds((gbl_void*)src[u], (lds_void*)(smem + slot * GSTAGE + dst[u]), 16, 0, 0);
+            src[u] += 32 * lda;
+        }
+    };
+    const int G = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    const int offa = (4 * G + q) * GRS + 64 * (wm0 / 16) + 8 * p, offb = 32 * GRS + (4 * G + q) * GRS + 64 * (wn0 / 16) + 8 * p;
+    v4f acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = v4f{0.f, 0.f, 0.f, 0.f};
+    constexpr int NS = GROWS / 32;
+    fetch(0);
+    int slot = 0;
+    for (int s = 0; s < NS; ++s) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (MODE != 3 && s + 1 < NS) fetch(slot ^ 1);
+        const char* base = smem + slot * GSTAGE;
+        h8 ah[4], al[4], bh[4], bl[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            ah[k] = tr8(base + offa + 64 * k); al[k] = tr8(base + offa + 64 * k + 32);
+            bh[k] = tr8(base + offb + 64 * k); bl[k] = tr8(base + offb + 64 * k + 32);
+        }
+        if constexpr (MODE != 2) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[a], bh[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+                }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k][0][0] += (float)ah[k][0] + (float)al[k][1] + (float)bh[k][2] + (float)bl[k][3];
+        }
+        slot ^= 1;
+    }
+    float sum = 0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) sum += acc[a][b][0] + acc[a][b][1] + acc[a][b][2] + acc[a][b][3];
+    if (sum == 123.456f) out[blockIdx.x] = sum;
+}
+template <int MODE> static void run_gram(const char* A, float* out, int64_t N, const char* what) {
+    constexpr int LDS = 2 * GSTAGE;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gram_loop<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    const int nb = 8, ntile = nb * (nb + 1) / 2;                          // K = 2048: the lower triangle of 8 x 8 blocks of 256
+    const int64_t nsplit = N / GROWS;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e30f;
+    for (int rep = 0; rep < 4; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(gram_loop<MODE>, dim3((unsigned)(ntile * nsplit)), dim3(1024), LDS, 0, A, out, (int64_t)KTOT * 4, ntile);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (rep > 0 && ms < best) best = ms;
+    }
+    const double flop = 2.0 * nsplit * GROWS * 256.0 * 256.0 * ntile;      // executed (lower tiles only), as the shipped Gram is priced
+    printf("%-62s %8.2f ms   %7.1f fp32-equivalent TFLOP/s executed (LDS %d KB)\n", what, best, flop / (best * 1e-3) / 1e12, LDS / 1024);
+    if (hipGetLastError() != hipSuccess) { printf("HIP error\n"); exit(1); }
+}
+
 __global__ void fill_kernel(unsigned* p, int64_t n) {
     for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) {
         unsigned x = (unsigned)k * 2654435761u + 12345u; x = x * 1664525u + 1013904223u;
@@ -166,5 +269,9 @@ int main(int argc, char** argv) {
     run<2>(A, B, out, N, "f16x3 without the MFMAs (DMA + LDS reads + barriers)");
     run<3>(A, B, out, N, "f16x3 without the DMA after the prologue (MFMAs + LDS reads)");
     printf("ratio fp32 / f16x3 on the same skeleton: %.2f\n", f32 / f16);
+    printf("Gram k loop (K = 2048: 36 lower tiles of 256 x 256, %d-row jobs, stages of 32 rows, transposing LDS reads); the shipped fp32 Gram runs at 0.87-0.91 x 157.3 executed\n", GROWS);
+    run_gram<0>(A, out, N, "f16x3 (3 x v_mfma_f32_16x16x32_f16 per tile and 32 rows)");
+    run_gram<2>(A, out, N, "f16x3 without the MFMAs (DMA + transposing reads + barriers)");
+    run_gram<3>(A, out, N, "f16x3 without the DMA after the prologue");
     return 0;
 }
