@@ -136,21 +136,6 @@ void apply_f16_kernel(const float* __restrict__ Phi, const unsigned* __restrict_
     }
 }
 
-// Phi (fp32, Np x Kp) -> packed pairs, scaled by 2^e with e = 14 - floor(log2 s): |Phi| <= s = e^b sqrt(2/M) (SCFGP/SCFGP.py:98,102)
-__global__ __launch_bounds__(256) void split_phi_kernel(const float* __restrict__ Phi, unsigned* __restrict__ out, int64_t n4, const Scal* __restrict__ sc) {
-    const float up = ldexpf(1.0f, 14 - ilogbf((float)sc->s));
-    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n4; k += (int64_t)gridDim.x * 256) {
-        const v4f x = reinterpret_cast<const v4f*>(Phi)[k] * up;
-        unsigned o[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const _Float16 h = (_Float16)x[e], l = (_Float16)(x[e] - (float)h);
-            const h2 hl = h2{h, l};
-            o[e] = *reinterpret_cast<const unsigned*>(&hl);
-        }
-        reinterpret_cast<uint4*>(out)[k] = uint4{o[0], o[1], o[2], o[3]};
-    }
-}
 // part[b] = max |M[i][j]|, i, j < K, of block b's share
 __global__ __launch_bounds__(256) void maxabs_kernel(const double* __restrict__ M, int K, int Kp, double* __restrict__ part) {
     __shared__ double r1[256];
@@ -186,9 +171,6 @@ __global__ __launch_bounds__(256) void split_operand_kernel(const double* __rest
     }
 }
 
-void F16x3Kernels::split_phi(const Geom& g, const float* Phi, unsigned* Phi16, const Scal* sc, hipStream_t st) {
-    hipLaunchKernelGGL(split_phi_kernel, dim3(8192), dim3(256), 0, st, Phi, Phi16, g.Np * g.Kp / 4, sc);
-}
 void F16x3Kernels::split_operand(const Geom& g, const double* M, char* B16, float* scale, double* part, const Scal* sc, hipStream_t st) {
     constexpr int NP = 512;
     hipLaunchKernelGGL(maxabs_kernel, dim3(NP), dim3(256), 0, st, M, g.K, g.Kp, part);

@@ -133,11 +133,10 @@ struct ApplyKernels {
                            hipStream_t st);
 };
 
-// ---- apply_f16.hip: compute mode SCFGP_F16X3 -- the square apply products as a three-term fp16 split (a labelled secondary mode) ----
-// operands of one product: Phi as packed (h, l) fp16 pairs (Np x Kp x 4 bytes), the K x K operand as derived pairs (Kp x Kp x 8 bytes),
-// scale[0] = 2^-(e_Phi + e_operand) on the device
+// ---- apply_f16.hip, gram_f16.hip: compute mode SCFGP_F16X3 -- the big products as a three-term fp16 split (a labelled secondary mode) ----
+// operands of one apply product: Phi as packed (h, l) fp16 pairs (Np x Kp x 4 bytes), the K x K operand as derived pairs (Kp x Kp x 8
+// bytes), scale[0] = 2^-(e_Phi + e_operand) on the device
 struct F16x3Kernels {
-    static void split_phi(const Geom& g, const float* Phi, unsigned* Phi16, const Scal* sc, hipStream_t st);
     // M: fp64, symmetric, K x K inside Kp x Kp; part: >= 512 doubles of scratch
     static void split_operand(const Geom& g, const double* M, char* B16, float* scale, double* part, const Scal* sc, hipStream_t st);
     // column tiles [col0, col0 + BN njt) (BN = 256, 128 or 64; vpart slots from slot0) of row blocks rb0 .. rb0 + nrb - 1, epilogue EPI 0
@@ -146,6 +145,22 @@ struct F16x3Kernels {
     static int apply(const Geom& g, int njt, int col0, int slot0, const float* Phi, const F16Operands& f, float* V,
                      double* vpart, const double* p, const double* q, const double* y, const double* alpha, const double* ut, double* mu,
                      hipStream_t st, int64_t rb0, int64_t nrb);
+    // gram_f16.hip.  "Plane form": Np x Kp elements of 4 bytes, per 16 columns [16 x h | 16 x l]; such arrays are allocated with
+    // F16_PAD bytes behind them (the Gram's last 256-column block may stick out of Kp).  tmp: 8 floats on the device; after a split
+    // pass tmp + 4 is the scale of the Gram product that follows.  sidepart: side_blocks(g) x Kp doubles, the block partials of M^T w
+    // (reduce_side sums them).
+    static constexpr size_t F16_PAD = 1024;
+    static int side_blocks(const Geom& g);
+    // Phi -> packed pairs (Phi16: the apply tiles' operand) and plane form (Phi16g); sidepart <- Phi^T y
+    static void split_phi(const Geom& g, const float* Phi, const double* y, const Scal* sc, unsigned* Phi16, unsigned* Phi16g, double* sidepart,
+                          float* tmp, hipStream_t st);
+    // V = Phi B -> plane forms of V and of diag(q) V; sidepart <- V^T p; B (fp64, symmetric, ld Kp) only bounds |V|
+    static void split_v(const Geom& g, const float* V, const double* B, const double* q, const double* p, const Scal* sc, unsigned* V16g,
+                        unsigned* qV16g, double* sidepart, float* tmp, hipStream_t st);
+    // slabs[chunk][tri(128-tile)][128 x 128] = scale[0] (A chunk)^T (B chunk) on the lower 128-tiles, every slab written; chunk rows per
+    // chunk (rounded up to 256): gram_chunks(g, chunk) chunks, to be summed by reduce_tri_tiles with nsplit = that number
+    static int gram_chunks(const Geom& g, int64_t chunk);
+    static void gram(const Geom& g, const unsigned* A16g, const unsigned* B16g, const float* scale, int64_t chunk, double* slabs, hipStream_t st);
 };
 
 // everything that sweeps the rows, under one name

@@ -149,7 +149,13 @@ struct scfgp_ctx {
     // compute mode SCFGP_F16X3 (apply_f16.hip): fp32 mode whose two square apply products run as a three-term fp16 split wherever
     // fp32 mode would use its 256-wide LDS-DMA tiles; Phi16 = Phi as packed (h, l) pairs, B16 = the K x K operand's derived pairs
     bool split16 = false; unsigned* d_Phi16 = nullptr; char* d_B16 = nullptr; float* d_f16scale = nullptr;
+    // ... and the two Gram products too (gram_f16.hip): plane forms of Phi, then V (one array: Phi's is dead after pass 1's Gram), and of
+    // diag(q) V; block partials of the side vectors; 8 floats of bounds and scales
+    unsigned* d_P16g = nullptr; unsigned* d_qV16g = nullptr; double* d_f16side = nullptr; float* d_f16tmp = nullptr;
+    int f16gram = 1;                                             // tuning knob "f16_gram": 0 keeps the fp32 Gram in this mode
     bool f16_on() const { return split16 && dma() == 2; }
+    int64_t f16_chunk() const { return gram_chunk > 0 ? std::max<int64_t>(gram_chunk, 2048) : 4096; }    // rows per fp32 accumulator (and per slab set)
+    bool f16_gram() const { return f16_on() && f16gram && !last_cform; }      // factor form (level 2) keeps its fp32 products
     F16Operands f16ops() const { return F16Operands{d_Phi16, d_B16, d_f16scale}; }
     // exchange buffers and K-stage
     // exchange buffers xp1/xp2 = [packed lower tiles | vector Kp | 8 scalars], x3 = [X~^T Zbar | 8 scalars];
@@ -279,7 +285,7 @@ static int xtz_split(int ntiles, int64_t Np) {
 
 static void free_rows(scfgp_ctx* c) {
     dfree(c->d_Xt); dfree(c->d_y); dfree(c->d_p); dfree(c->d_q); dfree(c->d_ws2); dfree(c->d_mu); dfree(c->d_vpart); dfree(c->d_Tt);
-    dfree(c->d_Phi); dfree(c->d_V); dfree(c->d_Phi16); dfree(c->d_slabs);
+    dfree(c->d_Phi); dfree(c->d_V); dfree(c->d_Phi16); dfree(c->d_P16g); dfree(c->d_qV16g); dfree(c->d_f16side); dfree(c->d_slabs);
     c->Ncap = 0; c->slabs_bytes = 0;
 }
 
@@ -323,6 +329,7 @@ static int ensure_rows(scfgp_ctx* c, int64_t N) {
     // the two row-contracted products of the rank-S backward projection (pass3): (Spp x Jp) and (Dpp x Sq) tile grids
     const int nt1 = (c->Spp / XT) * (g.Jp / XT), nt2 = (c->Dpp / XT) * (c->Sq / XT);
     const size_t lrb = std::max<size_t>((size_t)xtz_split(nt1, Np) * nt1, (size_t)xtz_split(nt2, Np) * nt2);
+    if (c->split16) gs = std::max(gs, F16x3Kernels::gram_chunks(g, c->f16_chunk()));       // the f16x3 Gram: one set of slabs per row chunk
     const size_t need = sizeof(double) * std::max<size_t>((size_t)gs * ntiles * g.tile * g.tile + (size_t)gs * g.Kp,
                                                           std::max<size_t>((size_t)xs * ntx, lrb) * XT * XT);
     if (need > c->slabs_bytes) {
@@ -333,7 +340,7 @@ static int ensure_rows(scfgp_ctx* c, int64_t N) {
     if (int rc = ensure_aux_rows(c)) return rc;
     if (Np <= c->Ncap) return SCFGP_OK;
     dfree(c->d_Xt); dfree(c->d_y); dfree(c->d_p); dfree(c->d_q); dfree(c->d_ws2); dfree(c->d_mu); dfree(c->d_vpart); dfree(c->d_Tt);
-    dfree(c->d_Phi); dfree(c->d_V); dfree(c->d_Phi16);
+    dfree(c->d_Phi); dfree(c->d_V); dfree(c->d_Phi16); dfree(c->d_P16g); dfree(c->d_qV16g); dfree(c->d_f16side);
     c->Ncap = 0;
     const size_t ts = c->tsize();
     int rc;
@@ -347,7 +354,14 @@ static int ensure_rows(scfgp_ctx* c, int64_t N) {
     if ((rc = dmalloc(c, &c->d_vpart, sizeof(double) * Np * (g.Kp / 64)))) return rc;          // <= one entry per 64 columns
     if ((rc = dmalloc(c, &c->d_Phi, ts * Np * g.Kp))) return rc;
     if ((rc = dmalloc(c, &c->d_V, ts * Np * g.Kp))) return rc;
-    if (c->split16 && (rc = dmalloc(c, &c->d_Phi16, sizeof(unsigned) * Np * g.Kp))) return rc;
+    if (c->split16) {
+        const size_t plane = sizeof(unsigned) * Np * g.Kp + F16x3Kernels::F16_PAD;
+        if ((rc = dmalloc(c, &c->d_Phi16, sizeof(unsigned) * Np * g.Kp))) return rc;
+        if ((rc = dmalloc(c, &c->d_P16g, plane)) || (rc = dmalloc(c, &c->d_qV16g, plane))) return rc;
+        if ((rc = dmalloc(c, &c->d_f16side, sizeof(double) * F16x3Kernels::side_blocks(g) * g.Kp))) return rc;
+        HIPCHK(c, hipMemsetAsync(c->d_P16g, 0, plane, c->st));            // the padding is read (into tiles nobody stores): keep it finite
+        HIPCHK(c, hipMemsetAsync(c->d_qV16g, 0, plane, c->st));
+    }
     HIPCHK(c, hipMemsetAsync(c->d_Phi, 0, ts * Np * g.Kp, c->st));       // padding columns >= K stay zero forever
     HIPCHK(c, hipMemsetAsync(c->d_V, 0, ts * Np * g.Kp, c->st));         // columns >= K are never written
     c->Ncap = Np;
@@ -400,6 +414,7 @@ extern "C" int scfgp_create(scfgp_ctx** out, int D, int S, int M, int dtype, int
     if (c->split16) {
         if ((rc = dmalloc(c, &c->d_B16, 8 * (size_t)K2))) return rc;
         if ((rc = dmalloc(c, &c->d_f16scale, sizeof(float) * 4))) return rc;
+        if ((rc = dmalloc(c, &c->d_f16tmp, sizeof(float) * 8))) return rc;
     }
     if ((rc = dmalloc(c, &c->d_vecs, sizeof(double) * 5 * Kp))) return rc;
     if ((rc = dmalloc(c, &c->d_scalars, sizeof(double) * 32))) return rc;
@@ -427,7 +442,7 @@ extern "C" void scfgp_destroy(scfgp_ctx* c) {
     dfree(c->d_Phi64); dfree(c->d_C); dfree(c->d_Xraw); dfree(c->d_yraw); dfree(c->d_idx); dfree(c->d_xscale); dfree(c->d_yscale);
     dfree(c->d_params); dfree(c->d_F); dfree(c->d_Fall); dfree(c->d_Lall); dfree(c->d_Rall); dfree(c->d_sc); dfree(c->p_Tt);
     dfree(c->d_xp1); dfree(c->d_xp2); dfree(c->d_x1); dfree(c->d_x2); dfree(c->d_x3); dfree(c->d_Li); dfree(c->d_B); dfree(c->d_T1); dfree(c->d_T2);
-    dfree(c->d_Abar); dfree(c->d_BT); dfree(c->d_AbarT); dfree(c->d_B16); dfree(c->d_f16scale); dfree(c->d_vecs); dfree(c->d_scalars); dfree(c->d_yy);
+    dfree(c->d_Abar); dfree(c->d_BT); dfree(c->d_AbarT); dfree(c->d_B16); dfree(c->d_f16scale); dfree(c->d_f16tmp); dfree(c->d_vecs); dfree(c->d_scalars); dfree(c->d_yy);
     dfree(c->d_flag); dfree(c->d_partial); dfree(c->d_work); dfree(c->d_grad);
     dfree(c->p_Xt); dfree(c->p_vpart); dfree(c->p_mupart); dfree(c->p_Phi);
     if (c->gexec) hipGraphExecDestroy(c->gexec);
@@ -508,6 +523,21 @@ template <typename T> struct Impl {
     static void gram_to(scfgp_ctx* c, const T* Mx, const double* w, const double* side, double* out, const char* name) {
         const Geom& g = c->g;
         const int nts = g.Kp / g.tile, ntiles = nts * (nts + 1) / 2;
+        if constexpr (sizeof(T) == 4) {
+            if (c->f16_gram()) {
+                // f16x3 mode: a split pass over the operand (which also leaves the side vector's block partials), then the fp16 Gram
+                // whose row chunks are the "splits" of the shared reduction
+                const int nch = F16x3Kernels::gram_chunks(g, c->f16_chunk());
+                { ProfScope ps(c, w ? "split_v" : "split_phi");
+                  if (w) F16x3Kernels::split_v(g, (const float*)Mx, c->d_B, w, side, c->d_sc, c->d_P16g, c->d_qV16g, c->d_f16side, c->d_f16tmp, c->st);
+                  else F16x3Kernels::split_phi(g, (const float*)Mx, side, c->d_sc, c->d_Phi16, c->d_P16g, c->d_f16side, c->d_f16tmp, c->st); }
+                { ProfScope ps(c, name);
+                  F16x3Kernels::gram(g, c->d_P16g, w ? c->d_qV16g : c->d_P16g, c->d_f16tmp + 4, c->f16_chunk(), c->d_slabs, c->st); }
+                { ProfScope ps(c, "reduce_tiles"); reduce_tri_tiles(c->d_slabs, nch, nts, g.tile, out, c->st);
+                  reduce_side(c->d_f16side, F16x3Kernels::side_blocks(g), g.Kp, g.gfull * g.tile + g.gstrip * 64, out + c->n_pk, c->st); }
+                return;
+            }
+        }
         const int gs = c->splits.nsplit;
         double* sidepart = c->d_slabs + (size_t)gs * ntiles * g.tile * g.tile;
         { ProfScope ps(c, name);
@@ -538,7 +568,11 @@ template <typename T> struct Impl {
         }
         { ProfScope ps(c, "featuremap"); SK::featuremap(g, c->d_Xt, proj, c->d_sc, (T*)c->d_Phi, c->st); }
         if constexpr (sizeof(T) == 4) {
-            if (c->f16_on()) { ProfScope ps(c, "split_phi"); F16x3Kernels::split_phi(g, (const float*)c->d_Phi, c->d_Phi16, c->d_sc, c->st); }
+            // f16x3 mode: the apply tiles' packed pairs; with the fp16 Gram they come out of gram_to's split pass instead
+            if (c->f16_on() && (use64 || !c->f16_gram())) {
+                ProfScope ps(c, "split_phi");
+                F16x3Kernels::split_phi(g, (const float*)c->d_Phi, c->d_y, c->d_sc, c->d_Phi16, c->d_P16g, c->d_f16side, c->d_f16tmp, c->st);
+            }
         }
         if (!use64) gram_to(c, (const T*)c->d_Phi, nullptr, c->d_y, c->d_xp1, "gram");
         c->last_used64 = use64 || sizeof(T) == 8; c->last_level = sizeof(T) == 8 ? 0 : c->level();
@@ -1416,6 +1450,7 @@ extern "C" int scfgp_set_option(scfgp_ctx* c, const char* name, int64_t value) {
     else if (s == "apply_dma") { if (value < -1 || value > 2) { c->err = "apply_dma: -1 auto, 0 off, 1 = 128-wide tiles, 2 = 256-wide (fp32)"; return SCFGP_EARG; }
                                  c->apply_dma = (int)value; }
     else if (s == "gram_chunk") c->gram_chunk = value;
+    else if (s == "f16_gram") c->f16gram = (int)value;
     else if (s == "lowrank_bwd") c->lowrank_bwd = (int)value;
     else if (s == "xtz_nsplit") c->xtz_nsplit = (int)value;
     else if (s == "use_graph") c->use_graph = (int)value;

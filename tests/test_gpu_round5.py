@@ -256,8 +256,8 @@ def test_training_with_the_sums_inside_the_library_equals_the_plain_loop(dtype):
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
-# Compute mode f16x3 (include/scfgp_hip.h: SCFGP_F16X3; scfgp_amd/csrc/apply_f16.hip): a labelled SECONDARY mode -- fp32 mode whose two
-# square apply products run as a three-term fp16 split.  It must pass fp32 mode's parity tier (|dcost| <= 1e-5
+# Compute mode f16x3 (include/scfgp_hip.h: SCFGP_F16X3; scfgp_amd/csrc/apply_f16.hip, gram_f16.hip): a labelled SECONDARY mode -- fp32 mode
+# whose two square apply products and two Gram products run as a three-term fp16 split.  It must pass fp32 mode's parity tier (|dcost| <= 1e-5
 # max(1, |cost|), per-block gradient norms <= 1e-3, alpha / Li / mu* / sigma* as fp32 mode) against fp64 mode = the reference's arithmetic.
 # ---------------------------------------------------------------------------------------------------------------------------
 def _blocks(g, D, S, M):
@@ -265,12 +265,15 @@ def _blocks(g, D, S, M):
     return g[:3], g[3:o], g[o:o + M * S]
 
 
+@pytest.mark.parametrize('f16_gram', [1, 0])
 @pytest.mark.parametrize('N,D,S,M,abc', [(20000, 16, 16, 256, (-1.0, 0.0, -1.0)), (33000, 8, 32, 256, (-1.0, 0.0, -1.0)),
                                           (40000, 32, 16, 496, (-2.0, 0.5, -1.0)), (30000, 24, 20, 300, (-0.5, -0.5, -2.0))])
-def test_f16x3_mode_passes_fp32_modes_parity_tier(N, D, S, M, abc):
+def test_f16x3_mode_passes_fp32_modes_parity_tier(N, D, S, M, abc, f16_gram):
     """K = 544, 576, 1024, 640: two or four 256-wide column tiles on the split (option apply_dma = 2 forces the 256-wide tiles below the
     size from which fp32 mode picks them itself) + an exact-fp32 remainder of 32 / 64 / 0 / 128 columns.  Against fp64 mode with fp32
-    mode's tolerances, against fp32 mode itself (no worse than 4x its error where that error is measurable), and bit-equal repeats."""
+    mode's tolerances, against fp32 mode itself (no worse than 4x its error where that error is measurable), and bit-equal repeats.
+    f16_gram = 0 keeps the fp32 Gram (the mode's apply half alone); with it on, K / 256 rounded up = 3, 3, 4, 3 column blocks of the
+    fp16 Gram, the last one sticking out of Kp = 640, 640, 1024, 640 in three of the shapes, and row chunks of 4096 (the last one short)."""
     from scfgp_amd import synth
     from scfgp_amd.engine import HipEngine
     seed = 0x5CF60A00 + M
@@ -281,12 +284,15 @@ def test_f16x3_mode_passes_fp32_modes_parity_tier(N, D, S, M, abc):
     for dtype in ('f64', 'f32', 'f16x3'):
         e = HipEngine(D, S, M, dtype)
         if dtype != 'f64':
-            e.set_option('gram64', 0); e.set_option('apply_dma', 2)      # plain fp32 Gram in both: the comparison is about the apply products
+            e.set_option('gram64', 0); e.set_option('apply_dma', 2)      # no fp64 Gram in either: the comparison is about the split products
+        if dtype == 'f16x3':
+            e.set_option('f16_gram', f16_gram)
         e.set_params(params); e.set_data(X, y)
         e.set_profiling(True)
         a = e.eval()
         names = [n for n, _ in e.timings()]
         assert ('split_phi' in names) == (dtype == 'f16x3')              # the split path ran (and only there)
+        assert ('split_v' in names) == (dtype == 'f16x3' and f16_gram == 1)
         b = e.eval()
         assert float(a[0]) == float(b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
         mu, sd = e.predict(Xs, a[2], a[3])
@@ -302,16 +308,21 @@ def test_f16x3_mode_passes_fp32_modes_parity_tier(N, D, S, M, abc):
     print('f16x3', {k: '%.1e' % v for k, v in err['f16x3'].items()})
     e16, e32 = err['f16x3'], err['f32']
     assert e16['cost'] < 1e-5 and e16['g0'] < 1e-3 and e16['g1'] < 1e-3 and e16['g2'] < 1e-3
-    # alpha and Li come from pass 1 (the fp32 Gram, untouched by the mode): identical to fp32 mode's
-    assert np.array_equal(outs['f16x3'][2], outs['f32'][2]) and np.array_equal(outs['f16x3'][3], outs['f32'][3])
-    for k in ('cost', 'g0', 'g1', 'g2'):
-        assert e16[k] <= 4 * e32[k] + 1e-9, (k, e16[k], e32[k])
+    if not f16_gram:       # alpha and Li come from pass 1 (the fp32 Gram, untouched then): identical to fp32 mode's
+        assert np.array_equal(outs['f16x3'][2], outs['f32'][2]) and np.array_equal(outs['f16x3'][3], outs['f32'][3])
+    # The fp16 Gram is the noisier of the two halves: the fp16 matrix instruction TRUNCATES when it adds into a large fp32 accumulator (the
+    # error grows with the length of the chain and is negative on the diagonal: profiles/r05_tuning.md), so over a 4096-row chunk G is
+    # 4e-8 from fp64's where the fp32 Gram is 5e-9 -- alpha / Li / mu* follow it.  Inside the tier by two orders; bounded here at 16x.
+    worse = 16 if f16_gram else 4
+    for k in ('cost', 'g0', 'g1', 'g2', 'alpha', 'Li', 'mu', 'sd'):
+        assert e16[k] <= worse * e32[k] + 2e-9, (k, e16[k], e32[k])
+    assert e16['alpha'] < 1e-3 and e16['Li'] < 1e-3 and e16['mu'] < 1e-3 and e16['sd'] < 1e-3
 
 
 def test_f16x3_mode_at_the_headline_shape():
     """N = 1e6, D = 64, S = 32, M = 1024 (the library picks the 256-wide tiles itself): f16x3 against fp32 mode on the same rows --
-    cost to 1e-9, gradient blocks to 2e-5 (fp32 mode itself is 2.5e-6 from fp64 mode there), alpha / Li bit-equal (pass 1 is
-    untouched), repeats bit-equal -- and the two apply stages at least twice as fast."""
+    cost to 1e-7, gradient blocks to 2e-5 (fp32 mode itself is 2.5e-6 from fp64 mode there), alpha / Li to 1e-4 norm-wise, repeats
+    bit-equal -- and the two apply stages and the two Gram products at least twice as fast."""
     import bench
     from scfgp_amd.engine import HipEngine
     N, D, S, M = bench.CONFIGS['H'][:4]
@@ -327,10 +338,14 @@ def test_f16x3_mode_at_the_headline_shape():
     c2, g2, _, _ = e1.eval()
     e1.close()
     assert float(c1) == float(c2) and np.array_equal(g1, g2)
-    assert np.array_equal(a1, a0) and np.array_equal(L1, L0)
-    assert abs(float(c1) - float(c0)) < 1e-9 * max(1.0, abs(float(c0)))
+    print('\ncost %.3e  alpha %.2e  Li %.2e  grad blocks %s' % (abs(float(c1) - float(c0)) / max(1.0, abs(float(c0))), rel(a1, a0), rel(L1, L0),
+          ['%.1e' % rel(u, v) for u, v in zip(_blocks(g1, D, S, M), _blocks(g0, D, S, M))]))
+    assert rel(a1, a0) < 1e-4 and rel(L1, L0) < 1e-4
+    assert abs(float(c1) - float(c0)) < 1e-7 * max(1.0, abs(float(c0)))
     for u, v in zip(_blocks(g1, D, S, M), _blocks(g0, D, S, M)):
         assert rel(u, v) < 2e-5, rel(u, v)
-    print('\napply_v %.2f -> %.2f ms, apply_phibar %.2f -> %.2f ms, split_phi %.2f ms' % (
-        t0['apply_v'], t1['apply_v'], t0['apply_phibar'], t1['apply_phibar'], t1['split_phi']))
+    print('apply_v %.2f -> %.2f ms, apply_phibar %.2f -> %.2f ms, gram %.2f -> %.2f ms, gram_w %.2f -> %.2f ms, split_phi %.2f ms, split_v %.2f ms,'
+          ' reduce_tiles %.2f -> %.2f ms' % (t0['apply_v'], t1['apply_v'], t0['apply_phibar'], t1['apply_phibar'], t0['gram'], t1['gram'],
+                                            t0['gram_w'], t1['gram_w'], t1['split_phi'], t1['split_v'], t0['reduce_tiles'], t1['reduce_tiles']))
     assert t1['apply_v'] < 0.5 * t0['apply_v'] and t1['apply_phibar'] < 0.5 * t0['apply_phibar']
+    assert t1['gram'] < 0.5 * t0['gram'] and t1['gram_w'] < 0.5 * t0['gram_w']
