@@ -1,23 +1,24 @@
 // Compute mode SCFGP_F16X3 (include/scfgp_hip.h; a labelled SECONDARY mode, never the headline): the two square apply products
-// V = Phi B and Phibar = 2 Phi Abar + ... as a THREE-TERM fp16 split on the fp16 matrix pipe; everything else of the evaluation
-// is fp32 mode's.  No reference counterpart (the reference is float64 throughout, SCFGP/SCFGP.py:95-96); what it must equal is
-// fp32 mode, whose parity tier it runs under (tests/test_gpu_round5.py).
+// V = Phi B and Phibar = 2 Phi Abar + ... as a THREE-TERM fp16 split on the fp16 matrix pipe (gram_f16.hip: the two Gram products);
+// everything else of the evaluation is fp32 mode's.  No reference counterpart (the reference is float64 throughout,
+// SCFGP/SCFGP.py:95-96); what it must equal is fp32 mode, whose parity tier it runs under (tests/test_gpu_round5.py).
 //
 // The split.  x = (h + l) 2^-e with h = fp16(x 2^e), l = fp16(x 2^e - h) and ONE power-of-two scale per operand matrix that puts its
 // largest entry in [2^14, 2^15): l then stays in fp16's normal range for every entry within 2^-18 of the largest, and h + l carries
-// 22-23 bits.  Products of two fp16 values are exact in fp32, so  a b ~ ah bh + al bh + ah bl  accumulated in fp32 loses only the
-// l.l term (2^-22 relative) against an exact-fp32 product: measured errors within 1.0-3.5x of fp32 mode's
-// (tests/cpu_f16x3_emulation.py, profiles/r05_f16x3_emulation.txt).
+// 22-24 bits.  Products of two fp16 values are exact in fp32, so  a b ~ ah bh + al bh + ah bl  loses only the l.l term (2^-24
+// relative) against an exact-fp32 product; what the mode really pays is the fp16 matrix instruction's accumulation, which truncates
+// (gram_f16.hip, profiles/r05_tuning.md).  Measured errors of the two products here: within 1.0-3.5x of fp32 mode's.
 //
-// The operands.  An element of Phi stays 4 bytes: the packed pair (h, l) -- so the LDS image of the A panel, its DMA and its HBM
-// traffic are exactly the fp32 tile's (apply.hip: apply_dma_kernel<float, ., 256>).  The small operand (B or Abar, K x K, cache
-// resident) is stored per element as 8 bytes, the derived pairs (bh, bh) and (bl, 0): with a lane's A vector
-// (ah0, al0, ah1, al1, ...) the two matrix instructions
-//       a . (bh0, bh0, bh1, bh1, ...) = sum_k (ah_k + al_k) bh_k          a . (bl0, 0, bl1, 0, ...) = sum_k ah_k bl_k
-// are the three terms.  v_mfma_f32_16x16x32_f16 takes 32 slots = 16 k: TWO instructions of 16 cycles per 16 x 16 output tile and
-// 16-k stage where exact fp32 needs four v_mfma_f32_16x16x4_f32 of 32 cycles.  The k loop is the plain staged one (wait, barrier,
-// fetch of stage s+2, fragment reads, MFMAs; compiler-scheduled): tools/f16x3_probe.hip measured it at 2.6x the fp32 loop before this
-// file existed; the LDS array, not the matrix pipe, is what it leans on (192 B per lane and stage against 32 MFMAs of 16 cycles).
+// The operands.  Both come in "plane form" (kernels.h): 4 bytes per element, per 16 consecutive k the 16 h's and then the 16 l's.  Phi's
+// is the array the fp16 Gram reads too (one split pass writes it, gram_f16.hip: split_rows_kernel); the small operand (B or Abar, K x K,
+// cache resident) is written row by row = output column by output column by split_operand.  A lane's 8 k of v_mfma_f32_16x16x32_f16 are
+// 16 bytes of ONE plane, so the three terms are three instructions into one accumulator, Ah.Bh + Al.Bh + Ah.Bl, per 16 x 16 output tile and
+// 32 k: 48 cycles where exact fp32 spends 256.  (The first version of this file kept Phi as packed (h, l) pairs against the derived
+// operand pairs (bh, bh), (bl, 0): two instructions per 16 k, i.e. four per 32 -- a third more matrix work and twice the operand bytes.)
+// Stage = 32 k: 128-byte rows of both images, ring of two stages (64 KiB each at BN = 256), fragment reads by hand (inline assembly with
+// counted lgkmcnt, three of the four fragment sets live at a time), the fetch of stage s+1 in flight while stage s is multiplied.
+// Both f16x3 kernels run the matrix pipe at 0.7-0.76 busy with the clock at ~1.65 GHz: the fp16 pipe at this rate is power-bound
+// (profiles/r05_tuning.md).
 #include "apply_epilogue.h"
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -26,22 +27,27 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
 
 namespace {
-constexpr int BM = 256, ROWA = 64, ROWB = 128;                              // bytes of one row's 16 k: packed pairs / derived pairs
+constexpr int BM = 256, ROW = 128;                                          // bytes of one row's 32 k in plane form: [16 h | 16 l] [16 h | 16 l]
 // tile widths as in fp32 mode's launch plan (apply.hip): 256 (16 waves), 128 (8 waves: an odd 128-column block, the thin last round's
 // row blocks), 64 (4 waves: the ragged remainder, K = 2112 = 8 x 256 + 64); wave tiles 64 x 64 throughout
 template <int BN_> struct F16Tile {
-    static constexpr int BN = BN_, WAVES = 4 * (BN / 64), STAGE = BM * ROWA + BN * ROWB, STAGES = 3, LDS_BYTES = STAGES * STAGE,
-                         DPW = STAGE / 1024 / WAVES, WAVES_PER_EU = WAVES == 4 ? 2 : 4;
+    static constexpr int BN = BN_, WAVES = 4 * (BN / 64), STAGE = (BM + BN) * ROW, STAGES = 2, LDS_BYTES = STAGES * STAGE,
+                         DPW = STAGE / 1024 / WAVES, WAVES_PER_EU = WAVES == 16 ? 4 : 2;   // one 16- or 8-wave workgroup per CU, two of 4 waves
     static_assert(STAGE / 1024 % WAVES == 0 && LDS_BYTES <= 160 * 1024, "whole DMA instructions per wave; the ring fits the LDS");
     typedef TileCfg<float, BM, BN, 16, 4, BN / 64, 16, true> Cfg;           // the fp32 tile's accumulator map (apply_epilogue.h)
 };
-// position swizzles of the two images (apply.hip): 64-byte rows f[(x >> 2) & 3], f = (0, 2, 3, 1); 128-byte rows f[(x >> 1) & 7]
-__device__ __forceinline__ int swz4(int x) { return (0x78 >> (2 * ((x >> 2) & 3))) & 3; }
+// position swizzle of the images (apply.hip): 16-byte chunk c of a 128-byte row x lies at position c ^ f[(x >> 1) & 7]
 __device__ __forceinline__ int swz8(int x) { return (int)((0x6BEB08u >> (3 * ((x >> 1) & 7))) & 7); }
+// fragment read by hand: through plain loads the compiler may put an s_waitcnt vmcnt(0) in front (it cannot tell the LDS-DMA of the NEXT
+// stage from the data being read: gram_f16.hip), and the release of the fragments is counted here (SCFGP_F16_WAIT)
+template <int OFF> __device__ __forceinline__ void lds_read(h8& out, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(out) : "v"(addr), "n"(OFF));
+}
+#define SCFGP_F16_WAIT(n, x) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]) :: "memory")
 }
 
-// One 256 x BN tile: column tile jt of the launch, row block rb0 + wid / njt.  Phi16: Np x Kp packed pairs; B16: Kp rows (= output
-// columns) of Kp derived elements, 128 bytes per 16 k: [16 x (bh, bh) | 16 x (bl, 0)]; scale[0] = 2^-(e_Phi + e_B).
+// One 256 x BN tile: column tile jt of the launch, row block rb0 + wid / njt.  Phi16: Np x Kp in plane form; B16: Kp rows (= output
+// columns) of Kp elements in plane form; scale[0] = 2^-(e_Phi + e_B).
 template <int EPI, int BN>
 __global__ __launch_bounds__((64 * F16Tile<BN>::WAVES))
 __attribute__((amdgpu_waves_per_eu(F16Tile<BN>::WAVES_PER_EU, F16Tile<BN>::WAVES_PER_EU)))
@@ -59,21 +65,18 @@ void apply_f16_kernel(const float* __restrict__ Phi, const unsigned* __restrict_
     const int64_t rb = rb0 + wid / njt;
     const int cbase = col0 + jt * BN;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // DMA instruction t = DPW wave + u of a stage: 1 KiB of the stacked image -- t < 16: A rows 16 t .. (4 chunks each), else B
-    // rows 8 (t - 16) .. (8 chunks each); chunk c of row x goes to position c ^ swz(x) (source-side swizzle, linear LDS writes).
-    // B rows are staged in the order that leaves an MFMA lane 4 ADJACENT output columns (apply.hip): LDS row tn 16 + i of a wave
-    // tile holds operand row 4 i + tn.
-    const char* src[DPW]; int dst[DPW], adv[DPW];
+    // DMA instruction t = DPW wave + u of a stage: 1 KiB = rows 8 t .. 8 t + 7 of the stacked image (A's 256 rows, then B's BN), 8 chunks
+    // each; chunk c of row x goes to position c ^ swz8(x) (source-side swizzle, linear LDS writes).  B rows are staged in the order
+    // that leaves an MFMA lane 4 ADJACENT output columns (apply.hip): LDS row tn 16 + i of a wave tile holds operand row 4 i + tn.
+    const char* src[DPW]; int dst[DPW];
 #pragma unroll
     for (int u = 0; u < DPW; ++u) {
-        const int t = DPW * wave + u;
-        if (t < BM * ROWA / 1024) {
-            const int x = 16 * t + lane / 4, c = (lane % 4) ^ swz4(x);
-            src[u] = reinterpret_cast<const char*>(Phi16 + (rb * BM + x) * Kp) + (c << 4); adv[u] = ROWA;
+        const int t = DPW * wave + u, x = 8 * t + lane / 8;
+        if (x < BM) {
+            src[u] = reinterpret_cast<const char*>(Phi16 + (rb * BM + x) * Kp) + (((lane % 8) ^ swz8(x)) << 4);
         } else {
-            const int xb = 8 * (t - BM * ROWA / 1024) + lane / 8, c = (lane % 8) ^ swz8(xb);
-            const int xcol = (xb & ~63) + 4 * (xb & 15) + ((xb >> 4) & 3);
-            src[u] = B16 + (int64_t)(cbase + xcol) * Kp * 8 + (c << 4); adv[u] = ROWB;
+            const int xb = x - BM, xcol = (xb & ~63) + 4 * (xb & 15) + ((xb >> 4) & 3);
+            src[u] = B16 + (int64_t)(cbase + xcol) * Kp * 4 + (((lane % 8) ^ swz8(xb)) << 4);
         }
         dst[u] = t * 1024;
     }
@@ -81,43 +84,54 @@ void apply_f16_kernel(const float* __restrict__ Phi, const unsigned* __restrict_
 #pragma unroll
         for (int u = 0; u < DPW; ++u) {
             __builtin_amdgcn_global_load_lds((gbl_void*)src[u], (lds_void*)(smem + slot * STAGE + dst[u]), 16, 0, 0);
-            src[u] += adv[u];
+            src[u] += ROW;
         }
     };
     const int i = lane & 15, qg = lane >> 4;
     const int wm0 = (wave / Cfg::WGN) * Cfg::WM, wn0 = (wave % Cfg::WGN) * Cfg::WN;
-    // this lane's 16 bytes (k = 4 qg .. 4 qg + 3) in the first fragment row of the wave's A tile; the (bh, bh) and (bl, 0) chunks of B
-    const int offa = (wm0 + i) * ROWA + ((qg ^ swz4(i)) << 4);
-    const int offd = BM * ROWA + (wn0 + i) * ROWB + ((qg ^ swz8(i)) << 4), offl = BM * ROWA + (wn0 + i) * ROWB + (((4 + qg) ^ swz8(i)) << 4);
+    // this lane's 8 k (8 qg .. 8 qg + 7) of a row: chunk 4 (qg >> 1) + (qg & 1) of the h's, two chunks further the l's
+    const int ch = 4 * (qg >> 1) + (qg & 1), sw = swz8(i);
+    const unsigned lds0 = (unsigned)(uintptr_t)smem;
+    const unsigned oah = (wm0 + i) * ROW + ((ch ^ sw) << 4), oal = (wm0 + i) * ROW + (((ch + 2) ^ sw) << 4);
+    const unsigned obh = (BM + wn0 + i) * ROW + ((ch ^ sw) << 4), obl = (BM + wn0 + i) * ROW + (((ch + 2) ^ sw) << 4);
     typename Cfg::MTr::acc_t acc[Cfg::TM][Cfg::TN];
     acc_zero<Cfg>(acc);
-    const int nst = (K + 15) / 16;
+    const int nst = (K + 31) / 32;
     fetch(0);
-    if (nst > 1) fetch(1);
     int slot = 0;
     for (int s = 0; s < nst; ++s) {
-        // this wave's share of stage s has landed when only the fetches of stage s+1 are outstanding
-        if (s + 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DPW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                          // everybody's has; nobody reads the slot of stage s-1 any more
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's share of stage s (issued a stage ago) has landed
+        __builtin_amdgcn_s_barrier();                          // everybody's has; nobody reads the other slot any more
         asm volatile("" ::: "memory");
-        if (s + 2 < nst) fetch(slot == 0 ? 2 : slot - 1);
-        const char* base = smem + slot * STAGE;
-        h8 fa[4], fd[4], fl[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            fa[t] = *reinterpret_cast<const h8*>(base + offa + t * 16 * ROWA);
-            fd[t] = *reinterpret_cast<const h8*>(base + offd + t * 16 * ROWB);
-            fl[t] = *reinterpret_cast<const h8*>(base + offl + t * 16 * ROWB);
-        }
-#pragma unroll
-        for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < 4; ++tn) {
-                acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[tm], fd[tn], acc[tm][tn], 0, 0, 0);
-                acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[tm], fl[tn], acc[tm][tn], 0, 0, 0);
-            }
-        slot = slot == 2 ? 0 : slot + 1;
+        if (s + 1 < nst) fetch(slot ^ 1);
+        const unsigned base = lds0 + slot * STAGE;
+        // at most three of the four fragment sets are live (48 registers beside the 64 accumulators): Ah, Bh and Al are read up front, Bl
+        // moves into Al's registers while the middle term is multiplied
+        h8 ah[4], al[4], bh[4], bl[4];
+        static_for<4>([&](auto tc) { lds_read<decltype(tc)::value * 16 * ROW>(ah[decltype(tc)::value], base + oah); });
+        static_for<4>([&](auto tc) { lds_read<decltype(tc)::value * 16 * ROW>(bh[decltype(tc)::value], base + obh); });
+        static_for<4>([&](auto tc) { lds_read<decltype(tc)::value * 16 * ROW>(al[decltype(tc)::value], base + oal); });
+        SCFGP_F16_WAIT(4, ah);
+        SCFGP_F16_WAIT(4, bh);
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<16>([&](auto ic) { constexpr int tm = decltype(ic)::value / 4, tn = decltype(ic)::value % 4;
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0); });
+        __builtin_amdgcn_sched_barrier(0);
+        SCFGP_F16_WAIT(0, al);
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<4>([&](auto mc) { constexpr int tm = decltype(mc)::value;
+            static_for<4>([&](auto nc) { constexpr int tn = decltype(nc)::value;
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0); });
+            __builtin_amdgcn_sched_barrier(0);
+            lds_read<tm * 16 * ROW>(bl[tm], base + obl);         // Al[tm] is dead: its registers are free
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        SCFGP_F16_WAIT(0, bl);
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<16>([&](auto ic) { constexpr int tm = decltype(ic)::value / 4, tn = decltype(ic)::value % 4;
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0); });
+        __builtin_amdgcn_sched_barrier(0);
+        slot ^= 1;
     }
     __syncthreads();                                           // the epilogue reuses the LDS
     const float sc = scale[0];
@@ -152,7 +166,7 @@ __global__ __launch_bounds__(256) void maxabs_kernel(const double* __restrict__ 
     }
     if (threadIdx.x == 0) part[blockIdx.x] = r1[0];
 }
-// M (fp64, symmetric K x K in a Kp x Kp array) -> derived pairs, row j = column j of M; scale[0] = 2^-(e_Phi + e_M); scale[1] = 2^e_M
+// M (fp64, symmetric K x K in a Kp x Kp array) -> plane form, row j = column j of M; scale[0] = 2^-(e_Phi + e_M); scale[1] = 2^e_M
 __global__ __launch_bounds__(256) void split_operand_kernel(const double* __restrict__ M, int K, int Kp, const double* __restrict__ part, int nparts,
                                                             const Scal* __restrict__ sc, char* __restrict__ out, float* __restrict__ scale) {
     double m = 0;
@@ -164,10 +178,8 @@ __global__ __launch_bounds__(256) void split_operand_kernel(const double* __rest
         const int j = (int)(e / Kp), k = (int)(e % Kp);
         const double x = j < K && k < K ? ldexp(M[(int64_t)k * Kp + j], em) : 0.0;       // M^T = M; read along k for the write's sake
         const _Float16 h = (_Float16)x, l = (_Float16)(x - (double)h);
-        const h2 dup = h2{h, h}, lo = h2{l, (_Float16)0};
-        char* row = out + (int64_t)j * Kp * 8 + (int64_t)(k / 16) * 128 + (k % 16) * 4;
-        *reinterpret_cast<unsigned*>(row) = *reinterpret_cast<const unsigned*>(&dup);
-        *reinterpret_cast<unsigned*>(row + 64) = *reinterpret_cast<const unsigned*>(&lo);
+        _Float16* row = reinterpret_cast<_Float16*>(out + (int64_t)j * Kp * 4 + (int64_t)(k / 16) * 64) + k % 16;
+        row[0] = h; row[16] = l;
     }
 }
 

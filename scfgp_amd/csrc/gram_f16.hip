@@ -146,13 +146,13 @@ void gram_f16_kernel(const unsigned* __restrict__ A16, const unsigned* __restric
             for (int b = 0; b < 4; ++b) slab[(16 * a + 4 * G + r) * 128 + 16 * b + i] = (double)acc[a][b][r] * sc;
 }
 
-// One pass over a resident fp32 matrix M (Np x Kp): its elements as packed pairs (out_pk, the apply tile's A operand; may be NULL), in
-// plane form (out_pl), and, times rw[n], in plane form again (out_w; with rw, or neither); the fp64 block partials of the side vector
+// One pass over a resident fp32 matrix M (Np x Kp): its elements in plane form (out_pl) and, times rw[n], in plane form again (out_w;
+// with rw, or neither); the fp64 block partials of the side vector
 // sum_n sw[n] M[n][j] -- part[block][Kp], SIDE_ROWS rows per block.  Scaled by 2^e, e = 14 - ilogb(bound): bnd[0] bounds |M|, bnd[0] bnd[1]
 // bounds |rw M|; es[0] = 2^-e, es[1] = 2^-e_w, es[2] = the scale of the Gram product that follows: 2^-(e + e_w), or 2^-2e without rw.
 __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ M, int64_t Np, int Kp, const double* __restrict__ rw,
                                                          const double* __restrict__ sw, const float* __restrict__ bnd,
-                                                         unsigned* __restrict__ out_pk, unsigned* __restrict__ out_pl, unsigned* __restrict__ out_w,
+                                                         unsigned* __restrict__ out_pl, unsigned* __restrict__ out_w,
                                                          double* __restrict__ part, float* __restrict__ es) {
     const float b0 = bnd[0], b1 = rw ? b0 * bnd[1] : 0.f;
     const int e0 = b0 > 0.f ? 14 - ilogbf(b0) : 0, e1 = b1 > 0.f ? 14 - ilogbf(b1) : 0;
@@ -173,11 +173,6 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
             _Float16 h[4], l[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) split2(xs[k], h[k], l[k]);
-            if (out_pk) {
-                const h2 pa = h2{h[0], l[0]}, pb = h2{h[1], l[1]}, pc = h2{h[2], l[2]}, pd = h2{h[3], l[3]};
-                *reinterpret_cast<uint4*>(out_pk + n * Kp + c) = uint4{__builtin_bit_cast(unsigned, pa), __builtin_bit_cast(unsigned, pb),
-                                                                       __builtin_bit_cast(unsigned, pc), __builtin_bit_cast(unsigned, pd)};
-            }
             char* row = reinterpret_cast<char*>(out_pl + n * Kp) + poff;
             *reinterpret_cast<h4*>(row) = h4{h[0], h[1], h[2], h[3]};
             *reinterpret_cast<h4*>(row + 32) = h4{l[0], l[1], l[2], l[3]};
@@ -223,19 +218,19 @@ __global__ __launch_bounds__(256) void v_bound_kernel(const double* __restrict__
 
 int F16x3Kernels::side_blocks(const Geom& g) { return (int)((g.Np + SIDE_ROWS - 1) / SIDE_ROWS); }
 
-void F16x3Kernels::split_phi(const Geom& g, const float* Phi, const double* y, const Scal* sc, unsigned* Phi16, unsigned* Phi16g, double* sidepart,
-                             float* tmp, hipStream_t st) {
+void F16x3Kernels::split_phi(const Geom& g, const float* Phi, const double* y, const Scal* sc, unsigned* Phi16, double* sidepart, float* tmp,
+                             hipStream_t st) {
     hipLaunchKernelGGL(phi_bound_kernel, dim3(1), dim3(64), 0, st, tmp, sc);
     hipLaunchKernelGGL(split_rows_kernel, dim3(side_blocks(g)), dim3(256), 0, st, Phi, g.Np, g.Kp, (const double*)nullptr, y, (const float*)tmp,
-                       Phi16, Phi16g, (unsigned*)nullptr, sidepart, tmp + 2);
+                       Phi16, (unsigned*)nullptr, sidepart, tmp + 2);
 }
 void F16x3Kernels::split_v(const Geom& g, const float* V, const double* B, const double* q, const double* p, const Scal* sc, unsigned* V16g,
                            unsigned* qV16g, double* sidepart, float* tmp, hipStream_t st) {
     hipMemsetAsync(tmp, 0, sizeof(float), st);
     hipLaunchKernelGGL(v_bound_kernel, dim3((g.K + 3) / 4), dim3(256), 0, st, B, g.K, g.Kp, sc, sqrt((double)g.M), tmp);
     hipLaunchKernelGGL(maxabs_vec_kernel, dim3(1), dim3(1024), 0, st, q, g.N, tmp + 1);
-    hipLaunchKernelGGL(split_rows_kernel, dim3(side_blocks(g)), dim3(256), 0, st, V, g.Np, g.Kp, q, p, (const float*)tmp,
-                       (unsigned*)nullptr, V16g, qV16g, sidepart, tmp + 2);
+    hipLaunchKernelGGL(split_rows_kernel, dim3(side_blocks(g)), dim3(256), 0, st, V, g.Np, g.Kp, q, p, (const float*)tmp, V16g, qV16g, sidepart,
+                       tmp + 2);
 }
 int F16x3Kernels::gram_chunks(const Geom& g, int64_t chunk) {
     if (chunk <= 0 || chunk > g.Np) chunk = g.Np;

@@ -134,8 +134,9 @@ struct ApplyKernels {
 };
 
 // ---- apply_f16.hip, gram_f16.hip: compute mode SCFGP_F16X3 -- the big products as a three-term fp16 split (a labelled secondary mode) ----
-// operands of one apply product: Phi as packed (h, l) fp16 pairs (Np x Kp x 4 bytes), the K x K operand as derived pairs (Kp x Kp x 8
-// bytes), scale[0] = 2^-(e_Phi + e_operand) on the device
+// "Plane form": 4 bytes per element, per 16 consecutive columns the 16 h's and then the 16 l's ([16 x h | 16 x l], 64 bytes).  Operands of
+// one apply product: Phi in plane form (Np x Kp), the K x K operand in plane form (row = output column), scale[0] = 2^-(e_Phi + e_operand)
+// on the device
 struct F16x3Kernels {
     // M: fp64, symmetric, K x K inside Kp x Kp; part: >= 512 doubles of scratch
     static void split_operand(const Geom& g, const double* M, char* B16, float* scale, double* part, const Scal* sc, hipStream_t st);
@@ -145,15 +146,14 @@ struct F16x3Kernels {
     static int apply(const Geom& g, int njt, int col0, int slot0, const float* Phi, const F16Operands& f, float* V,
                      double* vpart, const double* p, const double* q, const double* y, const double* alpha, const double* ut, double* mu,
                      hipStream_t st, int64_t rb0, int64_t nrb);
-    // gram_f16.hip.  "Plane form": Np x Kp elements of 4 bytes, per 16 columns [16 x h | 16 x l]; such arrays are allocated with
-    // F16_PAD bytes behind them (the Gram's last 256-column block may stick out of Kp).  tmp: 8 floats on the device; after a split
-    // pass tmp + 4 is the scale of the Gram product that follows.  sidepart: side_blocks(g) x Kp doubles, the block partials of M^T w
-    // (reduce_side sums them).
+    // gram_f16.hip.  The Np x Kp plane-form arrays are allocated with F16_PAD bytes behind them (the Gram's last 256-column block may
+    // stick out of Kp).  tmp: 8 floats on the device; after a split pass tmp + 4 is the scale of the Gram product that follows.
+    // sidepart: side_blocks(g) x Kp doubles, the block partials of M^T w (reduce_side sums them).
     static constexpr size_t F16_PAD = 1024;
     static int side_blocks(const Geom& g);
-    // Phi -> packed pairs (Phi16: the apply tiles' operand) and plane form (Phi16g); sidepart <- Phi^T y
-    static void split_phi(const Geom& g, const float* Phi, const double* y, const Scal* sc, unsigned* Phi16, unsigned* Phi16g, double* sidepart,
-                          float* tmp, hipStream_t st);
+    // Phi -> plane form (Phi16: the operand of the apply tiles and of pass 1's Gram); sidepart <- Phi^T y
+    static void split_phi(const Geom& g, const float* Phi, const double* y, const Scal* sc, unsigned* Phi16, double* sidepart, float* tmp,
+                          hipStream_t st);
     // V = Phi B -> plane forms of V and of diag(q) V; sidepart <- V^T p; B (fp64, symmetric, ld Kp) only bounds |V|
     static void split_v(const Geom& g, const float* V, const double* B, const double* q, const double* p, const Scal* sc, unsigned* V16g,
                         unsigned* qV16g, double* sidepart, float* tmp, hipStream_t st);

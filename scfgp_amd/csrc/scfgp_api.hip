@@ -147,11 +147,11 @@ struct scfgp_ctx {
     double *d_Xt = nullptr, *d_y = nullptr, *d_p = nullptr, *d_q = nullptr, *d_mu = nullptr, *d_vpart = nullptr;
     void *d_Phi = nullptr, *d_V = nullptr;
     // compute mode SCFGP_F16X3 (apply_f16.hip): fp32 mode whose two square apply products run as a three-term fp16 split wherever
-    // fp32 mode would use its 256-wide LDS-DMA tiles; Phi16 = Phi as packed (h, l) pairs, B16 = the K x K operand's derived pairs
+    // fp32 mode would use its 256-wide LDS-DMA tiles; Phi16 = Phi in plane form (kernels.h), B16 = the K x K operand in plane form
     bool split16 = false; unsigned* d_Phi16 = nullptr; char* d_B16 = nullptr; float* d_f16scale = nullptr;
-    // ... and the two Gram products too (gram_f16.hip): plane forms of Phi, then V (one array: Phi's is dead after pass 1's Gram), and of
-    // diag(q) V; block partials of the side vectors; 8 floats of bounds and scales
-    unsigned* d_P16g = nullptr; unsigned* d_qV16g = nullptr; double* d_f16side = nullptr; float* d_f16tmp = nullptr;
+    // ... and the two Gram products too (gram_f16.hip): pass 1's on Phi16, pass 2's on the plane forms of V and of diag(q) V; block
+    // partials of the side vectors; 8 floats of bounds and scales
+    unsigned* d_V16g = nullptr; unsigned* d_qV16g = nullptr; double* d_f16side = nullptr; float* d_f16tmp = nullptr;
     int f16gram = 1;                                             // tuning knob "f16_gram": 0 keeps the fp32 Gram in this mode
     bool f16_on() const { return split16 && dma() == 2; }
     int64_t f16_chunk() const { return gram_chunk > 0 ? std::max<int64_t>(gram_chunk, 2048) : 4096; }    // rows per fp32 accumulator (and per slab set)
@@ -285,7 +285,7 @@ static int xtz_split(int ntiles, int64_t Np) {
 
 static void free_rows(scfgp_ctx* c) {
     dfree(c->d_Xt); dfree(c->d_y); dfree(c->d_p); dfree(c->d_q); dfree(c->d_ws2); dfree(c->d_mu); dfree(c->d_vpart); dfree(c->d_Tt);
-    dfree(c->d_Phi); dfree(c->d_V); dfree(c->d_Phi16); dfree(c->d_P16g); dfree(c->d_qV16g); dfree(c->d_f16side); dfree(c->d_slabs);
+    dfree(c->d_Phi); dfree(c->d_V); dfree(c->d_Phi16); dfree(c->d_V16g); dfree(c->d_qV16g); dfree(c->d_f16side); dfree(c->d_slabs);
     c->Ncap = 0; c->slabs_bytes = 0;
 }
 
@@ -340,7 +340,7 @@ static int ensure_rows(scfgp_ctx* c, int64_t N) {
     if (int rc = ensure_aux_rows(c)) return rc;
     if (Np <= c->Ncap) return SCFGP_OK;
     dfree(c->d_Xt); dfree(c->d_y); dfree(c->d_p); dfree(c->d_q); dfree(c->d_ws2); dfree(c->d_mu); dfree(c->d_vpart); dfree(c->d_Tt);
-    dfree(c->d_Phi); dfree(c->d_V); dfree(c->d_Phi16); dfree(c->d_P16g); dfree(c->d_qV16g); dfree(c->d_f16side);
+    dfree(c->d_Phi); dfree(c->d_V); dfree(c->d_Phi16); dfree(c->d_V16g); dfree(c->d_qV16g); dfree(c->d_f16side);
     c->Ncap = 0;
     const size_t ts = c->tsize();
     int rc;
@@ -356,10 +356,10 @@ static int ensure_rows(scfgp_ctx* c, int64_t N) {
     if ((rc = dmalloc(c, &c->d_V, ts * Np * g.Kp))) return rc;
     if (c->split16) {
         const size_t plane = sizeof(unsigned) * Np * g.Kp + F16x3Kernels::F16_PAD;
-        if ((rc = dmalloc(c, &c->d_Phi16, sizeof(unsigned) * Np * g.Kp))) return rc;
-        if ((rc = dmalloc(c, &c->d_P16g, plane)) || (rc = dmalloc(c, &c->d_qV16g, plane))) return rc;
+        if ((rc = dmalloc(c, &c->d_Phi16, plane)) || (rc = dmalloc(c, &c->d_V16g, plane)) || (rc = dmalloc(c, &c->d_qV16g, plane))) return rc;
         if ((rc = dmalloc(c, &c->d_f16side, sizeof(double) * F16x3Kernels::side_blocks(g) * g.Kp))) return rc;
-        HIPCHK(c, hipMemsetAsync(c->d_P16g, 0, plane, c->st));            // the padding is read (into tiles nobody stores): keep it finite
+        HIPCHK(c, hipMemsetAsync(c->d_Phi16, 0, plane, c->st));           // the padding is read (into tiles nobody stores): keep it finite
+        HIPCHK(c, hipMemsetAsync(c->d_V16g, 0, plane, c->st));
         HIPCHK(c, hipMemsetAsync(c->d_qV16g, 0, plane, c->st));
     }
     HIPCHK(c, hipMemsetAsync(c->d_Phi, 0, ts * Np * g.Kp, c->st));       // padding columns >= K stay zero forever
@@ -412,7 +412,7 @@ extern "C" int scfgp_create(scfgp_ctx** out, int D, int S, int M, int dtype, int
     if ((rc = dmalloc(c, &c->d_BT, c->tsize() * K2))) return rc;        // sweep operands: typed, padding zeroed
     if ((rc = dmalloc(c, &c->d_AbarT, c->tsize() * K2))) return rc;
     if (c->split16) {
-        if ((rc = dmalloc(c, &c->d_B16, 8 * (size_t)K2))) return rc;
+        if ((rc = dmalloc(c, &c->d_B16, 4 * (size_t)K2))) return rc;
         if ((rc = dmalloc(c, &c->d_f16scale, sizeof(float) * 4))) return rc;
         if ((rc = dmalloc(c, &c->d_f16tmp, sizeof(float) * 8))) return rc;
     }
@@ -529,10 +529,10 @@ template <typename T> struct Impl {
                 // whose row chunks are the "splits" of the shared reduction
                 const int nch = F16x3Kernels::gram_chunks(g, c->f16_chunk());
                 { ProfScope ps(c, w ? "split_v" : "split_phi");
-                  if (w) F16x3Kernels::split_v(g, (const float*)Mx, c->d_B, w, side, c->d_sc, c->d_P16g, c->d_qV16g, c->d_f16side, c->d_f16tmp, c->st);
-                  else F16x3Kernels::split_phi(g, (const float*)Mx, side, c->d_sc, c->d_Phi16, c->d_P16g, c->d_f16side, c->d_f16tmp, c->st); }
+                  if (w) F16x3Kernels::split_v(g, (const float*)Mx, c->d_B, w, side, c->d_sc, c->d_V16g, c->d_qV16g, c->d_f16side, c->d_f16tmp, c->st);
+                  else F16x3Kernels::split_phi(g, (const float*)Mx, side, c->d_sc, c->d_Phi16, c->d_f16side, c->d_f16tmp, c->st); }
                 { ProfScope ps(c, name);
-                  F16x3Kernels::gram(g, c->d_P16g, w ? c->d_qV16g : c->d_P16g, c->d_f16tmp + 4, c->f16_chunk(), c->d_slabs, c->st); }
+                  F16x3Kernels::gram(g, w ? c->d_V16g : c->d_Phi16, w ? c->d_qV16g : c->d_Phi16, c->d_f16tmp + 4, c->f16_chunk(), c->d_slabs, c->st); }
                 { ProfScope ps(c, "reduce_tiles"); reduce_tri_tiles(c->d_slabs, nch, nts, g.tile, out, c->st);
                   reduce_side(c->d_f16side, F16x3Kernels::side_blocks(g), g.Kp, g.gfull * g.tile + g.gstrip * 64, out + c->n_pk, c->st); }
                 return;
@@ -571,7 +571,7 @@ template <typename T> struct Impl {
             // f16x3 mode: the apply tiles' packed pairs; with the fp16 Gram they come out of gram_to's split pass instead
             if (c->f16_on() && (use64 || !c->f16_gram())) {
                 ProfScope ps(c, "split_phi");
-                F16x3Kernels::split_phi(g, (const float*)c->d_Phi, c->d_y, c->d_sc, c->d_Phi16, c->d_P16g, c->d_f16side, c->d_f16tmp, c->st);
+                F16x3Kernels::split_phi(g, (const float*)c->d_Phi, c->d_y, c->d_sc, c->d_Phi16, c->d_f16side, c->d_f16tmp, c->st);
             }
         }
         if (!use64) gram_to(c, (const T*)c->d_Phi, nullptr, c->d_y, c->d_xp1, "gram");
