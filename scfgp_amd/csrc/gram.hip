@@ -928,16 +928,23 @@ void reduce_tri_tiles(const double* slabs, int nsplit, int nts, int tile, double
     hipLaunchKernelGGL(reduce_tri_kernel, dim3(ntiles, 16), dim3(256), 0, st, slabs, nsplit, ntiles, tile, packed);
 }
 // vec[j] = sum over splits of the Gram's side partials for j < ncov (columns covered by diagonal tiles), 0 beyond
-__global__ void reduce_side_kernel(const double* __restrict__ sidepart, int nsplit, int Kp, int ncov, double* __restrict__ vec) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= Kp) return;
+// (64 columns x 16 interleaved runs of splits per block, the runs joined in a fixed order: the f16x3 split passes leave a thousand partials)
+__global__ __launch_bounds__(1024) void reduce_side_kernel(const double* __restrict__ sidepart, int nsplit, int Kp, int ncov, double* __restrict__ vec) {
+    __shared__ double run[16][64];
+    const int j = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
     double s = 0;
     if (j < ncov)
-        for (int sp = 0; sp < nsplit; ++sp) s += sidepart[(int64_t)sp * Kp + j];
-    vec[j] = s;
+        for (int sp = sub; sp < nsplit; sp += 16) s += sidepart[(int64_t)sp * Kp + j];
+    run[sub][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (sub == 0 && j < Kp) {
+#pragma unroll
+        for (int k = 1; k < 16; ++k) s += run[k][threadIdx.x];
+        vec[j] = s;
+    }
 }
 void reduce_side(const double* sidepart, int nsplit, int Kp, int ncov, double* vec, hipStream_t st) {
-    hipLaunchKernelGGL(reduce_side_kernel, dim3((Kp + 255) / 256), dim3(256), 0, st, sidepart, nsplit, Kp, ncov, vec);
+    hipLaunchKernelGGL(reduce_side_kernel, dim3((Kp + 63) / 64), dim3(1024), 0, st, sidepart, nsplit, Kp, ncov, vec);
 }
 // full symmetric matrix (ld = Kp) from the packed lower tiles; diagonal tiles carry both triangles
 __global__ __launch_bounds__(256) void unpack_tri_kernel(const double* __restrict__ packed, int B, double* __restrict__ full, int64_t ld) {

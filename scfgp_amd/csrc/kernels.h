@@ -160,6 +160,7 @@ struct F16x3Kernels {
     // slabs[chunk][tri(128-tile)][128 x 128] = scale[0] (A chunk)^T (B chunk) on the lower 128-tiles, every slab written; chunk rows per
     // chunk (rounded up to 256): gram_chunks(g, chunk) chunks, to be summed by reduce_tri_tiles with nsplit = that number
     static int gram_chunks(const Geom& g, int64_t chunk);
+    static int gram_tiles(const Geom& g);                       // 256 x 128 tiles of one chunk
     static void gram(const Geom& g, const unsigned* A16g, const unsigned* B16g, const float* scale, int64_t chunk, double* slabs, hipStream_t st);
 };
 

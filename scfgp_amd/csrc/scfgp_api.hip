@@ -154,7 +154,12 @@ struct scfgp_ctx {
     unsigned* d_V16g = nullptr; unsigned* d_qV16g = nullptr; double* d_f16side = nullptr; float* d_f16tmp = nullptr;
     int f16gram = 1;                                             // tuning knob "f16_gram": 0 keeps the fp32 Gram in this mode
     bool f16_on() const { return split16 && dma() == 2; }
-    int64_t f16_chunk() const { return gram_chunk > 0 ? std::max<int64_t>(gram_chunk, 2048) : 4096; }    // rows per fp32 accumulator (and per slab set)
+    // rows per job and per slab set of the fp16 Gram (its fp32 chains end every 512 rows whatever this is): twice the fp32 Gram's flush
+    // interval, less where that would leave fewer than 512 jobs = two rounds of the chip
+    int64_t f16_chunk() const {
+        const int64_t top = gram_chunk > 0 ? 2 * gram_chunk : 8192, fill = g.Np * F16x3Kernels::gram_tiles(g) / 512 / 512 * 512;
+        return std::max<int64_t>(std::min(top, fill), 1024);
+    }
     bool f16_gram() const { return f16_on() && f16gram && !last_cform; }      // factor form (level 2) keeps its fp32 products
     F16Operands f16ops() const { return F16Operands{d_Phi16, d_B16, d_f16scale}; }
     // exchange buffers and K-stage

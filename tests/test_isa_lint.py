@@ -71,3 +71,19 @@ def test_gram_kernels_never_touch_a_fragment_in_flight():
     assert len(f32) == 2 and all(len(v) >= 4 for v in f32)      # a steady single-barrier loop per pipelined tile kind
     # the steady loops of the pipelined fp32 tiles: 8 MFMA tiles x 2 halves x TM ... per trip, no scratch in the tall / wide / pair bodies
     assert sum(b['scratch'] == 0 for v in f32 for b in v) >= 2 * 4
+
+
+def test_f16x3_kernels_never_touch_a_fragment_in_flight_and_keep_their_loops_out_of_scratch():
+    """apply_f16_kernel (6 instantiations: two-slot ring, 16 hand-issued ds_read_b128 and 48 matrix instructions per stage) and
+    gram_f16_kernel (three-slot ring whose counted vmcnt is the wave's three fetches, 24 transposing reads, 24 matrix instructions):
+    the fragment reads are inline assembly released by counted lgkmcnt waits, so the same replay applies."""
+    import isa_inflight
+    import isa_loops
+    import isa_source
+    r = isa_inflight.run(None, 'f16_kernel', shipped=isa_source.SHIPPED)
+    assert r['functions'] == 7 and r['inflight'] == 0 and r['ring'] == 0 and r['ring_loops'] >= 7 and r['ds_reads'] >= 6 * 16 + 24, r
+    loops = [(n, b) for n, b in isa_loops.census(None, 'f16_kernel', shipped=isa_source.SHIPPED) if 'mfma' in b]
+    assert len(loops) >= 7
+    for name, body in loops:
+        gram = name.startswith('gram')
+        assert body['scratch'] == 0 and body['barrier'] == 1 and (body['mfma'], body['ds_read']) == ((24, 24) if gram else (48, 16)), (name, body)

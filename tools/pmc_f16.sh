@@ -7,7 +7,7 @@ out=$root/gpurun_out/pmc_f16
 mkdir -p $out
 export TMPDIR=/tmp
 cd /tmp
-for pass in "busy:SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_MFMA" "lds:SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS" "fifo:SQ_LDS_CMD_FIFO_FULL SQ_LDS_DATA_FIFO_FULL SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_INST_VALU"; do
+for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "busy:SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_MFMA" "lds:SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS"; do
     name=${pass%%:*}; ctrs=${pass#*:}
     echo "== pass $name: $ctrs"
     rocprofv3 --pmc $ctrs --kernel-trace -d $out/$name -o $name --output-format csv -- \
@@ -18,7 +18,7 @@ f = glob.glob(sys.argv[1] + '/**/*counter_collection.csv', recursive=True)[0]
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
 for r in csv.DictReader(open(f)):
     k = r['Kernel_Name'].split('(')[0][:60]
-    if 'f16' not in k and 'gram' not in k: continue
+    if 'f16' not in k and 'split_' not in k: continue
     acc[k][r['Counter_Name']] += float(r['Counter_Value']); cnt[(k, r['Counter_Name'])] += 1
 for k, d in acc.items():
     print(k, {c: '%.4g' % (v / cnt[(k, c)]) for c, v in d.items()}, 'launches', max(cnt[(k, c)] for c in d))
