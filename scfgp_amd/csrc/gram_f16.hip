@@ -76,19 +76,24 @@ void gram_f16_kernel(const unsigned* __restrict__ A16, const unsigned* __restric
     double* slab = slabs + ((int64_t)ch * ntile128 + (stored ? i128 * (i128 + 1) / 2 + tj : 0)) * (128 * 128) + (int64_t)(wm0 & 127) * 128 + wn0;
     // DMA instruction u of this wave fills line 3 wave + u of the stage's 48: lines 0..31 = the A panel's rows; line 32 + rho = rows rho
     // (lanes 0..31) and rho + 16 (lanes 32..63) of the B panel
-    const char* src[3]; int dst[3];
+    // Lanes 0..31 of an A line carry the columns of 128-tile 2 ti, lanes 32..63 those of 2 ti + 1: the half nobody multiplies (see `stored`)
+    // is not fetched -- a third of the stage's bytes in 25 of the 89 tiles of a chunk at the headline shape.  Every instruction keeps
+    // some active lanes, so a wave's count of outstanding fetches is 3 per stage whatever the tile.
+    const char* src[3]; int dst[3]; bool need[3];
+    const int a128 = 2 * ti + (lane >> 5);
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
         const int ln = 3 * wave + u;
         if (ln < 32) src[u] = reinterpret_cast<const char*>(A16 + (r0 + ln) * ld16 + (int64_t)ti * 256) + lane * 16;
         else src[u] = reinterpret_cast<const char*>(B16 + (r0 + (ln - 32) + 16 * (lane >> 5)) * ld16 + (int64_t)tj * 128) + (lane & 31) * 16;
         dst[u] = ln * RS;
+        need[u] = ln >= 32 || (a128 >= tj && a128 < nts128);
     }
     const int64_t step = 32 * ld16 * 4;
     const auto fetch = [&](int slot) {
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
-            __builtin_amdgcn_global_load_lds((gbl_void*)src[u], (lds_void*)(smem + slot * FSTAGE + dst[u]), 16, 0, 0);
+            if (need[u]) __builtin_amdgcn_global_load_lds((gbl_void*)src[u], (lds_void*)(smem + slot * FSTAGE + dst[u]), 16, 0, 0);
             src[u] += step;
         }
     };
@@ -111,6 +116,11 @@ void gram_f16_kernel(const unsigned* __restrict__ A16, const unsigned* __restric
         __builtin_amdgcn_s_barrier();                          // everybody's has; nobody reads the slot of stage s-1 any more
         asm volatile("" ::: "memory");
         if (s + 2 < nst) fetch(slot == 0 ? 2 : slot - 1);
+        // a wave whose outputs nobody stores keeps its share of the fetches and the barriers but multiplies nothing: 14 % of the wave tiles
+        // at the headline shape (the upper half of a diagonal pair, the half of the last 256-block beyond Kp).  The launch is no shorter for
+        // it (15.2 ms either way: what bounds it is the rate at which the stages arrive, 8.8 TB/s from the L2s into the LDS, not the matrix
+        // pipe at 0.63 busy); the idle instructions just are not executed
+        if (!stored) { slot = slot == 2 ? 0 : slot + 1; continue; }
         const unsigned pa = lds0 + slot * FSTAGE + offa, pb = lds0 + slot * FSTAGE + offb;
         h4 ah[4][2], al[4][2], bh[2][2], bl[2][2];
         static_for<4>([&](auto kc) { constexpr int k = decltype(kc)::value;
