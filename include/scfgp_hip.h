@@ -55,12 +55,14 @@ typedef struct scfgp_ctx scfgp_ctx;
 #define SCFGP_F64 0             /* fp64 MFMA everywhere (reference numerics)             */
 #define SCFGP_F32 1             /* N-sized products in exact-fp32 MFMA, fp64 projection,
                                    fp64 cross-chunk accumulation and fp64 K x K stage    */
-#define SCFGP_F16X3 2           /* SECONDARY mode, never what a benchmark headline quotes: SCFGP_F32 in everything but the two
-                                   square apply products (V = Phi B, Phibar = 2 Phi Abar + ...), which run as a THREE-TERM fp16
-                                   split on the fp16 matrix pipe wherever fp32 mode uses its 256-wide LDS-DMA tiles (K >= 1024,
-                                   >= 65536 rows): x = (h + l) 2^-e, h, l fp16, one power-of-two scale per operand matrix;
-                                   h.h + l.h + h.l in fp32 accumulators (fp16 products are exact in fp32).  Errors within
-                                   1-3.5x of SCFGP_F32's (scfgp_amd/csrc/apply_f16.hip); it runs fp32 mode's parity tier        */
+#define SCFGP_F16X3 2           /* SECONDARY mode, never what a benchmark headline quotes: SCFGP_F32 in everything but the four
+                                   N-sized products (V = Phi B, Phibar = 2 Phi Abar + ..., Phi^T Phi, V^T diag(q) V), which run as a
+                                   THREE-TERM fp16 split on the fp16 matrix pipe wherever fp32 mode uses its 256-wide LDS-DMA tiles
+                                   (K >= 1024, >= 65536 rows) at precision level 0: x = (h + l) 2^-e, h, l fp16, one power-of-two
+                                   scale per operand matrix; h.h + l.h + h.l in fp32 accumulators (fp16 products are exact in
+                                   fp32; the Gram folds its accumulators every 512 rows because the instruction truncates).
+                                   Errors within 4x of SCFGP_F32's (scfgp_amd/csrc/apply_f16.hip, gram_f16.hip); it runs fp32
+                                   mode's parity tier.  Option "f16_gram" = 0 keeps the fp32 Gram in this mode               */
 
 /* ---- life cycle --------------------------------------------------------------------
  * Replaces SCFGP.build_theano_models (SCFGP/SCFGP.py:92-148): "compile" becomes "create a
@@ -256,7 +258,9 @@ int64_t scfgp_debug_read(scfgp_ctx* ctx, const char* name, void* host, int64_t m
 /* options (name, value):
  *   "gram_nsplit"  row-split units of the Gram products (0 = default)
  *   "gram_taper"   1: the last unit of every XCD group is cut into 1/2, 1/4, 1/8, 1/8; t >= 2: into t + 3 pieces down to 1/2^(t+2)
- *   "gram_chunk"   fp32 mode: rows between two flushes of the fp32 accumulators into the fp64 slabs (default 4096)
+ *   "gram_chunk"   fp32 mode: rows between two flushes of the fp32 accumulators into the fp64 slabs (default 4096; f16x3 mode:
+ *                  half the rows of a Gram job)
+ *   "f16_gram"     f16x3 mode: 1 (default) the two Gram products on the fp16 pipe too, 0 keep fp32 mode's
  *   "xtz_nsplit"   row splits of X~^T Zbar (0 = default)
  *   "use_graph"    0: scfgp_train launches every iteration eagerly instead of replaying a captured hipGraph (1, default: the
  *                  graph unless a communicator is attached; 2: the graph with a communicator too)

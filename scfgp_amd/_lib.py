@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SCFGP_LIB_VARIANT selects an alternative build (tuning experiments only, e.g. '_bk32')
 LIB_PATH = os.path.join(_HERE, 'lib', 'libscfgp_hip%s.so' % os.environ.get('SCFGP_LIB_VARIANT', ''))
 
-SCFGP_F64, SCFGP_F32, SCFGP_F16X3 = 0, 1, 2        # F16X3: fp32 mode with the square apply products as a three-term fp16 split (secondary)
+SCFGP_F64, SCFGP_F32, SCFGP_F16X3 = 0, 1, 2        # F16X3: fp32 mode with the four N-sized products as a three-term fp16 split (secondary)
 SCFGP_REDO = 1                           # scfgp_finish / scfgp_factor: run the stages again (precision level raised or agreed lower), not an error
 SCFGP_EPEER = -5
 ERRORS = {-1: 'bad argument', -2: 'HIP error', -3: 'not positive definite', -4: 'non-finite cost', -5: 'another rank failed'}

@@ -14,7 +14,7 @@ import numpy as np
 from . import _lib
 from ._lib import SCFGP_F16X3, SCFGP_F32, SCFGP_F64, dptr
 
-# 'f16x3': fp32 mode whose two square apply products run as a three-term fp16 split (include/scfgp_hip.h: SCFGP_F16X3) -- a
+# 'f16x3': fp32 mode whose four N-sized products (apply and Gram) run as a three-term fp16 split (include/scfgp_hip.h: SCFGP_F16X3) -- a
 # labelled secondary mode, chosen explicitly, never a default
 _DTYPES = {'f64': SCFGP_F64, 'float64': SCFGP_F64, 'f32': SCFGP_F32, 'float32': SCFGP_F32, 'f16x3': SCFGP_F16X3,
            SCFGP_F64: SCFGP_F64, SCFGP_F32: SCFGP_F32, SCFGP_F16X3: SCFGP_F16X3}
