@@ -382,3 +382,50 @@ def test_f16x3_training_loop_under_the_graph_equals_its_evaluations_and_tracks_f
         e.close()
     assert np.all(np.abs(hist['f16x3'] - hist['f32']) <= 1e-5 * np.maximum(1.0, np.abs(hist['f32']))), (hist['f16x3'], hist['f32'])
     assert hist['f32'][-1] < hist['f32'][0]
+
+
+@pytest.mark.parametrize('level', [1, 2])
+def test_f16x3_mode_under_the_precision_levels(level):
+    """The precision levels of fp32 mode keep their own products in f16x3 mode: level 1 forms pass 1's Gram in fp64 (the split of Phi is
+    then its own stage, the weighted Gram and both apply products stay on the fp16 pipe), level 2 runs pass 2 in factor form on fp32
+    tiles (only Phibar = 2 Phi Abar + ... is left to the split).  Forced by zero thresholds; against fp64 mode no worse than 4x fp32
+    mode at the same level, alpha and Li bit-equal to it at both levels (fp64 Gram in both modes), repeats bit-equal."""
+    from scfgp_amd import synth
+    from scfgp_amd.engine import HipEngine
+    N, D, S, M = 33000, 8, 32, 256
+    seed = 0x5CF60C00 + level
+    X = synth.make_X(seed, N, D); y = synth.normal(seed + 1, 0, N).reshape(-1, 1)
+    params = synth.make_params(seed + 2, D, S, M, abc=(-1.0, 0.0, -1.0))
+    outs = {}
+    for dtype in ('f64', 'f32', 'f16x3'):
+        e = HipEngine(D, S, M, dtype)
+        if dtype != 'f64':
+            e.set_option('apply_dma', 2); e.set_option('cond_threshold', 0)
+            if level == 2:
+                e.set_option('cond_threshold_w', 0)
+        e.set_params(params); e.set_data(X, y)
+        e.eval()                                                   # settles the level (the first evaluation repeats itself)
+        e.set_profiling(True)
+        a = e.eval()
+        names = [n for n, _ in e.timings()]
+        if dtype != 'f64':
+            assert int(e.condition()['level']) == level and 'gram64' in names
+            assert ('apply_c' in names) == (level == 2)
+        if dtype == 'f16x3':
+            assert 'split_phi' in names and ('split_v' in names) == (level == 1)
+        b = e.eval()
+        assert float(a[0]) == float(b[0]) and np.array_equal(a[1], b[1])
+        outs[dtype] = a
+        e.close()
+    c64, g64, a64, L64 = outs['f64']
+    err = {}
+    for dtype in ('f32', 'f16x3'):
+        c, g, a, L = outs[dtype]
+        err[dtype] = dict(cost=abs(float(c) - float(c64)) / max(1.0, abs(float(c64))), alpha=rel(a, a64), Li=rel(L, L64),
+                          **{'g%d' % k: rel(u, v) for k, (u, v) in enumerate(zip(_blocks(g, D, S, M), _blocks(g64, D, S, M)))})
+    print('\nf32  ', {k: '%.1e' % v for k, v in err['f32'].items()})
+    print('f16x3', {k: '%.1e' % v for k, v in err['f16x3'].items()})
+    assert np.array_equal(outs['f16x3'][2], outs['f32'][2]) and np.array_equal(outs['f16x3'][3], outs['f32'][3])
+    for k in ('cost', 'g0', 'g1', 'g2'):
+        assert err['f16x3'][k] <= 4 * err['f32'][k] + 2e-9, (k, err['f16x3'][k], err['f32'][k])
+    assert err['f16x3']['cost'] < 1e-5 and max(err['f16x3'][k] for k in ('g0', 'g1', 'g2')) < 1e-3
