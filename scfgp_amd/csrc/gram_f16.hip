@@ -209,18 +209,18 @@ __global__ __launch_bounds__(1024) void split_rows_kernel(const float* __restric
         d[0] = s0; d[1] = s1; d[2] = s2; d[3] = s3;
     }
 }
-// out[0] = max |v[n]|, n < N (one workgroup)
-__global__ __launch_bounds__(1024) void maxabs_vec_kernel(const double* __restrict__ v, int64_t N, float* __restrict__ out) {
-    __shared__ double r1[1024];
+// out[0] (as int bits, zeroed before) = max |v[n]|, n < N
+__global__ __launch_bounds__(256) void maxabs_vec_kernel(const double* __restrict__ v, int64_t N, float* __restrict__ out) {
+    __shared__ double r1[256];
     double m = 0;
-    for (int64_t n = threadIdx.x; n < N; n += 1024) m = fmax(m, fabs(v[n]));
+    for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < N; n += (int64_t)gridDim.x * 256) m = fmax(m, fabs(v[n]));
     r1[threadIdx.x] = m;
     __syncthreads();
-    for (int w = 512; w >= 1; w >>= 1) {
+    for (int w = 128; w >= 1; w >>= 1) {
         if ((int)threadIdx.x < w) r1[threadIdx.x] = fmax(r1[threadIdx.x], r1[threadIdx.x + w]);
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[0] = (float)(r1[0] * (1.0 + 1e-6));
+    if (threadIdx.x == 0) atomicMax(reinterpret_cast<int*>(out), __float_as_int((float)(r1[0] * (1.0 + 1e-6))));
 }
 // out[0] = s: |Phi| <= s = e^b sqrt(2/M) (SCFGP/SCFGP.py:98,102) -- the same number split_operand (apply_f16.hip) derives e_Phi from
 __global__ void phi_bound_kernel(float* out, const Scal* sc) { if (threadIdx.x == 0) out[0] = (float)sc->s; }
@@ -247,9 +247,9 @@ void F16x3Kernels::split_phi(const Geom& g, const float* Phi, const double* y, c
 }
 void F16x3Kernels::split_v(const Geom& g, const float* V, const double* B, const double* q, const double* p, const Scal* sc, unsigned* V16g,
                            unsigned* qV16g, double* sidepart, float* tmp, hipStream_t st) {
-    (void)hipMemsetAsync(tmp, 0, sizeof(float), st);
+    (void)hipMemsetAsync(tmp, 0, 2 * sizeof(float), st);
     hipLaunchKernelGGL(v_bound_kernel, dim3((g.K + 3) / 4), dim3(256), 0, st, B, g.K, g.Kp, sc, sqrt((double)g.M), tmp);
-    hipLaunchKernelGGL(maxabs_vec_kernel, dim3(1), dim3(1024), 0, st, q, g.N, tmp + 1);
+    hipLaunchKernelGGL(maxabs_vec_kernel, dim3(256), dim3(256), 0, st, q, g.N, tmp + 1);
     hipLaunchKernelGGL(split_rows_kernel, dim3(side_blocks(g)), dim3(split_threads(g)), 0, st, V, g.Np, g.Kp, q, p, (const float*)tmp, V16g, qV16g, sidepart,
                        tmp + 2);
 }
