@@ -328,29 +328,30 @@ def f64_leg_and_parity(X, y, params, D, S, M, local, f32_out, f32_eng, steps=5, 
         e16 = HipEngine(D, S, M, dtype='f16x3', device=local)
         e16.set_params(params); e16.set_data(X, y, n_global=N)
         ms16, st16, out16 = _timed_leg(e16, steps, warmup)
-        ap16 = float(np.median([st16.get('apply_v', 0), st16.get('apply_phibar', 0)]))
-        gr16 = float(np.median([st16.get('gram', 0), st16.get('gram_w', 0)]))
+        present = lambda names: float(np.median([st16[k] for k in names if st16.get(k, 0) > 0] or [0.0]))   # precision levels 1 / 2 replace stages
+        lvl16 = int(e16.condition()['level'])                      # level 1: pass 1's Gram is fp64; level 2: factor form, only Phibar's product is split
+        ap16, gr16 = present(('apply_v', 'apply_phibar')), present({0: ('gram', 'gram_w'), 1: ('gram_w',)}.get(lvl16, ()))
         n256 = (K // 128) // 2                                     # the 256-wide tiles run the split; the ragged remainder stays exact fp32
         fl16 = 3.0 * (2.0 * N * (256.0 * n256) * K)                 # three v_mfma_f32_16x16x32_f16 per tile and 32 k: 3 x the product's flops
-        nb = -(-(-(-K // 128) * 128) // 256)                       # 256-column blocks covering Kp; the Gram multiplies their lower block pairs
-        flg = 3.0 * 2.0 * N * 65536.0 * (nb * (nb + 1) // 2)
+        nts = -(-K // 128)                                           # the Gram multiplies the lower 128 x 128 tiles (diagonal ones whole)
+        flg = 3.0 * 2.0 * N * 16384.0 * (nts * (nts + 1) // 2)
         tf = lambda fl, ms: fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         f16 = {"what": "fp32 mode with V = Phi B, Phibar = 2 Phi Abar + ..., G = Phi^T Phi and V^T diag(q) V as a three-term fp16 split (h.h + l.h + "
                        "h.l, fp32 accumulators, power-of-two operand scales; scfgp_amd/csrc/apply_f16.hip, gram_f16.hip); feature map, row statistics, "
                        "K x K stage, backward projection and everything else exact fp32 mode",
                "evals_per_s": 1e3 / ms16, "ms_per_step": ms16, "steps": steps, "statistic": "median", "stages_ms": st16,
-               "cost": float(out16[0]), "precision_level": int(e16.condition()['level']),
+               "cost": float(out16[0]), "precision_level": lvl16,
                "roofline": {"bound": "mfma", "achieved": tf(fl16, ap16), "peak": 2500.0,
                             "unit": "TFLOP/s (fp16 MFMA, executed: three instructions per output tile and 32 k)",
                             "frac": tf(fl16, ap16) / 2500.0, "avg_launch_ms": ap16,
                             "fp32_equivalent_TFLOPs": tf(2.0 * N * K * K, ap16),
                             "kernel": "apply_f16_kernel (256-wide tiles) + the exact-fp32 64-wide remainder of the same product",
                             "note": "the peak is the datasheet's at 2.4 GHz; under this kernel the clock settles at 1.5-1.6 GHz with the matrix pipe "
-                                    "0.74 busy, under the Gram's at 1.7 GHz with 0.63 (profiles/r05_f16x3_pmc.txt) -- busy x clock is the same "
-                                    "0.46 of the peak for both: the fp16 pipe at this rate is power-bound"},
-               "roofline_gram": {"bound": "mfma", "achieved": tf(flg, gr16), "peak": 2500.0,
-                                 "unit": "TFLOP/s (fp16 MFMA, executed: three instructions per output tile and 32 rows, 256 x 256 tiles of the "
-                                         "lower block triangle incl. the part of the last block beyond K)",
+                                    "0.74-0.76 busy (busy x clock = 0.48-0.51 of the peak), under the Gram's at 1.7 GHz with 0.56 "
+                                    "(profiles/r05_f16x3_pmc.txt): the fp16 pipe at this rate is power-bound"},
+               "roofline_gram": None if gr16 <= 0 else {"bound": "mfma", "achieved": tf(flg, gr16), "peak": 2500.0,
+                                 "unit": "TFLOP/s (fp16 MFMA, executed: three instructions per output tile and 32 rows over the lower 128 x 128 "
+                                         "tiles of the Kp x Kp result, diagonal tiles whole)",
                                  "frac": tf(flg, gr16) / 2500.0, "avg_launch_ms": gr16, "fp32_equivalent_TFLOPs": tf(1.0 * N * K * K, gr16),
                                  "kernel": "gram_f16_kernel"},
                "parity_at_size": _parity(out16, ref, e16, e64, D, S, M, "f16x3 mode vs fp64 " + base)}
