@@ -429,3 +429,45 @@ def test_f16x3_mode_under_the_precision_levels(level):
     for k in ('cost', 'g0', 'g1', 'g2'):
         assert err['f16x3'][k] <= 4 * err['f32'][k] + 2e-9, (k, err['f16x3'][k], err['f32'][k])
     assert err['f16x3']['cost'] < 1e-5 and max(err['f16x3'][k] for k in ('g0', 'g1', 'g2')) < 1e-3
+
+
+def test_f16x3_mode_on_two_row_shards():
+    """The exchange buffers do not know the compute mode: two in-process ranks in f16x3 mode (20000 rows each, K = 576, sums done by the
+    test as an all-reduce would) against one f16x3 context on all 40000 rows -- equal up to the fp32 accumulation order (other chunk
+    boundaries) -- and against fp64 mode within fp32 mode's tier; every rank returns the same numbers."""
+    import torch
+    from scfgp_amd import synth
+    from scfgp_amd.engine import HipEngine
+    from scfgp_amd.sharded import shard_rows
+    N, D, S, M = 40000, 8, 32, 256
+    seed = 0x5CF60D00
+    X = synth.make_X(seed, N, D); y = synth.normal(seed + 1, 0, N).reshape(-1, 1)
+    params = synth.make_params(seed + 2, D, S, M, abc=(-1.0, 0.0, -1.0))
+    stream = torch.cuda.current_stream().cuda_stream
+    ref = {}
+    for dtype in ('f64', 'f16x3'):
+        e = HipEngine(D, S, M, dtype, stream=stream)
+        if dtype != 'f64':
+            e.set_option('gram64', 0); e.set_option('apply_dma', 2)
+        e.set_params(params); e.set_data(X, y)
+        ref[dtype] = e.eval()
+        e.close()
+    engs = []
+    for r in range(2):
+        lo, hi = shard_rows(N, r, 2)
+        e = HipEngine(D, S, M, 'f16x3', stream=stream)
+        e.set_option('gram64', 0); e.set_option('apply_dma', 2)
+        e.set_params(params); e.set_data(X[lo:hi], y[lo:hi], n_global=N)
+        e.set_profiling(True)
+        engs.append(e)
+    outs = _sharded_eval(engs)
+    assert 'split_v' in [n for n, _ in engs[1].timings()]
+    (c0, g0, a0, L0), (c1, g1, a1, L1) = outs
+    assert float(c0) == float(c1) and np.array_equal(g0, g1) and np.array_equal(a0, a1) and np.array_equal(L0, L1)
+    c16, g16, a16, L16 = ref['f16x3']
+    assert abs(float(c0) - float(c16)) < 1e-7 * max(1.0, abs(float(c16))) and rel(a0, a16) < 1e-4 and rel(L0, L16) < 1e-4
+    c64, g64, a64, L64 = ref['f64']
+    assert abs(float(c0) - float(c64)) < 1e-5 * max(1.0, abs(float(c64)))
+    for u, v in zip(_blocks(g0, D, S, M), _blocks(g64, D, S, M)):
+        assert rel(u, v) < 1e-3
+    for e in engs: e.close()
