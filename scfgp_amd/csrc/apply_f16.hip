@@ -22,6 +22,7 @@
 #include "apply_epilogue.h"
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
@@ -52,7 +53,7 @@ template <int EPI, int BN>
 __global__ __launch_bounds__((64 * F16Tile<BN>::WAVES))
 __attribute__((amdgpu_waves_per_eu(F16Tile<BN>::WAVES_PER_EU, F16Tile<BN>::WAVES_PER_EU)))
 void apply_f16_kernel(const float* __restrict__ Phi, const unsigned* __restrict__ Phi16, const char* __restrict__ B16, const float* __restrict__ scale,
-                      float* V, double* __restrict__ vpart, const double* __restrict__ p, const double* __restrict__ q,
+                      unsigned* __restrict__ V16, const float* __restrict__ vbound, float* V, double* __restrict__ vpart, const double* __restrict__ p, const double* __restrict__ q,
                       const double* __restrict__ y, const double* __restrict__ alpha, const double* __restrict__ ut,
                       int K, int Kp, int64_t Np, int njt, double* __restrict__ mu, int col0, int slot0, int64_t rb0) {
     typedef F16Tile<BN> D;
@@ -139,6 +140,32 @@ void apply_f16_kernel(const float* __restrict__ Phi, const unsigned* __restrict_
     for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn) acc[tm][tn] *= sc;
+    if constexpr (EPI == 0) {
+        // V in plane form for the weighted Gram (gram_f16.hip), straight from the accumulators: what split_v's pass over V would write,
+        // bit for bit (same values, same scale 2^e, e = 14 - ilogb(bound of |V|)).  A lane holds 4 adjacent columns of 16 rows.
+        if (V16) {
+            const float bnd = vbound[0], up = bnd > 0.f ? ldexpf(1.0f, 14 - ilogbf(bnd)) : 1.0f;
+            AccCoord<Cfg> co((int)threadIdx.x);
+            const int jg = cbase + co.wn0 + 4 * (co.lane & 15);
+            if (jg < K) {                                          // (columns >= K of the array stay the zeros they were allocated as)
+                const int64_t poff = 64 * (jg >> 4) + 2 * (jg & 15);
+#pragma unroll
+                for (int tm = 0; tm < Cfg::TM; ++tm)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        char* row = reinterpret_cast<char*>(V16 + (rb * BM + co.row(tm, r)) * Kp) + poff;
+                        _Float16 h[4], l[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float x = (jg + k < K ? acc[tm][k][r] : 0.f) * up;
+                            h[k] = (_Float16)x; l[k] = (_Float16)(x - (float)h[k]);
+                        }
+                        *reinterpret_cast<h4*>(row) = h4{h[0], h[1], h[2], h[3]};
+                        *reinterpret_cast<h4*>(row + 32) = h4{l[0], l[1], l[2], l[3]};
+                    }
+            }
+        }
+    }
     constexpr int SLOTS = BN >= 128 ? BN / 128 : 1;            // vpart / mupart slots: one per 128 columns of the full tiles, one per remainder tile
     const int vslot = slot0 + SLOTS * jt;
     int tid = (int)threadIdx.x;
@@ -196,7 +223,7 @@ int F16x3Kernels::apply(const Geom& g, int njt, int col0, int slot0, const float
     if (njt <= 0 || nrb <= 0) return 0;
     allow_big_lds(apply_f16_kernel<EPI, BN>, D::LDS_BYTES);
     hipLaunchKernelGGL((apply_f16_kernel<EPI, BN>), dim3((unsigned)(njt * nrb)), dim3(64 * D::WAVES), D::LDS_BYTES, st,
-                       Phi, f.Phi16, f.B16, f.scale, V, vpart, p, q, y, alpha, ut, g.K, g.Kp, g.Np, njt, mu, col0, slot0, rb0);
+                       Phi, f.Phi16, f.B16, f.scale, f.V16, f.vbound, V, vpart, p, q, y, alpha, ut, g.K, g.Kp, g.Np, njt, mu, col0, slot0, rb0);
     return (int)(njt * nrb);
 }
 #define SCFGP_F16_INST(EPI, BN)                                                                                                                       \

@@ -24,8 +24,9 @@
 // rows the sums are WRITTEN, as doubles, to the chunk's own 128 x 128 slabs -- a chunk is a "split" of the shared reduction
 // (reduce_tri_tiles), which sums the chunks in fp64.  (Read-modify-write flushes into per-split slabs, as the fp32 Gram does them, would
 // cost this kernel 40 %.)  Row weights cannot ride along (an MFMA sums 32 rows at once): the weighted product takes V as one operand and
-// q o V as the other, both written by split_v in one pass over V.  The side vectors Phi^T y and V^T p are by-products of the split
-// passes (fp64 block partials), not of this kernel.
+// q o V as the other -- V's planes come out of the epilogue of V = Phi B (apply_f16.hip), q o V's out of split_v's pass over V once the
+// row statistics have made q.  The side vectors Phi^T y and V^T p are by-products of the split passes (fp64 block partials), not of
+// this kernel.
 #include "kernels.h"
 #include "tile_cfgs.h"
 #include "tile_engine.h"
@@ -166,7 +167,7 @@ void gram_f16_kernel(const unsigned* __restrict__ A16, const unsigned* __restric
             for (int b = 0; b < 2; ++b) slab[(16 * a + 4 * G + r) * 128 + 16 * b + i] = (double)(sum[a][b][r] + acc[a][b][r]) * sc;
 }
 
-// One pass over a resident fp32 matrix M (Np x Kp): its elements in plane form (out_pl) and, times rw[n], in plane form again (out_w;
+// One pass over a resident fp32 matrix M (Np x Kp): its elements in plane form (out_pl; may be NULL) and, times rw[n], in plane form again (out_w;
 // with rw, or neither); the fp64 block partials of the side vector
 // sum_n sw[n] M[n][j] -- part[block][Kp], SIDE_ROWS rows per block.  Scaled by 2^e, e = 14 - ilogb(bound): bnd[0] bounds |M|, bnd[0] bnd[1]
 // bounds |rw M|; es[0] = 2^-e, es[1] = 2^-e_w, es[2] = the scale of the Gram product that follows: 2^-(e + e_w), or 2^-2e without rw.
@@ -194,8 +195,10 @@ __global__ __launch_bounds__(1024) void split_rows_kernel(const float* __restric
 #pragma unroll
             for (int k = 0; k < 4; ++k) split2(xs[k], h[k], l[k]);
             char* row = reinterpret_cast<char*>(out_pl + n * Kp) + poff;
-            *reinterpret_cast<h4*>(row) = h4{h[0], h[1], h[2], h[3]};
-            *reinterpret_cast<h4*>(row + 32) = h4{l[0], l[1], l[2], l[3]};
+            if (out_pl) {
+                *reinterpret_cast<h4*>(row) = h4{h[0], h[1], h[2], h[3]};
+                *reinterpret_cast<h4*>(row + 32) = h4{l[0], l[1], l[2], l[3]};
+            }
             if (rw) {
                 const float f = (float)(rw[n] * up1);
 #pragma unroll
@@ -245,13 +248,15 @@ void F16x3Kernels::split_phi(const Geom& g, const float* Phi, const double* y, c
     hipLaunchKernelGGL(split_rows_kernel, dim3(side_blocks(g)), dim3(split_threads(g)), 0, st, Phi, g.Np, g.Kp, (const double*)nullptr, y, (const float*)tmp,
                        Phi16, (unsigned*)nullptr, sidepart, tmp + 2);
 }
-void F16x3Kernels::split_v(const Geom& g, const float* V, const double* B, const double* q, const double* p, const Scal* sc, unsigned* V16g,
-                           unsigned* qV16g, double* sidepart, float* tmp, hipStream_t st) {
-    (void)hipMemsetAsync(tmp, 0, 2 * sizeof(float), st);
-    hipLaunchKernelGGL(v_bound_kernel, dim3((g.K + 3) / 4), dim3(256), 0, st, B, g.K, g.Kp, sc, sqrt((double)g.M), tmp);
-    hipLaunchKernelGGL(maxabs_vec_kernel, dim3(256), dim3(256), 0, st, q, g.N, tmp + 1);
-    hipLaunchKernelGGL(split_rows_kernel, dim3(side_blocks(g)), dim3(split_threads(g)), 0, st, V, g.Np, g.Kp, q, p, (const float*)tmp, V16g, qV16g, sidepart,
-                       tmp + 2);
+void F16x3Kernels::v_bound(const Geom& g, const double* B, const Scal* sc, float* tmp, hipStream_t st) {
+    (void)hipMemsetAsync(tmp + 5, 0, 2 * sizeof(float), st);         // tmp[5] = bound of |V|, tmp[6] = max |q| (split_v)
+    hipLaunchKernelGGL(v_bound_kernel, dim3((g.K + 3) / 4), dim3(256), 0, st, B, g.K, g.Kp, sc, sqrt((double)g.M), tmp + 5);
+}
+void F16x3Kernels::split_v(const Geom& g, const float* V, const double* q, const double* p, unsigned* V16g, unsigned* qV16g, double* sidepart,
+                           float* tmp, hipStream_t st) {
+    hipLaunchKernelGGL(maxabs_vec_kernel, dim3(256), dim3(256), 0, st, q, g.N, tmp + 6);
+    hipLaunchKernelGGL(split_rows_kernel, dim3(side_blocks(g)), dim3(split_threads(g)), 0, st, V, g.Np, g.Kp, q, p, (const float*)(tmp + 5), V16g, qV16g,
+                       sidepart, tmp + 2);
 }
 int F16x3Kernels::gram_chunks(const Geom& g, int64_t chunk) {
     if (chunk <= 0 || chunk > g.Np) chunk = g.Np;

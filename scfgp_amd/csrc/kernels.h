@@ -93,9 +93,10 @@ struct GramKernels {
                          hipStream_t st);
 };
 
-// operands of one apply product in compute mode SCFGP_F16X3 (apply_f16.hip): Phi as packed (h, l) fp16 pairs (Np x Kp x 4 bytes), the
-// K x K operand as derived pairs (Kp x Kp x 8 bytes), scale[0] = 2^-(e_Phi + e_operand) on the device
-struct F16Operands { const unsigned* Phi16; const char* B16; const float* scale; };
+// operands of one apply product in compute mode SCFGP_F16X3 (apply_f16.hip): Phi and the K x K operand in plane form (below), scale[0] =
+// 2^-(e_Phi + e_operand) on the device.  V16 (may be NULL): V = Phi B's epilogue also writes V in plane form, scaled by 2^e with
+// e = 14 - ilogb(vbound[0]) -- the array split_v would otherwise write
+struct F16Operands { const unsigned* Phi16; const char* B16; const float* scale; unsigned* V16; const float* vbound; };
 
 // ---- apply.hip: NT products (contraction over the feature columns) and the per-row statistics ------------------------
 //   dma: 0 = operands staged through registers; 1 / 2 = the full 128-column tiles by LDS-DMA, 128 / 256 wide (256: fp32 only)
@@ -154,9 +155,11 @@ struct F16x3Kernels {
     // Phi -> plane form (Phi16: the operand of the apply tiles and of pass 1's Gram); sidepart <- Phi^T y
     static void split_phi(const Geom& g, const float* Phi, const double* y, const Scal* sc, unsigned* Phi16, double* sidepart, float* tmp,
                           hipStream_t st);
-    // V = Phi B -> plane forms of V and of diag(q) V; sidepart <- V^T p; B (fp64, symmetric, ld Kp) only bounds |V|
-    static void split_v(const Geom& g, const float* V, const double* B, const double* q, const double* p, const Scal* sc, unsigned* V16g,
-                        unsigned* qV16g, double* sidepart, float* tmp, hipStream_t st);
+    // tmp[5] <- a bound of |V| = |Phi B| from B alone (fp64, symmetric, ld Kp): before the product, whose epilogue writes V's planes with it
+    static void v_bound(const Geom& g, const double* B, const Scal* sc, float* tmp, hipStream_t st);
+    // V = Phi B -> plane form of diag(q) V (and of V itself unless V16g is NULL: the product's epilogue wrote it); sidepart <- V^T p
+    static void split_v(const Geom& g, const float* V, const double* q, const double* p, unsigned* V16g, unsigned* qV16g, double* sidepart,
+                        float* tmp, hipStream_t st);
     // slabs[chunk][tri(128-tile)][128 x 128] = scale[0] (A chunk)^T (B chunk) on the lower 128-tiles, every slab written; chunk rows per
     // chunk (rounded up to 256): gram_chunks(g, chunk) chunks, to be summed by reduce_tri_tiles with nsplit = that number
     static int gram_chunks(const Geom& g, int64_t chunk);

@@ -161,7 +161,7 @@ struct scfgp_ctx {
         return std::max<int64_t>(std::min(top, fill), 1024);
     }
     bool f16_gram() const { return f16_on() && f16gram && !last_cform; }      // factor form (level 2) keeps its fp32 products
-    F16Operands f16ops() const { return F16Operands{d_Phi16, d_B16, d_f16scale}; }
+    F16Operands f16ops() const { return F16Operands{d_Phi16, d_B16, d_f16scale, nullptr, d_f16tmp + 5}; }
     // exchange buffers and K-stage
     // exchange buffers xp1/xp2 = [packed lower tiles | vector Kp | 8 scalars], x3 = [X~^T Zbar | 8 scalars];
     // x1/x2 = the same matrices unpacked to full Kp x Kp (+ vector) for the K x K stage
@@ -534,7 +534,8 @@ template <typename T> struct Impl {
                 // whose row chunks are the "splits" of the shared reduction
                 const int nch = F16x3Kernels::gram_chunks(g, c->f16_chunk());
                 { ProfScope ps(c, w ? "split_v" : "split_phi");
-                  if (w) F16x3Kernels::split_v(g, (const float*)Mx, c->d_B, w, side, c->d_sc, c->d_V16g, c->d_qV16g, c->d_f16side, c->d_f16tmp, c->st);
+                  // V's own planes were written by the epilogue of V = Phi B (pass2)
+                  if (w) F16x3Kernels::split_v(g, (const float*)Mx, w, side, nullptr, c->d_qV16g, c->d_f16side, c->d_f16tmp, c->st);
                   else F16x3Kernels::split_phi(g, (const float*)Mx, side, c->d_sc, c->d_Phi16, c->d_f16side, c->d_f16tmp, c->st); }
                 { ProfScope ps(c, name);
                   F16x3Kernels::gram(g, w ? c->d_V16g : c->d_Phi16, w ? c->d_qV16g : c->d_Phi16, c->d_f16tmp + 4, c->f16_chunk(), c->d_slabs, c->st); }
@@ -596,7 +597,10 @@ template <typename T> struct Impl {
             SK::convert_transposed(c->d_Li, (T*)c->d_AbarT, g.K, g.Kp, c->st);
         } else {
             SK::convert(c->d_B, (T*)c->d_BT, g.K, g.Kp, c->st);
-            if (c->f16_on()) F16x3Kernels::split_operand(g, c->d_B, c->d_B16, c->d_f16scale, c->d_partial, c->d_sc, c->st);
+            if (c->f16_on()) {
+                F16x3Kernels::split_operand(g, c->d_B, c->d_B16, c->d_f16scale, c->d_partial, c->d_sc, c->st);
+                F16x3Kernels::v_bound(g, c->d_B, c->d_sc, c->d_f16tmp, c->st);
+            }
         }
         HIPCHK(c, hipGetLastError());
         return SCFGP_OK;
@@ -614,7 +618,8 @@ template <typename T> struct Impl {
               SK::apply_vc(g, (const T*)c->d_C, (const T*)c->d_BT, (const T*)c->d_AbarT, (T*)c->d_V, c->st, dma); }
         } else {
             ProfScope ps(c, "apply_v");
-            const F16Operands f16 = c->f16ops();
+            F16Operands f16 = c->f16ops();
+            if (want_grad && c->f16_gram()) f16.V16 = c->d_V16g;      // the weighted Gram's operand, from this product's epilogue
             SK::apply_v(g, (const T*)c->d_Phi, (const T*)c->d_BT, (T*)c->d_V, c->d_vpart, c->alpha(), c->d_mu, c->st, c->dma(), c->f16_on() ? &f16 : nullptr);
         }
         const int nb = (int)std::min<int64_t>(g.Np / 4, 2048);
