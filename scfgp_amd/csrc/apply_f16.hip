@@ -142,28 +142,39 @@ void apply_f16_kernel(const float* __restrict__ Phi, const unsigned* __restrict_
         for (int tn = 0; tn < 4; ++tn) acc[tm][tn] *= sc;
     if constexpr (EPI == 0) {
         // V in plane form for the weighted Gram (gram_f16.hip), straight from the accumulators: what split_v's pass over V would write,
-        // bit for bit (same values, same scale 2^e, e = 14 - ilogb(bound of |V|)).  A lane holds 4 adjacent columns of 16 rows.
+        // bit for bit (same values, same scale 2^e, e = 14 - ilogb(bound of |V|)).  A lane holds 4 adjacent columns of 16 rows, the four
+        // lanes of a quad one 64-byte block [16 h | 16 l] of a row; they swap halves (two quad permutes) so that each lane stores 16
+        // contiguous bytes of it -- as 8-byte stores of its own h's and l's the launch was 1.9 ms longer (four times the cache-line
+        // requests of the fp32 V it writes anyway).
         if (V16) {
             const float bnd = vbound[0], up = bnd > 0.f ? ldexpf(1.0f, 14 - ilogbf(bnd)) : 1.0f;
             AccCoord<Cfg> co((int)threadIdx.x);
             const int jg = cbase + co.wn0 + 4 * (co.lane & 15);
-            if (jg < K) {                                          // (columns >= K of the array stay the zeros they were allocated as)
-                const int64_t poff = 64 * (jg >> 4) + 2 * (jg & 15);
+            const bool low = (co.lane & 2) == 0;                   // lanes 0, 1 of a quad store the h's, lanes 2, 3 the l's
+            const int64_t poff = 64 * (jg >> 4) + 16 * (co.lane & 3);
 #pragma unroll
-                for (int tm = 0; tm < Cfg::TM; ++tm)
+            for (int tm = 0; tm < Cfg::TM; ++tm)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        char* row = reinterpret_cast<char*>(V16 + (rb * BM + co.row(tm, r)) * Kp) + poff;
-                        _Float16 h[4], l[4];
+                for (int r = 0; r < 4; ++r) {
+                    _Float16 h[4], l[4];
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const float x = (jg + k < K ? acc[tm][k][r] : 0.f) * up;
-                            h[k] = (_Float16)x; l[k] = (_Float16)(x - (float)h[k]);
-                        }
-                        *reinterpret_cast<h4*>(row) = h4{h[0], h[1], h[2], h[3]};
-                        *reinterpret_cast<h4*>(row + 32) = h4{l[0], l[1], l[2], l[3]};
+                    for (int k = 0; k < 4; ++k) {
+                        const float x = (jg + k < K ? acc[tm][k][r] : 0.f) * up;
+                        h[k] = (_Float16)x; l[k] = (_Float16)(x - (float)h[k]);
                     }
-            }
+                    const h2 h01 = h2{h[0], h[1]}, h23 = h2{h[2], h[3]}, l01 = h2{l[0], l[1]}, l23 = h2{l[2], l[3]};
+                    int w[4] = {__builtin_bit_cast(int, h01), __builtin_bit_cast(int, h23), __builtin_bit_cast(int, l01), __builtin_bit_cast(int, l23)};
+                    int o[4];
+                    // first 8 bytes: the h's (lanes 0, 1) or l's (lanes 2, 3) of quad lane 0 / 2 / 0 / 2; second 8 bytes: of quad lane 1 / 3 / 1 / 3
+#pragma unroll
+                    for (int d = 0; d < 2; ++d) {
+                        const int ha = __builtin_amdgcn_update_dpp(0, w[d], 0x88, 0xF, 0xF, true), la = __builtin_amdgcn_update_dpp(0, w[2 + d], 0x88, 0xF, 0xF, true);
+                        const int hb = __builtin_amdgcn_update_dpp(0, w[d], 0xDD, 0xF, 0xF, true), lb = __builtin_amdgcn_update_dpp(0, w[2 + d], 0xDD, 0xF, 0xF, true);
+                        o[d] = low ? ha : la; o[2 + d] = low ? hb : lb;
+                    }
+                    char* row = reinterpret_cast<char*>(V16 + (rb * BM + co.row(tm, r)) * Kp) + poff;
+                    *reinterpret_cast<int4*>(row) = int4{o[0], o[1], o[2], o[3]};
+                }
         }
     }
     constexpr int SLOTS = BN >= 128 ? BN / 128 : 1;            // vpart / mupart slots: one per 128 columns of the full tiles, one per remainder tile
