@@ -84,6 +84,9 @@ def check(lines, name):
                 k += 1
                 continue
             queue = step(queue, l, ln, bad)
+            if len(queue) > 48:                                         # more reads in flight than any counted wait can tell apart: a path
+                bad[ln] = (ln, l, ['more than 48 LDS reads outstanding'])   # that issues reads and skips their waits (or a real leak)
+                break
             k += 1
     return [bad[k] for k in sorted(bad)]
 
@@ -102,41 +105,57 @@ def loops_with_fetches(ins):
             if any('global_load_lds' in x for x in ins[j:k + 1]) and any(x.startswith('v_mfma') for x in ins[j:k + 1])}
 
 
-def ring_check(ins, max_paths=1 << 14):
+def ring_check(ins):
     """Counted vmcnt waits of the LDS-DMA ring.  For every INNERMOST fetch-carrying loop: F = {number of global_load_lds issued on
-    a path from the loop's head around to a branch back to it}, W = {n of every `s_waitcnt vmcnt(n)` on such a path, n > 0};
-    returns [(first, last, sorted F, sorted W)] of the loops where W is not a subset of F (a wave would then let part of the
-    stage it is about to read stay in flight, or wait for its newest stage too), and the number of loops examined."""
+    a path from one `s_barrier` of the loop to the next (around the back edge if need be) -- a stage's fetches, however many stages
+    the compiler or the source put into one trip}, W = {n of every `s_waitcnt vmcnt(n)` in the loop, n > 0}; returns
+    [(first, last, sorted F, sorted W)] of the loops where W is not a subset of F (a wave would then let part of the stage it is about
+    to read stay in flight, or wait for its newest stage too), and the number of loops examined.  States (position, fetches so far)
+    are visited once: the bodies have a forward branch per predicated fetch."""
     loops = loops_with_fetches(ins)
     inner = [(j, k) for j, k in loops.items() if not any(j2 != j and j <= j2 and k2 <= k for j2, k2 in loops.items())]
     label_at = {l[:-1]: k for k, l in enumerate(ins) if l.endswith(':')}
     bad = []
     for j, k in inner:
-        F, W, npaths = set(), set(), 0
-        work = [(j + 1, 0, frozenset())]
+        W = set()
+        for l in ins[j:k + 1]:
+            mm = re.search(r'vmcnt\((\d+)\)', l) if l.startswith('s_waitcnt') else None
+            if mm and int(mm.group(1)) > 0:
+                W.add(int(mm.group(1)))
+        barriers = [p for p in range(j, k + 1) if ins[p].split()[0] == 's_barrier']
+        F, seen = set(), set()
+        work = [(b + 1, 0, False, 0) for b in barriers] if barriers else [(j + 1, 0, True, 0)]
         while work:
-            pos, f, w = work.pop()
-            while pos <= k:
+            pos, f, wrapped, out = work.pop()
+            while True:
+                # predicated fetches may sit in blocks laid out behind the loop that branch back into it: a path may stay outside
+                # [j, k] for a few instructions
+                out = 0 if j <= pos <= k else out + 1
+                if pos >= len(ins) or out > 24 or (pos, f, wrapped) in seen:
+                    break
+                seen.add((pos, f, wrapped))
                 l = ins[pos]
+                op = l.split()[0]
+                if op == 's_barrier':
+                    F.add(f)
+                    break
+                if op == 's_endpgm':
+                    break
                 m = re.match(r's_c?branch\w*\s+(\.LBB\d+_\d+)', l)
                 if m:
                     t = label_at.get(m.group(1), -1)
-                    if t == j:                                          # a back edge: one trip around the loop is complete
-                        F.add(f); W.update(w); npaths += 1
-                    elif j < t <= k and t > pos:
-                        work.append((t, f, w))                          # forward branch inside the body
-                    # (branches that leave the loop end the path there: the tail is another loop's business)
-                    if l.split()[0] == 's_branch':
+                    if t == j:                                          # a back edge: on into the next trip (once)
+                        if not barriers:
+                            F.add(f)
+                        elif not wrapped:
+                            work.append((j + 1, f, True, 0))
+                    elif t >= 0 and (t > pos or not (j <= t <= k)):
+                        work.append((t, f, wrapped, out))               # forward inside the body, or out to / back from an out-of-line block
+                    if op == 's_branch':
                         break
                 elif 'global_load_lds' in l:
                     f += 1
-                elif l.startswith('s_waitcnt'):
-                    mm = re.search(r'vmcnt\((\d+)\)', l)
-                    if mm and int(mm.group(1)) > 0:
-                        w = w | {int(mm.group(1))}
                 pos += 1
-            if npaths > max_paths:
-                raise RuntimeError('too many paths through the loop at %d-%d' % (j, k))
         if not W <= F:
             bad.append((j, k, sorted(F), sorted(W)))
     return bad, len(inner)
