@@ -4,9 +4,9 @@
 // SCFGP/SCFGP.py:95-96); what it must equal is fp32 mode, whose parity tier it runs under (tests/test_gpu_round5.py).
 //
 // The split.  x = (h + l) 2^-e with h = fp16(x 2^e), l = fp16(x 2^e - h) and ONE power-of-two scale per operand matrix that puts its
-// largest entry in [2^14, 2^15): l then stays in fp16's normal range for every entry within 2^-18 of the largest, and h + l carries
-// 22-24 bits.  Products of two fp16 values are exact in fp32, so  a b ~ ah bh + al bh + ah bl  loses only the l.l term (2^-24
-// relative) against an exact-fp32 product; what the mode really pays is the fp16 matrix instruction's accumulation, which truncates
+// largest entry in [2^14, 2^15): h + l is x to 2^-23 of x for every entry within about 2^-15 of the largest, to l's subnormal step
+// (2^-40 of the largest) below (tests/test_f16x3_split.py).  Products of two fp16 values are exact in fp32, so
+// a b ~ ah bh + al bh + ah bl  loses only the l.l term (at most 2^-22 of the operands' bounds) against an exact-fp32 product; what the mode really pays is the fp16 matrix instruction's accumulation, which truncates
 // (gram_f16.hip, profiles/r05_tuning.md).  Measured errors of the two products here: within 1.0-3.5x of fp32 mode's.
 //
 // The operands.  Both come in "plane form" (kernels.h): 4 bytes per element, per 16 consecutive k the 16 h's and then the 16 l's.  Phi's
